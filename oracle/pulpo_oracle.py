@@ -1,0 +1,433 @@
+"""CPU oracle for the PULPo registration hot path.  TEST INFRASTRUCTURE ONLY.
+
+A functional, state-dict-driven restatement (torch fp32 on the CPU) of the path
+BASELINE.json:north_star names, written from the reference's behaviour:
+
+    /root/reference/src/network_blocks.py   (ConvUnit, MuSigmaBlock, VelocityField, SpatialTransformer,
+                                             ResizeTransform, VecInt, gauss_sampler)
+    /root/reference/src/components/pulpo.py (DownPath, Autoencoder, PULPoEncoder, SVFDecoder, PULPoPrior)
+    /root/reference/src/losses.py           (KL_two_gauss_with_diag_cov, NCC_loss, L2_reg, Hierarchical*)
+    /root/reference/src/models.py           (loss-weight dictionaries, training_step arithmetic)
+
+Each function cites the reference lines it follows.  It consumes the reference's
+own state-dict key names, so loading a reference checkpoint into it is the
+checkpoint-compatibility test.
+
+PINNING: tests/test_oracle_golden.py checks every function here against the
+fixtures under tests/golden/, which tests/golden/make_golden.py produced by
+importing the real reference modules in the build container.
+
+WHO MAY IMPORT THIS: tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, as the checker / reported CPU baseline.  Nothing under
+pulpo_amd/ imports it; the product path has no CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+FEEDBACK_DEFAULT = ("samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed")
+
+
+# =============================================================================== configuration
+@dataclass
+class Cfg:
+    total_levels: int
+    latent_levels: int
+    input_size: Sequence[int]
+    n0: int = 32
+    feedback: Sequence[str] = FEEDBACK_DEFAULT
+    cp_depth: int = 3
+    zdim: int = 3
+    beta: float = 0.1
+    gamma: float = 0.05
+    lamb: float = 0.025
+
+    @property
+    def offset(self) -> int:                       # lk_offset, pulpo.py:22,86
+        return self.total_levels - self.latent_levels
+
+    def channels(self) -> List[int]:               # pulpo.py:26-28
+        mult = [1, 2, 4] + [6] * max(self.total_levels - 3, 0)
+        return [self.n0 * m for m in mult[: self.total_levels]]
+
+    def level_sizes(self) -> List[List[int]]:      # pulpo.py:93-96 (ceil halving)
+        sizes = [list(self.input_size)]
+        for _ in range(self.total_levels - 1):
+            sizes.append([(s + 1) // 2 for s in sizes[-1]])
+        return sizes
+
+
+def weight_tables(cfg: Cfg) -> Tuple[Dict[int, int], Dict[int, float], Dict[int, float], Dict[int, float]]:
+    """NCC window sizes and the three per-level loss-weight dictionaries (models.py:104-123,
+    df_resolution='level_res', similarity_pyramid=False)."""
+    L, nd, o = cfg.latent_levels, len(cfg.input_size), cfg.offset
+    window = {l: 1 + 2 * (L - l) for l in range(L)}
+    if L == 1:
+        window = {0: 9}
+    scale = {l: float((2.0 ** nd) ** l) for l in range(L)}
+    kl_w, rec_w, reg_w = dict(scale), dict(scale), dict(scale)
+    rec_w[0] = scale[0] / (2 ** (nd * o))
+    reg_w[0] = scale[0] / (2 ** (nd * o))
+    rec_w[0] *= 4
+    return window, kl_w, rec_w, reg_w
+
+
+# =============================================================================== elementary operators
+def conv_unit(h: Tensor, sd: Dict[str, Tensor], prefix: str, training: bool) -> Tensor:
+    """Conv3d(k3,p1,bias) -> BatchNorm3d(eps 1e-5, momentum 0.1) -> LeakyReLU(0.2)   network_blocks.py:22-26.
+    `prefix` names the ConvUnit ('..._op.0'); its children are '_op.0' (conv) and '_op.1' (bn).
+    In training mode the running statistics in `sd` are updated in place, as nn.BatchNorm3d does."""
+    w, b = sd[prefix + "._op.0.weight"], sd[prefix + "._op.0.bias"]
+    h = F.conv3d(h, w, b, stride=1, padding=1)
+    rm, rv = sd[prefix + "._op.1.running_mean"], sd[prefix + "._op.1.running_var"]
+    if training:
+        nbt = sd.get(prefix + "._op.1.num_batches_tracked")
+        if nbt is not None:
+            nbt += 1
+    h = F.batch_norm(h, rm, rv, sd[prefix + "._op.1.weight"], sd[prefix + "._op.1.bias"], training=training, momentum=0.1, eps=1e-5)
+    return F.leaky_relu(h, 0.2)
+
+
+def conv_sequence(h: Tensor, sd, prefix: str, depth: int, training: bool) -> Tensor:
+    """ConvSequence = `depth` ConvUnits, keys '<prefix>._op.<i>'   network_blocks.py:41-43"""
+    for i in range(depth):
+        h = conv_unit(h, sd, f"{prefix}._op.{i}", training)
+    return h
+
+
+def mu_sigma(h: Tensor, sd, prefix: str) -> Tuple[Tensor, Tensor]:
+    """two 1x1x1 convs; sigma = softplus   network_blocks.py:54-60"""
+    mu = F.conv3d(h, sd[prefix + "._conv_mu.weight"], sd[prefix + "._conv_mu.bias"])
+    sg = F.softplus(F.conv3d(h, sd[prefix + "._conv_sigma.0.weight"], sd[prefix + "._conv_sigma.0.bias"]))
+    return mu, sg
+
+
+def velocity_field(z: Tensor, sd, prefix: str, depth: int, training: bool) -> Tensor:
+    """depth>=2: (depth-1) ConvUnits then a 1x1x1 conv; depth 1: bare unpadded 3x3x3 conv; depth 0: identity.
+    network_blocks.py:74-82"""
+    if depth == 0:
+        return z
+    if depth == 1:
+        return F.conv3d(z, sd[prefix + "._op.0.weight"], sd[prefix + "._op.0.bias"])
+    h = z
+    for i in range(depth - 1):
+        h = conv_unit(h, sd, f"{prefix}._op.{i}", training)
+    return F.conv3d(h, sd[f"{prefix}._op.{depth - 1}.weight"], sd[f"{prefix}._op.{depth - 1}.bias"])
+
+
+def identity_grid(size: Sequence[int], dtype=torch.float32) -> Tensor:
+    """(1,3,D,H,W) voxel-index grid, 'ij' order   network_blocks.py:94-98"""
+    axes = [torch.arange(s, dtype=dtype) for s in size]
+    return torch.stack(torch.meshgrid(*axes, indexing="ij")).unsqueeze(0)
+
+
+def warp(df: Tensor, img: Tensor) -> Tensor:
+    """SpatialTransformer.forward   network_blocks.py:101-121.
+    Grid size = df's spatial size; the image may have a different size (models.py:330).
+    Normalisation uses (S-1) (align_corners=True convention) but sampling is align_corners=False."""
+    size = df.shape[2:]
+    loc = identity_grid(size, df.dtype).to(df.device) + df
+    comps = [2 * (loc[:, i] / (size[i] - 1) - 0.5) for i in range(3)]
+    grid = torch.stack(comps[::-1], dim=-1)          # channels last, xyz order (network_blocks.py:116-117)
+    return F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=False)
+
+
+def warp_explicit(df: Tensor, img: Tensor) -> Tensor:
+    """The same operator written as an explicit 8-corner gather: this is the arithmetic the HIP kernel
+    performs.  Sample coordinate along dim i:
+        n_i = 2*((p_i + d_i)/(Sg_i - 1) - 0.5);  c_i = ((n_i + 1)*Si_i - 1)/2, clamped to [0, Si_i-1]."""
+    B, _, *Sg = df.shape
+    Si = img.shape[2:]
+    loc = identity_grid(Sg, df.dtype) + df
+    idx0, idx1, frac = [], [], []
+    for i in range(3):
+        n = 2 * (loc[:, i] / (Sg[i] - 1) - 0.5)
+        c = (((n + 1) * Si[i] - 1) / 2).clamp(0, Si[i] - 1)
+        f0 = c.floor()
+        idx0.append(f0.long())
+        idx1.append((f0.long() + 1).clamp(max=Si[i] - 1))
+        frac.append(c - f0)
+    C = img.shape[1]
+    flat = img.reshape(B, C, -1)
+    out = torch.zeros(B, C, *Sg, dtype=img.dtype)
+    for cz in (0, 1):
+        for cy in (0, 1):
+            for cx in (0, 1):
+                iz = idx1[0] if cz else idx0[0]
+                iy = idx1[1] if cy else idx0[1]
+                ix = idx1[2] if cx else idx0[2]
+                wz = frac[0] if cz else 1 - frac[0]
+                wy = frac[1] if cy else 1 - frac[1]
+                wx = frac[2] if cx else 1 - frac[2]
+                lin = ((iz * Si[1] + iy) * Si[2] + ix).reshape(B, 1, -1).expand(B, C, -1)
+                out += (wz * wy * wx).unsqueeze(1) * flat.gather(2, lin).reshape(B, C, *Sg)
+    return out
+
+
+def vecint(v: Tensor, nsteps: int = 7) -> Tensor:
+    """scaling and squaring   network_blocks.py:173-177"""
+    v = v * (1.0 / (2 ** nsteps))
+    for _ in range(nsteps):
+        v = v + warp(v, v)
+    return v
+
+
+def resize_field(x: Tensor, vel_resize: float) -> Tensor:
+    """ResizeTransform   network_blocks.py:129-150 (factor = 1/vel_resize)"""
+    factor = 1.0 / vel_resize
+    if factor < 1:
+        x = F.interpolate(x, align_corners=False, scale_factor=factor, mode="trilinear")
+        x = factor * x
+    elif factor > 1:
+        x = factor * x
+        x = F.interpolate(x, align_corners=False, scale_factor=factor, mode="trilinear")
+    return x
+
+
+def pool2(x: Tensor) -> Tensor:
+    """AvgPool3d(2, 2, ceil_mode=True)   pulpo.py:33,174"""
+    return F.avg_pool3d(x, kernel_size=2, stride=2, padding=0, ceil_mode=True)
+
+
+def resize_to(x: Tensor, size) -> Tensor:
+    """F.interpolate(size=..., trilinear, align_corners=False)   pulpo.py:202, losses.py:313"""
+    return F.interpolate(x, size=tuple(size), mode="trilinear", align_corners=False)
+
+
+# =============================================================================== losses
+def kl_diag(mu0: Tensor, sigma0: Tensor, mu1: Optional[Tensor] = None, sigma1: Optional[Tensor] = None, eps: float = 1e-10) -> Tensor:
+    """KL[N(mu0,sigma0^2) || N(mu1,sigma1^2)], summed over features, mean over batch   losses.py:47-76.
+    Default second argument is the N(0,1) prior (pulpo.py:330-341)."""
+    if mu1 is None:
+        mu1 = torch.zeros_like(mu0)
+    if sigma1 is None:
+        sigma1 = torch.ones_like(sigma0)
+    s0 = sigma0.flatten(1) ** 2
+    s1 = sigma1.flatten(1) ** 2
+    term = (s0 + (mu1.flatten(1) - mu0.flatten(1)) ** 2) / (s1 + eps) + torch.log(s1 + eps) - torch.log(s0 + eps) - 1
+    return (0.5 * term.sum(dim=1)).mean()
+
+
+def box_sum(v: Tensor, w: int) -> Tensor:
+    """zero-padded w^3 box sum as the reference computes it: a dense ones-kernel conv   losses.py:99-122"""
+    k = torch.ones(1, 1, w, w, w, dtype=v.dtype, device=v.device)
+    return F.conv3d(v, k, stride=1, padding=w // 2)
+
+
+def ncc(pred: Tensor, true: Tensor, win: int = 9, gamma: float = 0.05) -> Tensor:
+    """local normalised cross-correlation   losses.py:85-135"""
+    I, J = true, pred
+    Is, Js = box_sum(I, win), box_sum(J, win)
+    I2s, J2s, IJs = box_sum(I * I, win), box_sum(J * J, win), box_sum(I * J, win)
+    n = float(win ** 3)
+    uI, uJ = Is / n, Js / n
+    cross = IJs - uJ * Is - uI * Js + uI * uJ * n
+    Iv = I2s - 2 * uI * Is + uI * uI * n
+    Jv = J2s - 2 * uJ * Js + uJ * uJ * n
+    cc = cross * cross / (Iv * Jv + 1e-8)
+    return -torch.sum(cc.mean(dim=0)) * gamma
+
+
+def ncc_grad_closed_form(pred: Tensor, true: Tensor, win: int, gamma: float) -> Tensor:
+    """d ncc / d pred in closed form (SURVEY.md §8 'Backward semantics'): what the HIP backward evaluates.
+    With box sums S_*, n = w^3, cross = S_IJ - S_I S_J/n, Iv = S_II - S_I^2/n, Jv = S_JJ - S_J^2/n, D = Iv Jv + 1e-8:
+      dL/dJ = -(gamma/B) [ box(-2 cross S_I/(n D) + 2 cross^2 Iv S_J/(n D^2)) + 2 J box(-cross^2 Iv / D^2) + I box(2 cross / D) ]"""
+    I, J = true.double(), pred.double()
+    n = float(win ** 3)
+    SI, SJ = box_sum(I, win), box_sum(J, win)
+    SII, SJJ, SIJ = box_sum(I * I, win), box_sum(J * J, win), box_sum(I * J, win)
+    cross = SIJ - SI * SJ / n
+    Iv = SII - SI * SI / n
+    Jv = SJJ - SJ * SJ / n
+    D = Iv * Jv + 1e-8
+    a = -2 * cross * SI / (n * D) + 2 * cross * cross * Iv * SJ / (n * D * D)
+    b = -cross * cross * Iv / (D * D)
+    c = 2 * cross / D
+    g = box_sum(a, win) + 2 * J * box_sum(b, win) + I * box_sum(c, win)
+    return (-(gamma / pred.shape[0]) * g).to(pred.dtype)
+
+
+def l2_reg(df: Tensor, lamb: float) -> Tensor:
+    """squared forward differences on the [1:,1:,1:] block, mean, times lamb*H*W*D   losses.py:217-222"""
+    H, W, D = df.shape[-3:]
+    c = df[:, :, 1:, 1:, 1:]
+    d = (c - df[:, :, :-1, 1:, 1:]) ** 2 + (c - df[:, :, 1:, :-1, 1:]) ** 2 + (c - df[:, :, 1:, 1:, :-1]) ** 2
+    return d.mean() * lamb * H * W * D
+
+
+# =============================================================================== network
+OUT_NAMES = ("mus", "sigmas", "samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed")
+
+
+def down_path(sd, cfg: Cfg, x: Tensor, y: Tensor, training: bool, prefix: str = "downpath") -> Dict[int, Tensor]:
+    """DownPath.forward   pulpo.py:47-62"""
+    h = torch.cat([x, y], dim=1)
+    acts = {0: conv_sequence(h, sd, f"{prefix}.down_blocks.0", 3, training)}
+    for k in range(1, cfg.total_levels):
+        acts[k] = conv_sequence(pool2(acts[k - 1]), sd, f"{prefix}.down_blocks.{k}", 3, training)
+    return acts
+
+
+def svf_decoder(sd, cfg: Cfg, prefix: str, z: Tensor, image: Tensor, combined_below: Optional[Tensor], out_ratio: float,
+                training: bool):
+    """SVFDecoder.forward   pulpo.py:301-319.  out_ratio = outsize[0]/insize[0] (pulpo.py:290)."""
+    ind = velocity_field(z, sd, prefix + ".velocity_field", cfg.cp_depth, training)
+    comb = ind if combined_below is None else resize_field(combined_below, 0.5) + ind
+    integ = vecint(comb, 7)
+    integ = resize_field(integ, 1.0 / out_ratio)
+    warped = warp(integ, image)
+    return ind, ind, comb, integ, warped
+
+
+def autoencoder(sd, cfg: Cfg, x: Tensor, acts: Dict[int, Tensor], eps: Optional[Dict[int, Tensor]], training: bool,
+                deterministic: bool = False, prefix: str = "autoencoder"):
+    """Autoencoder.forward   pulpo.py:160-215.  eps[l] is the injected standard-normal noise of level l
+    (the reference draws it in gauss_sampler, network_blocks.py:7-8)."""
+    L, o = cfg.latent_levels, cfg.offset
+    sizes = cfg.level_sizes()
+    # level_x: pulpo.py:171-179
+    lx = {0: x}
+    for _ in range(o):
+        lx[0] = pool2(lx[0])
+    for l in range(1, L):
+        lx[l] = pool2(lx[l - 1])
+    lx[0] = x
+    out = {n: {} for n in OUT_NAMES}
+    for l in reversed(range(L)):
+        k = l + o
+        enc = f"{prefix}.encoders.{l}"
+        if l == L - 1:
+            h = acts[k]
+        else:
+            fb = []
+            for item in cfg.feedback:
+                if item == "control_points":
+                    item = "velocity_fields"
+                if item not in OUT_NAMES:
+                    raise ValueError(f"Feedback list contains {item}. Not a known option.")
+                fb.append(resize_to(out[item][l + 1], acts[k].shape[2:]))
+            up = conv_sequence(torch.cat(fb, dim=1), sd, f"{prefix}.up_blocks.{k}", 2, training)
+            h = conv_sequence(torch.cat([up, acts[k]], dim=1), sd, enc + ".sample_merge_block", 2, training)
+        mu, sg = mu_sigma(h, sd, enc + ".mu_sigma")
+        if eps is None:
+            z = mu + sg * torch.randn_like(sg, dtype=torch.float32)
+        else:
+            z = mu + sg * eps[l]
+        out_ratio = (cfg.input_size[0] / sizes[k][0]) if l == 0 else 1.0          # pulpo.py:146,290
+        res = svf_decoder(sd, cfg, f"{prefix}.decoders.{l}", mu if deterministic else z, lx[l],
+                          None if l == L - 1 else out["combined_dfs"][l + 1], out_ratio, training)
+        out["mus"][l], out["sigmas"][l], out["samples"][l] = mu, sg, z
+        for nme, t in zip(OUT_NAMES[3:], res):
+            out[nme][l] = t
+    return tuple(out[n] for n in OUT_NAMES)
+
+
+def forward(sd, cfg: Cfg, x: Tensor, y: Tensor, eps=None, training: bool = True, deterministic: bool = False):
+    """downpath + autoencoder (models.py:138-139)"""
+    return autoencoder(sd, cfg, x, down_path(sd, cfg, x, y, training), eps, training, deterministic)
+
+
+def losses(outs, y: Tensor, cfg: Cfg):
+    """the loss block of training_step   models.py:151-164 with losses.py:246-355"""
+    mus, sigmas, _, _, _, _, final_dfs, yhat = outs
+    window, kl_w, rec_w, reg_w = weight_tables(cfg)
+    kl_l = {l: cfg.beta * (w * kl_diag(mus[l], sigmas[l])) for l, w in kl_w.items()}
+    kl = sum(w * kl_diag(mus[l], sigmas[l]) for l, w in kl_w.items()) * cfg.beta
+    rec_l = {l: (w * ncc(yhat[l], resize_to(y, yhat[l].shape[2:]), window[l], cfg.gamma)) / 1 for l, w in rec_w.items()}
+    rec = sum(rec_l.values())
+    reg_l = {l: w * l2_reg(final_dfs[l], cfg.lamb) for l, w in reg_w.items()}
+    reg = sum(reg_l.values())
+    return kl + rec + reg, kl, rec, reg, kl_l, rec_l, reg_l
+
+
+def combine_dfs(individual: Dict[int, Tensor], cfg: Cfg):
+    """PULPo.combine_dfs   models.py:349-368"""
+    L = cfg.latent_levels
+    comb, fin = {}, {}
+    for l in reversed(range(L)):
+        if l + 1 in comb:
+            ratio = individual[l].shape[2] / individual[l + 1].shape[2]
+            comb[l] = individual[l] + resize_field(comb[l + 1], 1.0 / ratio)
+        else:
+            comb[l] = individual[l]
+    for l in reversed(range(L)):
+        f = vecint(comb[l], 7)
+        tgt = cfg.input_size if l == 0 else comb[l].shape[2:]
+        fin[l] = resize_field(f, 1.0 / (tgt[0] / f.shape[2]))
+    return comb, fin
+
+
+# =============================================================================== state dict helpers
+def init_state_dict(cfg: Cfg, seed: int = 0) -> Dict[str, Tensor]:
+    """A reference-shaped state dict with PyTorch-default initialisation (kaiming-uniform(a=sqrt 5) conv weights,
+    U(-1/sqrt(fan_in), +) biases, BN gamma 1 / beta 0 / mean 0 / var 1).  Key inventory follows
+    tests/golden/state_keys.txt; persistent SpatialTransformer.grid buffers are included (network_blocks.py:99)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, Tensor] = {}
+
+    def conv(name, cin, cout, k):
+        fan_in = cin * k ** 3
+        bound = 1.0 / math.sqrt(fan_in)
+        sd[name + ".weight"] = (torch.rand(cout, cin, k, k, k, generator=g) * 2 - 1) * bound
+        sd[name + ".bias"] = (torch.rand(cout, generator=g) * 2 - 1) * bound
+
+    def unit(name, cin, cout):
+        conv(name + "._op.0", cin, cout, 3)
+        sd[name + "._op.1.weight"] = torch.ones(cout)
+        sd[name + "._op.1.bias"] = torch.zeros(cout)
+        sd[name + "._op.1.running_mean"] = torch.zeros(cout)
+        sd[name + "._op.1.running_var"] = torch.ones(cout)
+        sd[name + "._op.1.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+    def seq(name, cin, cout, depth):
+        for i in range(depth):
+            unit(f"{name}._op.{i}", cin if i == 0 else cout, cout)
+
+    ch, sizes, o, L, T = cfg.channels(), cfg.level_sizes(), cfg.offset, cfg.latent_levels, cfg.total_levels
+    for k in range(T):
+        seq(f"downpath.down_blocks.{k}", 2 if k == 0 else ch[k - 1], ch[k], 3)
+    fbc = sum({"samples": cfg.zdim, "transformed": 1}.get(i, 3) for i in cfg.feedback)
+    for k in range(o, T - 1):
+        seq(f"autoencoder.up_blocks.{k}", fbc, cfg.n0 * cfg.zdim, 2)
+    for l in range(L):
+        k = l + o
+        seq(f"autoencoder.encoders.{l}.sample_merge_block", ch[k] + cfg.n0 * cfg.zdim, ch[k], 2)
+        conv(f"autoencoder.encoders.{l}.mu_sigma._conv_mu", ch[k], cfg.zdim, 1)
+        conv(f"autoencoder.encoders.{l}.mu_sigma._conv_sigma.0", ch[k], cfg.zdim, 1)
+    for l in range(L):
+        k = l + o
+        d = f"autoencoder.decoders.{l}"
+        unit(d + ".velocity_field._op.0", cfg.zdim, cfg.n0)
+        for i in range(1, cfg.cp_depth - 1):
+            unit(d + f".velocity_field._op.{i}", cfg.n0, cfg.n0)
+        conv(d + f".velocity_field._op.{cfg.cp_depth - 1}", cfg.n0, 3, 1)
+        sd[d + ".integrate.transformer.grid"] = identity_grid(sizes[k])
+        sd[d + ".spatial_transform.grid"] = identity_grid(cfg.input_size if l == 0 else sizes[k])
+    return sd
+
+
+def clone_sd(sd, requires_grad: bool = False) -> Dict[str, Tensor]:
+    out = {}
+    for k, v in sd.items():
+        t = v.detach().clone()
+        if requires_grad and t.is_floating_point() and not ("running_" in k or k.endswith(".grid")):
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def train_step(sd, cfg: Cfg, x: Tensor, y: Tensor, eps):
+    """forward + losses + backward; returns (loss tuple, grads by state-dict key, outputs).  `sd` must hold leaf
+    tensors with requires_grad (clone_sd(..., True)); BN running stats in `sd` are updated."""
+    outs = forward(sd, cfg, x, y, eps, training=True)
+    ls = losses(outs, y, cfg)
+    params = {k: v for k, v in sd.items() if v.requires_grad}
+    gl = torch.autograd.grad(ls[0], list(params.values()), allow_unused=True)
+    return ls, {k: g for k, g in zip(params, gl)}, outs

@@ -1,0 +1,403 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs only in the build container (needs /root/reference); the reference never
+travels to the GPU box, these .npz fixtures do.  Everything is seeded, fp32, CPU.
+
+The reference modules that import cleanly here are used unmodified:
+  src.network_blocks, src.components.pulpo, src.losses   
+src.models needs pytorch_lightning/torchvision, which the image lacks; we do NOT
+write stand-ins for them.  The training step is assembled from the component
+modules exactly as models.py:134-164 does (DownPath -> Autoencoder -> Prior ->
+three Hierarchical* losses -> beta*KL + recon + reg), with the loss-weight
+dictionaries of models.py:104-123 evaluated in this script.
+
+usage:  python tests/golden/make_golden.py   (writes next to itself)
+"""
+import os
+import sys
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+# make sure `src` resolves to the reference, never to this repo's drop-in shim
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != os.path.abspath(os.path.join(HERE, "..", ".."))]
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import src.network_blocks as nb          # noqa: E402
+import src.components.pulpo as cp        # noqa: E402
+import src.losses as ls                  # noqa: E402
+
+assert os.path.abspath(nb.__file__).startswith(REF), nb.__file__
+torch.set_num_threads(4)
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %-28s %7.1f KiB  (%d arrays)" % (name + ".npz", os.path.getsize(path) / 1024, len(arrs)))
+
+
+# --------------------------------------------------------------------------- 1. warp3d
+def gen_warp():
+    g = torch.Generator().manual_seed(101)
+    out = {}
+    S = [6, 8, 10]
+    st = nb.SpatialTransformer(S)
+    # (a) random field, 1-channel image, upstream = ones and random
+    df = (torch.randn(2, 3, *S, generator=g) * 1.5).requires_grad_(True)
+    img = torch.rand(2, 1, *S, generator=g).requires_grad_(True)
+    up = torch.randn(2, 1, *S, generator=g)
+    o = st(df, img)
+    gdf1, gimg1 = torch.autograd.grad(o.sum(), [df, img], retain_graph=True)
+    gdf2, gimg2 = torch.autograd.grad((o * up).sum(), [df, img])
+    out.update(a_df=npy(df), a_img=npy(img), a_up=npy(up), a_out=npy(o), a_gdf_ones=npy(gdf1), a_gimg_ones=npy(gimg1),
+               a_gdf_rand=npy(gdf2), a_gimg_rand=npy(gimg2))
+    # (b) zero field is NOT the identity (Appendix A.2)
+    img = torch.rand(1, 1, *S, generator=g)
+    out.update(b_img=npy(img), b_out=npy(st(torch.zeros(1, 3, *S), img)))
+    # (c) 3-channel image (the VecInt use: image == field)
+    df = (torch.randn(1, 3, *S, generator=g) * 0.8).requires_grad_(True)
+    up = torch.randn(1, 3, *S, generator=g)
+    o = st(df, df)
+    gdf, = torch.autograd.grad((o * up).sum(), [df])
+    out.update(c_df=npy(df), c_up=npy(up), c_out=npy(o), c_gdf=npy(gdf))
+    # (d) image larger than the grid (models.py:330: full-res x warped by a level-res field)
+    Sg = [4, 5, 6]
+    stg = nb.SpatialTransformer(Sg)
+    df = torch.randn(1, 3, *Sg, generator=g) * 1.2
+    img = torch.rand(1, 1, 8, 10, 12, generator=g)
+    out.update(d_df=npy(df), d_img=npy(img), d_out=npy(stg(df, img)))
+    save("warp3d", **out)
+
+
+# --------------------------------------------------------------------------- 2. vecint
+def gen_vecint():
+    g = torch.Generator().manual_seed(102)
+    vi = nb.VecInt([8, 8, 8], nsteps=7)
+    v = (torch.randn(1, 3, 8, 8, 8, generator=g) * 2.0).requires_grad_(True)
+    up = torch.randn(1, 3, 8, 8, 8, generator=g)
+    o = vi(v)
+    gv, = torch.autograd.grad((o * up).sum(), [v])
+    vi2 = nb.VecInt([5, 6, 7], nsteps=7)
+    v2 = (torch.randn(2, 3, 5, 6, 7, generator=g) * 1.0).requires_grad_(True)
+    up2 = torch.randn(2, 3, 5, 6, 7, generator=g)
+    o2 = vi2(v2)
+    gv2, = torch.autograd.grad((o2 * up2).sum(), [v2])
+    save("vecint", v=npy(v), up=npy(up), out=npy(o), gv=npy(gv), v2=npy(v2), up2=npy(up2), out2=npy(o2), gv2=npy(gv2))
+
+
+# --------------------------------------------------------------------------- 3-5. resize / pool / interpolate
+def gen_resample():
+    g = torch.Generator().manual_seed(103)
+    out = {}
+    # ResizeTransform(1/2): x2 up with x2 magnitude (network_blocks.py:144-147)
+    rt = nb.ResizeTransform(0.5, 3)
+    x = torch.randn(1, 3, 4, 5, 6, generator=g).requires_grad_(True)
+    up = torch.randn(1, 3, 8, 10, 12, generator=g)
+    o = rt(x)
+    gx, = torch.autograd.grad((o * up).sum(), [x])
+    out.update(rt_x=npy(x), rt_up=npy(up), rt_out=npy(o), rt_gx=npy(gx))
+    # avg_pool3d k2 s2 ceil_mode on odd and even sizes (pulpo.py:33,174)
+    for tag, shp in (("odd", (2, 3, 5, 6, 7)), ("even", (1, 4, 6, 8, 4))):
+        x = torch.randn(*shp, generator=g).requires_grad_(True)
+        o = F.avg_pool3d(x, kernel_size=2, stride=2, padding=0, ceil_mode=True)
+        up = torch.randn(*o.shape, generator=g)
+        gx, = torch.autograd.grad((o * up).sum(), [x])
+        out.update({f"pool_{tag}_x": npy(x), f"pool_{tag}_up": npy(up), f"pool_{tag}_out": npy(o), f"pool_{tag}_gx": npy(gx)})
+    # F.interpolate(size=...) x2 up (feedback, pulpo.py:202) and 1/2, 1/4, 1/8 down (y_target, losses.py:313)
+    x = torch.randn(2, 3, 4, 6, 5, generator=g).requires_grad_(True)
+    o = F.interpolate(x, size=(8, 12, 10), mode="trilinear", align_corners=False)
+    up = torch.randn(*o.shape, generator=g)
+    gx, = torch.autograd.grad((o * up).sum(), [x])
+    out.update(up2_x=npy(x), up2_up=npy(up), up2_out=npy(o), up2_gx=npy(gx))
+    y = torch.rand(1, 1, 16, 16, 24, generator=g)
+    out["dn_y"] = npy(y)
+    for f in (1, 2, 4, 8):
+        out[f"dn_out{f}"] = npy(F.interpolate(y, size=(16 // f, 16 // f, 24 // f), mode="trilinear", align_corners=False))
+    # non-integer ratio (generic size= path)
+    x = torch.randn(1, 2, 5, 7, 6, generator=g)
+    out.update(gen_x=npy(x), gen_out=npy(F.interpolate(x, size=(8, 9, 11), mode="trilinear", align_corners=False)))
+    save("resample", **out)
+
+
+# --------------------------------------------------------------------------- 6. ConvUnit
+def gen_convunit():
+    torch.manual_seed(104)
+    g = torch.Generator().manual_seed(104)
+    out = {}
+    for tag, (cin, cout, S, B) in {"a": (3, 4, (6, 6, 6), 2), "b": (5, 7, (4, 6, 5), 1)}.items():
+        cu = nb.ConvUnit(list(S), cin, cout)
+        with torch.no_grad():  # non-trivial affine + running stats
+            cu._op[1].weight.copy_(torch.rand(cout, generator=g) + 0.5)
+            cu._op[1].bias.copy_(torch.randn(cout, generator=g) * 0.3)
+        sd0 = {k: npy(v) for k, v in cu.state_dict().items()}
+        x = torch.randn(B, cin, *S, generator=g).requires_grad_(True)
+        up = torch.randn(B, cout, *S, generator=g)
+        cu.train()
+        o = cu(x)
+        params = [cu._op[0].weight, cu._op[0].bias, cu._op[1].weight, cu._op[1].bias]
+        grads = torch.autograd.grad((o * up).sum(), [x] + params)
+        sd1 = {k: npy(v) for k, v in cu.state_dict().items()}
+        cu.eval()
+        oe = cu(x)
+        out.update({f"{tag}_x": npy(x), f"{tag}_up": npy(up), f"{tag}_out_train": npy(o), f"{tag}_out_eval": npy(oe),
+                    f"{tag}_gx": npy(grads[0]), f"{tag}_gw": npy(grads[1]), f"{tag}_gb": npy(grads[2]),
+                    f"{tag}_ggamma": npy(grads[3]), f"{tag}_gbeta": npy(grads[4])})
+        out.update({f"{tag}_sd0.{k}": v for k, v in sd0.items()})
+        out.update({f"{tag}_sd1.{k}": v for k, v in sd1.items()})
+    save("convunit", **out)
+
+
+# --------------------------------------------------------------------------- 7. MuSigma + sampler
+def gen_musigma():
+    torch.manual_seed(105)
+    g = torch.Generator().manual_seed(105)
+    ms = nb.MuSigmaBlock([4, 5, 6], 6, 3)
+    x = (torch.randn(2, 6, 4, 5, 6, generator=g) * 3).requires_grad_(True)
+    eps = torch.randn(2, 3, 4, 5, 6, generator=g)
+    mu, sigma = ms(x)
+    z = mu + sigma * eps                      # gauss_sampler with injected noise (network_blocks.py:7-8)
+    up = torch.randn(2, 3, 4, 5, 6, generator=g)
+    params = list(ms.parameters())
+    grads = torch.autograd.grad((z * up).sum() + (mu * mu).sum() + sigma.sum(), [x] + params)
+    out = {"x": npy(x), "eps": npy(eps), "up": npy(up), "mu": npy(mu), "sigma": npy(sigma), "z": npy(z), "gx": npy(grads[0])}
+    out.update({"sd." + k: npy(v) for k, v in ms.state_dict().items()})
+    for (n, _), gr in zip(ms.named_parameters(), grads[1:]):
+        out["g." + n] = npy(gr)
+    # VelocityField depth 3 (3->n0->n0 ConvUnits + 1x1x1), eval mode only here (train mode is covered by the full step)
+    vf = nb.VelocityField([4, 5, 6], 3, 8, 3)
+    vf.eval()
+    zz = torch.randn(1, 3, 4, 5, 6, generator=g)
+    out.update({"vf_z": npy(zz), "vf_out": npy(vf(zz))})
+    out.update({"vf_sd." + k: npy(v) for k, v in vf.state_dict().items()})
+    save("musigma", **out)
+
+
+# --------------------------------------------------------------------------- 8-9. losses
+def smooth_volume(g, S, B=1):
+    """smooth blob with zero background, like a skull-stripped scan"""
+    lo = torch.rand(B, 1, *(max(2, s // 4) for s in S), generator=g)
+    v = F.interpolate(lo, size=S, mode="trilinear", align_corners=False)
+    zz, yy, xx = torch.meshgrid(*[torch.linspace(-1, 1, s) for s in S], indexing="ij")
+    mask = ((zz ** 2 + yy ** 2 + xx ** 2) < 0.8).float()
+    return v * mask
+
+
+def gen_losses():
+    g = torch.Generator().manual_seed(106)
+    out = {}
+    for w, S, B in ((3, (12, 12, 12), 2), (5, (12, 14, 13), 1), (7, (14, 12, 16), 1), (9, (16, 16, 16), 2), (11, (16, 14, 12), 1)):
+        for kind in ("rand", "smooth"):
+            if kind == "rand":
+                yt = torch.rand(B, 1, *S, generator=g)
+                yp = torch.rand(B, 1, *S, generator=g).requires_grad_(True)
+            else:
+                yt = smooth_volume(g, S, B)
+                yp = (smooth_volume(g, S, B) * 0.7 + 0.3 * yt).requires_grad_(True)
+            loss = ls.NCC_loss(yp, yt, win_size=w, gamma=0.05)
+            gp, = torch.autograd.grad(loss, [yp])
+            out.update({f"ncc{w}_{kind}_true": npy(yt), f"ncc{w}_{kind}_pred": npy(yp), f"ncc{w}_{kind}_loss": npy(loss),
+                        f"ncc{w}_{kind}_gpred": npy(gp)})
+    # KL[posterior || N(0,1)] (losses.py:47-76 called as in losses.py:271-273)
+    mu = torch.randn(2, 3, 4, 5, 6, generator=g).requires_grad_(True)
+    sg = (F.softplus(torch.randn(2, 3, 4, 5, 6, generator=g))).requires_grad_(True)
+    kl = ls.KL_two_gauss_with_diag_cov(mu, sg, torch.zeros_like(mu), torch.ones_like(sg))
+    gmu, gsg = torch.autograd.grad(kl, [mu, sg])
+    out.update(kl_mu=npy(mu), kl_sigma=npy(sg), kl_loss=npy(kl), kl_gmu=npy(gmu), kl_gsigma=npy(gsg))
+    # general KL between two diagonal Gaussians
+    mu1 = torch.randn(2, 3, 4, 5, 6, generator=g)
+    sg1 = F.softplus(torch.randn(2, 3, 4, 5, 6, generator=g)) + 0.1
+    out.update(kl2_mu1=npy(mu1), kl2_sigma1=npy(sg1), kl2_loss=npy(ls.KL_two_gauss_with_diag_cov(mu, sg, mu1, sg1)))
+    # L2_reg (losses.py:208-222)
+    df = torch.randn(2, 3, 5, 6, 7, generator=g).requires_grad_(True)
+    r = ls.L2_reg(df, 0.025)
+    gdf, = torch.autograd.grad(r, [df])
+    out.update(reg_df=npy(df), reg_loss=npy(r), reg_gdf=npy(gdf))
+    save("losses", **out)
+
+
+# --------------------------------------------------------------------------- 10. full training step
+FEEDBACK = ["samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed"]
+
+
+def weight_dicts(T, L, ndims=3):
+    """models.py:104-123 (df_resolution == 'level_res', similarity_pyramid False)"""
+    o = T - L
+    window = {l: 1 + 2 * (L - l) for l in range(L)}
+    if L == 1:
+        window = {0: 9}
+    scale = {l: (2.0 ** ndims) ** l for l in range(L)}
+    kl_w = dict(scale)
+    rec_w = dict(scale)
+    reg_w = dict(scale)
+    rec_w[0] = scale[0] / (2 ** (ndims * o))
+    reg_w[0] = scale[0] / (2 ** (ndims * o))
+    rec_w[0] *= 4
+    return window, kl_w, rec_w, reg_w
+
+
+class Step:
+    """The reference's training_step assembled from its own component modules (no Lightning)."""
+
+    def __init__(self, T, L, size, n0, seed):
+        torch.manual_seed(seed)
+        self.T, self.L = T, L
+        self.down = cp.DownPath(T, L, list(size), 2, n0)
+        self.ae = cp.Autoencoder(nb.gauss_sampler, "SVF", T, L, 3, list(size), list(FEEDBACK), "level_res", n0, 3)
+        self.prior = cp.PULPoPrior()
+        window, kl_w, rec_w, reg_w = weight_dicts(T, L)
+        self.kl = ls.HierarchicalKLLoss(ls.KL_two_gauss_with_diag_cov, kl_w, False, None)
+        self.rec = ls.HierarchicalReconstructionLoss(["ncc"], rec_w, False, 3, window)
+        self.reg = ls.HierarchicalRegularization(ls.L2_reg, reg_w, False)
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():  # make BN affine + running stats non-trivial so eval mode is a real test
+            for m in list(self.down.modules()) + list(self.ae.modules()):
+                if isinstance(m, torch.nn.BatchNorm3d):
+                    m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.5 + 0.75)
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                    m.running_mean.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                    m.running_var.copy_(torch.rand(m.bias.shape, generator=g) * 0.5 + 0.75)
+
+    def state_dict(self):
+        sd = {"downpath." + k: v for k, v in self.down.state_dict().items()}
+        sd.update({"autoencoder." + k: v for k, v in self.ae.state_dict().items()})
+        return sd
+
+    def named_parameters(self):
+        for k, v in self.down.named_parameters():
+            yield "downpath." + k, v
+        for k, v in self.ae.named_parameters():
+            yield "autoencoder." + k, v
+
+    def set_eps(self, eps):
+        for l in range(self.L):
+            self.ae.encoders[l].sampler = (lambda mu, sigma, e=eps[l]: mu + sigma * e)
+
+    def forward(self, x, y, deterministic=False):
+        acts = self.down(x, y)
+        return self.ae(x, acts, deterministic=deterministic)
+
+    def losses(self, outs, y, beta=0.1, gamma=0.05, lamb=0.025):
+        mus, sigmas, samples, vfs, ind, comb, fin, yhat = outs
+        pm, ps = self.prior(mus, sigmas)
+        kl, kl_l = self.kl(pm, ps, mus, sigmas)
+        kl = kl * beta
+        kl_l = {n: beta * v for n, v in kl_l.items()}
+        rec, rec_l = self.rec(yhat, y, {k: None for k in fin}, None, gamma=gamma, dice_factor=1)
+        reg, reg_l = self.reg(fin, lamb=lamb)
+        return kl + rec + reg, kl, rec, reg, kl_l, rec_l, reg_l
+
+
+OUT_NAMES = ["mus", "sigmas", "samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed"]
+
+
+def gen_step(name, T, L, size, n0, B, seed, with_grads=True, smooth=False):
+    st = Step(T, L, size, n0, seed)
+    g = torch.Generator().manual_seed(seed + 2)
+    if smooth:
+        y = smooth_volume(g, tuple(size), B)
+        x = (0.6 * smooth_volume(g, tuple(size), B) + 0.4 * y)
+    else:
+        x = torch.rand(B, 1, *size, generator=g)
+        y = torch.rand(B, 1, *size, generator=g)
+    o = T - L
+    lvl = lambda l: [s // (2 ** (l + o)) for s in size]
+    eps = {l: torch.randn(B, 3, *lvl(l), generator=g) for l in range(L)}
+    st.set_eps(eps)
+    out = {"cfg": np.array([T, L, n0, B] + list(size), dtype=np.int64), "x": npy(x), "y": npy(y)}
+    out.update({f"eps.{l}": npy(e) for l, e in eps.items()})
+    # the persistent SpatialTransformer.grid buffers are pure aranges (network_blocks.py:94-99): inventoried in
+    # state_keys.txt, not stored
+    out.update({"sd0." + k: npy(v) for k, v in st.state_dict().items() if not k.endswith(".grid")})
+    # ---- training mode forward + backward
+    st.down.train(); st.ae.train()
+    outs = st.forward(x, y)
+    total, kl, rec, reg, kl_l, rec_l, reg_l = st.losses(outs, y)
+    for nme, d in zip(OUT_NAMES, outs):
+        out.update({f"train.{nme}.{l}": npy(v) for l, v in d.items()})
+    out.update({"train.total": npy(total), "train.kl": npy(kl), "train.rec": npy(rec), "train.reg": npy(reg)})
+    out.update({f"train.kl_l.{l}": npy(v) for l, v in kl_l.items()})
+    out.update({f"train.rec_l.{l}": npy(v) for l, v in rec_l.items()})
+    out.update({f"train.reg_l.{l}": npy(v) for l, v in reg_l.items()})
+    if with_grads:
+        total.backward()
+        for k, p in st.named_parameters():
+            if p.grad is not None:
+                out["grad." + k] = npy(p.grad)
+            else:
+                out["nograd." + k] = np.zeros(1, dtype=np.float32)
+    # buffers after the training forward (BN running stats, num_batches_tracked)
+    for k, v in st.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            out["sd1." + k] = npy(v)
+    # ---- eval mode: stochastic (same eps), deterministic, combine_dfs inputs
+    st.down.eval(); st.ae.eval()
+    with torch.no_grad():
+        outs_e = st.forward(x, y)
+        tot_e = st.losses(outs_e, y)
+        outs_d = st.forward(x, y, deterministic=True)
+    for nme, d in zip(OUT_NAMES, outs_e):
+        out.update({f"eval.{nme}.{l}": npy(v) for l, v in d.items()})
+    out.update({"eval.total": npy(tot_e[0]), "eval.kl": npy(tot_e[1]), "eval.rec": npy(tot_e[2]), "eval.reg": npy(tot_e[3])})
+    for nme in ("individual_dfs", "final_dfs", "transformed"):
+        d = outs_d[OUT_NAMES.index(nme)]
+        out.update({f"det.{nme}.{l}": npy(v) for l, v in d.items()})
+    save(name, **out)
+    return float(total)
+
+
+def gen_init_tables():
+    """models.py:104-123 evaluated for the (T, L) pairs SURVEY.md §8(c).11 lists"""
+    out = {}
+    for T, L in ((3, 2), (4, 3), (5, 4), (6, 5), (5, 5), (1, 1)):
+        window, kl_w, rec_w, reg_w = weight_dicts(T, L)
+        out[f"T{T}L{L}"] = np.array([[window[l], kl_w[l], rec_w[l], reg_w[l]] for l in range(L)], dtype=np.float64)
+    save("init_tables", **out)
+
+
+def gen_state_keys():
+    """state-dict key + shape inventory at the BASELINE configs (for checkpoint compatibility tests)"""
+    lines = []
+    for T, L, size, n0 in ((3, 2, (32, 32, 32), 32), (5, 4, (32, 32, 32), 32)):
+        torch.manual_seed(0)
+        down = cp.DownPath(T, L, list(size), 2, n0)
+        ae = cp.Autoencoder(nb.gauss_sampler, "SVF", T, L, 3, list(size), list(FEEDBACK), "level_res", n0, 3)
+        sd = {"downpath." + k: v for k, v in down.state_dict().items()}
+        sd.update({"autoencoder." + k: v for k, v in ae.state_dict().items()})
+        lines.append(f"# T={T} L={L} size={size} n0={n0}")
+        for k, v in sd.items():
+            lines.append(f"{T}/{L} {k} {tuple(v.shape)} {str(v.dtype).replace('torch.', '')}")
+    with open(os.path.join(HERE, "state_keys.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("wrote state_keys.txt", len(lines), "lines")
+    # the shipped default feedback list does not construct (Appendix A.1)
+    try:
+        cp.Autoencoder(nb.gauss_sampler, "SVF", 3, 2, 3, [16, 16, 16],
+                       ["samples", "velocity_field", "individual_dfs", "combined_dfs", "final_dfs", "transformed"], "level_res", 4, 3)
+        raise SystemExit("expected ValueError")
+    except ValueError as e:
+        print("default feedback list ->", e)
+
+
+if __name__ == "__main__":
+    gen_warp()
+    gen_vecint()
+    gen_resample()
+    gen_convunit()
+    gen_musigma()
+    gen_losses()
+    t = gen_step("step_T3L2_n4_16", T=3, L=2, size=[16, 16, 16], n0=4, B=2, seed=110)
+    print("   total loss", t)
+    t = gen_step("step_T4L3_n2_16x24x16", T=4, L=3, size=[16, 24, 16], n0=2, B=1, seed=120, smooth=True)
+    print("   total loss", t)
+    gen_init_tables()
+    gen_state_keys()

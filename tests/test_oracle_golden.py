@@ -1,0 +1,264 @@
+"""Pins the CPU oracle (oracle/pulpo_oracle.py) against golden vectors produced by the real reference
+(tests/golden/make_golden.py).  CPU only.  Tolerances: the oracle issues the same ATen ops as the reference, so
+outputs agree to a few ulp; gradients through BN/NCC accumulate rounding differently only where the op ORDER differs
+(it does not here), hence the tight bounds."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pulpo_oracle as O
+
+T = torch.from_numpy
+
+
+def close(a, b, atol=1e-6, rtol=1e-5):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+
+
+# ------------------------------------------------------------------------------------------------ warp / vecint
+def test_warp_matches_reference(golden):
+    g = golden("warp3d")
+    df, img = T(g["a_df"]).requires_grad_(True), T(g["a_img"]).requires_grad_(True)
+    out = O.warp(df, img)
+    close(out, g["a_out"])
+    gdf, gimg = torch.autograd.grad((out * T(g["a_up"])).sum(), [df, img])
+    close(gdf, g["a_gdf_rand"], atol=2e-6)
+    close(gimg, g["a_gimg_rand"], atol=2e-6)
+    # zero field is not the identity (reference quirk, network_blocks.py:107 vs :120)
+    zero = O.warp(torch.zeros(1, 3, 6, 8, 10), T(g["b_img"]))
+    close(zero, g["b_out"])
+    assert np.abs(g["b_out"] - g["b_img"]).max() > 0.1
+    # 3-channel self warp, image larger than grid
+    close(O.warp(T(g["c_df"]), T(g["c_df"])), g["c_out"])
+    close(O.warp(T(g["d_df"]), T(g["d_img"])), g["d_out"])
+
+
+def test_warp_explicit_gather_is_the_same_operator(golden):
+    g = golden("warp3d")
+    for tag in ("a", "d"):
+        close(O.warp_explicit(T(g[f"{tag}_df"]), T(g[f"{tag}_img"])), g[f"{tag}_out"], atol=3e-6)
+    close(O.warp_explicit(T(g["c_df"]), T(g["c_df"])), g["c_out"], atol=3e-6)
+
+
+def test_vecint(golden):
+    g = golden("vecint")
+    for s in ("", "2"):
+        v = T(g["v" + s]).requires_grad_(True)
+        out = O.vecint(v, 7)
+        close(out, g["out" + s], atol=2e-6)
+        gv, = torch.autograd.grad((out * T(g["up" + s])).sum(), [v])
+        close(gv, g["gv" + s], atol=5e-6)
+
+
+# ------------------------------------------------------------------------------------------------ resampling
+def test_resize_pool_interpolate(golden):
+    g = golden("resample")
+    x = T(g["rt_x"]).requires_grad_(True)
+    o = O.resize_field(x, 0.5)
+    close(o, g["rt_out"])
+    close(torch.autograd.grad((o * T(g["rt_up"])).sum(), [x])[0], g["rt_gx"])
+    for tag in ("odd", "even"):
+        x = T(g[f"pool_{tag}_x"]).requires_grad_(True)
+        o = O.pool2(x)
+        close(o, g[f"pool_{tag}_out"])
+        close(torch.autograd.grad((o * T(g[f"pool_{tag}_up"])).sum(), [x])[0], g[f"pool_{tag}_gx"])
+    x = T(g["up2_x"]).requires_grad_(True)
+    o = O.resize_to(x, (8, 12, 10))
+    close(o, g["up2_out"])
+    close(torch.autograd.grad((o * T(g["up2_up"])).sum(), [x])[0], g["up2_gx"])
+    y = T(g["dn_y"])
+    for f in (1, 2, 4, 8):
+        close(O.resize_to(y, (16 // f, 16 // f, 24 // f)), g[f"dn_out{f}"])
+    # x1/2 down == 2^3 average pool;  x1/4 == mean of the centre 2x2x2 taps
+    close(O.pool2(y), g["dn_out2"], atol=1e-6)
+    close(O.resize_to(T(g["gen_x"]), (8, 9, 11)), g["gen_out"])
+
+
+# ------------------------------------------------------------------------------------------------ ConvUnit / heads
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_conv_unit(golden, tag):
+    g = golden("convunit")
+    sd = {"u." + k[len(tag) + 5:]: T(v.copy()) for k, v in g.items() if k.startswith(tag + "_sd0.")}
+    for k in list(sd):
+        if sd[k].is_floating_point() and "running" not in k:
+            sd[k].requires_grad_(True)
+    x = T(g[tag + "_x"]).requires_grad_(True)
+    out = O.conv_unit(x, sd, "u", training=True)
+    close(out, g[tag + "_out_train"], atol=2e-6)
+    names = ["u._op.0.weight", "u._op.0.bias", "u._op.1.weight", "u._op.1.bias"]
+    grads = torch.autograd.grad((out * T(g[tag + "_up"])).sum(), [x] + [sd[n] for n in names])
+    for got, key in zip(grads, ("gx", "gw", "gb", "ggamma", "gbeta")):
+        close(got, g[f"{tag}_{key}"], atol=2e-5, rtol=1e-4)
+    # running statistics after one training call, then eval-mode output
+    for k in ("running_mean", "running_var", "num_batches_tracked"):
+        close(sd["u._op.1." + k], g[f"{tag}_sd1._op.1.{k}"])
+    close(O.conv_unit(x, sd, "u", training=False), g[tag + "_out_eval"], atol=2e-6)
+
+
+def test_mu_sigma_and_velocity_field(golden):
+    g = golden("musigma")
+    sd = {"m." + k[3:]: T(v.copy()).requires_grad_(True) for k, v in g.items() if k.startswith("sd.")}
+    x = T(g["x"]).requires_grad_(True)
+    mu, sg = O.mu_sigma(x, sd, "m")
+    z = mu + sg * T(g["eps"])
+    close(mu, g["mu"]); close(sg, g["sigma"]); close(z, g["z"])
+    names = [k[2:] for k in g if k.startswith("g.")]
+    grads = torch.autograd.grad((z * T(g["up"])).sum() + (mu * mu).sum() + sg.sum(), [x] + [sd["m." + n] for n in names])
+    close(grads[0], g["gx"], atol=1e-5)
+    for got, n in zip(grads[1:], names):
+        close(got, g["g." + n], atol=1e-4, rtol=1e-5)
+    vsd = {"v." + k[6:]: T(v.copy()) for k, v in g.items() if k.startswith("vf_sd.")}
+    close(O.velocity_field(T(g["vf_z"]), vsd, "v", 3, training=False), g["vf_out"], atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------ losses
+@pytest.mark.parametrize("w", [3, 5, 7, 9, 11])
+@pytest.mark.parametrize("kind", ["rand", "smooth"])
+def test_ncc(golden, w, kind):
+    g = golden("losses")
+    pred = T(g[f"ncc{w}_{kind}_pred"]).requires_grad_(True)
+    true = T(g[f"ncc{w}_{kind}_true"])
+    loss = O.ncc(pred, true, w, 0.05)
+    close(loss, g[f"ncc{w}_{kind}_loss"], rtol=1e-6)
+    gp, = torch.autograd.grad(loss, [pred])
+    close(gp, g[f"ncc{w}_{kind}_gpred"], atol=1e-6, rtol=1e-4)
+    # the closed-form backward the HIP kernel implements agrees with autograd of the reference.  The smooth,
+    # zero-background volumes have windows where both variances vanish (D -> 1e-8): fp32 autograd is itself
+    # only accurate to ~1e-3 relative there, so compare on the gradient's scale.
+    cf = O.ncc_grad_closed_form(pred.detach(), true, w, 0.05)
+    scale = np.abs(g[f"ncc{w}_{kind}_gpred"]).max()
+    assert np.abs(cf.numpy() - g[f"ncc{w}_{kind}_gpred"]).max() <= 2e-3 * scale + 1e-7
+
+
+def test_kl_and_l2reg(golden):
+    g = golden("losses")
+    mu, sg = T(g["kl_mu"]).requires_grad_(True), T(g["kl_sigma"]).requires_grad_(True)
+    kl = O.kl_diag(mu, sg)
+    close(kl, g["kl_loss"], rtol=1e-6)
+    gm, gs = torch.autograd.grad(kl, [mu, sg])
+    close(gm, g["kl_gmu"]); close(gs, g["kl_gsigma"], rtol=1e-5)
+    close(O.kl_diag(mu, sg, T(g["kl2_mu1"]), T(g["kl2_sigma1"])), g["kl2_loss"], rtol=1e-6)
+    # closed forms quoted in SURVEY §8 (prior N(0,1)): d/dmu = mu/(1+eps)/B ; d/dsigma = (sigma/(1+eps) - sigma/(sigma^2+eps))/B
+    B = mu.shape[0]
+    close(mu.detach() / B, g["kl_gmu"], atol=1e-6)
+    close((sg.detach() - sg.detach() / (sg.detach() ** 2 + 1e-10)) / B, g["kl_gsigma"], atol=1e-5, rtol=1e-5)
+    df = T(g["reg_df"]).requires_grad_(True)
+    r = O.l2_reg(df, 0.025)
+    close(r, g["reg_loss"], rtol=1e-6)
+    close(torch.autograd.grad(r, [df])[0], g["reg_gdf"], atol=1e-7, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ tables / keys
+def test_weight_tables(golden):
+    g = golden("init_tables")
+    for key, tab in g.items():
+        Tl, L = int(key[1]), int(key[3])
+        win, kl_w, rec_w, reg_w = O.weight_tables(O.Cfg(Tl, L, [32, 32, 32]))
+        got = np.array([[win[l], kl_w[l], rec_w[l], reg_w[l]] for l in range(L)])
+        np.testing.assert_array_equal(got, tab)
+    # literal values quoted in SURVEY.md §8 for the BASELINE config 3 (T5/L4)
+    win, kl_w, rec_w, reg_w = O.weight_tables(O.Cfg(5, 4, [160] * 3))
+    assert list(win.values()) == [9, 7, 5, 3]
+    assert list(kl_w.values()) == [1, 8, 64, 512]
+    assert list(rec_w.values()) == [0.5, 8, 64, 512]
+    assert list(reg_w.values()) == [0.125, 8, 64, 512]
+
+
+def test_state_dict_inventory_matches_reference():
+    import os
+    from conftest import GOLDEN
+    want = {}
+    for line in open(os.path.join(GOLDEN, "state_keys.txt")):
+        if line.startswith("#"):
+            continue
+        tl, key, rest = line.split(" ", 2)
+        shape, dt = rest.rsplit(" ", 1)
+        want.setdefault(tl, {})[key] = (eval(shape), dt.strip())
+    for tl, (Tl, L) in {"3/2": (3, 2), "5/4": (5, 4)}.items():
+        sd = O.init_state_dict(O.Cfg(Tl, L, [32, 32, 32], n0=32))
+        assert list(sd.keys()).sort() == list(want[tl].keys()).sort()
+        assert set(sd) == set(want[tl])
+        for k, v in sd.items():
+            assert tuple(v.shape) == want[tl][k][0], k
+            assert str(v.dtype).replace("torch.", "") == want[tl][k][1], k
+
+
+def test_unknown_feedback_item_raises():
+    cfg = O.Cfg(3, 2, [16, 16, 16], n0=4, feedback=["samples", "velocity_field"])
+    with pytest.raises((ValueError, KeyError)):
+        sd = O.init_state_dict(O.Cfg(3, 2, [16, 16, 16], n0=4))
+        O.forward(sd, cfg, torch.rand(1, 1, 16, 16, 16), torch.rand(1, 1, 16, 16, 16), training=False)
+
+
+# ------------------------------------------------------------------------------------------------ full step
+STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16"]
+
+
+def _load_step(g):
+    Tl, L, n0, B, *size = [int(v) for v in g["cfg"]]
+    cfg = O.Cfg(Tl, L, size, n0=n0)
+    sd = O.init_state_dict(cfg)                       # supplies the (deterministic) grid buffers
+    for k, v in g.items():
+        if k.startswith("sd0."):
+            assert k[4:] in sd, k
+            sd[k[4:]] = T(v.copy())
+    eps = {l: T(g[f"eps.{l}"]) for l in range(L)}
+    return cfg, sd, T(g["x"]), T(g["y"]), eps
+
+
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_full_training_step(golden, case):
+    g = golden(case)
+    cfg, sd, x, y, eps = _load_step(g)
+    sd = O.clone_sd(sd, requires_grad=True)
+    ls, grads, outs = O.train_step(sd, cfg, x, y, eps)
+    for name, d in zip(O.OUT_NAMES, outs):
+        for l, v in d.items():
+            close(v, g[f"train.{name}.{l}"], atol=1e-5, rtol=1e-5)
+    for key, val in zip(("total", "kl", "rec", "reg"), ls[:4]):
+        close(val, g["train." + key], rtol=2e-6)
+    for nm, d in zip(("kl_l", "rec_l", "reg_l"), ls[4:]):
+        for l, v in d.items():
+            close(v, g[f"train.{nm}.{l}"], rtol=2e-6)
+    n_checked = 0
+    for k, gr in grads.items():
+        if "grad." + k in g:
+            ref = g["grad." + k]
+            assert gr is not None, k
+            err = np.abs(gr.numpy() - ref).max()
+            assert err <= 1e-4 * max(1.0, np.abs(ref).max()), (k, err)
+            n_checked += 1
+        else:
+            assert "nograd." + k in g and gr is None, k      # encoders[L-1].sample_merge_block: never used (pulpo.py:252-253)
+    assert n_checked > 50
+    for k, v in g.items():
+        if k.startswith("sd1."):
+            close(sd[k[4:]], v, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_eval_and_deterministic_modes(golden, case):
+    g = golden(case)
+    cfg, sd, x, y, eps = _load_step(g)
+    # eval-mode goldens were produced after one training forward: bring the running stats to that state
+    for k, v in g.items():
+        if k.startswith("sd1."):
+            sd[k[4:]] = T(v.copy())
+    with torch.no_grad():
+        outs = O.forward(sd, cfg, x, y, eps, training=False)
+        ls = O.losses(outs, y, cfg)
+        det = O.forward(sd, cfg, x, y, eps, training=False, deterministic=True)
+    for name, d in zip(O.OUT_NAMES, outs):
+        for l, v in d.items():
+            close(v, g[f"eval.{name}.{l}"], atol=1e-5, rtol=1e-5)
+    for key, val in zip(("total", "kl", "rec", "reg"), ls[:4]):
+        close(val, g["eval." + key], rtol=2e-6)
+    for name in ("individual_dfs", "final_dfs", "transformed"):
+        for l, v in det[O.OUT_NAMES.index(name)].items():
+            close(v, g[f"det.{name}.{l}"], atol=1e-5, rtol=1e-5)
+    # combine_dfs (models.py:349-368) rebuilds combined/final fields from the individual ones
+    comb, fin = O.combine_dfs(outs[4], cfg)
+    for l in comb:
+        close(comb[l], g[f"eval.combined_dfs.{l}"], atol=1e-5)
+        close(fin[l], g[f"eval.final_dfs.{l}"], atol=1e-5)
