@@ -1,0 +1,131 @@
+/* pulpo_hip.h — C ABI of libpulpo_hip.so: PULPo's registration hot path as hand-written HIP kernels for
+ * AMD Instinct MI355X (gfx950, CDNA4).
+ *
+ * The reference (leonardsiegert/PULPo) has no native/FFI layer: its hot path is a sequence of ATen operators issued
+ * from Python.  Each entry point below replaces one of those operator call sites; the citation names
+ * the reference line that issues it.  The Python host (pulpo_amd/ops.py) binds these with ctypes inside
+ * torch.autograd.Function wrappers; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer to fp32 unless stated; the library never allocates, frees or synchronises:
+ *    outputs, scratch and saved-for-backward buffers are owned by the caller.  Work is only enqueued on `stream`
+ *    (a hipStream_t passed as void*; NULL = the default stream).  No global mutable state: safe to call from the
+ *    main thread and the autograd thread concurrently, and from one process per GPU.
+ *  - Return value: 0 on success, otherwise a non-zero code (hipError_t value, or -1 for an argument error);
+ *    pulpo_last_error() then returns a thread-local message.  Nothing throws.
+ *  - "channels-last" activations: element (b, voxel v, channel c) lives at  base + b*bs + v*ps + c*cs  (strides in
+ *    floats).  A contiguous (B,D,H,W,C) tensor has ps = C, cs = 1, bs = D*H*W*C; a channel slice of a wider
+ *    concatenation buffer keeps the buffer's ps.  Where only `ps` is passed, cs == 1 and bs == D*H*W*ps are implied.
+ *  - "planar": contiguous (B, C, D, H, W), the reference's own layout, used for 1- and 3-channel images and fields.
+ *  - voxel order is (D,H,W) = ('ij' indexing of dims 0,1,2), channel i of a displacement field moves along dim i
+ *    (src/network_blocks.py:94-98).
+ */
+#ifndef PULPO_HIP_H
+#define PULPO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------- runtime */
+int pulpo_abi_version(void);
+const char* pulpo_last_error(void);
+
+/* ------------------------------------------------------------------------- ConvUnit: Conv3d(k=3, pad=1, bias)
+ * replaces nn.Conv3d inside ConvUnit (src/network_blocks.py:23) = aten::convolution / convolution_backward.
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).  K = reduction channels, N = output channels.
+ *   forward : K = Cin,  N = Cout, weights packed with dgrad = 0
+ *   dgrad   : K = Cout, N = Cin,  weights packed with dgrad = 1 (transposed + tap-flipped), bias = NULL
+ * `stats` (nullable): [pulpo_conv3d_k3_stat_tiles()][2][N] per-tile (sum, sum of squares) of the outputs, the
+ * BatchNorm batch statistics partials (src/network_blocks.py:24). */
+size_t pulpo_conv3d_k3_packed_floats(int K, int N);
+int pulpo_conv3d_k3_pack_weight(const float* w /*[Cout][Cin][3][3][3]*/, float* wp, int Cin, int Cout, int dgrad, void* stream);
+int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W);
+int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, float* out,
+                        int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W, int K, int N, void* stream);
+/* weight gradient: dw[Cout][Cin][27] = sum_voxels in[v + tap - 1][ci] * dy[v][co]; scratch is overwritten */
+size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
+int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs, int64_t dy_ps,
+                          int64_t dy_cs, float* dw, float* scratch, int B, int D, int H, int W, int Cin, int Cout, void* stream);
+
+/* ------------------------------------------------------------- ConvUnit: BatchNorm3d + LeakyReLU(0.2, inplace)
+ * replaces nn.BatchNorm3d / nn.LeakyReLU (src/network_blocks.py:24-25) = aten::native_batch_norm(+_backward),
+ * aten::leaky_relu_(+_backward).  coef = [4][C]: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale. */
+int pulpo_colsum(const float* partials, int nrow, int ncol, float* out, float scale, void* stream);
+int pulpo_bn_fwd_finalize(const float* stats, int ntile, int C, double count, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float momentum, float eps, float* coef, void* stream);
+int pulpo_bn_eval_coef(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
+                       float* coef, void* stream);
+int pulpo_bn_lrelu_apply(const float* y, int64_t yps, float* z, int64_t zps, const float* coef, int64_t npix, int C, float slope, void* stream);
+int pulpo_bn_bwd_blocks(int64_t npix, int C);
+int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, int64_t npix, int C, float slope,
+                              float* partial /*[blocks][2C]*/, void* stream);
+int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const float* tot /*[2C]: dbeta|dgamma*/,
+                             double count, float* dy, int64_t dyps, int64_t npix, int C, float slope, float* partial2 /*[blocks][C]*/,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------- 1x1x1 heads (channel mixing C -> 3)
+ * nout = 6: MuSigmaBlock + gauss_sampler (src/network_blocks.py:54-60, :7-8; eps = injected N(0,1) noise, NULL -> z = mu)
+ * nout = 3: VelocityField's last conv (src/network_blocks.py:81).   Wt = [nout][C], bias = [nout]; outputs planar (B,3,V). */
+int pulpo_heads_fwd(const float* h, int64_t ps, const float* Wt, const float* bias, const float* eps, float* o0, float* o1, float* o2, int nout,
+                    int B, int64_t V, int C, void* stream);
+int pulpo_heads_bwd_blocks(int B, int64_t V, int C);
+int pulpo_heads_bwd(const float* h, int64_t ps, const float* Wt, const float* g0, const float* g1, const float* g2, const float* eps,
+                    const float* sigma, float* dh, int64_t dps, float* partial /*[blocks][nout*C+nout]*/, int nout, int B, int64_t V, int C,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------- resampling
+ * avgpool2: nn.AvgPool3d(2,2,ceil_mode=True) (src/components/pulpo.py:33,59,174-177), channels-last, any C (C = 1: images)
+ * resize_trilinear: F.interpolate(trilinear, align_corners=False) on planar tensors (pulpo.py:202; network_blocks.py:141-147
+ *   with `mult` = ResizeTransform's factor and `add` = DFAdder's second operand, network_blocks.py:156-157; losses.py:313)
+ * feedback_up2: the x2 up-sampling + torch.cat of the feedback tensors (pulpo.py:195-206), planar sources -> channels-last out */
+int pulpo_avgpool2_fwd(const float* in, int64_t ips, float* out, int64_t ops, int B, int D, int H, int W, int C, void* stream);
+int pulpo_avgpool2_bwd(const float* gout, int64_t gops, float* gin, int64_t gips, int B, int D, int H, int W, int C, void* stream);
+int pulpo_resize_trilinear_fwd(const float* in, const float* add, float* out, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                               float mult, void* stream);
+int pulpo_resize_trilinear_bwd(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo, float mult,
+                               void* stream);
+int pulpo_feedback_up2_fwd(const float* const* srcs /*host array of device ptrs*/, const int* chans /*host*/, int nsrc, float* out, int64_t ops,
+                           int B, int Di, int Hi, int Wi, void* stream);
+int pulpo_feedback_up2_bwd(const float* gout, int64_t gops, float* const* gsrcs /*host array, entries may be NULL*/, const int* chans, int nsrc,
+                           int B, int Di, int Hi, int Wi, void* stream);
+
+/* ------------------------------------------------------------------------------ warp and scaling-and-squaring
+ * warp3d: SpatialTransformer.forward (src/network_blocks.py:101-121) = grid_sample(bilinear, border, align_corners=False)
+ *   on coordinates normalised by (S-1); image size may differ from the grid size (src/models.py:330).
+ * vecint: VecInt.forward (src/network_blocks.py:173-177).  work = (nsteps+1) field buffers, result = the last one. */
+int pulpo_warp3d_fwd(const float* df, const float* img, float* out, int B, int C, int Dg, int Hg, int Wg, int Di, int Hi, int Wi, void* stream);
+int pulpo_warp3d_bwd(const float* df, const float* img, const float* gout, float* gdf, float* gimg, int B, int C, int Dg, int Hg, int Wg, int Di,
+                     int Hi, int Wi, void* stream);
+int pulpo_vecint_fwd(const float* v, float* work, int B, int D, int H, int W, int nsteps, void* stream);
+int pulpo_vecint_bwd(const float* work, const float* gout, float* gin, float* tmp /*2 field buffers*/, int B, int D, int H, int W, int nsteps,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------ losses
+ * ncc:   NCC_loss (src/losses.py:85-135); I = y_true, J = y_pred, planar (B,1,D,H,W); N = B*D*H*W.
+ * kl:    KL_two_gauss_with_diag_cov against the N(0,1) prior (src/losses.py:47-76, src/components/pulpo.py:330-341)
+ * l2reg: L2_reg (src/losses.py:208-222).
+ * Forward kernels write pulpo_loss_blocks(n) partial sums; pulpo_colsum(partial, blocks, 1, out, scale) finishes the
+ * scalar.  Backward kernels take the upstream scalar gradient as a device pointer `gscale` (nullable = 1). */
+int pulpo_loss_blocks(int64_t n);
+int pulpo_ncc_fwd(const float* I, const float* J, float* S /*5N, saved*/, float* T /*10N scratch*/, float* partial, int B, int D, int H, int W,
+                  int win, void* stream);
+int pulpo_ncc_bwd(const float* I, const float* J, const float* S, float* T /*6N scratch*/, const float* gscale, float coef, float* gJ, int B, int D,
+                  int H, int W, int win, void* stream);
+int pulpo_kl_fwd(const float* mu, const float* sigma, int64_t n, float* partial, void* stream);
+int pulpo_kl_bwd(const float* mu, const float* sigma, const float* gscale, float coef, float* gmu, float* gsigma, int64_t n, void* stream);
+int pulpo_l2reg_fwd(const float* df, int64_t nplanes, int D, int H, int W, float* partial, void* stream);
+int pulpo_l2reg_bwd(const float* df, const float* gscale, float coef, float* gdf, int64_t nplanes, int D, int H, int W, void* stream);
+
+/* --------------------------------------------------------------------------------------------------- optimizer
+ * torch.optim.Adam(lr) defaults (src/models.py:398-400) over a flat fp32 arena; gscale pre-multiplies the gradient. */
+int pulpo_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float gscale,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PULPO_HIP_H */

@@ -1,0 +1,207 @@
+// 1x1x1 channel-mixing heads C -> 3 (or C -> 3+3):
+//   MuSigmaBlock + gauss_sampler  (reference: src/network_blocks.py:49-60, :7-8):  mu = Wm h + bm ;
+//        sigma = softplus(Ws h + bs) ; z = mu + sigma * eps
+//   VelocityField's last layer    (reference: src/network_blocks.py:81):           v = W h + b
+// Input h is channels-last [pixel][C]; outputs are planar (B, 3, D*H*W) like the reference's tensors.
+// HBM-bound (reads C floats, writes 3-9 per voxel): 8 lanes share one voxel, each lane streams float4 channel
+// slices (one 128-byte line per voxel per step), partial dot products are combined with wave shuffles.
+#include "common.h"
+
+namespace {
+
+constexpr int G = 8;   // lanes per voxel
+
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// NOUT = 3: plain head.  NOUT = 6: rows 0-2 mu, rows 3-5 sigma pre-activation.
+template <int NOUT, bool VEC>
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ h, long ps, const float* __restrict__ Wt,
+                                                          const float* __restrict__ bias, const float* __restrict__ eps, float* __restrict__ o0,
+                                                          float* __restrict__ o1, float* __restrict__ o2, int B, long V, int C) {
+    extern __shared__ float wl[];              // [NOUT][C]
+    for (int j = threadIdx.x; j < NOUT * C; j += blockDim.x) wl[j] = Wt[j];
+    __syncthreads();
+    const int g = threadIdx.x & (G - 1);
+    const long npix = (long)B * V;
+    const long pstep = (long)gridDim.x * (blockDim.x / G);
+    for (long p0 = (long)blockIdx.x * (blockDim.x / G); p0 < npix; p0 += pstep) {   // uniform trip count per block
+        const long p = p0 + threadIdx.x / G;
+        const bool live = p < npix;
+        float acc[NOUT];
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) acc[j] = 0.f;
+        if (live) {
+            const float* hp = h + p * ps;
+            if constexpr (VEC) {
+                for (int c = 4 * g; c < C; c += 4 * G) {
+                    const float4 x = *reinterpret_cast<const float4*>(hp + c);
+#pragma unroll
+                    for (int j = 0; j < NOUT; ++j) {
+                        const float* w = wl + j * C + c;
+                        acc[j] += x.x * w[0] + x.y * w[1] + x.z * w[2] + x.w * w[3];
+                    }
+                }
+            } else {
+                for (int c = g; c < C; c += G) {
+                    const float x = hp[c];
+#pragma unroll
+                    for (int j = 0; j < NOUT; ++j) acc[j] += x * wl[j * C + c];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) acc[j] = group_sum(acc[j]);
+        if (live && g == 0) {
+            const long b = p / V, v = p - b * V;
+            const long base = b * 3 * V + v;
+            if constexpr (NOUT == 3) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) o0[base + j * V] = acc[j] + bias[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float mu = acc[j] + bias[j];
+                    const float sg = softplus_f(acc[3 + j] + bias[3 + j]);
+                    o0[base + j * V] = mu;
+                    o1[base + j * V] = sg;
+                    o2[base + j * V] = eps != nullptr ? mu + sg * eps[base + j * V] : mu;
+                }
+            }
+        }
+    }
+}
+
+// backward.  dpre[j] (j < NOUT) per voxel is formed from the upstream gradients:
+//   NOUT == 3 : dpre = g0
+//   NOUT == 6 : dmu = g0 + g2 ; dsigma = g1 + g2 * eps ; dpre[3+j] = dsigma * (1 - exp(-sigma))   (softplus' = sigmoid)
+// outputs: dh[pixel][C] ;  partial[blk][NOUT*C + NOUT] = per-block sums for dW and db.
+// Thread (col,row) owns VEC channels and walks the block's pixels, so dW accumulates in NOUT*VEC registers.
+template <int NOUT, int VEC>
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ h, long ps, const float* __restrict__ Wt,
+                                                          const float* __restrict__ g0, const float* __restrict__ g1, const float* __restrict__ g2,
+                                                          const float* __restrict__ eps, const float* __restrict__ sigma, float* __restrict__ dh,
+                                                          long dps, float* __restrict__ partial, int B, long V, int C) {
+    extern __shared__ float red[];             // [RB][NOUT*C + NOUT]
+    const int CV = C / VEC, RB = blockDim.x / CV;
+    const int col = threadIdx.x % CV, row = threadIdx.x / CV;
+    const int c = col * VEC;
+    const int ROWLEN = NOUT * C + NOUT;
+    const long npix = (long)B * V;
+    float dw[NOUT][VEC], db[NOUT], w[NOUT][VEC];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+        db[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { dw[j][k] = 0.f; w[j][k] = (row < RB) ? Wt[j * C + c + k] : 0.f; }
+    }
+    if (row < RB) {
+        for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
+            const long b = p / V, v = p - b * V;
+            const long base = b * 3 * V + v;
+            float dpre[NOUT];
+            if constexpr (NOUT == 3) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) dpre[j] = g0[base + j * V];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float gz = g2 != nullptr ? g2[base + j * V] : 0.f;
+                    const float gm = (g0 != nullptr ? g0[base + j * V] : 0.f) + gz;
+                    float gs = (g1 != nullptr ? g1[base + j * V] : 0.f);
+                    if (eps != nullptr) gs += gz * eps[base + j * V];
+                    dpre[j] = gm;
+                    dpre[3 + j] = gs * (1.f - expf(-sigma[base + j * V]));
+                }
+            }
+            float x[VEC], o[VEC];
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(h + p * ps + c);
+                x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+            } else {
+                x[0] = h[p * ps + c];
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) {
+                db[j] += dpre[j];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) { o[k] += dpre[j] * w[j][k]; dw[j][k] += dpre[j] * x[k]; }
+            }
+            if constexpr (VEC == 4) *reinterpret_cast<float4*>(dh + p * dps + c) = make_float4(o[0], o[1], o[2], o[3]);
+            else dh[p * dps + c] = o[0];
+        }
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) red[row * ROWLEN + j * C + c + k] = dw[j][k];
+            if (col == 0) red[row * ROWLEN + NOUT * C + j] = db[j];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < ROWLEN; j += blockDim.x) {
+        float t = 0.f;
+        for (int r = 0; r < RB; ++r) t += red[r * ROWLEN + j];
+        partial[(long)blockIdx.x * ROWLEN + j] = t;
+    }
+}
+
+inline int heads_blocks(long npix) { return (int)std::max<long>(1, std::min<long>((npix + 31) / 32, 1024)); }
+
+}  // namespace
+
+// Wt: [NOUT][C] (rows 0-2 = first conv, rows 3-5 = second conv for NOUT == 6); bias: [NOUT]
+PULPO_API int pulpo_heads_fwd(const float* h, int64_t ps, const float* Wt, const float* bias, const float* eps, float* o0, float* o1,
+                              float* o2, int nout, int B, int64_t V, int C, void* stream) {
+    PULPO_REQUIRE(h && Wt && bias && o0 && B > 0 && V > 0 && C > 0, "heads_fwd: bad arguments");
+    PULPO_REQUIRE(nout == 3 || (nout == 6 && o1 && o2), "heads_fwd: nout must be 3 or 6");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = C % 4 == 0 && ps % 4 == 0 && (((uintptr_t)h) & 15) == 0;
+    const int nblk = heads_blocks((long)B * V);
+    const size_t lds = (size_t)nout * C * sizeof(float);
+    if (nout == 3) {
+        if (vec) hipLaunchKernelGGL((heads_fwd_kernel<3, true>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, bias, eps, o0, o1, o2, B, V, C);
+        else hipLaunchKernelGGL((heads_fwd_kernel<3, false>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, bias, eps, o0, o1, o2, B, V, C);
+    } else {
+        if (vec) hipLaunchKernelGGL((heads_fwd_kernel<6, true>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, bias, eps, o0, o1, o2, B, V, C);
+        else hipLaunchKernelGGL((heads_fwd_kernel<6, false>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, bias, eps, o0, o1, o2, B, V, C);
+    }
+    return pulpo::check_launch("heads_fwd");
+}
+
+PULPO_API int pulpo_heads_bwd_blocks(int B, int64_t V, int C) {
+    const int vec = (C % 4 == 0) ? 4 : 1;
+    const int RB = std::max(1, 256 / (C / vec));
+    const long npix = (long)B * V;
+    return (int)std::max<long>(1, std::min<long>((npix + RB * 8 - 1) / (RB * 8), 1024));
+}
+
+// partial: [pulpo_heads_bwd_blocks][nout*C + nout]; reduce with pulpo_colsum -> (dW[nout][C] | db[nout])
+PULPO_API int pulpo_heads_bwd(const float* h, int64_t ps, const float* Wt, const float* g0, const float* g1, const float* g2, const float* eps,
+                              const float* sigma, float* dh, int64_t dps, float* partial, int nout, int B, int64_t V, int C, void* stream) {
+    PULPO_REQUIRE(h && Wt && dh && partial && B > 0 && V > 0 && C > 0, "heads_bwd: bad arguments");
+    PULPO_REQUIRE((nout == 3 && g0) || (nout == 6 && sigma), "heads_bwd: nout must be 3 (with g0) or 6 (with sigma)");
+    hipStream_t st = (hipStream_t)stream;
+    const bool v4 = C % 4 == 0;
+    if (v4) PULPO_REQUIRE(ps % 4 == 0 && dps % 4 == 0 && ((((uintptr_t)h) | ((uintptr_t)dh)) & 15) == 0, "heads_bwd: unaligned operands");
+    PULPO_REQUIRE(C / (v4 ? 4 : 1) <= 256, "heads_bwd: too many channels");
+    const int nblk = pulpo_heads_bwd_blocks(B, V, C);
+    const int RB = std::max(1, 256 / (C / (v4 ? 4 : 1)));
+    const size_t lds = (size_t)RB * (nout * C + nout) * sizeof(float);
+    PULPO_REQUIRE(lds <= 64 * 1024, "heads_bwd: LDS budget exceeded");
+    if (nout == 3) {
+        if (v4) hipLaunchKernelGGL((heads_bwd_kernel<3, 4>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, g0, g1, g2, eps, sigma, dh, dps, partial, B, V, C);
+        else hipLaunchKernelGGL((heads_bwd_kernel<3, 1>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, g0, g1, g2, eps, sigma, dh, dps, partial, B, V, C);
+    } else {
+        if (v4) hipLaunchKernelGGL((heads_bwd_kernel<6, 4>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, g0, g1, g2, eps, sigma, dh, dps, partial, B, V, C);
+        else hipLaunchKernelGGL((heads_bwd_kernel<6, 1>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, g0, g1, g2, eps, sigma, dh, dps, partial, B, V, C);
+    }
+    return pulpo::check_launch("heads_bwd");
+}

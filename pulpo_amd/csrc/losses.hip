@@ -1,0 +1,280 @@
+// Loss stack: local normalised cross-correlation, diagonal-Gaussian KL against N(0,1), gradient-L2 regulariser.
+// Reference: src/losses.py:85-135 (NCC_loss), :47-76 (KL_two_gauss_with_diag_cov), :208-222 (L2_reg).
+//
+// NCC: the reference evaluates five dense w^3 ones-kernel convolutions (zero padded).  Here the box sums are
+// separable: the W pass holds 64 consecutive voxels of a row in a wavefront and forms the window sum with
+// wave shuffles (no LDS), the H and D passes are strided streaming sums.  All passes are HBM/L2 bound.
+// Every reduction is two-stage (per-block partial -> pulpo_colsum in double), hence deterministic.
+#include "common.h"
+
+namespace {
+
+inline int eblocks(long items, int cap = 4096) { return (int)std::max<long>(1, std::min<long>((items + 255) / 256, cap)); }
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = pulpo::wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) t = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return t;   // valid in thread 0
+}
+
+// ------------------------------------------------------------------------------------------------ box sums
+// W-axis pass.  MODE 0: in = (I, J) -> out = box_x of (I, J, I*I, J*J, I*J) [5 channels, planar stride N]
+//               MODE 1: in = nch planes (stride N) -> out = box_x of each
+// One wave covers 64 consecutive x of one row starting at x0 - pad; lanes pad .. 63-pad produce outputs.
+template <int MODE>
+__global__ __launch_bounds__(256) void box_x_kernel(const float* __restrict__ in0, const float* __restrict__ in1, float* __restrict__ out, long N,
+                                                      long nrows, int W, int pad, int nch, int segs_per_row) {
+    const int lane = threadIdx.x & 63;
+    const int span = 64 - 2 * pad;
+    const long nwork = nrows * segs_per_row;
+    const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nwave = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long wk = wave0; wk < nwork; wk += nwave) {
+        const long row = wk / segs_per_row;
+        const int seg = (int)(wk - row * segs_per_row);
+        const int x = seg * span - pad + lane;
+        const bool inb = x >= 0 && x < W;
+        const long idx = row * W + x;
+        const bool owner = lane >= pad && lane < 64 - pad && x < W;
+        if constexpr (MODE == 0) {
+            const float I = inb ? in0[idx] : 0.f, J = inb ? in1[idx] : 0.f;
+            float v[5] = {I, J, I * I, J * J, I * J};
+            float s[5] = {v[0], v[1], v[2], v[3], v[4]};
+            for (int k = 1; k <= pad; ++k) {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) s[c] += __shfl(v[c], lane - k, 64) + __shfl(v[c], lane + k, 64);
+            }
+            if (owner) {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) out[c * N + idx] = s[c];
+            }
+        } else {
+            for (int c = 0; c < nch; ++c) {
+                const float v = inb ? in0[c * N + idx] : 0.f;
+                float s = v;
+                for (int k = 1; k <= pad; ++k) s += __shfl(v, lane - k, 64) + __shfl(v, lane + k, 64);
+                if (owner) out[c * N + idx] = s;
+            }
+        }
+    }
+}
+
+// strided axis pass (H: stride W, extent H ; D: stride H*W, extent D) over nch planar channels
+__global__ __launch_bounds__(256) void box_axis_kernel(const float* __restrict__ in, float* __restrict__ out, long N, int nch, int extent, long stride,
+                                                         int pad) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
+        const int pos = (int)((e / stride) % extent);
+        const int lo = max(-pad, -pos), hi = min(pad, extent - 1 - pos);
+        for (int c = 0; c < nch; ++c) {
+            const float* s = in + c * N + e;
+            float acc = 0.f;
+            for (int k = lo; k <= hi; ++k) acc += s[k * stride];
+            out[c * N + e] = acc;
+        }
+    }
+}
+
+// last (D) pass fused with the correlation coefficient and its block reduction.  S (5 channels) is kept for backward.
+__global__ __launch_bounds__(256) void ncc_final_kernel(const float* __restrict__ in, float* __restrict__ S, long N, int extent, long stride, int pad,
+                                                          float nwin, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float local = 0.f;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
+        const int pos = (int)((e / stride) % extent);
+        const int lo = max(-pad, -pos), hi = min(pad, extent - 1 - pos);
+        float s[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const float* q = in + c * N + e;
+            float acc = 0.f;
+            for (int k = lo; k <= hi; ++k) acc += q[k * stride];
+            s[c] = acc;
+            S[c * N + e] = acc;
+        }
+        // losses.py:125-132, same expression order
+        const float uI = s[0] / nwin, uJ = s[1] / nwin;
+        const float cross = s[4] - uJ * s[0] - uI * s[1] + uI * uJ * nwin;
+        const float Iv = s[2] - 2.f * uI * s[0] + uI * uI * nwin;
+        const float Jv = s[3] - 2.f * uJ * s[1] + uJ * uJ * nwin;
+        local += cross * cross / (Iv * Jv + 1e-8f);
+    }
+    const float t = block_sum_256(local, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// backward stage 1: from the saved box sums form the three fields that get box-filtered again
+__global__ __launch_bounds__(256) void ncc_abc_kernel(const float* __restrict__ S, float* __restrict__ A, long N, float nwin) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
+        const float SI = S[e], SJ = S[N + e], SII = S[2 * N + e], SJJ = S[3 * N + e], SIJ = S[4 * N + e];
+        const float cross = SIJ - SI * SJ / nwin;
+        const float Iv = SII - SI * SI / nwin;
+        const float Jv = SJJ - SJ * SJ / nwin;
+        const float Dn = Iv * Jv + 1e-8f;
+        const float r = cross / Dn;                       // cross / D
+        A[e] = -2.f * r * SI / nwin + 2.f * r * r * Iv * SJ / nwin;
+        A[N + e] = -r * r * Iv;
+        A[2 * N + e] = 2.f * r;
+    }
+}
+
+// backward last (D) pass fused with the combine:  gJ = coef * (box(a) + 2 J box(b) + I box(c))
+__global__ __launch_bounds__(256) void ncc_bwd_final_kernel(const float* __restrict__ in, const float* __restrict__ I, const float* __restrict__ J,
+                                                              const float* __restrict__ gscale, float coef, float* __restrict__ gJ, long N, int extent,
+                                                              long stride, int pad) {
+    const float k0 = coef * (gscale != nullptr ? gscale[0] : 1.f);
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
+        const int pos = (int)((e / stride) % extent);
+        const int lo = max(-pad, -pos), hi = min(pad, extent - 1 - pos);
+        float s[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* q = in + c * N + e;
+            float acc = 0.f;
+            for (int k = lo; k <= hi; ++k) acc += q[k * stride];
+            s[c] = acc;
+        }
+        gJ[e] = k0 * (s[0] + 2.f * J[e] * s[1] + I[e] * s[2]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ KL vs N(0,1)
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma, long n, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float local = 0.f;
+    const float eps = 1e-10f;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const float s0 = sigma[e] * sigma[e], m = mu[e];
+        // losses.py:55-73 with mu1 = 0, sigma1 = 1:  (s0 + m^2)/(1+eps) + log(1+eps) - log(s0+eps) - 1
+        local += (s0 + m * m) / (1.f + eps) + logf(1.f + eps) - logf(s0 + eps) - 1.f;
+    }
+    const float t = block_sum_256(local, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ gscale,
+                                                       float coef, float* __restrict__ gmu, float* __restrict__ gsigma, long n) {
+    const float k0 = coef * (gscale != nullptr ? gscale[0] : 1.f);
+    const float eps = 1e-10f;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const float s = sigma[e], m = mu[e];
+        gmu[e] = k0 * m / (1.f + eps);
+        gsigma[e] = k0 * (s / (1.f + eps) - s / (s * s + eps));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ L2 regulariser
+__global__ __launch_bounds__(256) void l2reg_fwd_kernel(const float* __restrict__ df, long nplanes, int D, int H, int W, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float local = 0.f;
+    const long V = (long)D * H * W, total = nplanes * V;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long v = e % V;
+        const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((long)W * H));
+        if (x >= 1 && y >= 1 && z >= 1) {
+            const float c = df[e];
+            const float a = c - df[e - (long)H * W], b = c - df[e - W], d = c - df[e - 1];
+            local += a * a + b * b + d * d;
+        }
+    }
+    const float t = block_sum_256(local, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void l2reg_bwd_kernel(const float* __restrict__ df, const float* __restrict__ gscale, float coef,
+                                                          float* __restrict__ gdf, long nplanes, int D, int H, int W) {
+    const float k0 = 2.f * coef * (gscale != nullptr ? gscale[0] : 1.f);
+    const long V = (long)D * H * W, total = nplanes * V;
+    const long sz = (long)H * W, sy = W;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long v = e % V;
+        const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / sz);
+        const float c = df[e];
+        float g = 0.f;
+        if (x >= 1 && y >= 1 && z >= 1) g += (c - df[e - sz]) + (c - df[e - sy]) + (c - df[e - 1]);   // as the centre voxel
+        if (z + 1 < D && y >= 1 && x >= 1) g -= df[e + sz] - c;                                         // as the -z neighbour
+        if (y + 1 < H && z >= 1 && x >= 1) g -= df[e + sy] - c;
+        if (x + 1 < W && z >= 1 && y >= 1) g -= df[e + 1] - c;
+        gdf[e] = k0 * g;
+    }
+}
+
+}  // namespace
+
+PULPO_API int pulpo_loss_blocks(int64_t n) { return eblocks(n, 1024); }
+
+// I = y_true, J = y_pred, planar (B,1,D,H,W).  S: 5*N floats (saved for backward), T: 10*N floats scratch (N = B*D*H*W).
+// partial: pulpo_loss_blocks(N) floats.  loss = -gamma/B * sum(partial)  (finish with pulpo_colsum(scale = -gamma/B)).
+PULPO_API int pulpo_ncc_fwd(const float* I, const float* J, float* S, float* T, float* partial, int B, int D, int H, int W, int win, void* stream) {
+    PULPO_REQUIRE(I && J && S && T && partial && B > 0 && D > 0 && H > 0 && W > 0, "ncc_fwd: bad arguments");
+    PULPO_REQUIRE(win >= 1 && (win & 1) && win <= 31, "ncc_fwd: window must be odd and <= 31");
+    hipStream_t st = (hipStream_t)stream;
+    const long N = (long)B * D * H * W;
+    const int pad = win / 2, span = 64 - 2 * pad, segs = pulpo::cdiv(W, span);
+    const long nrows = (long)B * D * H;
+    float* T1 = T;
+    float* T2 = T + 5 * N;
+    hipLaunchKernelGGL(box_x_kernel<0>, dim3(eblocks(nrows * segs * 64)), dim3(256), 0, st, I, J, T1, N, nrows, W, pad, 5, segs);
+    int rc = pulpo::check_launch("ncc box_x");
+    if (rc) return rc;
+    hipLaunchKernelGGL(box_axis_kernel, dim3(eblocks(N)), dim3(256), 0, st, T1, T2, N, 5, H, (long)W, pad);
+    rc = pulpo::check_launch("ncc box_y");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ncc_final_kernel, dim3(pulpo_loss_blocks(N)), dim3(256), 0, st, T2, S, N, D, (long)H * W, pad, (float)(win * win * win), partial);
+    return pulpo::check_launch("ncc final");
+}
+
+// gJ = gscale[0] * (-gamma/B) * d(sum cc)/dJ.   T: 6*N floats scratch.
+PULPO_API int pulpo_ncc_bwd(const float* I, const float* J, const float* S, float* T, const float* gscale, float coef, float* gJ, int B, int D, int H,
+                            int W, int win, void* stream) {
+    PULPO_REQUIRE(I && J && S && T && gJ && B > 0 && D > 0 && H > 0 && W > 0, "ncc_bwd: bad arguments");
+    PULPO_REQUIRE(win >= 1 && (win & 1) && win <= 31, "ncc_bwd: window must be odd and <= 31");
+    hipStream_t st = (hipStream_t)stream;
+    const long N = (long)B * D * H * W;
+    const int pad = win / 2, span = 64 - 2 * pad, segs = pulpo::cdiv(W, span);
+    const long nrows = (long)B * D * H;
+    float* T1 = T;
+    float* T2 = T + 3 * N;
+    hipLaunchKernelGGL(ncc_abc_kernel, dim3(eblocks(N)), dim3(256), 0, st, S, T1, N, (float)(win * win * win));
+    int rc = pulpo::check_launch("ncc abc");
+    if (rc) return rc;
+    hipLaunchKernelGGL(box_x_kernel<1>, dim3(eblocks(nrows * segs * 64)), dim3(256), 0, st, T1, nullptr, T2, N, nrows, W, pad, 3, segs);
+    rc = pulpo::check_launch("ncc bwd box_x");
+    if (rc) return rc;
+    hipLaunchKernelGGL(box_axis_kernel, dim3(eblocks(N)), dim3(256), 0, st, T2, T1, N, 3, H, (long)W, pad);
+    rc = pulpo::check_launch("ncc bwd box_y");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ncc_bwd_final_kernel, dim3(eblocks(N)), dim3(256), 0, st, T1, I, J, gscale, coef, gJ, N, D, (long)H * W, pad);
+    return pulpo::check_launch("ncc bwd final");
+}
+
+// KL[N(mu, sigma^2) || N(0,1)] summed over everything; finish with pulpo_colsum(scale = 0.5 / B)
+PULPO_API int pulpo_kl_fwd(const float* mu, const float* sigma, int64_t n, float* partial, void* stream) {
+    PULPO_REQUIRE(mu && sigma && partial && n > 0, "kl_fwd: bad arguments");
+    hipLaunchKernelGGL(kl_fwd_kernel, dim3(pulpo_loss_blocks(n)), dim3(256), 0, (hipStream_t)stream, mu, sigma, (long)n, partial);
+    return pulpo::check_launch("kl_fwd");
+}
+
+// gmu = gscale[0]*coef*mu ; gsigma = gscale[0]*coef*(sigma - sigma/(sigma^2+eps)),  coef = 1/B
+PULPO_API int pulpo_kl_bwd(const float* mu, const float* sigma, const float* gscale, float coef, float* gmu, float* gsigma, int64_t n, void* stream) {
+    PULPO_REQUIRE(mu && sigma && gmu && gsigma && n > 0, "kl_bwd: bad arguments");
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3(eblocks(n)), dim3(256), 0, (hipStream_t)stream, mu, sigma, gscale, coef, gmu, gsigma, (long)n);
+    return pulpo::check_launch("kl_bwd");
+}
+
+// sum of squared forward differences on the [1:,1:,1:] block of nplanes = B*3 volumes;
+// finish with pulpo_colsum(scale = lamb*D*H*W / (nplanes*(D-1)*(H-1)*(W-1)))
+PULPO_API int pulpo_l2reg_fwd(const float* df, int64_t nplanes, int D, int H, int W, float* partial, void* stream) {
+    PULPO_REQUIRE(df && partial && nplanes > 0 && D > 1 && H > 1 && W > 1, "l2reg_fwd: bad arguments");
+    hipLaunchKernelGGL(l2reg_fwd_kernel, dim3(pulpo_loss_blocks(nplanes * D * H * W)), dim3(256), 0, (hipStream_t)stream, df, (long)nplanes, D, H, W, partial);
+    return pulpo::check_launch("l2reg_fwd");
+}
+
+PULPO_API int pulpo_l2reg_bwd(const float* df, const float* gscale, float coef, float* gdf, int64_t nplanes, int D, int H, int W, void* stream) {
+    PULPO_REQUIRE(df && gdf && nplanes > 0 && D > 1 && H > 1 && W > 1, "l2reg_bwd: bad arguments");
+    hipLaunchKernelGGL(l2reg_bwd_kernel, dim3(eblocks(nplanes * D * H * W)), dim3(256), 0, (hipStream_t)stream, df, gscale, coef, gdf, (long)nplanes, D, H, W);
+    return pulpo::check_launch("l2reg_bwd");
+}

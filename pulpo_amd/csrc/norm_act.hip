@@ -1,0 +1,296 @@
+// BatchNorm3d (training / eval) + LeakyReLU(0.2) around the conv epilogue statistics.
+// Reference: src/network_blocks.py:24-25 (nn.BatchNorm3d(eps 1e-5, momentum 0.1) -> nn.LeakyReLU(0.2, inplace)).
+// All kernels are HBM-bound streaming passes over channels-last [pixel][C] activations (pixel stride explicit,
+// so a channel slice of a concatenation buffer is a valid operand).  Reductions are two-stage and deterministic:
+// per-block fp32 partials, then a double-precision column sum.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- column sums
+// out[c] = sum_r partials[r][c]   (r < nrow), accumulated in double.  grid = ceil(ncol/32), block = (32, 32)
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ partials, int nrow, int ncol, float* __restrict__ out,
+                                                        float scale) {
+    __shared__ double red[32][33];
+    const int cx = threadIdx.x, ry = threadIdx.y;
+    const int c = blockIdx.x * 32 + cx;
+    double s = 0.0;
+    if (c < ncol)
+        for (int r = ry; r < nrow; r += 32) s += (double)partials[(long)r * ncol + c];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < ncol) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += red[k][cx];
+        out[c] = (float)(t * (double)scale);
+    }
+}
+
+// stats[ntile][2][C] (sum, sumsq of conv output) -> coef[4][C] = mean, rstd, scale, shift ; running stats update
+__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(const float* __restrict__ stats, int ntile, int C, double count,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                 float momentum, float eps, float* __restrict__ coef) {
+    __shared__ double red[2][32][33];
+    const int cx = threadIdx.x, ry = threadIdx.y;
+    const int c = blockIdx.x * 32 + cx;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = ry; r < ntile; r += 32) {
+            s += (double)stats[((long)r * 2 + 0) * C + c];
+            q += (double)stats[((long)r * 2 + 1) * C + c];
+        }
+    red[0][ry][cx] = s;
+    red[1][ry][cx] = q;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        double ts = 0.0, tq = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { ts += red[0][k][cx]; tq += red[1][k][cx]; }
+        const double mean = ts / count;
+        double var = tq / count - mean * mean;      // biased batch variance
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * rstd;
+        coef[0 * C + c] = (float)mean;
+        coef[1 * C + c] = rstd;
+        coef[2 * C + c] = sc;
+        coef[3 * C + c] = beta[c] - (float)mean * sc;
+        if (running_mean != nullptr) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                    const float* __restrict__ rv, float eps, int C, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = 1.f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * rstd;
+    coef[0 * C + c] = rm[c];
+    coef[1 * C + c] = rstd;
+    coef[2 * C + c] = sc;
+    coef[3 * C + c] = beta[c] - rm[c] * sc;
+}
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+    using T = float4;
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <>
+struct Vec<1> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[1]) { v[0] = *p; }
+    static __device__ __forceinline__ void st(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+
+// z = leaky_relu(y * scale[c] + shift[c])
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(const float* __restrict__ y, long yps, float* __restrict__ z, long zps,
+                                                               const float* __restrict__ coef, long npix, int C, float slope) {
+    const int CV = C / VEC;
+    const long total = npix * CV;
+    const float* scale = coef + 2 * C;
+    const float* shift = coef + 3 * C;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long p = e / CV;
+        const int c = (int)(e - p * CV) * VEC;
+        float v[VEC], sc[VEC], sh[VEC];
+        Vec<VEC>::ld(y + p * yps + c, v);
+        Vec<VEC>::ld(scale + c, sc);
+        Vec<VEC>::ld(shift + c, sh);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float t = v[k] * sc[k] + sh[k];
+            v[k] = t > 0.f ? t : t * slope;
+        }
+        Vec<VEC>::st(z + p * zps + c, v);
+    }
+}
+
+// pass 1 of the backward: partial[blk][0][c] = sum dbn, partial[blk][1][c] = sum dbn * xhat
+//   dbn = dz * (bn_out > 0 ? 1 : slope),  bn_out = y*scale + shift,  xhat = (y - mean) * rstd
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* __restrict__ dz, long dzps, const float* __restrict__ y,
+                                                                    long yps, const float* __restrict__ coef, long npix, int C,
+                                                                    float slope, float* __restrict__ partial) {
+    extern __shared__ float red[];                 // [RB][2][C]
+    const int CV = C / VEC, RB = blockDim.x / CV;
+    const int col = threadIdx.x % CV, row = threadIdx.x / CV;
+    const int c = col * VEC;
+    float s0[VEC], s1[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s0[k] = s1[k] = 0.f;
+    if (row < RB) {
+        float mean[VEC], rstd[VEC], sc[VEC], sh[VEC];
+        Vec<VEC>::ld(coef + 0 * C + c, mean);
+        Vec<VEC>::ld(coef + 1 * C + c, rstd);
+        Vec<VEC>::ld(coef + 2 * C + c, sc);
+        Vec<VEC>::ld(coef + 3 * C + c, sh);
+        for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
+            float g[VEC], v[VEC];
+            Vec<VEC>::ld(dz + p * dzps + c, g);
+            Vec<VEC>::ld(y + p * yps + c, v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float bn = v[k] * sc[k] + sh[k];
+                const float d = bn > 0.f ? g[k] : g[k] * slope;
+                s0[k] += d;
+                s1[k] += d * ((v[k] - mean[k]) * rstd[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            red[(row * 2 + 0) * C + c + k] = s0[k];
+            red[(row * 2 + 1) * C + c + k] = s1[k];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * C; j += blockDim.x) {
+        float t = 0.f;
+        for (int r = 0; r < RB; ++r) t += red[r * 2 * C + j];
+        partial[(long)blockIdx.x * 2 * C + j] = t;
+    }
+}
+
+// pass 2: dy = scale * (dbn - mean(dbn) - xhat * mean(dbn*xhat));  partial2[blk][c] = sum dy  (conv-bias gradient)
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __restrict__ dz, long dzps, const float* __restrict__ y,
+                                                                   long yps, const float* __restrict__ coef, const float* __restrict__ tot,
+                                                                   float inv_count, float* __restrict__ dy, long dyps, long npix, int C,
+                                                                   float slope, float* __restrict__ partial2) {
+    extern __shared__ float red[];                 // [RB][C]
+    const int CV = C / VEC, RB = blockDim.x / CV;
+    const int col = threadIdx.x % CV, row = threadIdx.x / CV;
+    const int c = col * VEC;
+    float s0[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s0[k] = 0.f;
+    if (row < RB) {
+        float mean[VEC], rstd[VEC], sc[VEC], sh[VEC], c1[VEC], c2[VEC];
+        Vec<VEC>::ld(coef + 0 * C + c, mean);
+        Vec<VEC>::ld(coef + 1 * C + c, rstd);
+        Vec<VEC>::ld(coef + 2 * C + c, sc);
+        Vec<VEC>::ld(coef + 3 * C + c, sh);
+        Vec<VEC>::ld(tot + 0 * C + c, c1);
+        Vec<VEC>::ld(tot + 1 * C + c, c2);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { c1[k] *= inv_count; c2[k] *= inv_count; }
+        for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
+            float g[VEC], v[VEC], o[VEC];
+            Vec<VEC>::ld(dz + p * dzps + c, g);
+            Vec<VEC>::ld(y + p * yps + c, v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float bn = v[k] * sc[k] + sh[k];
+                const float d = bn > 0.f ? g[k] : g[k] * slope;
+                const float xh = (v[k] - mean[k]) * rstd[k];
+                o[k] = sc[k] * (d - c1[k] - xh * c2[k]);
+                s0[k] += o[k];
+            }
+            Vec<VEC>::st(dy + p * dyps + c, o);
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) red[row * C + c + k] = s0[k];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < C; j += blockDim.x) {
+        float t = 0.f;
+        for (int r = 0; r < RB; ++r) t += red[r * C + j];
+        partial2[(long)blockIdx.x * C + j] = t;
+    }
+}
+
+inline bool vec_ok(const void* a, long aps, const void* b, long bps, int C) {
+    return C % 4 == 0 && aps % 4 == 0 && bps % 4 == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+}
+inline int stream_blocks(long items) { return (int)std::max<long>(1, std::min<long>((items + 255) / 256, 4096)); }
+
+}  // namespace
+
+PULPO_API int pulpo_colsum(const float* partials, int nrow, int ncol, float* out, float scale, void* stream) {
+    PULPO_REQUIRE(partials && out && nrow > 0 && ncol > 0, "colsum: bad arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3(pulpo::cdiv(ncol, 32)), dim3(32, 32), 0, (hipStream_t)stream, partials, nrow, ncol, out, scale);
+    return pulpo::check_launch("colsum");
+}
+
+PULPO_API int pulpo_bn_fwd_finalize(const float* stats, int ntile, int C, double count, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps, float* coef, void* stream) {
+    PULPO_REQUIRE(stats && gamma && beta && coef && ntile > 0 && C > 0 && count > 0, "bn_fwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(pulpo::cdiv(C, 32)), dim3(32, 32), 0, (hipStream_t)stream, stats, ntile, C, count, gamma,
+                       beta, running_mean, running_var, momentum, eps, coef);
+    return pulpo::check_launch("bn_fwd_finalize");
+}
+
+PULPO_API int pulpo_bn_eval_coef(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                                 int C, float* coef, void* stream) {
+    PULPO_REQUIRE(gamma && beta && running_mean && running_var && coef && C > 0, "bn_eval_coef: bad arguments");
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(pulpo::cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, eps, C, coef);
+    return pulpo::check_launch("bn_eval_coef");
+}
+
+PULPO_API int pulpo_bn_lrelu_apply(const float* y, int64_t yps, float* z, int64_t zps, const float* coef, int64_t npix, int C, float slope,
+                                   void* stream) {
+    PULPO_REQUIRE(y && z && coef && npix > 0 && C > 0, "bn_lrelu_apply: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (vec_ok(y, yps, z, zps, C) && (((uintptr_t)coef & 15) == 0))
+        hipLaunchKernelGGL(bn_lrelu_apply_kernel<4>, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope);
+    else
+        hipLaunchKernelGGL(bn_lrelu_apply_kernel<1>, dim3(stream_blocks(npix * C)), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope);
+    return pulpo::check_launch("bn_lrelu_apply");
+}
+
+// number of partial rows the two backward passes write (caller allocates partial[nblk][2C] and partial2[nblk][C])
+PULPO_API int pulpo_bn_bwd_blocks(int64_t npix, int C) {
+    const int vec = (C % 4 == 0) ? 4 : 1;
+    const int RB = std::max(1, 256 / (C / vec));
+    return (int)std::max<long>(1, std::min<long>((npix + RB * 8 - 1) / (RB * 8), 2048));
+}
+
+PULPO_API int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, int64_t npix, int C,
+                                        float slope, float* partial, void* stream) {
+    PULPO_REQUIRE(dz && y && coef && partial && npix > 0 && C > 0, "bn_lrelu_bwd_reduce: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const bool v4 = vec_ok(dz, dzps, y, yps, C) && (((uintptr_t)coef & 15) == 0);
+    PULPO_REQUIRE(C / (C % 4 == 0 ? 4 : 1) <= 256, "bn_lrelu_bwd_reduce: too many channels (%d)", C);
+    const int nblk = pulpo_bn_bwd_blocks(npix, C);
+    if (C % 4 == 0 && !v4) return pulpo::fail(-1, "bn_lrelu_bwd_reduce: operands must be 16-byte aligned when C %% 4 == 0");
+    const int RB = std::max(1, 256 / (C / (v4 ? 4 : 1)));
+    const size_t lds = (size_t)RB * 2 * C * sizeof(float);
+    if (v4) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<4>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, npix, C, slope, partial);
+    else hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, npix, C, slope, partial);
+    return pulpo::check_launch("bn_lrelu_bwd_reduce");
+}
+
+PULPO_API int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const float* tot,
+                                       double count, float* dy, int64_t dyps, int64_t npix, int C, float slope, float* partial2,
+                                       void* stream) {
+    PULPO_REQUIRE(dz && y && coef && tot && dy && partial2 && npix > 0 && C > 0, "bn_lrelu_bwd_apply: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const bool v4 = vec_ok(dz, dzps, y, yps, C) && vec_ok(dy, dyps, coef, 4, C) && (((uintptr_t)tot & 15) == 0);
+    if (C % 4 == 0 && !v4) return pulpo::fail(-1, "bn_lrelu_bwd_apply: operands must be 16-byte aligned when C %% 4 == 0");
+    const int nblk = pulpo_bn_bwd_blocks(npix, C);
+    const int RB = std::max(1, 256 / (C / (v4 ? 4 : 1)));
+    const size_t lds = (size_t)RB * C * sizeof(float);
+    const float inv = (float)(1.0 / count);
+    if (v4)
+        hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel<4>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, tot, inv, dy, dyps, npix, C,
+                           slope, partial2);
+    else
+        hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel<1>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, tot, inv, dy, dyps, npix, C,
+                           slope, partial2);
+    return pulpo::check_launch("bn_lrelu_bwd_apply");
+}

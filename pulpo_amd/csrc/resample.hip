@@ -1,0 +1,323 @@
+// Pyramid resampling operators (all HBM-bound streaming kernels):
+//   avg_pool3d(k2, s2, ceil_mode)                  reference: src/components/pulpo.py:33,59,174-177
+//   F.interpolate(trilinear, align_corners=False)  reference: pulpo.py:202 (feedback), network_blocks.py:141-147
+//                                                  (ResizeTransform), losses.py:313 (y_target)
+//   feedback gather: x2 trilinear up-sampling of the six planar level-(l+1) tensors fused with their channel
+//   concatenation into one channels-last 16-channel tensor (pulpo.py:195-206)
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ avg pool (channels-last)
+template <int VEC>
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ in, long ips, float* __restrict__ out, long ops, int B,
+                                                             int D, int H, int W, int Do, int Ho, int Wo, int C) {
+    const int CV = C / VEC;
+    const long total = (long)B * Do * Ho * Wo * CV;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % CV) * VEC;
+        long p = e / CV;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho); p /= Ho;
+        const int oz = (int)(p % Do);
+        const int b = (int)(p / Do);
+        const int z1 = min(2 * oz + 2, D), y1 = min(2 * oy + 2, H), x1 = min(2 * ox + 2, W);
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        for (int z = 2 * oz; z < z1; ++z)
+            for (int y = 2 * oy; y < y1; ++y)
+                for (int x = 2 * ox; x < x1; ++x) {
+                    const float* s = in + ((((long)b * D + z) * H + y) * W + x) * ips + c;
+                    if constexpr (VEC == 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(s);
+                        acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+                    } else {
+                        acc[0] += s[0];
+                    }
+                }
+        const float inv = 1.f / (float)((z1 - 2 * oz) * (y1 - 2 * oy) * (x1 - 2 * ox));   // ceil_mode: divisor = in-bounds taps
+        float* d = out + ((((long)b * Do + oz) * Ho + oy) * Wo + ox) * ops + c;
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(d) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+        else d[0] = acc[0] * inv;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ gout, long gops, float* __restrict__ gin, long gips, int B,
+                                                             int D, int H, int W, int Do, int Ho, int Wo, int C) {
+    const int CV = C / VEC;
+    const long total = (long)B * D * H * W * CV;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % CV) * VEC;
+        long p = e / CV;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H); p /= H;
+        const int z = (int)(p % D);
+        const int b = (int)(p / D);
+        const int oz = z >> 1, oy = y >> 1, ox = x >> 1;
+        const int cnt = (min(2 * oz + 2, D) - 2 * oz) * (min(2 * oy + 2, H) - 2 * oy) * (min(2 * ox + 2, W) - 2 * ox);
+        const float inv = 1.f / (float)cnt;
+        const float* s = gout + ((((long)b * Do + oz) * Ho + oy) * Wo + ox) * gops + c;
+        float* d = gin + ((((long)b * D + z) * H + y) * W + x) * gips + c;
+        if constexpr (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(s);
+            *reinterpret_cast<float4*>(d) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+        } else {
+            d[0] = s[0] * inv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ trilinear (planar)
+// PyTorch's area_pixel_compute_source_index for align_corners=False: src = scale*(dst+0.5)-0.5, clamped at 0
+__device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& lam) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    lam = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict__ in, const float* __restrict__ add, float* __restrict__ out,
+                                                           long nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo, float sd, float sh, float sw,
+                                                           float mult) {
+    const long total = nplanes * Do * Ho * Wo;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long p = e;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho); p /= Ho;
+        const int oz = (int)(p % Do);
+        const long pl = p / Do;
+        int z0, z1, y0, y1, x0, x1;
+        float lz, ly, lx;
+        src_index(oz, sd, Di, z0, z1, lz);
+        src_index(oy, sh, Hi, y0, y1, ly);
+        src_index(ox, sw, Wi, x0, x1, lx);
+        const float* s = in + pl * (long)Di * Hi * Wi;
+        auto at = [&](int z, int y, int x) { return s[((long)z * Hi + y) * Wi + x]; };
+        // same association as ATen's upsample_trilinear3d: w0 = 1 - lambda, sum of 8 weighted taps
+        const float wz0 = 1.f - lz, wy0 = 1.f - ly, wx0 = 1.f - lx;
+        const float v = wz0 * (wy0 * (wx0 * at(z0, y0, x0) + lx * at(z0, y0, x1)) + ly * (wx0 * at(z0, y1, x0) + lx * at(z0, y1, x1))) +
+                        lz * (wy0 * (wx0 * at(z1, y0, x0) + lx * at(z1, y0, x1)) + ly * (wx0 * at(z1, y1, x0) + lx * at(z1, y1, x1)));
+        out[e] = add != nullptr ? v * mult + add[e] : v * mult;
+    }
+}
+
+// generic transpose: scatter with float atomics into a zeroed gin
+__global__ __launch_bounds__(256) void resize_bwd_atomic_kernel(const float* __restrict__ gout, float* __restrict__ gin, long nplanes, int Di, int Hi,
+                                                                  int Wi, int Do, int Ho, int Wo, float sd, float sh, float sw, float mult) {
+    const long total = nplanes * Do * Ho * Wo;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long p = e;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho); p /= Ho;
+        const int oz = (int)(p % Do);
+        const long pl = p / Do;
+        int z0, z1, y0, y1, x0, x1;
+        float lz, ly, lx;
+        src_index(oz, sd, Di, z0, z1, lz);
+        src_index(oy, sh, Hi, y0, y1, ly);
+        src_index(ox, sw, Wi, x0, x1, lx);
+        const float g = gout[e] * mult;
+        float* d = gin + pl * (long)Di * Hi * Wi;
+        const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+        const int zi[2] = {z0, z1}, yi[2] = {y0, y1}, xi[2] = {x0, x1};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) atomicAdd(d + ((long)zi[a] * Hi + yi[b2]) * Wi + xi[c], g * wz[a] * wy[b2] * wx[c]);
+    }
+}
+
+// weight with which coarse index m contributes to fine index o (exact x2 up-sampling), 0 if none
+__device__ __forceinline__ float up2_weight(int o, int m, int in_size) {
+    int i0, i1;
+    float lam;
+    src_index(o, 0.5f, in_size, i0, i1, lam);
+    return (i0 == m ? 1.f - lam : 0.f) + (i1 == m ? lam : 0.f);
+}
+
+// deterministic transpose for Do == 2*Di etc.: every coarse voxel gathers its <= 4x4x4 fine contributors
+__global__ __launch_bounds__(256) void resize_up2_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, long nplanes, int Di, int Hi,
+                                                               int Wi, float mult) {
+    const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+    const long total = nplanes * Di * Hi * Wi;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long p = e;
+        const int x = (int)(p % Wi); p /= Wi;
+        const int y = (int)(p % Hi); p /= Hi;
+        const int z = (int)(p % Di);
+        const long pl = p / Di;
+        const float* g = gout + pl * (long)Do * Ho * Wo;
+        float acc = 0.f;
+        for (int oz = max(2 * z - 1, 0); oz <= min(2 * z + 2, Do - 1); ++oz) {
+            const float wz = up2_weight(oz, z, Di);
+            for (int oy = max(2 * y - 1, 0); oy <= min(2 * y + 2, Ho - 1); ++oy) {
+                const float wzy = wz * up2_weight(oy, y, Hi);
+                for (int ox = max(2 * x - 1, 0); ox <= min(2 * x + 2, Wo - 1); ++ox)
+                    acc += wzy * up2_weight(ox, x, Wi) * g[((long)oz * Ho + oy) * Wo + ox];
+            }
+        }
+        gin[e] = acc * mult;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ feedback gather
+constexpr int kMaxSrc = 8;
+struct FeedbackArgs {
+    const float* src[kMaxSrc];    // planar (B, ch, Di, Hi, Wi)
+    float* gsrc[kMaxSrc];         // backward only
+    int ch[kMaxSrc];
+    int nsrc, ctot;
+    int B, Di, Hi, Wi;
+};
+
+// out[b][fine voxel][ctot] (pixel stride ops) = concat_s up2(src_s)
+__global__ __launch_bounds__(256) void feedback_fwd_kernel(FeedbackArgs a, float* __restrict__ out, long ops) {
+    const int Do = 2 * a.Di, Ho = 2 * a.Hi, Wo = 2 * a.Wi;
+    const long Vi = (long)a.Di * a.Hi * a.Wi;
+    const long total = (long)a.B * Do * Ho * Wo;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long p = e;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho); p /= Ho;
+        const int oz = (int)(p % Do);
+        const int b = (int)(p / Do);
+        int z0, z1, y0, y1, x0, x1;
+        float lz, ly, lx;
+        src_index(oz, 0.5f, a.Di, z0, z1, lz);
+        src_index(oy, 0.5f, a.Hi, y0, y1, ly);
+        src_index(ox, 0.5f, a.Wi, x0, x1, lx);
+        const long o00 = ((long)z0 * a.Hi + y0) * a.Wi, o01 = ((long)z0 * a.Hi + y1) * a.Wi;
+        const long o10 = ((long)z1 * a.Hi + y0) * a.Wi, o11 = ((long)z1 * a.Hi + y1) * a.Wi;
+        const float wz0 = 1.f - lz, wy0 = 1.f - ly, wx0 = 1.f - lx;
+        float* d = out + e * ops;
+        int cc = 0;
+        for (int s = 0; s < a.nsrc; ++s) {
+            for (int c = 0; c < a.ch[s]; ++c, ++cc) {
+                const float* q = a.src[s] + ((long)b * a.ch[s] + c) * Vi;
+                d[cc] = wz0 * (wy0 * (wx0 * q[o00 + x0] + lx * q[o00 + x1]) + ly * (wx0 * q[o01 + x0] + lx * q[o01 + x1])) +
+                        lz * (wy0 * (wx0 * q[o10 + x0] + lx * q[o10 + x1]) + ly * (wx0 * q[o11 + x0] + lx * q[o11 + x1]));
+            }
+        }
+    }
+}
+
+// gsrc_s[b][c][coarse voxel] = sum over fine contributors of w * gout[b][fine][choff_s + c]   (deterministic gather)
+__global__ __launch_bounds__(256) void feedback_bwd_kernel(FeedbackArgs a, const float* __restrict__ gout, long gops) {
+    const int Do = 2 * a.Di, Ho = 2 * a.Hi, Wo = 2 * a.Wi;
+    const long Vi = (long)a.Di * a.Hi * a.Wi;
+    const long total = (long)a.B * Vi;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long p = e;
+        const int x = (int)(p % a.Wi); p /= a.Wi;
+        const int y = (int)(p % a.Hi); p /= a.Hi;
+        const int z = (int)(p % a.Di);
+        const int b = (int)(p / a.Di);
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        for (int oz = max(2 * z - 1, 0); oz <= min(2 * z + 2, Do - 1); ++oz) {
+            const float wz = up2_weight(oz, z, a.Di);
+            for (int oy = max(2 * y - 1, 0); oy <= min(2 * y + 2, Ho - 1); ++oy) {
+                const float wzy = wz * up2_weight(oy, y, a.Hi);
+                for (int ox = max(2 * x - 1, 0); ox <= min(2 * x + 2, Wo - 1); ++ox) {
+                    const float w = wzy * up2_weight(ox, x, a.Wi);
+                    const float* g = gout + ((((long)b * Do + oz) * Ho + oy) * Wo + ox) * gops;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (k < a.ctot) acc[k] += w * g[k];
+                }
+            }
+        }
+        const long v = e - (long)b * Vi;
+        int cc = 0;
+        for (int s = 0; s < a.nsrc; ++s)
+            for (int c = 0; c < a.ch[s]; ++c, ++cc) {
+                float val = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) val = (k == cc) ? acc[k] : val;
+                if (a.gsrc[s] != nullptr) a.gsrc[s][((long)b * a.ch[s] + c) * Vi + v] = val;
+            }
+    }
+}
+
+inline int eblocks(long items) { return (int)std::max<long>(1, std::min<long>((items + 255) / 256, 8192)); }
+
+}  // namespace
+
+PULPO_API int pulpo_avgpool2_fwd(const float* in, int64_t ips, float* out, int64_t ops, int B, int D, int H, int W, int C, void* stream) {
+    PULPO_REQUIRE(in && out && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "avgpool2_fwd: bad arguments");
+    const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const bool v4 = C % 4 == 0 && ips % 4 == 0 && ops % 4 == 0 && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
+    const long items = (long)B * Do * Ho * Wo * (C / (v4 ? 4 : 1));
+    if (v4) hipLaunchKernelGGL(avgpool2_fwd_kernel<4>, dim3(eblocks(items)), dim3(256), 0, (hipStream_t)stream, in, ips, out, ops, B, D, H, W, Do, Ho, Wo, C);
+    else hipLaunchKernelGGL(avgpool2_fwd_kernel<1>, dim3(eblocks(items)), dim3(256), 0, (hipStream_t)stream, in, ips, out, ops, B, D, H, W, Do, Ho, Wo, C);
+    return pulpo::check_launch("avgpool2_fwd");
+}
+
+PULPO_API int pulpo_avgpool2_bwd(const float* gout, int64_t gops, float* gin, int64_t gips, int B, int D, int H, int W, int C, void* stream) {
+    PULPO_REQUIRE(gout && gin && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "avgpool2_bwd: bad arguments");
+    const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const bool v4 = C % 4 == 0 && gips % 4 == 0 && gops % 4 == 0 && ((((uintptr_t)gin) | ((uintptr_t)gout)) & 15) == 0;
+    const long items = (long)B * D * H * W * (C / (v4 ? 4 : 1));
+    if (v4) hipLaunchKernelGGL(avgpool2_bwd_kernel<4>, dim3(eblocks(items)), dim3(256), 0, (hipStream_t)stream, gout, gops, gin, gips, B, D, H, W, Do, Ho, Wo, C);
+    else hipLaunchKernelGGL(avgpool2_bwd_kernel<1>, dim3(eblocks(items)), dim3(256), 0, (hipStream_t)stream, gout, gops, gin, gips, B, D, H, W, Do, Ho, Wo, C);
+    return pulpo::check_launch("avgpool2_bwd");
+}
+
+// planar tensors: in (nplanes, Di, Hi, Wi) -> out (nplanes, Do, Ho, Wo); out = mult * interpolate(in) (+ add, nullable:
+// the DFAdder of src/network_blocks.py:152-158 fused into ResizeTransform)
+PULPO_API int pulpo_resize_trilinear_fwd(const float* in, const float* add, float* out, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                         float mult, void* stream) {
+    PULPO_REQUIRE(in && out && nplanes > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, "resize_fwd: bad arguments");
+    const float sd = (float)Di / (float)Do, sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+    hipLaunchKernelGGL(resize_fwd_kernel, dim3(eblocks(nplanes * Do * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, in, add, out, (long)nplanes, Di,
+                       Hi, Wi, Do, Ho, Wo, sd, sh, sw, mult);
+    return pulpo::check_launch("resize_fwd");
+}
+
+PULPO_API int pulpo_resize_trilinear_bwd(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo, float mult,
+                                         void* stream) {
+    PULPO_REQUIRE(gout && gin && nplanes > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, "resize_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (Do == 2 * Di && Ho == 2 * Hi && Wo == 2 * Wi) {
+        hipLaunchKernelGGL(resize_up2_bwd_kernel, dim3(eblocks(nplanes * Di * Hi * Wi)), dim3(256), 0, st, gout, gin, (long)nplanes, Di, Hi, Wi, mult);
+        return pulpo::check_launch("resize_up2_bwd");
+    }
+    hipError_t e = hipMemsetAsync(gin, 0, sizeof(float) * nplanes * Di * Hi * Wi, st);
+    if (e != hipSuccess) return pulpo::fail((int)e, "resize_bwd memset: %s", hipGetErrorString(e));
+    const float sd = (float)Di / (float)Do, sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+    hipLaunchKernelGGL(resize_bwd_atomic_kernel, dim3(eblocks(nplanes * Do * Ho * Wo)), dim3(256), 0, st, gout, gin, (long)nplanes, Di, Hi, Wi, Do,
+                       Ho, Wo, sd, sh, sw, mult);
+    return pulpo::check_launch("resize_bwd_atomic");
+}
+
+// srcs[i]: planar (B, chans[i], Di, Hi, Wi); out: channels-last (B, 2Di, 2Hi, 2Wi, sum chans) with pixel stride ops
+PULPO_API int pulpo_feedback_up2_fwd(const float* const* srcs, const int* chans, int nsrc, float* out, int64_t ops, int B, int Di, int Hi, int Wi,
+                                     void* stream) {
+    PULPO_REQUIRE(srcs && chans && out && nsrc > 0 && nsrc <= kMaxSrc && B > 0, "feedback_up2_fwd: bad arguments");
+    FeedbackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nsrc = nsrc; a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi;
+    for (int i = 0; i < nsrc; ++i) { a.src[i] = srcs[i]; a.ch[i] = chans[i]; a.ctot += chans[i]; }
+    PULPO_REQUIRE(a.ctot <= 16, "feedback_up2_fwd: more than 16 feedback channels");
+    hipLaunchKernelGGL(feedback_fwd_kernel, dim3(eblocks((long)B * 8 * Di * Hi * Wi)), dim3(256), 0, (hipStream_t)stream, a, out, (long)ops);
+    return pulpo::check_launch("feedback_up2_fwd");
+}
+
+PULPO_API int pulpo_feedback_up2_bwd(const float* gout, int64_t gops, float* const* gsrcs, const int* chans, int nsrc, int B, int Di, int Hi, int Wi,
+                                     void* stream) {
+    PULPO_REQUIRE(gout && gsrcs && chans && nsrc > 0 && nsrc <= kMaxSrc && B > 0, "feedback_up2_bwd: bad arguments");
+    FeedbackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nsrc = nsrc; a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi;
+    for (int i = 0; i < nsrc; ++i) { a.gsrc[i] = gsrcs[i]; a.ch[i] = chans[i]; a.ctot += chans[i]; }
+    PULPO_REQUIRE(a.ctot <= 16, "feedback_up2_bwd: more than 16 feedback channels");
+    hipLaunchKernelGGL(feedback_bwd_kernel, dim3(eblocks((long)B * Di * Hi * Wi)), dim3(256), 0, (hipStream_t)stream, a, gout, (long)gops);
+    return pulpo::check_launch("feedback_up2_bwd");
+}

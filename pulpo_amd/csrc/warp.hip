@@ -1,0 +1,192 @@
+// Deformable warp (SpatialTransformer) and scaling-and-squaring integration (VecInt).
+// Reference: src/network_blocks.py:88-121 (grid + df -> normalise by (S-1) -> grid_sample(bilinear, border,
+// align_corners=False)) and :160-177 (v/2^n, then n times v <- v + warp(v, v)).
+// The coordinate arithmetic repeats the reference's operation order (divide by S-1, -0.5, *2, then ATen's
+// ((n+1)*S-1)/2 un-normalisation and clamp) so results agree to rounding, including the reference's quirk that a
+// zero field is not the identity.
+// HBM/L2-bound gather kernels: one thread per output voxel, displacement planes read coalesced, 8-corner gather
+// served by L1/L2; the backward scatters with float atomics (memory-side adds, MI355X_MICROARCH.md).
+#include "common.h"
+
+namespace {
+
+struct Corner {
+    int i0, i1;
+    float f;       // fraction towards i1
+    float dscale;  // d(coord)/d(displacement); 0 where the coordinate was clamped
+};
+
+__device__ __forceinline__ Corner sample_coord(float pos, float disp, int Sg, int Si) {
+    float t = pos + disp;
+    t = t / (float)(Sg - 1);
+    t = t - 0.5f;
+    t = 2.f * t;
+    float c = ((t + 1.f) * (float)Si - 1.f) / 2.f;
+    Corner r;
+    const float hi = (float)(Si - 1);
+    r.dscale = (c > 0.f && c < hi) ? (float)Si / (float)(Sg - 1) : 0.f;   // ATen clip_coordinates_set_grad
+    c = fminf(hi, fmaxf(c, 0.f));
+    const float fl = floorf(c);
+    r.i0 = (int)fl;
+    r.i1 = min(r.i0 + 1, Si - 1);
+    r.f = c - fl;
+    return r;
+}
+
+// out[b][c][v] = trilinear(img[b][c], grid position v displaced by df[b][:, v]);  optional residual: out += add[b][c][v]
+template <int C>
+__global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__ df, const float* __restrict__ img, const float* __restrict__ add,
+                                                         float* __restrict__ out, int B, int Dg, int Hg, int Wg, int Di, int Hi, int Wi, int Cr) {
+    const long Vg = (long)Dg * Hg * Wg, Vi = (long)Di * Hi * Wi;
+    const long total = (long)B * Vg;
+    const int nch = C > 0 ? C : Cr;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long b = e / Vg, v = e - b * Vg;
+        const int x = (int)(v % Wg), y = (int)((v / Wg) % Hg), z = (int)(v / ((long)Wg * Hg));
+        const float* d = df + b * 3 * Vg + v;
+        const Corner cz = sample_coord((float)z, d[0], Dg, Di);
+        const Corner cy = sample_coord((float)y, d[Vg], Hg, Hi);
+        const Corner cx = sample_coord((float)x, d[2 * Vg], Wg, Wi);
+        const long o00 = ((long)cz.i0 * Hi + cy.i0) * Wi, o01 = ((long)cz.i0 * Hi + cy.i1) * Wi;
+        const long o10 = ((long)cz.i1 * Hi + cy.i0) * Wi, o11 = ((long)cz.i1 * Hi + cy.i1) * Wi;
+        const float wz0 = 1.f - cz.f, wy0 = 1.f - cy.f, wx0 = 1.f - cx.f;
+        for (int c = 0; c < nch; ++c) {
+            const float* s = img + (b * nch + c) * Vi;
+            float val = wz0 * wy0 * wx0 * s[o00 + cx.i0] + wz0 * wy0 * cx.f * s[o00 + cx.i1] + wz0 * cy.f * wx0 * s[o01 + cx.i0] +
+                        wz0 * cy.f * cx.f * s[o01 + cx.i1] + cz.f * wy0 * wx0 * s[o10 + cx.i0] + cz.f * wy0 * cx.f * s[o10 + cx.i1] +
+                        cz.f * cy.f * wx0 * s[o11 + cx.i0] + cz.f * cy.f * cx.f * s[o11 + cx.i1];
+            const long oi = (b * nch + c) * Vg + v;
+            if (add != nullptr) val += add[oi];
+            out[oi] = val;
+        }
+    }
+}
+
+// gdf (nullable) and gimg (nullable) are ACCUMULATED with float atomics (caller zero-fills or pre-loads them).
+// gdf_direct: write gdf with plain stores instead (only legal when nothing else adds to gdf concurrently).
+template <bool GDF_ATOMIC>
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ df, const float* __restrict__ img, const float* __restrict__ gout,
+                                                         float* __restrict__ gdf, float* __restrict__ gimg, int B, int Dg, int Hg, int Wg, int Di,
+                                                         int Hi, int Wi, int nch) {
+    const long Vg = (long)Dg * Hg * Wg, Vi = (long)Di * Hi * Wi;
+    const long total = (long)B * Vg;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long b = e / Vg, v = e - b * Vg;
+        const int x = (int)(v % Wg), y = (int)((v / Wg) % Hg), z = (int)(v / ((long)Wg * Hg));
+        const float* d = df + b * 3 * Vg + v;
+        const Corner cz = sample_coord((float)z, d[0], Dg, Di);
+        const Corner cy = sample_coord((float)y, d[Vg], Hg, Hi);
+        const Corner cx = sample_coord((float)x, d[2 * Vg], Wg, Wi);
+        const long o00 = ((long)cz.i0 * Hi + cy.i0) * Wi, o01 = ((long)cz.i0 * Hi + cy.i1) * Wi;
+        const long o10 = ((long)cz.i1 * Hi + cy.i0) * Wi, o11 = ((long)cz.i1 * Hi + cy.i1) * Wi;
+        const float wz0 = 1.f - cz.f, wy0 = 1.f - cy.f, wx0 = 1.f - cx.f;
+        float gz = 0.f, gy = 0.f, gx = 0.f;
+        for (int c = 0; c < nch; ++c) {
+            const float g = gout[(b * nch + c) * Vg + v];
+            const float* s = img + (b * nch + c) * Vi;
+            const float s000 = s[o00 + cx.i0], s001 = s[o00 + cx.i1], s010 = s[o01 + cx.i0], s011 = s[o01 + cx.i1];
+            const float s100 = s[o10 + cx.i0], s101 = s[o10 + cx.i1], s110 = s[o11 + cx.i0], s111 = s[o11 + cx.i1];
+            // d/dfz, d/dfy, d/dfx of the trilinear interpolant (same expansion as ATen's grid_sampler_3d_backward)
+            gz += g * (wy0 * wx0 * (s100 - s000) + wy0 * cx.f * (s101 - s001) + cy.f * wx0 * (s110 - s010) + cy.f * cx.f * (s111 - s011));
+            gy += g * (wz0 * wx0 * (s010 - s000) + wz0 * cx.f * (s011 - s001) + cz.f * wx0 * (s110 - s100) + cz.f * cx.f * (s111 - s101));
+            gx += g * (wz0 * wy0 * (s001 - s000) + wz0 * cy.f * (s011 - s010) + cz.f * wy0 * (s101 - s100) + cz.f * cy.f * (s111 - s110));
+            if (gimg != nullptr) {
+                float* q = gimg + (b * nch + c) * Vi;
+                atomicAdd(q + o00 + cx.i0, g * wz0 * wy0 * wx0);
+                atomicAdd(q + o00 + cx.i1, g * wz0 * wy0 * cx.f);
+                atomicAdd(q + o01 + cx.i0, g * wz0 * cy.f * wx0);
+                atomicAdd(q + o01 + cx.i1, g * wz0 * cy.f * cx.f);
+                atomicAdd(q + o10 + cx.i0, g * cz.f * wy0 * wx0);
+                atomicAdd(q + o10 + cx.i1, g * cz.f * wy0 * cx.f);
+                atomicAdd(q + o11 + cx.i0, g * cz.f * cy.f * wx0);
+                atomicAdd(q + o11 + cx.i1, g * cz.f * cy.f * cx.f);
+            }
+        }
+        if (gdf != nullptr) {
+            float* q = gdf + b * 3 * Vg + v;
+            if constexpr (GDF_ATOMIC) {
+                atomicAdd(q, gz * cz.dscale);
+                atomicAdd(q + Vg, gy * cy.dscale);
+                atomicAdd(q + 2 * Vg, gx * cx.dscale);
+            } else {
+                q[0] = gz * cz.dscale;
+                q[Vg] = gy * cy.dscale;
+                q[2 * Vg] = gx * cx.dscale;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ in, float* __restrict__ out, float s, long n) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) out[e] = in[e] * s;
+}
+
+inline int eblocks(long items) { return (int)std::max<long>(1, std::min<long>((items + 255) / 256, 8192)); }
+
+}  // namespace
+
+// df: (B,3,Dg,Hg,Wg) planar; img: (B,C,Di,Hi,Wi) planar; out: (B,C,Dg,Hg,Wg)
+PULPO_API int pulpo_warp3d_fwd(const float* df, const float* img, float* out, int B, int C, int Dg, int Hg, int Wg, int Di, int Hi, int Wi,
+                               void* stream) {
+    PULPO_REQUIRE(df && img && out && B > 0 && C > 0, "warp3d_fwd: bad arguments");
+    PULPO_REQUIRE(Dg > 1 && Hg > 1 && Wg > 1 && Di > 0 && Hi > 0 && Wi > 0, "warp3d_fwd: grid dims must be > 1");
+    const long total = (long)B * Dg * Hg * Wg;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 1) hipLaunchKernelGGL(warp_fwd_kernel<1>, dim3(eblocks(total)), dim3(256), 0, st, df, img, nullptr, out, B, Dg, Hg, Wg, Di, Hi, Wi, C);
+    else if (C == 3) hipLaunchKernelGGL(warp_fwd_kernel<3>, dim3(eblocks(total)), dim3(256), 0, st, df, img, nullptr, out, B, Dg, Hg, Wg, Di, Hi, Wi, C);
+    else hipLaunchKernelGGL(warp_fwd_kernel<0>, dim3(eblocks(total)), dim3(256), 0, st, df, img, nullptr, out, B, Dg, Hg, Wg, Di, Hi, Wi, C);
+    return pulpo::check_launch("warp3d_fwd");
+}
+
+// gdf: (B,3,grid) written; gimg: (B,C,img) zero-filled here then accumulated.  Either may be null.
+PULPO_API int pulpo_warp3d_bwd(const float* df, const float* img, const float* gout, float* gdf, float* gimg, int B, int C, int Dg, int Hg, int Wg,
+                               int Di, int Hi, int Wi, void* stream) {
+    PULPO_REQUIRE(df && img && gout && B > 0 && C > 0, "warp3d_bwd: bad arguments");
+    PULPO_REQUIRE(Dg > 1 && Hg > 1 && Wg > 1, "warp3d_bwd: grid dims must be > 1");
+    hipStream_t st = (hipStream_t)stream;
+    if (gimg != nullptr) {
+        hipError_t e = hipMemsetAsync(gimg, 0, sizeof(float) * (size_t)B * C * Di * Hi * Wi, st);
+        if (e != hipSuccess) return pulpo::fail((int)e, "warp3d_bwd memset: %s", hipGetErrorString(e));
+    }
+    const long total = (long)B * Dg * Hg * Wg;
+    hipLaunchKernelGGL(warp_bwd_kernel<false>, dim3(eblocks(total)), dim3(256), 0, st, df, img, gout, gdf, gimg, B, Dg, Hg, Wg, Di, Hi, Wi, C);
+    return pulpo::check_launch("warp3d_bwd");
+}
+
+// work: (nsteps+1) buffers of B*3*D*H*W floats; work[k] is the field after k squarings, work[nsteps] the result.
+PULPO_API int pulpo_vecint_fwd(const float* v, float* work, int B, int D, int H, int W, int nsteps, void* stream) {
+    PULPO_REQUIRE(v && work && B > 0 && D > 1 && H > 1 && W > 1 && nsteps >= 0, "vecint_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const long n = (long)B * 3 * D * H * W, total = (long)B * D * H * W;
+    hipLaunchKernelGGL(scale_kernel, dim3(eblocks(n)), dim3(256), 0, st, v, work, 1.0f / (float)(1 << nsteps), n);
+    int rc = pulpo::check_launch("vecint scale");
+    if (rc) return rc;
+    for (int k = 0; k < nsteps; ++k) {
+        const float* cur = work + (long)k * n;
+        hipLaunchKernelGGL(warp_fwd_kernel<3>, dim3(eblocks(total)), dim3(256), 0, st, cur, cur, cur, work + (long)(k + 1) * n, B, D, H, W, D, H, W, 3);
+        rc = pulpo::check_launch("vecint step");
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// gin = d loss / d v given gout = d loss / d work[nsteps].  tmp: 2 buffers of B*3*D*H*W floats.
+PULPO_API int pulpo_vecint_bwd(const float* work, const float* gout, float* gin, float* tmp, int B, int D, int H, int W, int nsteps, void* stream) {
+    PULPO_REQUIRE(work && gout && gin && tmp && B > 0 && D > 1 && H > 1 && W > 1 && nsteps >= 0, "vecint_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const long n = (long)B * 3 * D * H * W, total = (long)B * D * H * W;
+    const float* g = gout;
+    for (int k = nsteps - 1; k >= 0; --k) {
+        float* gp = tmp + (long)(k & 1) * n;
+        // v_{k+1} = v_k + warp(v_k, v_k):  g_k = g_{k+1} (identity) + scatter (image role) + d/d field
+        hipError_t e = hipMemcpyAsync(gp, g, sizeof(float) * n, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return pulpo::fail((int)e, "vecint_bwd copy: %s", hipGetErrorString(e));
+        const float* cur = work + (long)k * n;
+        hipLaunchKernelGGL(warp_bwd_kernel<true>, dim3(eblocks(total)), dim3(256), 0, st, cur, cur, g, gp, gp, B, D, H, W, D, H, W, 3);
+        int rc = pulpo::check_launch("vecint_bwd step");
+        if (rc) return rc;
+        g = gp;
+    }
+    hipLaunchKernelGGL(scale_kernel, dim3(eblocks(n)), dim3(256), 0, st, g, gin, 1.0f / (float)(1 << nsteps), n);
+    return pulpo::check_launch("vecint_bwd scale");
+}

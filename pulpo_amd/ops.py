@@ -1,0 +1,513 @@
+"""torch.autograd.Function wrappers around the libpulpo_hip.so C ABI (include/pulpo_hip.h).
+
+PyTorch supplies device memory, the current HIP stream and the autograd tape; every arithmetic step of the hot path
+is a hand-written HIP kernel.  No operator here has a CPU path: tensors must live on a ROCm device.
+
+Layouts: multi-channel activations are torch.channels_last_3d (N,D,H,W,C in memory) — possibly channel slices of a
+wider buffer; 1- and 3-channel images / fields are plain contiguous (N,C,D,H,W) like the reference's tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import PulpoHipError, lib
+
+CL = torch.channels_last_3d
+LRELU_SLOPE = 0.2
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu(*ts: Optional[torch.Tensor]):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise PulpoHipError("pulpo_amd operators run on the GPU only (got a CPU tensor); there is no CPU fallback")
+        if t.dtype != torch.float32:
+            raise PulpoHipError(f"pulpo_amd operators are fp32 (got {t.dtype})")
+
+
+def _dense_grid(t: torch.Tensor) -> bool:
+    """spatial dims form a dense voxel grid with a single pixel stride"""
+    _, _, D, H, W = t.shape
+    ps = t.stride(4)
+    return (W == 1 or ps > 0) and (H == 1 or t.stride(3) == W * ps) and (D == 1 or t.stride(2) == H * W * ps)
+
+
+def grid_strides(t: torch.Tensor) -> Tuple[int, int, int]:
+    """(batch, pixel, channel) strides in elements of a (B,C,D,H,W) tensor whose voxels form a dense grid"""
+    return t.stride(0), t.stride(4), t.stride(1)
+
+
+def as_grid(t: torch.Tensor) -> torch.Tensor:
+    """any 5-D tensor -> one the conv kernels can address (planar or channels-last, incl. channel slices)"""
+    if _dense_grid(t) and (t.shape[1] == 1 or t.stride(1) in (1, t.shape[2] * t.shape[3] * t.shape[4] * t.stride(4))):
+        return t
+    return t.contiguous(memory_format=CL) if t.shape[1] > 3 else t.contiguous()
+
+
+def is_cl(t: torch.Tensor) -> bool:
+    B, C, D, H, W = t.shape
+    return _dense_grid(t) and (t.stride(1) == 1 or C == 1) and t.stride(0) == D * H * W * t.stride(4)
+
+
+def to_cl(t: torch.Tensor) -> torch.Tensor:
+    """channels-last view/copy with cs == 1 and bs == V*ps (what the streaming kernels assume)"""
+    if is_cl(t) and (t.shape[1] > 1 or t.stride(4) == 1):
+        return t
+    if t.shape[1] == 1:
+        return t.contiguous()
+    return t.contiguous(memory_format=CL)
+
+
+def new_cl(B: int, C: int, D: int, H: int, W: int, device) -> torch.Tensor:
+    return torch.empty((B, C, D, H, W), device=device, dtype=torch.float32, memory_format=CL)
+
+
+def planar(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _colsum(partials: torch.Tensor, nrow: int, ncol: int, scale: float = 1.0) -> torch.Tensor:
+    out = torch.empty(ncol, device=partials.device, dtype=torch.float32)
+    lib.call("pulpo_colsum", _ptr(partials), nrow, ncol, _ptr(out), scale, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ conv 3x3x3
+def _pack_weight(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+    Cout, Cin = w.shape[0], w.shape[1]
+    K, N = (Cout, Cin) if dgrad else (Cin, Cout)
+    wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_floats", K, N), device=w.device, dtype=torch.float32)
+    lib.call("pulpo_conv3d_k3_pack_weight", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
+    return wp
+
+
+def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, K: int, N: int,
+              stats: Optional[torch.Tensor]):
+    B, _, D, H, W = x.shape
+    xb, xp, xc = grid_strides(x)
+    ob, op, oc = grid_strides(out)
+    lib.call("pulpo_conv3d_k3_fwd", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc, _ptr(stats), B, D, H, W, K, N, _stream())
+
+
+def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int) -> torch.Tensor:
+    B, _, D, H, W = x.shape
+    dw = torch.empty((Cout, Cin, 3, 3, 3), device=x.device, dtype=torch.float32)
+    scratch = torch.empty(lib.query("pulpo_conv3d_k3_wgrad_scratch_floats", Cin, Cout), device=x.device, dtype=torch.float32)
+    xb, xp, xc = grid_strides(x)
+    db, dp, dc = grid_strides(dy)
+    lib.call("pulpo_conv3d_k3_wgrad", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), _ptr(scratch), B, D, H, W, Cin, Cout, _stream())
+    return dw
+
+
+class _ConvBNLReLU(torch.autograd.Function):
+    """ConvUnit: Conv3d(k3,p1,bias) -> BatchNorm3d -> LeakyReLU(0.2)   (reference src/network_blocks.py:22-26)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training: bool, momentum: float, eps: float):
+        _require_gpu(x, weight, bias, gamma, beta)
+        x = as_grid(x)
+        B, Cin, D, H, W = x.shape
+        Cout = weight.shape[0]
+        dev = x.device
+        wp = _pack_weight(weight, dgrad=False)
+        y = new_cl(B, Cout, D, H, W, dev)
+        coef = torch.empty(4 * Cout, device=dev, dtype=torch.float32)
+        if training:
+            ntile = lib.query("pulpo_conv3d_k3_stat_tiles", B, D, H, W)
+            stats = torch.empty(ntile * 2 * Cout, device=dev, dtype=torch.float32)
+            _conv_raw(x, wp, bias, y, Cin, Cout, stats)
+            lib.call("pulpo_bn_fwd_finalize", _ptr(stats), ntile, Cout, float(B * D * H * W), _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                     _ptr(running_var), momentum, eps, _ptr(coef), _stream())
+        else:
+            _conv_raw(x, wp, bias, y, Cin, Cout, None)
+            lib.call("pulpo_bn_eval_coef", _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps, Cout, _ptr(coef), _stream())
+        z = new_cl(B, Cout, D, H, W, dev)
+        lib.call("pulpo_bn_lrelu_apply", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
+        ctx.save_for_backward(x, weight, y, coef)
+        ctx.training = training
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight, y, coef = ctx.saved_tensors
+        B, Cin, D, H, W = x.shape
+        Cout = weight.shape[0]
+        dev = x.device
+        npix = B * D * H * W
+        dz = to_cl(dz)
+        nblk = lib.query("pulpo_bn_bwd_blocks", npix, Cout)
+        if ctx.training:
+            part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
+            lib.call("pulpo_bn_lrelu_bwd_reduce", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE, _ptr(part),
+                     _stream())
+            tot = _colsum(part, nblk, 2 * Cout)
+            tot_apply = tot
+        else:   # eval-mode BN is a fixed affine map: dy = scale * dbn
+            part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
+            lib.call("pulpo_bn_lrelu_bwd_reduce", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE, _ptr(part),
+                     _stream())
+            tot = _colsum(part, nblk, 2 * Cout)
+            tot_apply = torch.zeros_like(tot)
+        dy = new_cl(B, Cout, D, H, W, dev)
+        part2 = torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
+        lib.call("pulpo_bn_lrelu_bwd_apply", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), _ptr(tot_apply), float(npix), _ptr(dy),
+                 dy.stride(4), npix, Cout, LRELU_SLOPE, _ptr(part2), _stream())
+        dbias = _colsum(part2, nblk, Cout)
+        dbeta, dgamma = tot[:Cout], tot[Cout:]
+        dw = _wgrad_raw(x, dy, Cin, Cout) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wpt = _pack_weight(weight, dgrad=True)
+            dx = torch.empty_like(x) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, dev)
+            _conv_raw(dy, wpt, None, dx, Cout, Cin, None)
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None
+
+
+def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5):
+    return _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps))
+
+
+class _Conv3dK3(torch.autograd.Function):
+    """bare padded 3x3x3 convolution (no norm / activation); used by tests and by VelocityField-like heads"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_gpu(x, weight, bias)
+        x = as_grid(x)
+        B, Cin, D, H, W = x.shape
+        Cout = weight.shape[0]
+        y = new_cl(B, Cout, D, H, W, x.device)
+        _conv_raw(x, _pack_weight(weight, False), bias, y, Cin, Cout, None)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, Cin, D, H, W = x.shape
+        Cout = weight.shape[0]
+        dy = as_grid(dy)
+        dw = _wgrad_raw(x, dy, Cin, Cout) if ctx.needs_input_grad[1] else None
+        db = dy.sum(dim=(0, 2, 3, 4)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, x.device)
+            _conv_raw(dy, _pack_weight(weight, True), None, dx, Cout, Cin, None)
+        return dx, dw, db
+
+
+def conv3d_k3(x, weight, bias=None):
+    return _Conv3dK3.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------ 1x1x1 heads
+class _Heads(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, Wt, bias, eps, nout: int):
+        _require_gpu(h, Wt, bias, eps)
+        h = to_cl(h)
+        B, C, D, H, W = h.shape
+        V = D * H * W
+        dev = h.device
+        outs = [torch.empty((B, 3, D, H, W), device=dev, dtype=torch.float32) for _ in range(1 if nout == 3 else 3)]
+        epsc = planar(eps) if eps is not None else None
+        lib.call("pulpo_heads_fwd", _ptr(h), h.stride(4), _ptr(Wt), _ptr(bias), _ptr(epsc), _ptr(outs[0]), _ptr(outs[1]) if nout == 6 else None,
+                 _ptr(outs[2]) if nout == 6 else None, nout, B, V, C, _stream())
+        ctx.nout = nout
+        ctx.save_for_backward(h, Wt, epsc, outs[1] if nout == 6 else None)
+        return outs[0] if nout == 3 else tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        h, Wt, eps, sigma = ctx.saved_tensors
+        nout = ctx.nout
+        B, C, D, H, W = h.shape
+        V = D * H * W
+        dev = h.device
+        g = [planar(t) if t is not None else None for t in gs] + [None, None]
+        if nout == 3 and g[0] is None:
+            g[0] = torch.zeros((B, 3, D, H, W), device=dev)
+        dh = new_cl(B, C, D, H, W, dev)
+        nblk = lib.query("pulpo_heads_bwd_blocks", B, V, C)
+        rowlen = nout * C + nout
+        part = torch.empty(nblk * rowlen, device=dev, dtype=torch.float32)
+        lib.call("pulpo_heads_bwd", _ptr(h), h.stride(4), _ptr(Wt), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(eps), _ptr(sigma), _ptr(dh),
+                 dh.stride(4), _ptr(part), nout, B, V, C, _stream())
+        tot = _colsum(part, nblk, rowlen)
+        return dh, tot[: nout * C].view(nout, C), tot[nout * C:], None, None
+
+
+def mu_sigma_sample(h, w_mu, b_mu, w_sigma, b_sigma, eps):
+    """MuSigmaBlock + sampler: returns (mu, sigma, z) planar (B,3,D,H,W); eps=None -> z = mu.
+    w_*: (3, C, 1, 1, 1) conv weights (reference src/network_blocks.py:54-57)"""
+    C = w_mu.shape[1]
+    Wt = torch.cat([w_mu.reshape(3, C), w_sigma.reshape(3, C)], dim=0)
+    bias = torch.cat([b_mu, b_sigma], dim=0)
+    return _Heads.apply(h, Wt, bias, eps, 6)
+
+
+def conv1x1_to3(h, w, b):
+    """Conv3d(C, 3, kernel_size=1) with planar output (reference src/network_blocks.py:81)"""
+    return _Heads.apply(h, w.reshape(3, w.shape[1]), b, None, 3)
+
+
+# ------------------------------------------------------------------------------------------------ resampling
+class _AvgPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        x = to_cl(x)
+        B, C, D, H, W = x.shape
+        out = new_cl(B, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, x.device) if C > 1 else \
+            torch.empty((B, 1, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32)
+        lib.call("pulpo_avgpool2_fwd", _ptr(x), x.stride(4), _ptr(out), out.stride(4), B, D, H, W, C, _stream())
+        ctx.shape = (B, C, D, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, D, H, W = ctx.shape
+        g = to_cl(g)
+        gin = new_cl(B, C, D, H, W, g.device) if C > 1 else torch.empty((B, 1, D, H, W), device=g.device, dtype=torch.float32)
+        lib.call("pulpo_avgpool2_bwd", _ptr(g), g.stride(4), _ptr(gin), gin.stride(4), B, D, H, W, C, _stream())
+        return gin
+
+
+def avg_pool2(x):
+    """AvgPool3d(kernel 2, stride 2, ceil_mode=True)"""
+    return _AvgPool2.apply(x)
+
+
+class _Resize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size, mult: float, add):
+        _require_gpu(x, add)
+        x = planar(x)
+        B, C, Di, Hi, Wi = x.shape
+        Do, Ho, Wo = size
+        out = torch.empty((B, C, Do, Ho, Wo), device=x.device, dtype=torch.float32)
+        addc = planar(add) if add is not None else None
+        lib.call("pulpo_resize_trilinear_fwd", _ptr(x), _ptr(addc), _ptr(out), B * C, Di, Hi, Wi, Do, Ho, Wo, mult, _stream())
+        ctx.dims = (B, C, Di, Hi, Wi, Do, Ho, Wo)
+        ctx.mult = mult
+        ctx.has_add = add is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, Di, Hi, Wi, Do, Ho, Wo = ctx.dims
+        g = planar(g)
+        gin = None
+        if ctx.needs_input_grad[0]:
+            gin = torch.empty((B, C, Di, Hi, Wi), device=g.device, dtype=torch.float32)
+            lib.call("pulpo_resize_trilinear_bwd", _ptr(g), _ptr(gin), B * C, Di, Hi, Wi, Do, Ho, Wo, ctx.mult, _stream())
+        return gin, None, None, (g if ctx.has_add and ctx.needs_input_grad[3] else None)
+
+
+def resize_trilinear(x, size, mult: float = 1.0, add=None):
+    """mult * F.interpolate(x, size, 'trilinear', align_corners=False) (+ add)"""
+    return _Resize.apply(x, tuple(int(s) for s in size), float(mult), add)
+
+
+class _FeedbackUp2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *srcs):
+        _require_gpu(*srcs)
+        srcs = [planar(s) for s in srcs]
+        B, _, Di, Hi, Wi = srcs[0].shape
+        chans = [int(s.shape[1]) for s in srcs]
+        ctot = sum(chans)
+        out = new_cl(B, ctot, 2 * Di, 2 * Hi, 2 * Wi, srcs[0].device)
+        n = len(srcs)
+        ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+        ch = (ctypes.c_int * n)(*chans)
+        lib.call("pulpo_feedback_up2_fwd", ptrs, ch, n, _ptr(out), out.stride(4), B, Di, Hi, Wi, _stream())
+        ctx.meta = (B, Di, Hi, Wi, chans)
+        ctx.keep = srcs      # keep the sources alive until the kernel has been enqueued (same stream: safe afterwards)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Di, Hi, Wi, chans = ctx.meta
+        g = to_cl(g)
+        n = len(chans)
+        gs = [torch.empty((B, c, Di, Hi, Wi), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[i] else None
+              for i, c in enumerate(chans)]
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in gs])
+        ch = (ctypes.c_int * n)(*chans)
+        lib.call("pulpo_feedback_up2_bwd", _ptr(g), g.stride(4), ptrs, ch, n, B, Di, Hi, Wi, _stream())
+        return tuple(gs)
+
+
+def feedback_up2(srcs: Sequence[torch.Tensor]) -> torch.Tensor:
+    """cat([interpolate(s, x2) for s in srcs], dim=1) as one channels-last tensor"""
+    return _FeedbackUp2.apply(*srcs)
+
+
+# ------------------------------------------------------------------------------------------------ warp / vecint
+class _Warp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, df, img):
+        _require_gpu(df, img)
+        df, img = planar(df), planar(img)
+        B, _, Dg, Hg, Wg = df.shape
+        _, C, Di, Hi, Wi = img.shape
+        out = torch.empty((B, C, Dg, Hg, Wg), device=df.device, dtype=torch.float32)
+        lib.call("pulpo_warp3d_fwd", _ptr(df), _ptr(img), _ptr(out), B, C, Dg, Hg, Wg, Di, Hi, Wi, _stream())
+        ctx.save_for_backward(df, img)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        df, img = ctx.saved_tensors
+        g = planar(g)
+        B, _, Dg, Hg, Wg = df.shape
+        _, C, Di, Hi, Wi = img.shape
+        gdf = torch.empty_like(df) if ctx.needs_input_grad[0] else None
+        gimg = torch.empty_like(img) if ctx.needs_input_grad[1] else None
+        lib.call("pulpo_warp3d_bwd", _ptr(df), _ptr(img), _ptr(g), _ptr(gdf), _ptr(gimg), B, C, Dg, Hg, Wg, Di, Hi, Wi, _stream())
+        return gdf, gimg
+
+
+def warp3d(df, img):
+    """SpatialTransformer.forward(df, img)"""
+    return _Warp.apply(df, img)
+
+
+class _VecInt(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, nsteps: int):
+        _require_gpu(v)
+        v = planar(v)
+        B, _, D, H, W = v.shape
+        work = torch.empty((nsteps + 1, B, 3, D, H, W), device=v.device, dtype=torch.float32)
+        lib.call("pulpo_vecint_fwd", _ptr(v), _ptr(work), B, D, H, W, nsteps, _stream())
+        ctx.save_for_backward(work)
+        ctx.nsteps = nsteps
+        return work[nsteps]
+
+    @staticmethod
+    def backward(ctx, g):
+        (work,) = ctx.saved_tensors
+        g = planar(g)
+        _, B, _, D, H, W = work.shape
+        gin = torch.empty((B, 3, D, H, W), device=g.device, dtype=torch.float32)
+        tmp = torch.empty((2, B, 3, D, H, W), device=g.device, dtype=torch.float32)
+        lib.call("pulpo_vecint_bwd", _ptr(work), _ptr(g), _ptr(gin), _ptr(tmp), B, D, H, W, ctx.nsteps, _stream())
+        return gin, None
+
+
+def vecint(v, nsteps: int = 7):
+    return _VecInt.apply(v, int(nsteps))
+
+
+# ------------------------------------------------------------------------------------------------ losses
+class _NCC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, true, win: int, gamma: float):
+        _require_gpu(pred, true)
+        pred, true = planar(pred), planar(true)
+        B, C, D, H, W = pred.shape
+        if C != 1:
+            raise PulpoHipError("ncc: single-channel volumes expected")
+        N = B * D * H * W
+        dev = pred.device
+        S = torch.empty(5 * N, device=dev, dtype=torch.float32)
+        T = torch.empty(10 * N, device=dev, dtype=torch.float32)
+        nblk = lib.query("pulpo_loss_blocks", N)
+        part = torch.empty(nblk, device=dev, dtype=torch.float32)
+        lib.call("pulpo_ncc_fwd", _ptr(true), _ptr(pred), _ptr(S), _ptr(T), _ptr(part), B, D, H, W, win, _stream())
+        loss = _colsum(part, nblk, 1, -gamma / B)
+        ctx.save_for_backward(pred, true, S)
+        ctx.win, ctx.gamma = win, gamma
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, true, S = ctx.saved_tensors
+        B, _, D, H, W = pred.shape
+        N = B * D * H * W
+        T = torch.empty(6 * N, device=pred.device, dtype=torch.float32)
+        gJ = torch.empty_like(pred)
+        g = g.contiguous()
+        lib.call("pulpo_ncc_bwd", _ptr(true), _ptr(pred), _ptr(S), _ptr(T), _ptr(g), -ctx.gamma / B, _ptr(gJ), B, D, H, W, ctx.win, _stream())
+        return gJ, None, None, None
+
+
+def ncc_loss(pred, true, win: int = 9, gamma: float = 0.05):
+    return _NCC.apply(pred, true, int(win), float(gamma))
+
+
+class _KL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, sigma):
+        _require_gpu(mu, sigma)
+        mu, sigma = planar(mu), planar(sigma)
+        n = mu.numel()
+        nblk = lib.query("pulpo_loss_blocks", n)
+        part = torch.empty(nblk, device=mu.device, dtype=torch.float32)
+        lib.call("pulpo_kl_fwd", _ptr(mu), _ptr(sigma), n, _ptr(part), _stream())
+        ctx.save_for_backward(mu, sigma)
+        return _colsum(part, nblk, 1, 0.5 / mu.shape[0]).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, sigma = ctx.saved_tensors
+        gmu, gsg = torch.empty_like(mu), torch.empty_like(sigma)
+        g = g.contiguous()
+        lib.call("pulpo_kl_bwd", _ptr(mu), _ptr(sigma), _ptr(g), 1.0 / mu.shape[0], _ptr(gmu), _ptr(gsg), mu.numel(), _stream())
+        return gmu, gsg
+
+
+def kl_std_normal(mu, sigma):
+    """KL[N(mu, sigma^2) || N(0, 1)] (sum over features, mean over batch)"""
+    return _KL.apply(mu, sigma)
+
+
+class _L2Reg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, df, lamb: float):
+        _require_gpu(df)
+        df = planar(df)
+        B, C, D, H, W = df.shape
+        n = df.numel()
+        nblk = lib.query("pulpo_loss_blocks", n)
+        part = torch.empty(nblk, device=df.device, dtype=torch.float32)
+        lib.call("pulpo_l2reg_fwd", _ptr(df), B * C, D, H, W, _ptr(part), _stream())
+        coef = lamb * D * H * W / float(B * C * (D - 1) * (H - 1) * (W - 1))
+        ctx.save_for_backward(df)
+        ctx.coef = coef
+        return _colsum(part, nblk, 1, coef).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (df,) = ctx.saved_tensors
+        B, C, D, H, W = df.shape
+        gdf = torch.empty_like(df)
+        g = g.contiguous()
+        lib.call("pulpo_l2reg_bwd", _ptr(df), _ptr(g), ctx.coef, _ptr(gdf), B * C, D, H, W, _stream())
+        return gdf, None
+
+
+def l2_reg(df, lamb: float = 0.0):
+    return _L2Reg.apply(df, float(lamb))
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, gscale: float = 1.0):
+    _require_gpu(p, g, m, v)
+    lib.call("pulpo_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, int(step), gscale, _stream())

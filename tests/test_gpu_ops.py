@@ -1,0 +1,286 @@
+"""GPU parity tests: every HIP operator (through the C ABI, via pulpo_amd.ops) against
+  (1) the golden vectors produced by the real reference (tests/golden), and
+  (2) the CPU oracle (oracle/pulpo_oracle.py) on seeded random inputs, including ragged / odd sizes.
+Stated fp32 tolerances: fields / warped volumes atol 1e-4, loss terms rtol 1e-4,
+gradients relative-L2 <= 1e-3 (<= 32^3 cases)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import pulpo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from pulpo_amd import ops as _ops
+    from pulpo_amd._lib import lib
+    lib.load()
+    return _ops
+
+
+def dev(a):
+    t = T(a) if isinstance(a, np.ndarray) else a
+    return t.to("cuda")
+
+
+def close(a, b, atol=1e-5, rtol=1e-5):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(a).double()
+    b = b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(b).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ================================================================================================ warp / vecint
+def test_warp_golden(ops, golden):
+    g = golden("warp3d")
+    df, img = dev(g["a_df"]).requires_grad_(True), dev(g["a_img"]).requires_grad_(True)
+    out = ops.warp3d(df, img)
+    close(out, g["a_out"], atol=2e-6)
+    gdf, gimg = torch.autograd.grad((out * dev(g["a_up"])).sum(), [df, img])
+    close(gdf, g["a_gdf_rand"], atol=1e-5)
+    close(gimg, g["a_gimg_rand"], atol=1e-5)
+    close(ops.warp3d(torch.zeros(1, 3, 6, 8, 10, device="cuda"), dev(g["b_img"])), g["b_out"], atol=2e-6)   # zero field != identity
+    close(ops.warp3d(dev(g["c_df"]), dev(g["c_df"])), g["c_out"], atol=3e-6)
+    close(ops.warp3d(dev(g["d_df"]), dev(g["d_img"])), g["d_out"], atol=2e-6)                                # image larger than grid
+    # self-warp gradient (field is also the image)
+    v = dev(g["c_df"]).requires_grad_(True)
+    gv, = torch.autograd.grad((ops.warp3d(v, v) * dev(g["c_up"])).sum(), [v])
+    close(gv, g["c_gdf"], atol=1e-5)
+
+
+def test_warp_large_random_vs_oracle(ops):
+    gen = torch.Generator().manual_seed(5)
+    df = torch.randn(2, 3, 17, 20, 33, generator=gen) * 3
+    img = torch.rand(2, 1, 17, 20, 33, generator=gen)
+    close(ops.warp3d(df.cuda(), img.cuda()), O.warp(df, img), atol=1e-5)
+    # constant image is a fixed point whatever the field (size-independent property)
+    c = torch.full((1, 1, 40, 40, 40), 0.37, device="cuda")
+    out = ops.warp3d(torch.randn(1, 3, 40, 40, 40, device="cuda") * 5, c)
+    assert float((out - 0.37).abs().max()) < 1e-6
+
+
+def test_vecint_golden(ops, golden):
+    g = golden("vecint")
+    for s in ("", "2"):
+        v = dev(g["v" + s]).requires_grad_(True)
+        out = ops.vecint(v, 7)
+        close(out, g["out" + s], atol=1e-5)
+        gv, = torch.autograd.grad((out * dev(g["up" + s])).sum(), [v])
+        assert rel_l2(gv, g["gv" + s]) < 1e-4
+
+
+# ================================================================================================ resampling
+def test_resample_golden(ops, golden):
+    g = golden("resample")
+    x = dev(g["rt_x"]).requires_grad_(True)
+    o = ops.resize_trilinear(x, (8, 10, 12), 2.0)                      # ResizeTransform(1/2)
+    close(o, g["rt_out"], atol=1e-6)
+    close(torch.autograd.grad((o * dev(g["rt_up"])).sum(), [x])[0], g["rt_gx"], atol=1e-5)
+    x = dev(g["up2_x"]).requires_grad_(True)
+    o = ops.resize_trilinear(x, (8, 12, 10))
+    close(o, g["up2_out"], atol=1e-6)
+    close(torch.autograd.grad((o * dev(g["up2_up"])).sum(), [x])[0], g["up2_gx"], atol=1e-5)
+    y = dev(g["dn_y"])
+    for f in (1, 2, 4, 8):
+        close(ops.resize_trilinear(y, (16 // f, 16 // f, 24 // f)), g[f"dn_out{f}"], atol=1e-6)
+    close(ops.resize_trilinear(dev(g["gen_x"]), (8, 9, 11)), g["gen_out"], atol=1e-6)      # non-integer ratio
+    # generic (atomic) backward path on the non-integer ratio
+    xg = dev(g["gen_x"]).requires_grad_(True)
+    up = torch.randn(1, 2, 8, 9, 11)
+    gx, = torch.autograd.grad((ops.resize_trilinear(xg, (8, 9, 11)) * up.cuda()).sum(), [xg])
+    xc = T(g["gen_x"]).requires_grad_(True)
+    gref, = torch.autograd.grad((O.resize_to(xc, (8, 9, 11)) * up).sum(), [xc])
+    close(gx, gref, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["odd", "even"])
+def test_avgpool_golden(ops, golden, tag):
+    g = golden("resample")
+    x = dev(g[f"pool_{tag}_x"]).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    o = ops.avg_pool2(x)
+    close(o, g[f"pool_{tag}_out"], atol=1e-6)
+    close(torch.autograd.grad((o * dev(g[f"pool_{tag}_up"])).sum(), [x])[0], g[f"pool_{tag}_gx"], atol=1e-6)
+
+
+def test_feedback_up2_vs_oracle(ops):
+    gen = torch.Generator().manual_seed(7)
+    srcs = [torch.randn(2, c, 3, 5, 4, generator=gen) for c in (3, 3, 3, 3, 3, 1)]
+    up = torch.randn(2, 16, 6, 10, 8, generator=gen)
+    cs = [s.clone().requires_grad_(True) for s in srcs]
+    ref = torch.cat([O.resize_to(s, (6, 10, 8)) for s in cs], dim=1)
+    gref = torch.autograd.grad((ref * up).sum(), cs)
+    ds = [s.cuda().requires_grad_(True) for s in srcs]
+    out = ops.feedback_up2(ds)
+    close(out, ref, atol=1e-6)
+    gout = torch.autograd.grad((out * up.cuda()).sum(), ds)
+    for a, b in zip(gout, gref):
+        close(a, b, atol=1e-5)
+
+
+# ================================================================================================ ConvUnit
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_conv_unit_golden(ops, golden, tag):
+    g = golden("convunit")
+    sd = {k[len(tag) + 5:]: dev(v.copy()) for k, v in g.items() if k.startswith(tag + "_sd0.")}
+    w, b = sd["_op.0.weight"].requires_grad_(True), sd["_op.0.bias"].requires_grad_(True)
+    gam, bet = sd["_op.1.weight"].requires_grad_(True), sd["_op.1.bias"].requires_grad_(True)
+    rm, rv = sd["_op.1.running_mean"], sd["_op.1.running_var"]
+    x = dev(g[tag + "_x"]).requires_grad_(True)
+    out = ops.conv_bn_lrelu(x, w, b, gam, bet, rm, rv, training=True)
+    close(out, g[tag + "_out_train"], atol=2e-5)
+    grads = torch.autograd.grad((out * dev(g[tag + "_up"])).sum(), [x, w, b, gam, bet])
+    for got, key in zip(grads, ("gx", "gw", "gb", "ggamma", "gbeta")):
+        ref = g[f"{tag}_{key}"]
+        if key == "gb":          # bias feeding BatchNorm: true gradient is 0, the reference holds rounding noise
+            assert np.abs(got.cpu().numpy()).max() <= 1e-4 * max(1.0, np.abs(g[f"{tag}_gw"]).max())
+            continue
+        assert rel_l2(got, ref) < 1e-4, key
+    close(rm, g[f"{tag}_sd1._op.1.running_mean"], atol=1e-6)
+    close(rv, g[f"{tag}_sd1._op.1.running_var"], atol=1e-6)
+    oe = ops.conv_bn_lrelu(x, w, b, gam, bet, rm, rv, training=False)
+    close(oe, g[tag + "_out_eval"], atol=2e-5)
+
+
+CONV_CASES = [
+    # B, Cin, Cout, size, channels-last input?
+    (1, 2, 32, (9, 11, 13), False),
+    (2, 3, 32, (8, 8, 8), False),
+    (1, 16, 96, (6, 10, 9), True),
+    (1, 32, 32, (16, 16, 16), True),
+    (2, 32, 64, (5, 9, 17), True),
+    (1, 64, 64, (8, 8, 16), True),
+    (1, 160, 64, (4, 8, 8), True),
+    (1, 20, 12, (7, 6, 5), True),       # odd channel counts (generic path)
+    (1, 192, 192, (3, 5, 4), True),
+    (1, 32, 3, (6, 7, 8), True),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,size,cl", CONV_CASES)
+def test_conv3d_vs_oracle(ops, B, Cin, Cout, size, cl):
+    gen = torch.Generator().manual_seed(B * 1000 + Cin * 10 + Cout)
+    x = torch.randn(B, Cin, *size, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (27 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    up = torch.randn(B, Cout, *size, generator=gen)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv3d(xr.double(), wr.double(), br.double(), padding=1)
+    gref = torch.autograd.grad((ref * up.double()).sum(), [xr, wr, br])
+    xd = x.cuda()
+    if cl:
+        xd = xd.contiguous(memory_format=torch.channels_last_3d)
+    xd.requires_grad_(True)
+    wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    out = ops.conv3d_k3(xd, wd, bd)
+    assert out.shape == ref.shape
+    assert rel_l2(out, ref) < 2e-6
+    gx, gw, gb = torch.autograd.grad((out * up.cuda()).sum(), [xd, wd, bd])
+    assert rel_l2(gx, gref[0]) < 2e-6
+    assert rel_l2(gw, gref[1]) < 1e-5
+    assert rel_l2(gb, gref[2]) < 1e-5
+
+
+def test_conv_linearity_at_full_channel_width(ops):
+    """size-independent property at a BASELINE layer shape (32->32 @ 48^3): conv(a*x1 + x2) = a*conv(x1) + conv(x2) (no bias)"""
+    gen = torch.Generator().manual_seed(3)
+    x1 = torch.randn(1, 32, 48, 48, 48, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    x2 = torch.randn(1, 32, 48, 48, 48, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(32, 32, 3, 3, 3, generator=gen) / 30).cuda()
+    lhs = ops.conv3d_k3(2.5 * x1 + x2, w)
+    rhs = 2.5 * ops.conv3d_k3(x1, w) + ops.conv3d_k3(x2, w)
+    assert rel_l2(lhs, rhs) < 1e-6
+
+
+# ================================================================================================ heads
+def test_mu_sigma_golden(ops, golden):
+    g = golden("musigma")
+    sd = {k[3:]: dev(v.copy()).requires_grad_(True) for k, v in g.items() if k.startswith("sd.")}
+    x = dev(g["x"]).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    mu, sg, z = ops.mu_sigma_sample(x, sd["_conv_mu.weight"], sd["_conv_mu.bias"], sd["_conv_sigma.0.weight"], sd["_conv_sigma.0.bias"],
+                                    dev(g["eps"]))
+    close(mu, g["mu"], atol=1e-5); close(sg, g["sigma"], atol=1e-5); close(z, g["z"], atol=1e-5)
+    names = [k[2:] for k in g if k.startswith("g.")]
+    grads = torch.autograd.grad((z * dev(g["up"])).sum() + (mu * mu).sum() + sg.sum(), [x] + [sd[n] for n in names])
+    assert rel_l2(grads[0], g["gx"]) < 1e-5
+    for got, n in zip(grads[1:], names):
+        assert rel_l2(got.reshape(-1), g["g." + n].reshape(-1)) < 1e-5, n
+
+
+def test_velocity_field_eval_golden(ops, golden):
+    g = golden("musigma")
+    sd = {k[6:]: dev(v.copy()) for k, v in g.items() if k.startswith("vf_sd.")}
+    h = dev(g["vf_z"])
+    for i in (0, 1):
+        p = f"_op.{i}._op."
+        h = ops.conv_bn_lrelu(h, sd[p + "0.weight"], sd[p + "0.bias"], sd[p + "1.weight"], sd[p + "1.bias"], sd[p + "1.running_mean"],
+                              sd[p + "1.running_var"], training=False)
+    out = ops.conv1x1_to3(h, sd["_op.2.weight"], sd["_op.2.bias"])
+    close(out, g["vf_out"], atol=2e-5)
+
+
+# ================================================================================================ losses
+@pytest.mark.parametrize("w", [3, 5, 7, 9, 11])
+@pytest.mark.parametrize("kind", ["rand", "smooth"])
+def test_ncc_golden(ops, golden, w, kind):
+    g = golden("losses")
+    pred = dev(g[f"ncc{w}_{kind}_pred"]).requires_grad_(True)
+    true = dev(g[f"ncc{w}_{kind}_true"])
+    loss = ops.ncc_loss(pred, true, w, 0.05)
+    close(loss, g[f"ncc{w}_{kind}_loss"], rtol=1e-4, atol=1e-6)
+    gp, = torch.autograd.grad(loss * 1.7, [pred])
+    ref = g[f"ncc{w}_{kind}_gpred"] * 1.7
+    # where both window variances vanish (zero background) the fp32 reference gradient is itself only ~1e-3 accurate
+    assert np.abs(gp.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7
+
+
+def test_ncc_wide_row_vs_oracle(ops):
+    """rows longer than one wavefront segment (W = 150 > 64 - 2*pad) and B = 2"""
+    gen = torch.Generator().manual_seed(11)
+    t, p = torch.rand(2, 1, 6, 7, 150, generator=gen), torch.rand(2, 1, 6, 7, 150, generator=gen)
+    close(ops.ncc_loss(p.cuda(), t.cuda(), 9, 0.05), O.ncc(p, t, 9, 0.05), rtol=1e-4)
+
+
+def test_kl_l2reg_golden(ops, golden):
+    g = golden("losses")
+    mu, sg = dev(g["kl_mu"]).requires_grad_(True), dev(g["kl_sigma"]).requires_grad_(True)
+    kl = ops.kl_std_normal(mu, sg)
+    close(kl, g["kl_loss"], rtol=1e-5)
+    gm, gs = torch.autograd.grad(kl, [mu, sg])
+    close(gm, g["kl_gmu"], atol=1e-6); close(gs, g["kl_gsigma"], atol=1e-5, rtol=1e-5)
+    df = dev(g["reg_df"]).requires_grad_(True)
+    r = ops.l2_reg(df, 0.025)
+    close(r, g["reg_loss"], rtol=1e-5)
+    close(torch.autograd.grad(r, [df])[0], g["reg_gdf"], atol=1e-7, rtol=1e-4)
+
+
+# ================================================================================================ optimizer
+def test_adam_matches_torch(ops):
+    gen = torch.Generator().manual_seed(2)
+    p0 = torch.randn(1003, generator=gen)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = p0.cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        gr = torch.randn(1003, generator=gen)
+        ref.grad = gr.clone()
+        opt.step()
+        ops.adam_step(p, gr.cuda(), m, v, 1e-3, step)
+    close(p, ref, atol=1e-6)
+
+
+def test_cpu_tensor_is_refused(ops):
+    from pulpo_amd._lib import PulpoHipError
+    with pytest.raises(PulpoHipError):
+        ops.warp3d(torch.zeros(1, 3, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
