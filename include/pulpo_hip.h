@@ -106,7 +106,7 @@ int pulpo_vecint_bwd(const float* work, const float* gout, float* gin, float* tm
 
 /* ------------------------------------------------------------------------------------------------------ losses
  * ncc:   NCC_loss (src/losses.py:85-135); I = y_true, J = y_pred, planar (B,1,D,H,W); N = B*D*H*W.
- * kl:    KL_two_gauss_with_diag_cov against the N(0,1) prior (src/losses.py:47-76, src/components/pulpo.py:330-341)
+ * kl:    KL_two_gauss_with_diag_cov (src/losses.py:47-76); mu1/sigma1 NULL = the N(0,1) prior (src/components/pulpo.py:330-341)
  * l2reg: L2_reg (src/losses.py:208-222).
  * Forward kernels write pulpo_loss_blocks(n) partial sums; pulpo_colsum(partial, blocks, 1, out, scale) finishes the
  * scalar.  Backward kernels take the upstream scalar gradient as a device pointer `gscale` (nullable = 1). */
@@ -115,8 +115,10 @@ int pulpo_ncc_fwd(const float* I, const float* J, float* S /*5N, saved*/, float*
                   int win, void* stream);
 int pulpo_ncc_bwd(const float* I, const float* J, const float* S, float* T /*6N scratch*/, const float* gscale, float coef, float* gJ, int B, int D,
                   int H, int W, int win, void* stream);
-int pulpo_kl_fwd(const float* mu, const float* sigma, int64_t n, float* partial, void* stream);
-int pulpo_kl_bwd(const float* mu, const float* sigma, const float* gscale, float coef, float* gmu, float* gsigma, int64_t n, void* stream);
+int pulpo_kl_fwd(const float* mu, const float* sigma, const float* mu1 /*nullable: 0*/, const float* sigma1 /*nullable: 1*/, int64_t n,
+                 float* partial, void* stream);
+int pulpo_kl_bwd(const float* mu, const float* sigma, const float* mu1, const float* sigma1, const float* gscale, float coef, float* gmu,
+                 float* gsigma, int64_t n, void* stream);
 int pulpo_l2reg_fwd(const float* df, int64_t nplanes, int D, int H, int W, float* partial, void* stream);
 int pulpo_l2reg_bwd(const float* df, const float* gscale, float coef, float* gdf, int64_t nplanes, int D, int H, int W, void* stream);
 

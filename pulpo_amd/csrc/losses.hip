@@ -141,28 +141,35 @@ __global__ __launch_bounds__(256) void ncc_bwd_final_kernel(const float* __restr
     }
 }
 
-// ------------------------------------------------------------------------------------------------ KL vs N(0,1)
-__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma, long n, float* __restrict__ partial) {
+// ------------------------------------------------------------------------------------------------ KL (diagonal Gaussians)
+// mu1 / sigma1 nullable = the N(0,1) prior of PULPoPrior (src/components/pulpo.py:330-341)
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ mu1,
+                                                       const float* __restrict__ sigma1, long n, float* __restrict__ partial) {
     __shared__ float sh[4];
     float local = 0.f;
     const float eps = 1e-10f;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const float s0 = sigma[e] * sigma[e], m = mu[e];
-        // losses.py:55-73 with mu1 = 0, sigma1 = 1:  (s0 + m^2)/(1+eps) + log(1+eps) - log(s0+eps) - 1
-        local += (s0 + m * m) / (1.f + eps) + logf(1.f + eps) - logf(s0 + eps) - 1.f;
+        const float s0 = sigma[e] * sigma[e];
+        const float s1 = sigma1 != nullptr ? sigma1[e] * sigma1[e] : 1.f;
+        const float dm = (mu1 != nullptr ? mu1[e] : 0.f) - mu[e];
+        // losses.py:55-73:  (s0 + (mu1-mu0)^2)/(s1+eps) + log(s1+eps) - log(s0+eps) - 1
+        local += (s0 + dm * dm) / (s1 + eps) + logf(s1 + eps) - logf(s0 + eps) - 1.f;
     }
     const float t = block_sum_256(local, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ gscale,
-                                                       float coef, float* __restrict__ gmu, float* __restrict__ gsigma, long n) {
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ mu1,
+                                                       const float* __restrict__ sigma1, const float* __restrict__ gscale, float coef,
+                                                       float* __restrict__ gmu, float* __restrict__ gsigma, long n) {
     const float k0 = coef * (gscale != nullptr ? gscale[0] : 1.f);
     const float eps = 1e-10f;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const float s = sigma[e], m = mu[e];
-        gmu[e] = k0 * m / (1.f + eps);
-        gsigma[e] = k0 * (s / (1.f + eps) - s / (s * s + eps));
+        const float s1 = sigma1 != nullptr ? sigma1[e] * sigma1[e] : 1.f;
+        const float m1 = mu1 != nullptr ? mu1[e] : 0.f;
+        gmu[e] = k0 * (m - m1) / (s1 + eps);
+        gsigma[e] = k0 * (s / (s1 + eps) - s / (s * s + eps));
     }
 }
 
@@ -251,17 +258,18 @@ PULPO_API int pulpo_ncc_bwd(const float* I, const float* J, const float* S, floa
     return pulpo::check_launch("ncc bwd final");
 }
 
-// KL[N(mu, sigma^2) || N(0,1)] summed over everything; finish with pulpo_colsum(scale = 0.5 / B)
-PULPO_API int pulpo_kl_fwd(const float* mu, const float* sigma, int64_t n, float* partial, void* stream) {
+// sum over all elements of the KL integrand; finish with pulpo_colsum(scale = 0.5 / B).  mu1 / sigma1 nullable = N(0,1).
+PULPO_API int pulpo_kl_fwd(const float* mu, const float* sigma, const float* mu1, const float* sigma1, int64_t n, float* partial, void* stream) {
     PULPO_REQUIRE(mu && sigma && partial && n > 0, "kl_fwd: bad arguments");
-    hipLaunchKernelGGL(kl_fwd_kernel, dim3(pulpo_loss_blocks(n)), dim3(256), 0, (hipStream_t)stream, mu, sigma, (long)n, partial);
+    hipLaunchKernelGGL(kl_fwd_kernel, dim3(pulpo_loss_blocks(n)), dim3(256), 0, (hipStream_t)stream, mu, sigma, mu1, sigma1, (long)n, partial);
     return pulpo::check_launch("kl_fwd");
 }
 
-// gmu = gscale[0]*coef*mu ; gsigma = gscale[0]*coef*(sigma - sigma/(sigma^2+eps)),  coef = 1/B
-PULPO_API int pulpo_kl_bwd(const float* mu, const float* sigma, const float* gscale, float coef, float* gmu, float* gsigma, int64_t n, void* stream) {
+// gradients w.r.t. the first distribution only (the prior is a constant in the reference); coef = 1/B
+PULPO_API int pulpo_kl_bwd(const float* mu, const float* sigma, const float* mu1, const float* sigma1, const float* gscale, float coef, float* gmu,
+                           float* gsigma, int64_t n, void* stream) {
     PULPO_REQUIRE(mu && sigma && gmu && gsigma && n > 0, "kl_bwd: bad arguments");
-    hipLaunchKernelGGL(kl_bwd_kernel, dim3(eblocks(n)), dim3(256), 0, (hipStream_t)stream, mu, sigma, gscale, coef, gmu, gsigma, (long)n);
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3(eblocks(n)), dim3(256), 0, (hipStream_t)stream, mu, sigma, mu1, sigma1, gscale, coef, gmu, gsigma, (long)n);
     return pulpo::check_launch("kl_bwd");
 }
 

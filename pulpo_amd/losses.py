@@ -1,0 +1,148 @@
+"""Loss stack of PULPo on HIP kernels, with the reference's public names (src/losses.py).
+
+On the hot path (BASELINE configs: recon_loss=['ncc'], regularizer='L2', diagonal KL):
+    KL_two_gauss_with_diag_cov (:47-76), NCC_loss (:85-135), L2_reg (:208-222) and the three Hierarchical*
+    wrappers (:225-355).
+Named by the reference's importers but NOT on the hot path (alternative hyper-parameters / evaluation metrics,
+SURVEY.md §8(f) rows 3-4): KL_nondiagonal, L2_loss, Soft_dice_loss, jacobian_det, JDetStd.  They are declared so
+that `from src.losses import ...` keeps working and raise NotImplementedError until their kernels land.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _off_path(name: str):
+    raise NotImplementedError(
+        f"{name} is outside the MI355X hot path built so far (SURVEY.md §8(f)); the BASELINE configurations "
+        "use recon_loss=['ncc'], regularizer='L2' and the diagonal KL.")
+
+
+class KL_nondiagonal:
+    def __init__(self, inshape, prior_lambda=20) -> None:
+        _off_path("KL_nondiagonal")
+
+
+def L2_loss(input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    _off_path("L2_loss")
+
+
+def Soft_dice_loss(input: torch.Tensor, target: torch.Tensor, dice_factor=1) -> torch.Tensor:
+    _off_path("Soft_dice_loss")
+
+
+def jacobian_det(deformation_field: torch.Tensor, lamb=None, normalize=True) -> torch.Tensor:
+    _off_path("jacobian_det")
+
+
+def JDetStd(deformation_field: torch.Tensor, lamb=0, normalize=True) -> torch.Tensor:
+    _off_path("JDetStd")
+
+
+def _is_std_normal(mu1, sigma1) -> bool:
+    return getattr(mu1, "_pulpo_std_normal", False) and getattr(sigma1, "_pulpo_std_normal", False)
+
+
+def KL_two_gauss_with_diag_cov(mu0: torch.Tensor, sigma0: torch.Tensor, mu1: torch.Tensor, sigma1: torch.Tensor, eps: float = 1e-10) -> torch.Tensor:
+    """KL[p0 || p1] for diagonal Gaussians: sum over features, mean over the batch.  eps is fixed at the reference's 1e-10."""
+    if eps != 1e-10:
+        raise NotImplementedError("KL_two_gauss_with_diag_cov: the HIP kernel uses the reference's eps = 1e-10")
+    if _is_std_normal(mu1, sigma1):
+        return ops.kl_diag(mu0, sigma0, None, None)
+    return ops.kl_diag(mu0, sigma0, mu1, sigma1)
+
+
+def NCC_loss(y_pred: torch.Tensor, y_true: torch.Tensor, win_size: int = 9, gamma: float = 0.05) -> torch.Tensor:
+    """-gamma * sum_voxels mean_batch(local squared NCC) with a win_size^3 zero-padded window"""
+    if y_pred.dim() != 5:
+        raise NotImplementedError("NCC_loss: only 3-D volumes have a HIP path")
+    return ops.ncc_loss(y_pred, y_true, win_size, gamma)
+
+
+def L2_reg(deformation_field: torch.Tensor, lamb=0) -> torch.Tensor:
+    """lamb * H*W*D * mean of squared forward differences over the [1:,1:,1:] block"""
+    if deformation_field.dim() != 5:
+        raise NotImplementedError("L2_reg: only 3-D fields have a HIP path")
+    return ops.l2_reg(deformation_field, lamb)
+
+
+def _apply_pyramid(weight_dict: Dict[int, float], similarity_pyramid: bool) -> Dict[int, float]:
+    if similarity_pyramid:                      # in place, like the reference (losses.py:238-240)
+        for l in weight_dict.keys():
+            weight_dict[l] = weight_dict[l] / 2 ** l
+    return weight_dict
+
+
+class HierarchicalKLLoss(nn.Module):
+    """sum_l w_l * KL_l; also returns the per-level terms (losses.py:225-276)"""
+
+    def __init__(self, KL_divergence, weight_dict: Dict[int, float], similarity_pyramid: bool, level_sizes: Dict[int, torch.Tensor] = None) -> None:
+        super().__init__()
+        self.weight_dict = _apply_pyramid(weight_dict, similarity_pyramid)
+        self.KL_divergence = KL_divergence
+        if KL_divergence == KL_nondiagonal:
+            _off_path("KL_nondiagonal")
+
+    def forward(self, prior_mus, prior_sigmas, posterior_mus, posterior_sigmas):
+        assert self.weight_dict.keys() == prior_mus.keys()
+        assert prior_mus.keys() == prior_sigmas.keys() == posterior_mus.keys() == posterior_sigmas.keys()
+        kl_loss = 0.0
+        all_levels = {}
+        for l, w in self.weight_dict.items():
+            all_levels[l] = w * self.KL_divergence(posterior_mus[l], posterior_sigmas[l], prior_mus[l], prior_sigmas[l])
+            kl_loss = kl_loss + all_levels[l]
+        return kl_loss, all_levels
+
+
+class HierarchicalReconstructionLoss(nn.Module):
+    """sum_l w_l * recon(y_hat_l, y resized to level l) / len(recon_loss)   (losses.py:279-325)"""
+
+    def __init__(self, recon_loss: List[str], weight_dict: Dict[int, float], similarity_pyramid: bool, ndims: int, window_size: Dict[int, float]) -> None:
+        super().__init__()
+        self.recon_loss = recon_loss
+        self.weight_dict = _apply_pyramid(weight_dict, similarity_pyramid)
+        self.window_size = window_size
+        self.ndims = ndims
+        self.mode = "trilinear" if ndims == 3 else "bilinear"
+        for name in recon_loss:
+            if name not in ("ncc", "mse", "dice"):
+                continue
+            if name != "ncc":
+                _off_path(f"recon_loss '{name}'")
+
+    def forward(self, y_hat, y, y_hat_seg=None, seg_y=None, gamma: float = 0.05, dice_factor: int = 1):
+        loss = 0.0
+        all_levels = {}
+        for l, w in self.weight_dict.items():
+            size = y_hat[l].shape[2:]
+            # F.interpolate(y, size) of the reference; the identity resize at full resolution is skipped
+            y_target = y if tuple(size) == tuple(y.shape[2:]) else ops.resize_trilinear(y, size)
+            term = 0.0
+            if "ncc" in self.recon_loss:
+                term = term + w * NCC_loss(y_hat[l], y_target, gamma=gamma, win_size=self.window_size[l])
+            all_levels[l] = term / len(self.recon_loss)
+            loss = loss + all_levels[l]
+        return loss, all_levels
+
+
+class HierarchicalRegularization(nn.Module):
+    """sum_l w_l * regularizer(df_l, lamb)   (losses.py:327-355)"""
+
+    def __init__(self, regularizer, weight_dict: Dict[int, float], similarity_pyramid: bool) -> None:
+        super().__init__()
+        self.regularizer = regularizer
+        self.weight_dict = _apply_pyramid(weight_dict, similarity_pyramid)
+
+    def forward(self, dfs: Dict[int, torch.Tensor], lamb: float = 0):
+        assert self.weight_dict.keys() == dfs.keys()
+        total_loss = 0.0
+        all_levels = {}
+        for l, w in self.weight_dict.items():
+            all_levels[l] = w * self.regularizer(dfs[l], lamb)
+            total_loss = total_loss + all_levels[l]
+        return total_loss, all_levels

@@ -454,28 +454,36 @@ def ncc_loss(pred, true, win: int = 9, gamma: float = 0.05):
 
 class _KL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mu, sigma):
-        _require_gpu(mu, sigma)
+    def forward(ctx, mu, sigma, mu1, sigma1):
+        _require_gpu(mu, sigma, mu1, sigma1)
         mu, sigma = planar(mu), planar(sigma)
+        mu1 = planar(mu1) if mu1 is not None else None
+        sigma1 = planar(sigma1) if sigma1 is not None else None
         n = mu.numel()
         nblk = lib.query("pulpo_loss_blocks", n)
         part = torch.empty(nblk, device=mu.device, dtype=torch.float32)
-        lib.call("pulpo_kl_fwd", _ptr(mu), _ptr(sigma), n, _ptr(part), _stream())
-        ctx.save_for_backward(mu, sigma)
+        lib.call("pulpo_kl_fwd", _ptr(mu), _ptr(sigma), _ptr(mu1), _ptr(sigma1), n, _ptr(part), _stream())
+        ctx.save_for_backward(mu, sigma, mu1, sigma1)
         return _colsum(part, nblk, 1, 0.5 / mu.shape[0]).reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        mu, sigma = ctx.saved_tensors
+        mu, sigma, mu1, sigma1 = ctx.saved_tensors
         gmu, gsg = torch.empty_like(mu), torch.empty_like(sigma)
         g = g.contiguous()
-        lib.call("pulpo_kl_bwd", _ptr(mu), _ptr(sigma), _ptr(g), 1.0 / mu.shape[0], _ptr(gmu), _ptr(gsg), mu.numel(), _stream())
-        return gmu, gsg
+        lib.call("pulpo_kl_bwd", _ptr(mu), _ptr(sigma), _ptr(mu1), _ptr(sigma1), _ptr(g), 1.0 / mu.shape[0], _ptr(gmu), _ptr(gsg), mu.numel(),
+                 _stream())
+        return gmu, gsg, None, None
+
+
+def kl_diag(mu, sigma, mu1=None, sigma1=None):
+    """KL[N(mu, sigma^2) || N(mu1, sigma1^2)] (sum over features, mean over batch); mu1/sigma1 None = N(0,1).
+    Gradients flow to (mu, sigma) only: the prior is a constant in the reference (pulpo.py:330-341)."""
+    return _KL.apply(mu, sigma, mu1, sigma1)
 
 
 def kl_std_normal(mu, sigma):
-    """KL[N(mu, sigma^2) || N(0, 1)] (sum over features, mean over batch)"""
-    return _KL.apply(mu, sigma)
+    return _KL.apply(mu, sigma, None, None)
 
 
 class _L2Reg(torch.autograd.Function):

@@ -1,0 +1,257 @@
+"""GPU parity of the whole training step (DownPath -> Autoencoder -> losses -> backward) through the drop-in API
+(`src.models.PULPo`), against
+  (1) the full-step golden vectors generated from the real reference (state dict, inputs, noise -> all 8 output
+      dictionaries, the loss terms and every parameter gradient), and
+  (2) the CPU oracle at a BASELINE-like channel width (n0 = 32), plus size-independent properties at larger sizes.
+Stated fp32 tolerances: fields / warped atol 1e-4 (scaled by the tensor's magnitude), loss terms rtol 1e-4,
+parameter gradients relative-L2 <= 1e-3 at these sizes; biases that feed a BatchNorm have a true gradient of 0 and
+are compared on the scale of their layer's weight gradient (SURVEY.md §7 'hard parts')."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pulpo_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+FB = list(O.FEEDBACK_DEFAULT)
+OUT = O.OUT_NAMES
+
+
+@pytest.fixture(scope="module")
+def api():
+    assert torch.cuda.is_available()
+    import src.models as models
+    import src.network_blocks as nb
+    from pulpo_amd._lib import lib
+    lib.load()
+    return models, nb
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(a).double()
+    b = b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(b).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def build_from_golden(models, nb, g, key="sd0."):
+    Tl, L, n0, B, *size = [int(v) for v in g["cfg"]]
+    model = models.PULPo(Tl, L, 0.1, size, feedback=FB, n0=n0)
+    sd = model.state_dict()
+    loaded = 0
+    for k, v in g.items():
+        if k.startswith(key):
+            assert k[len(key):] in sd, k
+            sd[k[len(key):]] = T(v.copy())
+            loaded += 1
+    missing, unexpected = model.load_state_dict(sd, strict=True), None
+    assert loaded > 50
+    model = model.cuda()
+    for l in range(L):
+        model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(T(g[f"eps.{l}"]).cuda())
+    return model, (Tl, L, n0, B, size)
+
+
+def check_outputs(outs, g, prefix, atol=1e-4):
+    for name, d in zip(OUT, outs):
+        for l, v in d.items():
+            ref = g[f"{prefix}.{name}.{l}"]
+            assert tuple(v.shape) == ref.shape, (name, l, v.shape, ref.shape)
+            err = np.abs(v.detach().cpu().numpy() - ref).max()
+            assert err <= atol * max(1.0, np.abs(ref).max()), (name, l, err)
+
+
+STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16"]
+
+
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_training_step_matches_reference_golden(api, golden, case):
+    models, nb = api
+    g = golden(case)
+    model, (Tl, L, n0, B, size) = build_from_golden(models, nb, g)
+    model.train()
+    x, y = T(g["x"]).cuda(), T(g["y"]).cuda()
+    outs, priors, (total, kl, rec, reg), levels = model._forward_and_losses(x, y)
+    check_outputs(outs, g, "train")
+    for key, val in zip(("total", "kl", "rec", "reg"), (total, kl, rec, reg)):
+        np.testing.assert_allclose(float(val), float(g["train." + key]), rtol=1e-4)
+    for nm, d in zip(("kl_l", "rec_l", "reg_l"), levels):
+        for l, v in d.items():
+            np.testing.assert_allclose(float(v), float(g[f"train.{nm}.{l}"]), rtol=1e-4, atol=1e-6)
+    total.backward()
+    named = dict(model.named_parameters())
+    n_checked = 0
+    worst = 0.0
+    for k, p in named.items():
+        if "grad." + k in g:
+            ref = g["grad." + k]
+            assert p.grad is not None, k
+            if k.endswith("_op.0.bias") and "velocity_field._op.2" not in k:
+                # conv bias in front of a BatchNorm: the true gradient is zero, the reference holds rounding noise
+                wref = np.abs(g["grad." + k[:-4] + "weight"]).max()
+                assert np.abs(p.grad.cpu().numpy()).max() <= 1e-3 * max(wref, 1e-3), k
+                continue
+            e = rel_l2(p.grad, ref)
+            worst = max(worst, e)
+            assert e < 1e-3, (k, e)
+            n_checked += 1
+        else:
+            assert "nograd." + k in g, k
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k     # encoders[L-1].sample_merge_block is never used
+    assert n_checked > 40
+    # BatchNorm running statistics after exactly one training forward
+    sd = model.state_dict()
+    for k, v in g.items():
+        if k.startswith("sd1."):
+            np.testing.assert_allclose(sd[k[4:]].cpu().numpy(), v, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_eval_deterministic_and_inference_api(api, golden, case):
+    models, nb = api
+    g = golden(case)
+    model, (Tl, L, n0, B, size) = build_from_golden(models, nb, g)
+    sd = model.state_dict()
+    for k, v in g.items():                     # eval goldens were taken after one training forward
+        if k.startswith("sd1."):
+            sd[k[4:]] = T(v.copy())
+    model.load_state_dict(sd)
+    model.eval()
+    x, y = T(g["x"]).cuda(), T(g["y"]).cuda()
+    with torch.no_grad():
+        outs, _, (total, kl, rec, reg), _ = model._forward_and_losses(x, y)
+        check_outputs(outs, g, "eval")
+        for key, val in zip(("total", "kl", "rec", "reg"), (total, kl, rec, reg)):
+            np.testing.assert_allclose(float(val), float(g["eval." + key]), rtol=1e-4)
+        det_out, det_ind = model.predict_deterministic(x, y)
+        for l in det_out:
+            np.testing.assert_allclose(det_out[l].cpu().numpy(), g[f"det.transformed.{l}"], atol=1e-4)
+            np.testing.assert_allclose(det_ind[l].cpu().numpy(), g[f"det.individual_dfs.{l}"], atol=1e-4)
+        comb, fin = model.combine_dfs(outs[4])
+        for l in comb:
+            np.testing.assert_allclose(comb[l].cpu().numpy(), g[f"eval.combined_dfs.{l}"], atol=1e-4)
+            np.testing.assert_allclose(fin[l].cpu().numpy(), g[f"eval.final_dfs.{l}"], atol=1e-4)
+        np.testing.assert_allclose(model(x, y).cpu().numpy(), g["eval.transformed.0"], atol=1e-4)
+        # predict(): N copies on the batch axis with the SAME injected noise -> the averaged fields equal the single
+        # ones; every level warps the full-resolution image (grid smaller than the image for l >= 1)
+        for l in range(L):
+            e = model.autoencoder.encoders[l].sampler.fixed_eps
+            model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(e.repeat(2, 1, 1, 1, 1))
+        o_s, d_s = model.predict_output_samples(x, y, N=2)
+        for l in o_s:
+            assert tuple(o_s[l].shape[:3]) == (B, 2, 1) and tuple(d_s[l].shape[:3]) == (B, 2, 3)
+            np.testing.assert_allclose(o_s[l][:, 0].cpu().numpy(), g[f"eval.transformed.{l}"], atol=1e-4)
+            np.testing.assert_allclose(d_s[l][:, 1].cpu().numpy(), g[f"eval.individual_dfs.{l}"], atol=1e-4)
+        avg_out, avg_dfs = model.predict(x, y, N=2)
+        _, fin_o = O.combine_dfs({l: T(g[f"eval.individual_dfs.{l}"]) for l in range(L)}, O.Cfg(Tl, L, size, n0=n0))
+        for l in avg_out:
+            ref = O.warp(fin_o[l], T(g["x"]))
+            np.testing.assert_allclose(avg_out[l].cpu().numpy(), ref.numpy(), atol=1e-4)
+
+
+def _copy_oracle_sd_into(model, sd):
+    msd = model.state_dict()
+    assert set(msd) == set(sd), set(msd) ^ set(sd)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()})
+
+
+def test_step_vs_oracle_at_baseline_width(api):
+    """n0 = 32 (the BASELINE channel plan: 32/64/128 + 96-channel feedback path), 32^3, T=3/L=2, B=1: config 1 of BASELINE.json"""
+    models, nb = api
+    cfg = O.Cfg(3, 2, [32, 32, 32], n0=32)
+    sd = O.init_state_dict(cfg, seed=1)
+    gen = torch.Generator().manual_seed(9)
+    x, y = torch.rand(1, 1, 32, 32, 32, generator=gen), torch.rand(1, 1, 32, 32, 32, generator=gen)
+    eps = {0: torch.randn(1, 3, 16, 16, 16, generator=gen), 1: torch.randn(1, 3, 8, 8, 8, generator=gen)}
+    model = models.PULPo(3, 2, 0.1, [32, 32, 32], feedback=FB, n0=32)
+    _copy_oracle_sd_into(model, sd)
+    model = model.cuda().train()
+    for l in range(2):
+        model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(eps[l].cuda())
+    osd = O.clone_sd(sd, requires_grad=True)
+    ls, grads, outs_o = O.train_step(osd, cfg, x, y, eps)
+    outs, _, (total, kl, rec, reg), _ = model._forward_and_losses(x.cuda(), y.cuda())
+    for name, d, do in zip(OUT, outs, outs_o):
+        for l in d:
+            err = float((d[l].cpu() - do[l]).abs().max())
+            assert err <= 1e-4 * max(1.0, float(do[l].abs().max())), (name, l, err)
+    for a, b in zip((total, kl, rec, reg), ls[:4]):
+        np.testing.assert_allclose(float(a), float(b), rtol=1e-4)
+    total.backward()
+    checked = 0
+    for k, p in model.named_parameters():
+        gr = grads.get(k)
+        if gr is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        if k.endswith("_op.0.bias") and "velocity_field._op.2" not in k:
+            continue                              # zero-mean gradient (BatchNorm follows): noise on both sides
+        e = rel_l2(p.grad, gr)
+        assert e < 1e-3, (k, e)
+        checked += 1
+    assert checked > 60
+
+
+def test_fused_adam_arena_step_matches_torch_adam(api):
+    """DataParallelStepper (flat arenas + fused Adam, world size 1) vs torch.optim.Adam on the same model"""
+    models, nb = api
+    from pulpo_amd.dp import DataParallelStepper
+    torch.manual_seed(0)
+    gen = torch.Generator().manual_seed(4)
+    x, y = torch.rand(1, 1, 16, 16, 16, generator=gen).cuda(), torch.rand(1, 1, 16, 16, 16, generator=gen).cuda()
+    eps = [torch.randn(1, 3, 8, 8, 8, generator=gen).cuda(), torch.randn(1, 3, 4, 4, 4, generator=gen).cuda()]
+    empty = torch.empty((0,))
+    batch = (x, y, empty, empty, empty, empty, empty, empty)
+
+    def make():
+        torch.manual_seed(0)
+        m = models.PULPo(3, 2, 0.1, [16, 16, 16], feedback=FB, n0=8, lr=1e-3).cuda().train()
+        for l in range(2):
+            m.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(eps[l])
+        return m
+
+    a, b = make(), make()
+    stepper = DataParallelStepper(a)
+    opt = b.configure_optimizers()
+    for _ in range(2):
+        stepper.step(batch)
+        opt.zero_grad()
+        b.training_step(batch, 0).backward()
+        opt.step()
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if k.endswith("_op.0.bias") and "velocity_field._op.2" not in k:
+            continue      # Adam normalises pure rounding noise on these (documented): not comparable element-wise
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), atol=2e-4, rtol=0)
+
+
+def test_full_resolution_properties_96(api):
+    """BASELINE config 2 shape (96^3, T=4/L=3, B=2, n0=32): no oracle at this size in the test budget; check
+    size-independent properties instead: finite outputs, shapes, KL >= 0, NCC in [-gamma*w*V, 0], gradient present on
+    every used parameter, and determinism of the forward given fixed noise."""
+    models, nb = api
+    torch.manual_seed(0)
+    size = [96, 96, 96]
+    model = models.PULPo(4, 3, 0.1, size, feedback=FB, n0=32).cuda().train()
+    gen = torch.Generator().manual_seed(1)
+    x, y = torch.rand(2, 1, *size, generator=gen).cuda(), torch.rand(2, 1, *size, generator=gen).cuda()
+    for l in range(3):
+        s = 96 // (2 ** (l + 1))
+        model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(torch.randn(2, 3, s, s, s, generator=gen).cuda())
+    outs, _, (total, kl, rec, reg), levels = model._forward_and_losses(x, y)
+    assert outs[7][0].shape == (2, 1, 96, 96, 96) and outs[6][0].shape == (2, 3, 96, 96, 96)
+    assert outs[7][1].shape == (2, 1, 24, 24, 24) and outs[5][0].shape == (2, 3, 48, 48, 48)
+    for d in outs:
+        for v in d.values():
+            assert bool(torch.isfinite(v).all())
+    assert float(kl) >= 0 and float(reg) >= 0 and float(rec) <= 0
+    total.backward()
+    for k, p in model.named_parameters():
+        if "encoders.2.sample_merge_block" in k:
+            assert p.grad is None
+        else:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+    with torch.no_grad():
+        model.eval()
+        a = model(x, y)
+        b = model(x, y)
+        assert bool((a == b).all())        # the forward path has no atomics: bitwise reproducible

@@ -1,0 +1,167 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol the header declares, the host mirror of
+the reference API has the reference's state-dict inventory / hyper-parameter tables / error behaviour, the product
+path refuses to run without a GPU (no CPU fallback), and the data-parallel plumbing works over gloo (world size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+FB = ["samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed"]
+
+
+def test_library_exports_every_declared_symbol():
+    from pulpo_amd._lib import HEADER, LIB_PATH, lib, parse_header
+    protos = parse_header()
+    declared = set(re.findall(r"\b(pulpo_\w+)\s*\(", re.sub(r"/\*.*?\*/", " ", open(HEADER).read(), flags=re.S)))
+    assert declared == set(protos), declared ^ set(protos)
+    assert len(protos) >= 36
+    assert os.path.exists(LIB_PATH), "build the library first: python -m pulpo_amd.build"
+    dll = ctypes.CDLL(LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), f"{name} declared in include/pulpo_hip.h but not exported"
+    lib.load()
+    assert lib.query("pulpo_abi_version") == 1
+    # pure host-side size queries (no device work)
+    assert lib.query("pulpo_conv3d_k3_packed_floats", 32, 32) == 27 * 32 * 64
+    assert lib.query("pulpo_conv3d_k3_packed_floats", 2, 32) == 27 * 4 * 64
+    assert lib.query("pulpo_conv3d_k3_stat_tiles", 1, 160, 160, 160) == 80 * 20 * 20
+    assert lib.query("pulpo_conv3d_k3_wgrad_scratch_floats", 160, 64) == 27 * 160 * 64
+
+
+def test_bad_arguments_return_error_codes_not_crashes():
+    from pulpo_amd._lib import lib
+    lib.load()
+    rc = lib.raw("pulpo_conv3d_k3_fwd")(None, 0, 0, 0, None, None, None, 0, 0, 0, None, 1, 8, 8, 8, 4, 4, None)
+    assert rc != 0 and b"null pointer" in lib.raw("pulpo_last_error")()
+    rc = lib.raw("pulpo_ncc_fwd")(None, None, None, None, None, 1, 8, 8, 8, 4, None)
+    assert rc != 0
+
+
+def test_state_dict_inventory_matches_reference():
+    from src.models import PULPo
+    want = {}
+    for line in open(os.path.join(GOLDEN, "state_keys.txt")):
+        if line.startswith("#"):
+            continue
+        tl, key, rest = line.split(" ", 2)
+        shape, dt = rest.rsplit(" ", 1)
+        want.setdefault(tl, []).append((key, eval(shape), dt.strip()))
+    for tl, (Tl, L) in {"3/2": (3, 2), "5/4": (5, 4)}.items():
+        model = PULPo(Tl, L, 0.1, [32, 32, 32], feedback=FB, n0=32)
+        sd = model.state_dict()
+        assert [k for k, _, _ in want[tl]] == list(sd.keys())          # same keys in the same order
+        for k, shape, dt in want[tl]:
+            assert tuple(sd[k].shape) == shape and str(sd[k].dtype).replace("torch.", "") == dt, k
+
+
+def test_hparams_tables_and_errors(golden):
+    from src.models import PULPo
+    from src.components.pulpo import Autoencoder
+    from src.network_blocks import gauss_sampler
+    g = golden("init_tables")
+    for key, tab in g.items():
+        Tl, L = int(key[1]), int(key[3])
+        m = PULPo(Tl, L, 0.1, [32, 32, 32], feedback=FB, n0=2)
+        got = np.array([[m.window_size[l], m.hierarchical_kl_loss.weight_dict[l], m.hierarchical_recon_loss.weight_dict[l],
+                         m.hierarchical_regularization.weight_dict[l]] for l in range(L)])
+        np.testing.assert_array_equal(got, tab)
+        assert m.lk_offset == Tl - L and m.ndims == 3 and m.hparams.lr == 1e-4 and m.hparams.beta == 0.1
+    with pytest.raises(ValueError, match="velocity_field"):       # the shipped default list does not construct (Appendix A.1)
+        PULPo(3, 2, 0.1, [16, 16, 16], n0=2)
+    with pytest.raises(ValueError, match="regularizer"):
+        PULPo(3, 2, 0.1, [16, 16, 16], feedback=FB, n0=2, regularizer="tv")
+    with pytest.raises(ValueError, match="Decoder"):
+        Autoencoder(gauss_sampler, "bspline", 3, 2, 3, [16, 16, 16], FB, "level_res", 2, 3)
+    m = PULPo(3, 2, 0.1, [16, 16, 16], feedback=["samples", "control_points"], n0=2)    # old alias is accepted
+    assert m.autoencoder.up_blocks[1]._op[0]._op[0].in_channels == 6
+
+
+def test_module_int_dict():
+    import torch.nn as nn
+    from src.utils import ModuleIntDict
+    d = ModuleIntDict({0: nn.Linear(1, 1)})
+    d[3] = nn.Linear(2, 2)
+    assert list(d.keys()) == [0, 3] and 3 in d and d[3].in_features == 2
+    assert [k for k, _ in d.items()] == [0, 3]
+    holder = nn.Module()
+    holder.blocks = d
+    assert list(holder.state_dict().keys()) == ["blocks.0.weight", "blocks.0.bias", "blocks.3.weight", "blocks.3.bias"]
+
+
+def test_product_path_has_no_cpu_fallback():
+    from pulpo_amd._lib import PulpoHipError
+    from src.models import PULPo
+    m = PULPo(3, 2, 0.1, [16, 16, 16], feedback=FB, n0=2)
+    x = torch.rand(1, 1, 16, 16, 16)
+    with pytest.raises(PulpoHipError, match="GPU only"):
+        m(x, x)
+    # nothing under pulpo_amd/ or src/ imports the oracle
+    for base in ("pulpo_amd", "src"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith(".py"):
+                    text = open(os.path.join(dirpath, f)).read()
+                    assert "oracle" not in text.replace("# oracle", ""), os.path.join(dirpath, f)
+
+
+def test_flat_arena_views_and_zero_grad():
+    from pulpo_amd.dp import FlatArena
+    lin = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.Linear(5, 2))
+    ref = [p.detach().clone() for p in lin.parameters()]
+    arena = FlatArena(lin)
+    for p, r in zip(lin.parameters(), ref):
+        assert torch.equal(p.detach(), r)
+        assert p.data_ptr() >= arena.data.data_ptr() and p.grad.data_ptr() >= arena.grad.data_ptr()
+    lin(torch.ones(4, 3)).sum().backward()
+    assert float(arena.grad.abs().sum()) > 0          # autograd accumulated straight into the arena
+    g0 = arena.grad.clone()
+    lin(torch.ones(4, 3)).sum().backward()
+    assert torch.allclose(arena.grad, 2 * g0)
+    arena.zero_grad()
+    assert float(arena.grad.abs().sum()) == 0 and all(float(p.grad.abs().sum()) == 0 for p in lin.parameters())
+
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pulpo_amd.dp import FlatArena, allreduce_sum_, init_from_env, world
+init_from_env("gloo")
+rank = dist.get_rank()
+torch.manual_seed(100 + rank)                       # different initial weights per rank on purpose
+net = torch.nn.Sequential(torch.nn.Linear(4, 6), torch.nn.Linear(6, 3))
+arena = FlatArena(net)
+dist.broadcast(arena.data, src=0)                   # what DataParallelStepper does at start-up
+w0 = arena.data.clone()
+x = torch.full((2, 4), float(rank + 1))             # rank-dependent shard of the batch
+arena.zero_grad()
+net(x).sum().backward()
+local = arena.grad.clone()
+allreduce_sum_(arena.grad)
+gathered = [torch.zeros_like(local) for _ in range(world())]
+dist.all_gather(gathered, local)
+assert torch.allclose(arena.grad, sum(gathered)), "all-reduce != sum of per-rank gradients"
+wl = [torch.zeros_like(w0) for _ in range(world())]
+dist.all_gather(wl, w0)
+assert all(torch.equal(w, wl[0]) for w in wl), "weights differ after broadcast"
+print(f"rank {rank} ok world {world()}")
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_plumbing_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok world 2" in o
