@@ -53,7 +53,8 @@ int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t
 
 /* ------------------------------------------------------------- ConvUnit: BatchNorm3d + LeakyReLU(0.2, inplace)
  * replaces nn.BatchNorm3d / nn.LeakyReLU (src/network_blocks.py:24-25) = aten::native_batch_norm(+_backward),
- * aten::leaky_relu_(+_backward).  coef = [4][C]: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale. */
+ * aten::leaky_relu_(+_backward).  coef = 8*C floats: [4][C] floats (mean, rstd, scale = gamma*rstd, shift = beta - mean*scale)
+ * followed by [2][C] doubles (mean, rstd): the backward carries the per-channel means in double, as ATen's CPU kernels do. */
 int pulpo_colsum(const float* partials, int nrow, int ncol, float* out, float scale, void* stream);
 int pulpo_bn_fwd_finalize(const float* stats, int ntile, int C, double count, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, float momentum, float eps, float* coef, void* stream);
@@ -63,9 +64,10 @@ int pulpo_bn_lrelu_apply(const float* y, int64_t yps, float* z, int64_t zps, con
 int pulpo_bn_bwd_blocks(int64_t npix, int C);
 int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, int64_t npix, int C, float slope,
                               float* partial /*[blocks][2C]*/, void* stream);
-int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const float* tot /*[2C]: dbeta|dgamma*/,
-                             double count, float* dy, int64_t dyps, int64_t npix, int C, float slope, float* partial2 /*[blocks][C]*/,
-                             void* stream);
+int pulpo_bn_bwd_finalize(const float* partial, int nrow, int C, double count, int use_means, float* grads /*[2C]: dbeta|dgamma*/,
+                          double* totd /*[2C]: mean(dbn) | mean(dbn*xhat)*/, void* stream);
+int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd, float* dy,
+                             int64_t dyps, int64_t npix, int C, float slope, float* partial2 /*[blocks][C]*/, void* stream);
 
 /* ---------------------------------------------------------------------------- 1x1x1 heads (channel mixing C -> 3)
  * nout = 6: MuSigmaBlock + gauss_sampler (src/network_blocks.py:54-60, :7-8; eps = injected N(0,1) noise, NULL -> z = mu)

@@ -57,6 +57,9 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(const float* __re
         coef[1 * C + c] = rstd;
         coef[2 * C + c] = sc;
         coef[3 * C + c] = beta[c] - (float)mean * sc;
+        double* cd = reinterpret_cast<double*>(coef + 4 * C);     // [2][C] doubles: mean, rstd (used by the backward)
+        cd[c] = mean;
+        cd[C + c] = 1.0 / sqrt(var + (double)eps);
         if (running_mean != nullptr) {
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
@@ -75,6 +78,9 @@ __global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float
     coef[1 * C + c] = rstd;
     coef[2 * C + c] = sc;
     coef[3 * C + c] = beta[c] - rm[c] * sc;
+    double* cd = reinterpret_cast<double*>(coef + 4 * C);
+    cd[c] = (double)rm[c];
+    cd[C + c] = 1.0 / sqrt((double)rv[c] + (double)eps);
 }
 
 template <int VEC>
@@ -134,11 +140,13 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < VEC; ++k) s0[k] = s1[k] = 0.f;
     if (row < RB) {
-        float mean[VEC], rstd[VEC], sc[VEC], sh[VEC];
-        Vec<VEC>::ld(coef + 0 * C + c, mean);
-        Vec<VEC>::ld(coef + 1 * C + c, rstd);
+        float sc[VEC], sh[VEC];
+        double mean[VEC], rstd[VEC];
+        const double* cd = reinterpret_cast<const double*>(coef + 4 * C);
         Vec<VEC>::ld(coef + 2 * C + c, sc);
         Vec<VEC>::ld(coef + 3 * C + c, sh);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { mean[k] = cd[c + k]; rstd[k] = cd[C + c + k]; }
         for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
             float g[VEC], v[VEC];
             Vec<VEC>::ld(dz + p * dzps + c, g);
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* _
                 const float bn = v[k] * sc[k] + sh[k];
                 const float d = bn > 0.f ? g[k] : g[k] * slope;
                 s0[k] += d;
-                s1[k] += d * ((v[k] - mean[k]) * rstd[k]);
+                s1[k] += (float)((double)d * (((double)v[k] - mean[k]) * rstd[k]));
             }
         }
 #pragma unroll
@@ -168,8 +176,8 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* _
 // pass 2: dy = scale * (dbn - mean(dbn) - xhat * mean(dbn*xhat));  partial2[blk][c] = sum dy  (conv-bias gradient)
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __restrict__ dz, long dzps, const float* __restrict__ y,
-                                                                   long yps, const float* __restrict__ coef, const float* __restrict__ tot,
-                                                                   float inv_count, float* __restrict__ dy, long dyps, long npix, int C,
+                                                                   long yps, const float* __restrict__ coef, const double* __restrict__ totd,
+                                                                   float* __restrict__ dy, long dyps, long npix, int C,
                                                                    float slope, float* __restrict__ partial2) {
     extern __shared__ float red[];                 // [RB][C]
     const int CV = C / VEC, RB = blockDim.x / CV;
@@ -179,15 +187,16 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __
 #pragma unroll
     for (int k = 0; k < VEC; ++k) s0[k] = 0.f;
     if (row < RB) {
-        float mean[VEC], rstd[VEC], sc[VEC], sh[VEC], c1[VEC], c2[VEC];
-        Vec<VEC>::ld(coef + 0 * C + c, mean);
-        Vec<VEC>::ld(coef + 1 * C + c, rstd);
+        // The per-channel means are carried in double and subtracted in double: a mean rounded to fp32 would shift every
+        // dy of the channel by the same amount, an error that the following weight-gradient sum amplifies by the voxel
+        // count (ATen's CPU BatchNorm accumulates in double for the same reason).
+        float sc[VEC], sh[VEC];
+        double mean[VEC], rstd[VEC], c1[VEC], c2[VEC];
+        const double* cd = reinterpret_cast<const double*>(coef + 4 * C);
         Vec<VEC>::ld(coef + 2 * C + c, sc);
         Vec<VEC>::ld(coef + 3 * C + c, sh);
-        Vec<VEC>::ld(tot + 0 * C + c, c1);
-        Vec<VEC>::ld(tot + 1 * C + c, c2);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) { c1[k] *= inv_count; c2[k] *= inv_count; }
+        for (int k = 0; k < VEC; ++k) { mean[k] = cd[c + k]; rstd[k] = cd[C + c + k]; c1[k] = totd[c + k]; c2[k] = totd[C + c + k]; }
         for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
             float g[VEC], v[VEC], o[VEC];
             Vec<VEC>::ld(dz + p * dzps + c, g);
@@ -196,8 +205,8 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __
             for (int k = 0; k < VEC; ++k) {
                 const float bn = v[k] * sc[k] + sh[k];
                 const float d = bn > 0.f ? g[k] : g[k] * slope;
-                const float xh = (v[k] - mean[k]) * rstd[k];
-                o[k] = sc[k] * (d - c1[k] - xh * c2[k]);
+                const double xh = ((double)v[k] - mean[k]) * rstd[k];
+                o[k] = (float)((double)sc[k] * ((double)d - c1[k] - xh * c2[k]));
                 s0[k] += o[k];
             }
             Vec<VEC>::st(dy + p * dyps + c, o);
@@ -210,6 +219,27 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __
         float t = 0.f;
         for (int r = 0; r < RB; ++r) t += red[r * C + j];
         partial2[(long)blockIdx.x * C + j] = t;
+    }
+}
+
+// partial[nblk][2C] -> grads[2C] = (dbeta | dgamma) as floats, totd[2C] = (mean dbn | mean dbn*xhat) as doubles.
+// use_means == 0 (eval-mode BatchNorm is a fixed affine map): totd = 0.
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nrow, int C, double count, int use_means,
+                                                                 float* __restrict__ grads, double* __restrict__ totd) {
+    __shared__ double red[32][33];
+    const int cx = threadIdx.x, ry = threadIdx.y;
+    const int c = blockIdx.x * 32 + cx;          // column in [0, 2C)
+    double s = 0.0;
+    if (c < 2 * C)
+        for (int r = ry; r < nrow; r += 32) s += (double)partial[(long)r * 2 * C + c];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < 2 * C) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += red[k][cx];
+        grads[c] = (float)t;
+        totd[c] = use_means ? t / count : 0.0;
     }
 }
 
@@ -275,22 +305,25 @@ PULPO_API int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const flo
     return pulpo::check_launch("bn_lrelu_bwd_reduce");
 }
 
-PULPO_API int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const float* tot,
-                                       double count, float* dy, int64_t dyps, int64_t npix, int C, float slope, float* partial2,
-                                       void* stream) {
-    PULPO_REQUIRE(dz && y && coef && tot && dy && partial2 && npix > 0 && C > 0, "bn_lrelu_bwd_apply: bad arguments");
+PULPO_API int pulpo_bn_bwd_finalize(const float* partial, int nrow, int C, double count, int use_means, float* grads, double* totd, void* stream) {
+    PULPO_REQUIRE(partial && grads && totd && nrow > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pulpo::cdiv(2 * C, 32)), dim3(32, 32), 0, (hipStream_t)stream, partial, nrow, C, count, use_means,
+                       grads, totd);
+    return pulpo::check_launch("bn_bwd_finalize");
+}
+
+PULPO_API int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd, float* dy,
+                                       int64_t dyps, int64_t npix, int C, float slope, float* partial2, void* stream) {
+    PULPO_REQUIRE(dz && y && coef && totd && dy && partial2 && npix > 0 && C > 0, "bn_lrelu_bwd_apply: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    const bool v4 = vec_ok(dz, dzps, y, yps, C) && vec_ok(dy, dyps, coef, 4, C) && (((uintptr_t)tot & 15) == 0);
+    const bool v4 = vec_ok(dz, dzps, y, yps, C) && vec_ok(dy, dyps, coef, 4, C);
     if (C % 4 == 0 && !v4) return pulpo::fail(-1, "bn_lrelu_bwd_apply: operands must be 16-byte aligned when C %% 4 == 0");
     const int nblk = pulpo_bn_bwd_blocks(npix, C);
     const int RB = std::max(1, 256 / (C / (v4 ? 4 : 1)));
     const size_t lds = (size_t)RB * C * sizeof(float);
-    const float inv = (float)(1.0 / count);
     if (v4)
-        hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel<4>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, tot, inv, dy, dyps, npix, C,
-                           slope, partial2);
+        hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel<4>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2);
     else
-        hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel<1>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, tot, inv, dy, dyps, npix, C,
-                           slope, partial2);
+        hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel<1>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2);
     return pulpo::check_launch("bn_lrelu_bwd_apply");
 }

@@ -124,7 +124,7 @@ class _ConvBNLReLU(torch.autograd.Function):
         dev = x.device
         wp = _pack_weight(weight, dgrad=False)
         y = new_cl(B, Cout, D, H, W, dev)
-        coef = torch.empty(4 * Cout, device=dev, dtype=torch.float32)
+        coef = torch.empty(8 * Cout, device=dev, dtype=torch.float32)      # [4][C] floats + [2][C] doubles
         if training:
             ntile = lib.query("pulpo_conv3d_k3_stat_tiles", B, D, H, W)
             stats = torch.empty(ntile * 2 * Cout, device=dev, dtype=torch.float32)
@@ -149,22 +149,16 @@ class _ConvBNLReLU(torch.autograd.Function):
         npix = B * D * H * W
         dz = to_cl(dz)
         nblk = lib.query("pulpo_bn_bwd_blocks", npix, Cout)
-        if ctx.training:
-            part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
-            lib.call("pulpo_bn_lrelu_bwd_reduce", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE, _ptr(part),
-                     _stream())
-            tot = _colsum(part, nblk, 2 * Cout)
-            tot_apply = tot
-        else:   # eval-mode BN is a fixed affine map: dy = scale * dbn
-            part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
-            lib.call("pulpo_bn_lrelu_bwd_reduce", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE, _ptr(part),
-                     _stream())
-            tot = _colsum(part, nblk, 2 * Cout)
-            tot_apply = torch.zeros_like(tot)
+        part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
+        lib.call("pulpo_bn_lrelu_bwd_reduce", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE, _ptr(part), _stream())
+        tot = torch.empty(2 * Cout, device=dev, dtype=torch.float32)           # dbeta | dgamma
+        totd = torch.empty(2 * Cout, device=dev, dtype=torch.float64)          # mean(dbn) | mean(dbn * xhat), kept in double
+        # eval-mode BatchNorm is a fixed affine map (dy = scale * dbn): the batch means do not enter
+        lib.call("pulpo_bn_bwd_finalize", _ptr(part), nblk, Cout, float(npix), int(ctx.training), _ptr(tot), _ptr(totd), _stream())
         dy = new_cl(B, Cout, D, H, W, dev)
         part2 = torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
-        lib.call("pulpo_bn_lrelu_bwd_apply", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), _ptr(tot_apply), float(npix), _ptr(dy),
-                 dy.stride(4), npix, Cout, LRELU_SLOPE, _ptr(part2), _stream())
+        lib.call("pulpo_bn_lrelu_bwd_apply", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4), npix, Cout,
+                 LRELU_SLOPE, _ptr(part2), _stream())
         dbias = _colsum(part2, nblk, Cout)
         dbeta, dgamma = tot[:Cout], tot[Cout:]
         dw = _wgrad_raw(x, dy, Cin, Cout) if ctx.needs_input_grad[1] else None

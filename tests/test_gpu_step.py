@@ -4,8 +4,9 @@
       dictionaries, the loss terms and every parameter gradient), and
   (2) the CPU oracle at a BASELINE-like channel width (n0 = 32), plus size-independent properties at larger sizes.
 Stated fp32 tolerances: fields / warped atol 1e-4 (scaled by the tensor's magnitude), loss terms rtol 1e-4,
-parameter gradients relative-L2 <= 1e-3 at these sizes; biases that feed a BatchNorm have a true gradient of 0 and
-are compared on the scale of their layer's weight gradient (SURVEY.md §7 'hard parts')."""
+parameter gradients relative-L2 <= 1e-3 on the golden cases (<= 5e-3 where LeakyReLU slope flips against fp64 occur, see
+test_step_vs_oracle_at_baseline_width); biases that feed a BatchNorm have a true gradient of 0 and are compared on the
+scale of their layer's weight gradient (SURVEY.md §7 'hard parts')."""
 import numpy as np
 import pytest
 import torch
@@ -156,7 +157,14 @@ def _copy_oracle_sd_into(model, sd):
 
 
 def test_step_vs_oracle_at_baseline_width(api):
-    """n0 = 32 (the BASELINE channel plan: 32/64/128 + 96-channel feedback path), 32^3, T=3/L=2, B=1: config 1 of BASELINE.json"""
+    """n0 = 32 (the BASELINE channel plan: 32/64/128 + 96-channel feedback path), 32^3, T=3/L=2, B=1: config 1 of BASELINE.json.
+
+    Gradients are judged against an fp64 run of the oracle.  LeakyReLU's derivative jumps (1 <-> 0.2) where a BatchNorm
+    output is ~0: any fp32 evaluation (this one, or the reference's own CPU path) flips the slope of a few of the ~5e6
+    activations relative to fp64, and ONE flip moves the gradient of every upstream parameter by ~1e-3 relative
+    (scripts/step_accuracy.py shows the three flips of this seed and that every kernel on its own is at 1e-7).  The
+    test therefore counts the flips and applies the tight bound when there are none, the SURVEY.md §8(c) envelope
+    (5e-3) otherwise."""
     models, nb = api
     cfg = O.Cfg(3, 2, [32, 32, 32], n0=32)
     sd = O.init_state_dict(cfg, seed=1)
@@ -168,8 +176,29 @@ def test_step_vs_oracle_at_baseline_width(api):
     model = model.cuda().train()
     for l in range(2):
         model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(eps[l].cuda())
+    gpu_units = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, nb.ConvUnit):
+            mod.register_forward_hook(lambda m, i, o, name=name: gpu_units.__setitem__(name, o.detach()))
+
+    # oracle in fp32 (values) and fp64 (gradient ground truth), recording every ConvUnit output
+    ref_units = {}
+    orig_unit = O.conv_unit
+
+    def recording_unit(h, sd_, prefix, training):
+        out = orig_unit(h, sd_, prefix, training)
+        ref_units[prefix] = out.detach()
+        return out
+
     osd = O.clone_sd(sd, requires_grad=True)
     ls, grads, outs_o = O.train_step(osd, cfg, x, y, eps)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    O.conv_unit = recording_unit
+    try:
+        _, grads64, _ = O.train_step(O.clone_sd(sd64, requires_grad=True), cfg, x.double(), y.double(), {l: e.double() for l, e in eps.items()})
+    finally:
+        O.conv_unit = orig_unit
+
     outs, _, (total, kl, rec, reg), _ = model._forward_and_losses(x.cuda(), y.cuda())
     for name, d, do in zip(OUT, outs, outs_o):
         for l in d:
@@ -178,17 +207,24 @@ def test_step_vs_oracle_at_baseline_width(api):
     for a, b in zip((total, kl, rec, reg), ls[:4]):
         np.testing.assert_allclose(float(a), float(b), rtol=1e-4)
     total.backward()
+    flips = sum(int(((gpu_units[k].cpu() > 0) != (ref_units[k] > 0)).sum()) for k in ref_units)
+    n_act = sum(v.numel() for v in ref_units.values())
+    assert set(gpu_units) == set(ref_units) and flips <= 1e-5 * n_act, (flips, n_act)
+    bound = 2e-4 if flips == 0 else 5e-3
     checked = 0
+    worst_gpu = worst_cpu = 0.0
     for k, p in model.named_parameters():
-        gr = grads.get(k)
+        gr = grads64.get(k)
         if gr is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         if k.endswith("_op.0.bias") and "velocity_field._op.2" not in k:
             continue                              # zero-mean gradient (BatchNorm follows): noise on both sides
-        e = rel_l2(p.grad, gr)
-        assert e < 1e-3, (k, e)
+        e_gpu, e_cpu = rel_l2(p.grad, gr), rel_l2(grads[k], gr)
+        worst_gpu, worst_cpu = max(worst_gpu, e_gpu), max(worst_cpu, e_cpu)
+        assert e_gpu < bound, (k, e_gpu, e_cpu, flips)
         checked += 1
+    print(f"LeakyReLU slope flips vs fp64: {flips} of {n_act}; worst grad rel-L2 vs fp64: gpu {worst_gpu:.2e}, cpu-fp32 oracle {worst_cpu:.2e}")
     assert checked > 60
 
 
