@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Throughput of PULPo's registration training step (forward + backward + gradient all-reduce + Adam) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json `metric`): synthetic 160^3 fp32 volume pairs, 4-level latent pyramid (total_levels 5,
+latent_levels 4, n0 = 32), batch 1 per GPU, weak scaling over GPUs.  One "step" = one training step on one pair per
+GPU.  Inputs live in HBM before the timed region.  Rank 0 prints ONE JSON line (see the task contract) carrying
+  roofline      : the dominant kernel (the MFMA 3x3x3 convolution), algorithmic FLOP / launch over its HIP-event
+                  measured mean launch time inside the timed region, against the dense fp32 MFMA peak (157.3 TFLOP/s);
+  cpu_baseline  : the CPU oracle (oracle/pulpo_oracle.py, the same ATen op sequence as the reference) timed on this
+                  host's cores for ONE forward+backward step of the same 160^3 workload (N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FEEDBACK = ["samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed"]
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
+FLOP_ALG_PER_PAIR_160 = 5.708e12       # conv FLOPs fwd+bwd per pair at 160^3 / T5 / L4
+BYTES_ALG_PER_PAIR_160 = 41.98e9       # fused-kernel compulsory bytes per pair
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, nargs=3, default=[160, 160, 160])
+    ap.add_argument("--levels", type=int, nargs=2, default=[5, 4], help="total_levels latent_levels")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trace", action="store_true", help="do not bracket conv launches with HIP events")
+    return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """cores this process may actually use: min(affinity mask, cgroup CPU quota); os.cpu_count() reports the whole host"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return int(os.environ.get("PULPO_CPU_CORES", min(n, 32)))
+
+
+def cpu_baseline(size, T, L, B):
+    """one un-warmed forward+backward of the CPU oracle on the same workload (bounded sample: 1 step)"""
+    from oracle import pulpo_oracle as O
+    torch.set_num_threads(usable_cores())
+    cfg = O.Cfg(T, L, list(size), n0=32)
+    sd = O.clone_sd(O.init_state_dict(cfg, seed=0), requires_grad=True)
+    g = torch.Generator().manual_seed(1234)
+    x, y = torch.rand(B, 1, *size, generator=g), torch.rand(B, 1, *size, generator=g)
+    t0 = time.perf_counter()
+    O.train_step(sd, cfg, x, y, None)
+    dt = time.perf_counter() - t0
+    return {"value": B / dt, "unit": "volume-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 un-warmed fwd+bwd step (no optimizer) of the same {size[0]}x{size[1]}x{size[2]} T{T}/L{L} B={B} fp32 workload, "
+                      f"oracle/pulpo_oracle.py on torch-CPU, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    from pulpo_amd import dp, ops
+    from pulpo_amd._lib import lib
+    local = dp.init_from_env("nccl")
+    world = dp.world()
+    rank = dist.get_rank() if world > 1 else 0
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE is {world}; using {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib.load()
+
+    from src.models import PULPo
+    T, L = args.levels
+    size, B = list(args.size), args.batch
+    torch.manual_seed(0)
+    model = PULPo(T, L, 0.1, size, feedback=FEEDBACK, n0=32).to(dev).train()
+    stepper = dp.DataParallelStepper(model)
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand(B, 1, *size, generator=g).to(dev)
+    y = torch.rand(B, 1, *size, generator=g).to(dev)
+    empty = torch.empty((0,), device=dev)
+    batch = (x, y, empty, empty, empty, empty, empty, empty)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stepper.step(batch)
+    barrier()
+    if not args.no_trace:
+        ops.CONV_TRACE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = stepper.step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    trace, ops.CONV_TRACE = ops.CONV_TRACE, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if not bool(torch.isfinite(loss)):
+        raise SystemExit("bench: non-finite loss")
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / dt
+        # ---- dominant kernel from the live HIP-event trace
+        roof = None
+        per_kernel = {}
+        if trace:
+            for name, flops, s, e in trace:
+                k = per_kernel.setdefault(name, [0, 0.0, 0.0])
+                k[0] += 1
+                k[1] += flops
+                k[2] += s.elapsed_time(e) * 1e-3
+            dom = max(per_kernel.items(), key=lambda kv: kv[1][2])
+            n, fl, sec = dom[1]
+            roof = {"bound": "mfma", "kernel": dom[0], "achieved": fl / sec / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "launches": n, "avg_launch_ms": sec / n * 1e3,
+                    "flop_per_launch": fl / n}
+        is160 = size == [160, 160, 160] and (T, L) == (5, 4)
+        out = {
+            "metric": "volume-pairs/sec fwd+bwd, 160^3 fp32",
+            "value": value, "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic U[0,1) volumes, default-initialised weights (manual_seed 0)",
+            "config": {"workload": f"{size[0]}x{size[1]}x{size[2]} synthetic pair, {L}-level pyramid (total_levels {T}), fp32, batch {B} per GPU, "
+                                   "fwd+bwd+grad all-reduce+Adam", "global_batch": world * B, "parallelism": f"dp{world}"},
+            "roofline": roof,
+            "conv_kernels": {k: {"launches": v[0], "TFLOP/s": v[1] / v[2] / 1e12, "ms_total_per_step": v[2] / args.steps * 1e3}
+                             for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][2])},
+        }
+        if is160:
+            per_gpu = value / world
+            out["step_rooflines"] = {"conv_flop_frac_of_157.3TF": FLOP_ALG_PER_PAIR_160 * per_gpu / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                     "alg_bytes_frac_of_8TBps": BYTES_ALG_PER_PAIR_160 * per_gpu / 8.0e12}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(size, T, L, B)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,7 @@ const char* pulpo_last_error(void);
 size_t pulpo_conv3d_k3_packed_floats(int K, int N);
 int pulpo_conv3d_k3_pack_weight(const float* w /*[Cout][Cin][3][3][3]*/, float* wp, int Cin, int Cout, int dgrad, void* stream);
 int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W);
+int pulpo_conv3d_k3_tile_config(int K, int N); /* CH*1000 + NT of the kernel instantiation used (for profiling) */
 int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, float* out,
                         int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W, int K, int N, void* stream);
 /* weight gradient: dw[Cout][Cin][27] = sum_voxels in[v + tap - 1][ci] * dy[v][co]; scratch is overwritten */

@@ -371,6 +371,12 @@ PULPO_API int pulpo_conv3d_k3_pack_weight(const float* w, float* wp, int Cin, in
     return pulpo::check_launch("pack_weight");
 }
 
+// which kernel instantiation pulpo_conv3d_k3_fwd dispatches to: CH * 1000 + NT (vector/scalar staging is decided by the strides)
+PULPO_API int pulpo_conv3d_k3_tile_config(int K, int N) {
+    const int NT = (N % 64 == 0 || N > 96) ? 64 : 32;
+    return pick_ch(K) * 1000 + NT;
+}
+
 // Generic entry: computes out[b][vox][n] = sum_{tap,k} in[b][vox+tap-1][k] * wp[...] (+ bias[n]).
 // K / N are the GEMM's reduction / output channel counts (forward: Cin/Cout; dgrad: Cout/Cin with dgrad-packed wp).
 PULPO_API int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
@@ -385,8 +391,8 @@ PULPO_API int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps,
     a.stats = stats;
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
     a.ntz = pulpo::cdiv(D, TZ); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
-    const int CH = pick_ch(K);
-    const int NT = (N % 64 == 0 || N > 96) ? 64 : 32;
+    const int cfg = pulpo_conv3d_k3_tile_config(K, N);
+    const int CH = cfg / 1000, NT = cfg % 1000;
     a.ncot = pulpo::cdiv(N, NT);
     const long nblk_l = (long)B * a.ntz * a.nty * a.ntx * a.ncot;
     PULPO_REQUIRE(nblk_l < (1L << 31), "conv3d_k3_fwd: grid too large");

@@ -86,6 +86,27 @@ def _colsum(partials: torch.Tensor, nrow: int, ncol: int, scale: float = 1.0) ->
 
 
 # ------------------------------------------------------------------------------------------------ conv 3x3x3
+# Optional live kernel timing (bench.py): when CONV_TRACE is a list, every conv / wgrad launch is bracketed by HIP events
+# recorded on the launch stream and (kernel name, algorithmic FLOPs, start, end) is appended.  No synchronisation here.
+CONV_TRACE = None
+
+
+def _trace_begin():
+    if CONV_TRACE is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _trace_end(start, name: str, flops: float):
+    if start is None:
+        return
+    end = torch.cuda.Event(enable_timing=True)
+    end.record()
+    CONV_TRACE.append((name, flops, start, end))
+
+
 def _pack_weight(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
     Cout, Cin = w.shape[0], w.shape[1]
     K, N = (Cout, Cin) if dgrad else (Cin, Cout)
@@ -99,7 +120,12 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
     B, _, D, H, W = x.shape
     xb, xp, xc = grid_strides(x)
     ob, op, oc = grid_strides(out)
+    t0 = _trace_begin()
     lib.call("pulpo_conv3d_k3_fwd", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc, _ptr(stats), B, D, H, W, K, N, _stream())
+    if t0 is not None:
+        cfg = lib.query("pulpo_conv3d_k3_tile_config", K, N)
+        vec = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0 and cfg // 1000 >= 16
+        _trace_end(t0, f"conv3d_k3_mfma<{cfg // 1000},{cfg % 1000},{'true' if vec else 'false'}>", 54.0 * K * N * B * D * H * W)
 
 
 def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int) -> torch.Tensor:
@@ -108,7 +134,9 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int) -> torch.
     scratch = torch.empty(lib.query("pulpo_conv3d_k3_wgrad_scratch_floats", Cin, Cout), device=x.device, dtype=torch.float32)
     xb, xp, xc = grid_strides(x)
     db, dp, dc = grid_strides(dy)
+    t0 = _trace_begin()
     lib.call("pulpo_conv3d_k3_wgrad", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), _ptr(scratch), B, D, H, W, Cin, Cout, _stream())
+    _trace_end(t0, "conv3d_k3_wgrad_mfma(+memset,unpack)", 54.0 * Cin * Cout * B * D * H * W)
     return dw
 
 
