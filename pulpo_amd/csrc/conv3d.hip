@@ -6,11 +6,12 @@
 //
 // Data layout: activations are channels-last (N,D,H,W,C) with explicit batch/pixel/channel strides, so channel
 // slices of a concatenation buffer and planar 1-3 channel volumes go through the same kernels.
-// One workgroup = 256 threads = 4 waves (one per SIMD), 2 workgroups per CU.  A workgroup owns a 2x8x8 voxel tile;
-// the (4x10x10)-voxel halo of a 32-channel input chunk is staged once in LDS ([voxel][CH+1], odd stride ->
-// conflict-free ds_read_b32 for the A fragment) and re-used by all 27 taps; the 27 weight slabs stream through a
-// double-buffered LDS tile, prefetched global->registers one tap ahead.
+// One workgroup = 256 threads = 4 waves (one per SIMD), 4 workgroups per CU.  A workgroup owns a 2x8x8 voxel tile;
+// the (4x10x10)-voxel halo of a 16-channel input chunk is staged once in LDS ([voxel][CH+1], odd stride ->
+// conflict-free ds_read_b32 for the A fragment; all global loads of the tile issued back to back) and re-used by all
+// 27 taps; the 27 weight slabs stream through a double-buffered LDS tile, prefetched global->registers one tap ahead.
 #include "common.h"
+#include <stdlib.h>
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -31,6 +32,14 @@ struct ConvArgs {
     int ntz, nty, ntx, ncot;
 };
 
+// 64 bytes of zeros: source address of out-of-volume / out-of-channel lanes of an LDS-DMA piece
+__device__ float4 g_zero_page[4];
+
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS starting at the WAVE-UNIFORM address lds_piece
+__device__ __forceinline__ void dma16(const float* src, float* lds_piece) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+}
+
 __device__ __forceinline__ int tap_halo_offset(int tap) {
     return ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
 }
@@ -41,16 +50,29 @@ __device__ __forceinline__ void stage_halo(float* xs, const float* __restrict__ 
                                            int z0, int y0, int x0, int D, int H, int W, int tid) {
     constexpr int CP = CH + 1;
     if constexpr (VEC) {
+        // all loads of the tile are issued back to back (NIT float4 per thread in flight), then written to LDS:
+        // one exposed memory latency per chunk instead of one per loop iteration
         constexpr int Q = CH / 4;
-        for (int j = tid; j < HV * Q; j += 256) {
+        constexpr int NIT = (HV * Q + 255) / 256;
+        float4 v[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int j = tid + u * 256;
             const int hv = j / Q, q = j - hv * Q;
             const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
             const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c0 + 4 * q < Cin)
-                v = *reinterpret_cast<const float4*>(in + ((long)(gz * H + gy) * W + gx) * in_ps + c0 + 4 * q);
-            float* d = xs + hv * CP + 4 * q;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < HV * Q && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c0 + 4 * q < Cin)
+                v[u] = *reinterpret_cast<const float4*>(in + ((long)(gz * H + gy) * W + gx) * in_ps + c0 + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int j = tid + u * 256;
+            if (j < HV * Q) {
+                const int hv = j / Q, q = j - hv * Q;
+                float* d = xs + hv * CP + 4 * q;
+                d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+            }
         }
     } else {
         for (int j = tid; j < HV * CH; j += 256) {
@@ -132,6 +154,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(ConvArgs a) {
             if (it + 1 < niter) load_w(it + 1);
             const float* xa = xs + (hb + tap_halo_offset(tap)) * CP + kk;
             const float* wb = ws + buf * CH * NT + kk * NT + i;
+            // (fragment reads are left to hipcc's placement here: with 4 waves per SIMD the other waves cover each read's
+            //  latency, and forcing all reads of the tap ahead of its MFMAs measured ~8 % slower)
 #pragma unroll
             for (int s = 0; s < CH / 2; ++s) {
                 const float av = xa[2 * s];
@@ -221,14 +245,15 @@ struct WgradArgs {
     int ntz, nty, ntx, ncit, ncot, nsplit;
 };
 
-constexpr int WG_CH = 32, WG_NT = 32, WG_CP = WG_CH + 1, WG_MAXT = 7;
+constexpr int WG_CH = 32, WG_NT = 32, WG_CP = WG_CH + 1;
 
-template <bool VEC>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma(WgradArgs a) {
+// NTW = row tiles (32 (tap,ci) pairs each) per wave: 7 for a full 32-channel ci tile (27 tiles over 4 waves), fewer for
+// narrow inputs.  The MFMAs of the hot loop are unconditional (rows beyond the matrix are fed zeros), so the loop
+// body is one basic block and the compiler can run the LDS reads ahead of the matrix pipe.
+template <bool VEC, int NTW>
+__global__ __launch_bounds__(256, VEC ? 1 : 2) void conv3d_k3_wgrad_mfma(WgradArgs a) {
     constexpr int XS = (HV * WG_CP + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;
-    float* dys = smem + XS;       // [MV][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
@@ -238,21 +263,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma(WgradArgs a) {
     const int ci0 = cit * WG_CH, co0 = cot * WG_NT;
     const int Cc = min(WG_CH, a.Cin - ci0);
     const int rows = 27 * Cc;
-    const int nrt = (rows + 31) >> 5;                 // row tiles of 32 (tap,ci) pairs
+    const int nrt = (rows + 31) >> 5;                 // row tiles of 32 (tap,ci) pairs; host guarantees nrt <= 4 * NTW
     const int i = lane & 31, kk = lane >> 5;
+    constexpr int STR = VEC ? 32 : WG_CP;             // voxel stride of the halo image (DMA image is unpadded)
 
-    int rowoff[WG_MAXT];
-    bool rvalid[WG_MAXT];
+    int rowoff[NTW];
 #pragma unroll
-    for (int u = 0; u < WG_MAXT; ++u) {
+    for (int u = 0; u < NTW; ++u) {
         const int r = 32 * (wave + 4 * u) + i;
-        rvalid[u] = r < rows;
-        const int tap = rvalid[u] ? r / Cc : 0, ci = rvalid[u] ? r - tap * Cc : 0;
-        rowoff[u] = tap_halo_offset(tap) * WG_CP + ci;
+        const int tap = r < rows ? r / Cc : 0, ci = r < rows ? r - tap * Cc : 0;
+        rowoff[u] = tap_halo_offset(tap) * STR + ci;
     }
-    f32x16 acc[WG_MAXT];
+    f32x16 acc[NTW];
 #pragma unroll
-    for (int u = 0; u < WG_MAXT; ++u)
+    for (int u = 0; u < NTW; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
 
@@ -260,50 +284,123 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma(WgradArgs a) {
     const int per = (ntile + a.nsplit - 1) / a.nsplit;
     const int t_begin = split * per, t_end = min(ntile, t_begin + per);
 
-    for (int tl = t_begin; tl < t_end; ++tl) {
+    auto decode = [&](int tl, int& b, int& z0, int& y0, int& x0) {
         int t = tl;
         const int tx_ = t % a.ntx; t /= a.ntx;
         const int ty_ = t % a.nty; t /= a.nty;
         const int tz_ = t % a.ntz;
-        const int b = t / a.ntz;
-        const int z0 = tz_ * TZ, y0 = ty_ * TY, x0 = tx_ * TX;
-        __syncthreads();
-        stage_halo<WG_CH, VEC>(xs, a.in + (long)b * a.in_bs, a.in_ps, a.in_cs, ci0, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
-        {   // dY tile [MV][32]
-            const float* dyb = a.dy + (long)b * a.dy_bs;
-            if constexpr (VEC) {
-                for (int j = tid; j < MV * 8; j += 256) {
-                    const int vv = j >> 3, q = j & 7;
-                    const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
-                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (gz < a.D && gy < a.H && gx < a.W && co0 + 4 * q < a.Cout)
-                        val = *reinterpret_cast<const float4*>(dyb + ((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + co0 + 4 * q);
-                    *reinterpret_cast<float4*>(dys + vv * WG_NT + 4 * q) = val;
+        b = t / a.ntz;
+        z0 = tz_ * TZ; y0 = ty_ * TY; x0 = tx_ * TX;
+    };
+    // One "body" = 4 voxel-pair steps.  Rows beyond the matrix (last partial row tile, or a whole spare tile) read valid
+    // LDS words of tap 0 and accumulate garbage into accumulator rows that the flush never writes: MFMA rows are independent,
+    // so no masking is needed.
+    auto load_body = [&](float (&A)[4][NTW], float (&Bv)[4], const float* xs_c, const float* dys_c, int sb) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int vox = 2 * (sb * 4 + q4) + kk;
+            const int hbk = (((vox >> 6) * HY + ((vox >> 3) & 7)) * HX + (vox & 7)) * STR;
+            Bv[q4] = dys_c[vox * WG_NT + i];
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) A[q4][u] = xs_c[rowoff[u] + hbk];
+        }
+    };
+    auto mma_body = [&](const float (&A)[4][NTW], const float (&Bv)[4]) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q4][u], Bv[q4], acc[u], 0, 0, 0);
+    };
+    float A0[4][NTW], A1[4][NTW], B0[4], B1[4];       // register double buffer of the fragments
+
+    if constexpr (VEC) {
+        // LDS-DMA pipeline.  The A-operand lanes index consecutive (tap, ci) rows, so the halo image needs no padding
+        // ([halo voxel][32 ci], 128 B per voxel) and is filled by global_load_lds: no staging registers.  Two image sets
+        // (X 50 KiB + dY 16 KiB each) ping-pong: the 17 DMA pieces of tile t+1 are issued one per 4 voxel-pair steps inside
+        // the MFMA loop of tile t (their address arithmetic hides behind the matrix pipe) and are drained by the
+        // s_waitcnt vmcnt(0) + barrier at the tile boundary.
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const float* zero = reinterpret_cast<const float*>(g_zero_page);
+        int nb = 0, nz0 = 0, ny0 = 0, nx0 = 0;          // next tile
+        auto issue_piece = [&](int pc, float* xd) {     // pc in [0, 17): 0..12 halo pieces (13th only waves 0,1), 13..16 dY
+            if (pc < 13) {
+                if (pc < 12 || wave_u < 2) {
+                    const int j = tid + pc * 256;
+                    const int hv = j >> 3, q = j & 7;
+                    const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+                    const int gz = nz0 - 1 + hz, gy = ny0 - 1 + hy, gx = nx0 - 1 + hx;
+                    const bool ok = (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && ci0 + 4 * q < a.Cin;
+                    const float* src = ok ? a.in + (long)nb * a.in_bs + ((long)(gz * a.H + gy) * a.W + gx) * a.in_ps + ci0 + 4 * q : zero;
+                    dma16(src, xd + (wave_u + 4 * pc) * 256);
                 }
             } else {
-                for (int j = tid; j < MV * WG_NT; j += 256) {
-                    const int vv = j >> 5, c = j & 31;
-                    const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
-                    float val = 0.f;
-                    if (gz < a.D && gy < a.H && gx < a.W && co0 + c < a.Cout)
-                        val = dyb[((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + (long)(co0 + c) * a.dy_cs];
-                    dys[vv * WG_NT + c] = val;
+                const int u = pc - 13;
+                const int j = tid + u * 256;
+                const int vv = j >> 3, q = j & 7;
+                const int gz = nz0 + (vv >> 6), gy = ny0 + ((vv >> 3) & 7), gx = nx0 + (vv & 7);
+                const bool ok = gz < a.D && gy < a.H && gx < a.W && co0 + 4 * q < a.Cout;
+                const float* src = ok ? a.dy + (long)nb * a.dy_bs + ((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + co0 + 4 * q : zero;
+                dma16(src, xd + HV * 32 + (wave_u + 4 * u) * 256);
+            }
+        };
+        constexpr int SET = HV * 32 + MV * WG_NT;     // floats per image set
+        if (t_begin < t_end) {
+            decode(t_begin, nb, nz0, ny0, nx0);
+#pragma unroll
+            for (int pc = 0; pc < 17; ++pc) issue_piece(pc, smem);
+        }
+        int cur = 0;
+        for (int tl = t_begin; tl < t_end; ++tl, cur ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile tl have landed
+            __syncthreads();      // (a) everybody's pieces have landed  (b) everybody left the other image set
+            const bool more = tl + 1 < t_end;
+            if (more) decode(tl + 1, nb, nz0, ny0, nx0);
+            const float* xs_c = smem + cur * SET;
+            const float* dys_c = xs_c + HV * 32;
+            float* xnext = smem + (cur ^ 1) * SET;
+            load_body(A0, B0, xs_c, dys_c, 0);
+#pragma unroll 1
+            for (int sb = 0; sb < 16; sb += 2) {            // 16 bodies of 4 steps: 64 voxel pairs; fragments one body ahead
+                load_body(A1, B1, xs_c, dys_c, sb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) issue_piece(sb, xnext);
+                mma_body(A0, B0);
+                load_body(A0, B0, xs_c, dys_c, (sb + 2) & 15);   // (wraps to body 0 on the last trip: harmless re-read)
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    issue_piece(sb + 1, xnext);
+                    if (sb == 14) issue_piece(16, xnext);
                 }
+                mma_body(A1, B1);
             }
         }
-        __syncthreads();
-#pragma unroll 4
-        for (int s = 0; s < MV / 2; ++s) {
-            const int vox = 2 * s + kk;
-            const int hbk = (((vox >> 6) * HY + ((vox >> 3) & 7)) * HX + (vox & 7)) * WG_CP;
-            const float bv = dys[vox * WG_NT + i];
-#pragma unroll
-            for (int u = 0; u < WG_MAXT; ++u) {
-                if (wave + 4 * u < nrt) {
-                    float av = xs[rowoff[u] + hbk];
-                    av = rvalid[u] ? av : 0.f;
-                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u], 0, 0, 0);
-                }
+    } else {
+        float* xs = smem;
+        float* dys = smem + XS;
+        for (int tl = t_begin; tl < t_end; ++tl) {
+            int b, z0, y0, x0;
+            decode(tl, b, z0, y0, x0);
+            __syncthreads();
+            stage_halo<WG_CH, false>(xs, a.in + (long)b * a.in_bs, a.in_ps, a.in_cs, ci0, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+            const float* dyb = a.dy + (long)b * a.dy_bs;
+            for (int j = tid; j < MV * WG_NT; j += 256) {
+                const int vv = j >> 5, c = j & 31;
+                const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
+                float val = 0.f;
+                if (gz < a.D && gy < a.H && gx < a.W && co0 + c < a.Cout)
+                    val = dyb[((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + (long)(co0 + c) * a.dy_cs];
+                dys[vv * WG_NT + c] = val;
+            }
+            __syncthreads();
+            load_body(A0, B0, xs, dys, 0);
+#pragma unroll 1
+            for (int sb = 0; sb < 16; sb += 2) {
+                load_body(A1, B1, xs, dys, sb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_body(A0, B0);
+                load_body(A0, B0, xs, dys, (sb + 2) & 15);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_body(A1, B1);
             }
         }
     }
@@ -312,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma(WgradArgs a) {
     const int co = co0 + i;
     if (co < a.Cout) {
 #pragma unroll
-        for (int u = 0; u < WG_MAXT; ++u) {
+        for (int u = 0; u < NTW; ++u) {
             if (wave + 4 * u < nrt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -336,7 +433,9 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
     }
 }
 
-int pick_ch(int K) { return K <= 4 ? 4 : (K <= 16 ? 16 : 32); }
+// Cin chunk staged per pass: 16 channels (27 KB halo tile + 8 KB weight double buffer => 4 workgroups per CU; measured
+// faster than 32- and 8-channel chunks on MI355X), 4 for the 2-/3-channel input layers
+int pick_ch(int K) { return K <= 4 ? 4 : 16; }
 int npad(int N) { return (N + 63) & ~63; }
 
 template <int CH, int NT, bool VEC>
@@ -400,12 +499,8 @@ PULPO_API int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps,
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0) && CH >= 16;
     hipStream_t st = (hipStream_t)stream;
     if (CH == 4) return NT == 64 ? launch_conv<4, 64, false>(a, nblk, st) : launch_conv<4, 32, false>(a, nblk, st);
-    if (CH == 16) {
-        if (vec) return NT == 64 ? launch_conv<16, 64, true>(a, nblk, st) : launch_conv<16, 32, true>(a, nblk, st);
-        return NT == 64 ? launch_conv<16, 64, false>(a, nblk, st) : launch_conv<16, 32, false>(a, nblk, st);
-    }
-    if (vec) return NT == 64 ? launch_conv<32, 64, true>(a, nblk, st) : launch_conv<32, 32, true>(a, nblk, st);
-    return NT == 64 ? launch_conv<32, 64, false>(a, nblk, st) : launch_conv<32, 32, false>(a, nblk, st);
+    if (vec) return NT == 64 ? launch_conv<16, 64, true>(a, nblk, st) : launch_conv<16, 32, true>(a, nblk, st);
+    return NT == 64 ? launch_conv<16, 64, false>(a, nblk, st) : launch_conv<16, 32, false>(a, nblk, st);
 }
 
 PULPO_API int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W) {
@@ -430,27 +525,40 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
     a.ncit = pulpo::cdiv(Cin, WG_CH); a.ncot = pulpo::cdiv(Cout, WG_NT);
     const int ntile = B * a.ntz * a.nty * a.ntx;
     const int npair = a.ncit * a.ncot;
-    int nsplit = std::max(1, 1024 / npair);
+    const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)in & 15) == 0) &&
+                     (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
+    // DMA variant: one resident workgroup per CU -> one round of <= 256 persistent workgroups (fewest atomic flushes);
+    // scalar variant: two per CU
+    int nsplit = std::max(1, (vec ? 256 : 512) / npair);
     nsplit = std::min(nsplit, ntile);
     a.nsplit = nsplit;
     hipError_t e = hipMemsetAsync(scratch, 0, pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout) * sizeof(float), st);
     if (e != hipSuccess) return pulpo::fail((int)e, "wgrad memset: %s", hipGetErrorString(e));
-    const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)in & 15) == 0) &&
-                     (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
+    const int nrt_max = (27 * std::min(Cin, WG_CH) + 31) / 32;
+    const int ntw = (nrt_max + 3) / 4;                 // 1..7
     constexpr size_t lds = (size_t)(((HV * WG_CP + 3) & ~3) + MV * WG_NT) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_mfma<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_mfma<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e1 != hipSuccess || e2 != hipSuccess) return pulpo::fail((int)(e1 != hipSuccess ? e1 : e2), "hipFuncSetAttribute(wgrad)");
-        attr_set = true;
-    }
+    constexpr size_t lds_dma = (size_t)2 * (HV * 32 + MV * WG_NT) * sizeof(float);
     const int nblk = npair * nsplit;
-    if (vec) hipLaunchKernelGGL(conv3d_k3_wgrad_mfma<true>, dim3(nblk), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(conv3d_k3_wgrad_mfma<false>, dim3(nblk), dim3(256), lds, st, a);
-    int rc = pulpo::check_launch("conv3d_k3_wgrad_mfma");
+    int rc = 0;
+#define PULPO_WGRAD(VECV, NTWV)                                                                                                   \
+    {                                                                                                                             \
+        static bool attr = false;                                                                                                 \
+        const size_t bytes = VECV ? lds_dma : lds;                                                                                \
+        if (!attr) {                                                                                                              \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_mfma<VECV, NTWV>),                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                        \
+            if (ea != hipSuccess) return pulpo::fail((int)ea, "hipFuncSetAttribute(wgrad): %s", hipGetErrorString(ea));           \
+            attr = true;                                                                                                          \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((conv3d_k3_wgrad_mfma<VECV, NTWV>), dim3(nblk), dim3(256), bytes, st, a);                              \
+    }
+    if (vec) {
+        if (ntw <= 1) PULPO_WGRAD(true, 1) else if (ntw <= 2) PULPO_WGRAD(true, 2) else if (ntw <= 4) PULPO_WGRAD(true, 4) else PULPO_WGRAD(true, 7)
+    } else {
+        if (ntw <= 1) PULPO_WGRAD(false, 1) else if (ntw <= 2) PULPO_WGRAD(false, 2) else if (ntw <= 4) PULPO_WGRAD(false, 4) else PULPO_WGRAD(false, 7)
+    }
+#undef PULPO_WGRAD
+    rc = pulpo::check_launch("conv3d_k3_wgrad_mfma");
     if (rc) return rc;
     const long total = (long)Cout * Cin * 27;
     const int ub = (int)std::min<long>((total + 255) / 256, 4096);
