@@ -321,30 +321,34 @@ __global__ __launch_bounds__(256, VEC ? 1 : 2) void conv3d_k3_wgrad_mfma(WgradAr
         // s_waitcnt vmcnt(0) + barrier at the tile boundary.
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         const float* zero = reinterpret_cast<const float*>(g_zero_page);
-        int nb = 0, nz0 = 0, ny0 = 0, nx0 = 0;          // next tile
-        auto issue_piece = [&](int pc, float* xd) {     // pc in [0, 17): 0..12 halo pieces (13th only waves 0,1), 13..16 dY
+        constexpr int XIMG = 13 * 4 * 256;            // halo image padded to 52 DMA pieces (50 used): every piece is unconditional
+        constexpr int SET = XIMG + MV * WG_NT;        // floats per image set
+        int nb = 0, nz0 = 0, ny0 = 0, nx0 = 0;        // next tile
+        bool more = false;
+        // piece pc in [0, 17): 0..12 = halo (piece 12 of waves 2,3 is padding), 13..16 = dY.  Branch-free: lanes with nothing
+        // to fetch (out of volume / channel range / no next tile / padding) source the zero page.
+        auto issue_piece = [&](int pc, float* xd) {
             if (pc < 13) {
-                if (pc < 12 || wave_u < 2) {
-                    const int j = tid + pc * 256;
-                    const int hv = j >> 3, q = j & 7;
-                    const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
-                    const int gz = nz0 - 1 + hz, gy = ny0 - 1 + hy, gx = nx0 - 1 + hx;
-                    const bool ok = (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && ci0 + 4 * q < a.Cin;
-                    const float* src = ok ? a.in + (long)nb * a.in_bs + ((long)(gz * a.H + gy) * a.W + gx) * a.in_ps + ci0 + 4 * q : zero;
-                    dma16(src, xd + (wave_u + 4 * pc) * 256);
-                }
+                const int j = tid + pc * 256;
+                const int hv = j >> 3, q = j & 7;
+                const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+                const int gz = nz0 - 1 + hz, gy = ny0 - 1 + hy, gx = nx0 - 1 + hx;
+                const bool ok = more && hv < HV && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
+                                ci0 + 4 * q < a.Cin;
+                const float* src = ok ? a.in + (long)nb * a.in_bs + ((long)(gz * a.H + gy) * a.W + gx) * a.in_ps + ci0 + 4 * q : zero;
+                dma16(src, xd + (wave_u + 4 * pc) * 256);
             } else {
                 const int u = pc - 13;
                 const int j = tid + u * 256;
                 const int vv = j >> 3, q = j & 7;
                 const int gz = nz0 + (vv >> 6), gy = ny0 + ((vv >> 3) & 7), gx = nx0 + (vv & 7);
-                const bool ok = gz < a.D && gy < a.H && gx < a.W && co0 + 4 * q < a.Cout;
+                const bool ok = more && gz < a.D && gy < a.H && gx < a.W && co0 + 4 * q < a.Cout;
                 const float* src = ok ? a.dy + (long)nb * a.dy_bs + ((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + co0 + 4 * q : zero;
-                dma16(src, xd + HV * 32 + (wave_u + 4 * u) * 256);
+                dma16(src, xd + XIMG + (wave_u + 4 * u) * 256);
             }
         };
-        constexpr int SET = HV * 32 + MV * WG_NT;     // floats per image set
         if (t_begin < t_end) {
+            more = true;
             decode(t_begin, nb, nz0, ny0, nx0);
 #pragma unroll
             for (int pc = 0; pc < 17; ++pc) issue_piece(pc, smem);
@@ -353,27 +357,26 @@ __global__ __launch_bounds__(256, VEC ? 1 : 2) void conv3d_k3_wgrad_mfma(WgradAr
         for (int tl = t_begin; tl < t_end; ++tl, cur ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile tl have landed
             __syncthreads();      // (a) everybody's pieces have landed  (b) everybody left the other image set
-            const bool more = tl + 1 < t_end;
+            more = tl + 1 < t_end;
             if (more) decode(tl + 1, nb, nz0, ny0, nx0);
             const float* xs_c = smem + cur * SET;
-            const float* dys_c = xs_c + HV * 32;
+            const float* dys_c = xs_c + XIMG;
             float* xnext = smem + (cur ^ 1) * SET;
             load_body(A0, B0, xs_c, dys_c, 0);
-#pragma unroll 1
-            for (int sb = 0; sb < 16; sb += 2) {            // 16 bodies of 4 steps: 64 voxel pairs; fragments one body ahead
+#pragma unroll
+            for (int sb = 0; sb < 16; sb += 2) {            // fully unrolled: 16 bodies of 4 steps, fragments one body ahead
                 load_body(A1, B1, xs_c, dys_c, sb + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) issue_piece(sb, xnext);
+                issue_piece(sb, xnext);
                 mma_body(A0, B0);
                 load_body(A0, B0, xs_c, dys_c, (sb + 2) & 15);   // (wraps to body 0 on the last trip: harmless re-read)
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-                    issue_piece(sb + 1, xnext);
-                    if (sb == 14) issue_piece(16, xnext);
-                }
+                issue_piece(sb + 1, xnext);
+                if (sb == 14) issue_piece(16, xnext);
                 mma_body(A1, B1);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the (zero-sourced) pieces issued during the last tile
     } else {
         float* xs = smem;
         float* dys = smem + XS;
@@ -537,7 +540,7 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
     const int nrt_max = (27 * std::min(Cin, WG_CH) + 31) / 32;
     const int ntw = (nrt_max + 3) / 4;                 // 1..7
     constexpr size_t lds = (size_t)(((HV * WG_CP + 3) & ~3) + MV * WG_NT) * sizeof(float);
-    constexpr size_t lds_dma = (size_t)2 * (HV * 32 + MV * WG_NT) * sizeof(float);
+    constexpr size_t lds_dma = (size_t)2 * (13 * 4 * 256 + MV * WG_NT) * sizeof(float);
     const int nblk = npair * nsplit;
     int rc = 0;
 #define PULPO_WGRAD(VECV, NTWV)                                                                                                   \
