@@ -50,22 +50,25 @@ int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps, int64_t i
 /* weight gradient: dw[Cout][Cin][27] = sum_voxels in[v + tap - 1][ci] * dy[v][co]; scratch is overwritten */
 size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
 int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs, int64_t dy_ps,
-                          int64_t dy_cs, float* dw, float* scratch, int B, int D, int H, int W, int Cin, int Cout, void* stream);
+                          int64_t dy_cs, float* dw, int accumulate /*dw += instead of dw =*/, float* scratch, int B, int D, int H, int W, int Cin,
+                          int Cout, void* stream);
 
 /* ------------------------------------------------------------- ConvUnit: BatchNorm3d + LeakyReLU(0.2, inplace)
  * replaces nn.BatchNorm3d / nn.LeakyReLU (src/network_blocks.py:24-25) = aten::native_batch_norm(+_backward),
  * aten::leaky_relu_(+_backward).  coef = 8*C floats: [4][C] floats (mean, rstd, scale = gamma*rstd, shift = beta - mean*scale)
  * followed by [2][C] doubles (mean, rstd): the backward carries the per-channel means in double, as ATen's CPU kernels do. */
-int pulpo_colsum(const float* partials, int nrow, int ncol, float* out, float scale, void* stream);
+int pulpo_colsum(const float* partials, int nrow, int ncol, float* out, float scale, int accumulate, void* stream);
+size_t pulpo_bn_fwd_finalize_scratch_doubles(int ntile, int C);
 int pulpo_bn_fwd_finalize(const float* stats, int ntile, int C, double count, const float* gamma, const float* beta, float* running_mean,
-                          float* running_var, float momentum, float eps, float* coef, void* stream);
+                          float* running_var, int64_t* num_batches_tracked /*nullable, += 1*/, float momentum, float eps, float* coef,
+                          double* scratch, void* stream);
 int pulpo_bn_eval_coef(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
                        float* coef, void* stream);
 int pulpo_bn_lrelu_apply(const float* y, int64_t yps, float* z, int64_t zps, const float* coef, int64_t npix, int C, float slope, void* stream);
 int pulpo_bn_bwd_blocks(int64_t npix, int C);
 int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, int64_t npix, int C, float slope,
                               float* partial /*[blocks][2C]*/, void* stream);
-int pulpo_bn_bwd_finalize(const float* partial, int nrow, int C, double count, int use_means, float* grads /*[2C]: dbeta|dgamma*/,
+int pulpo_bn_bwd_finalize(const float* partial, int nrow, int C, double count, int use_means, float* dbeta, float* dgamma, int accumulate,
                           double* totd /*[2C]: mean(dbn) | mean(dbn*xhat)*/, void* stream);
 int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd, float* dy,
                              int64_t dyps, int64_t npix, int C, float slope, float* partial2 /*[blocks][C]*/, void* stream);

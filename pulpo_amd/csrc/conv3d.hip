@@ -427,12 +427,13 @@ __global__ __launch_bounds__(256, VEC ? 1 : 2) void conv3d_k3_wgrad_mfma(WgradAr
     }
 }
 
-__global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cin, int Cout, int NPad, long total) {
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cin, int Cout, int NPad, long total, int accumulate) {
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int tap = (int)(e % 27);
         const long r = e / 27;
         const int ci = (int)(r % Cin), co = (int)(r / Cin);
-        dw[e] = dwp[((long)tap * Cin + ci) * NPad + co];
+        const float val = dwp[((long)tap * Cin + ci) * NPad + co];
+        dw[e] = accumulate ? dw[e] + val : val;
     }
 }
 
@@ -512,10 +513,11 @@ PULPO_API int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W) {
 
 PULPO_API size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout) { return (size_t)27 * Cin * npad(Cout); }
 
-// dw[Cout][Cin][27] = sum_vox in[vox+tap-1][ci] * dy[vox][co].   scratch: pulpo_conv3d_k3_wgrad_scratch_floats floats.
+// dw[Cout][Cin][27] (+)= sum_vox in[vox+tap-1][ci] * dy[vox][co]  (accumulate != 0 adds to dw, e.g. a parameter's .grad storage).
+// scratch: pulpo_conv3d_k3_wgrad_scratch_floats floats.
 PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
-                                    int64_t dy_ps, int64_t dy_cs, float* dw, float* scratch, int B, int D, int H, int W, int Cin,
-                                    int Cout, void* stream) {
+                                    int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, int B, int D, int H, int W,
+                                    int Cin, int Cout, void* stream) {
     PULPO_REQUIRE(in && dy && dw && scratch, "conv3d_k3_wgrad: null pointer");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3d_k3_wgrad: bad dims");
     hipStream_t st = (hipStream_t)stream;
@@ -565,6 +567,6 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
     if (rc) return rc;
     const long total = (long)Cout * Cin * 27;
     const int ub = (int)std::min<long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ub), dim3(256), 0, st, scratch, dw, Cin, Cout, a.NPad, total);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ub), dim3(256), 0, st, scratch, dw, Cin, Cout, a.NPad, total, accumulate);
     return pulpo::check_launch("unpack_wgrad");
 }

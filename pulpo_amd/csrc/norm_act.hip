@@ -10,7 +10,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------- column sums
 // out[c] = sum_r partials[r][c]   (r < nrow), accumulated in double.  grid = ceil(ncol/32), block = (32, 32)
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ partials, int nrow, int ncol, float* __restrict__ out,
-                                                        float scale) {
+                                                        float scale, int accumulate) {
     __shared__ double red[32][33];
     const int cx = threadIdx.x, ry = threadIdx.y;
     const int c = blockIdx.x * 32 + cx;
@@ -23,27 +23,55 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 32; ++k) t += red[k][cx];
-        out[c] = (float)(t * (double)scale);
+        const float r = (float)(t * (double)scale);
+        out[c] = accumulate ? out[c] + r : r;
     }
 }
 
-// stats[ntile][2][C] (sum, sumsq of conv output) -> coef[4][C] = mean, rstd, scale, shift ; running stats update
-__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(const float* __restrict__ stats, int ntile, int C, double count,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+// stage 1 (large tile counts only): slice-wise double-precision column sums  part[S][ncol],  grid = (ceil(ncol/32), S)
+__global__ __launch_bounds__(1024) void colsum_slices_kernel(const float* __restrict__ rows, int nrow, int ncol, double* __restrict__ part) {
+    __shared__ double red[32][33];
+    const int cx = threadIdx.x, ry = threadIdx.y;
+    const int c = blockIdx.x * 32 + cx;
+    const int S = gridDim.y, sl = blockIdx.y;
+    double s = 0.0;
+    if (c < ncol)
+        for (int r = sl * 32 + ry; r < nrow; r += 32 * S) s += (double)rows[(long)r * ncol + c];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < ncol) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += red[k][cx];
+        part[(long)sl * ncol + c] = t;
+    }
+}
+
+// stats (fp32 tile partials [ntile][2][C], or - when part != nullptr - their double slice sums [nslice][2][C])
+//   -> coef = [4][C] floats (mean, rstd, scale, shift) + [2][C] doubles (mean, rstd); running statistics update
+__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(const float* __restrict__ stats, const double* __restrict__ part, int nrow, int C,
+                                                                 double count, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                                 float momentum, float eps, float* __restrict__ coef) {
+                                                                 long long* __restrict__ num_batches_tracked, float momentum, float eps,
+                                                                 float* __restrict__ coef) {
     __shared__ double red[2][32][33];
     const int cx = threadIdx.x, ry = threadIdx.y;
     const int c = blockIdx.x * 32 + cx;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int r = ry; r < ntile; r += 32) {
-            s += (double)stats[((long)r * 2 + 0) * C + c];
-            q += (double)stats[((long)r * 2 + 1) * C + c];
+        for (int r = ry; r < nrow; r += 32) {
+            if (part != nullptr) {
+                s += part[((long)r * 2 + 0) * C + c];
+                q += part[((long)r * 2 + 1) * C + c];
+            } else {
+                s += (double)stats[((long)r * 2 + 0) * C + c];
+                q += (double)stats[((long)r * 2 + 1) * C + c];
+            }
         }
     red[0][ry][cx] = s;
     red[1][ry][cx] = q;
     __syncthreads();
+    if (blockIdx.x == 0 && cx == 0 && ry == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;
     if (ry == 0 && c < C) {
         double ts = 0.0, tq = 0.0;
 #pragma unroll
@@ -225,7 +253,8 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __
 // partial[nblk][2C] -> grads[2C] = (dbeta | dgamma) as floats, totd[2C] = (mean dbn | mean dbn*xhat) as doubles.
 // use_means == 0 (eval-mode BatchNorm is a fixed affine map): totd = 0.
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nrow, int C, double count, int use_means,
-                                                                 float* __restrict__ grads, double* __restrict__ totd) {
+                                                                 float* __restrict__ dbeta, float* __restrict__ dgamma, int accumulate,
+                                                                 double* __restrict__ totd) {
     __shared__ double red[32][33];
     const int cx = threadIdx.x, ry = threadIdx.y;
     const int c = blockIdx.x * 32 + cx;          // column in [0, 2C)
@@ -238,7 +267,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 32; ++k) t += red[k][cx];
-        grads[c] = (float)t;
+        float* dst = c < C ? dbeta + c : dgamma + (c - C);
+        *dst = accumulate ? *dst + (float)t : (float)t;
         totd[c] = use_means ? t / count : 0.0;
     }
 }
@@ -250,17 +280,34 @@ inline int stream_blocks(long items) { return (int)std::max<long>(1, std::min<lo
 
 }  // namespace
 
-PULPO_API int pulpo_colsum(const float* partials, int nrow, int ncol, float* out, float scale, void* stream) {
+// out[c] (+)= scale * sum_r partials[r][c];  accumulate != 0 adds to the existing value (gradient accumulation into a .grad)
+PULPO_API int pulpo_colsum(const float* partials, int nrow, int ncol, float* out, float scale, int accumulate, void* stream) {
     PULPO_REQUIRE(partials && out && nrow > 0 && ncol > 0, "colsum: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3(pulpo::cdiv(ncol, 32)), dim3(32, 32), 0, (hipStream_t)stream, partials, nrow, ncol, out, scale);
+    hipLaunchKernelGGL(colsum_kernel, dim3(pulpo::cdiv(ncol, 32)), dim3(32, 32), 0, (hipStream_t)stream, partials, nrow, ncol, out, scale, accumulate);
     return pulpo::check_launch("colsum");
 }
 
+PULPO_API size_t pulpo_bn_fwd_finalize_scratch_doubles(int ntile, int C) { return ntile > 2048 ? (size_t)32 * 2 * C : 0; }
+
+// scratch: pulpo_bn_fwd_finalize_scratch_doubles(ntile, C) doubles (may be NULL when that is 0).
+// num_batches_tracked (nullable): int64 counter of nn.BatchNorm3d, incremented here.
 PULPO_API int pulpo_bn_fwd_finalize(const float* stats, int ntile, int C, double count, const float* gamma, const float* beta,
-                                    float* running_mean, float* running_var, float momentum, float eps, float* coef, void* stream) {
+                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                                    float* coef, double* scratch, void* stream) {
     PULPO_REQUIRE(stats && gamma && beta && coef && ntile > 0 && C > 0 && count > 0, "bn_fwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(pulpo::cdiv(C, 32)), dim3(32, 32), 0, (hipStream_t)stream, stats, ntile, C, count, gamma,
-                       beta, running_mean, running_var, momentum, eps, coef);
+    hipStream_t st = (hipStream_t)stream;
+    const double* part = nullptr;
+    int nrow = ntile;
+    if (ntile > 2048) {
+        PULPO_REQUIRE(scratch != nullptr, "bn_fwd_finalize: scratch required for %d tiles", ntile);
+        hipLaunchKernelGGL(colsum_slices_kernel, dim3(pulpo::cdiv(2 * C, 32), 32), dim3(32, 32), 0, st, stats, ntile, 2 * C, scratch);
+        int rc = pulpo::check_launch("bn stats slices");
+        if (rc) return rc;
+        part = scratch;
+        nrow = 32;
+    }
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(pulpo::cdiv(C, 32)), dim3(32, 32), 0, st, stats, part, nrow, C, count, gamma, beta,
+                       running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, coef);
     return pulpo::check_launch("bn_fwd_finalize");
 }
 
@@ -305,10 +352,12 @@ PULPO_API int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const flo
     return pulpo::check_launch("bn_lrelu_bwd_reduce");
 }
 
-PULPO_API int pulpo_bn_bwd_finalize(const float* partial, int nrow, int C, double count, int use_means, float* grads, double* totd, void* stream) {
-    PULPO_REQUIRE(partial && grads && totd && nrow > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
+// dbeta / dgamma: [C] each, written (accumulate = 0) or added to (accumulate = 1, e.g. the parameters' .grad storage)
+PULPO_API int pulpo_bn_bwd_finalize(const float* partial, int nrow, int C, double count, int use_means, float* dbeta, float* dgamma, int accumulate,
+                                    double* totd, void* stream) {
+    PULPO_REQUIRE(partial && dbeta && dgamma && totd && nrow > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pulpo::cdiv(2 * C, 32)), dim3(32, 32), 0, (hipStream_t)stream, partial, nrow, C, count, use_means,
-                       grads, totd);
+                       dbeta, dgamma, accumulate, totd);
     return pulpo::check_launch("bn_bwd_finalize");
 }
 

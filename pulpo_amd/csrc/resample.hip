@@ -207,42 +207,33 @@ __global__ __launch_bounds__(256) void feedback_fwd_kernel(FeedbackArgs a, float
     }
 }
 
-// gsrc_s[b][c][coarse voxel] = sum over fine contributors of w * gout[b][fine][choff_s + c]   (deterministic gather)
+// gsrc_s[b][c][coarse voxel] = sum over the <= 4x4x4 fine contributors of w * gout[b][fine][choff_s + c]   (deterministic gather).
+// One thread per (coarse voxel, channel): 16 consecutive lanes read one 64-byte channel vector of a fine voxel.
 __global__ __launch_bounds__(256) void feedback_bwd_kernel(FeedbackArgs a, const float* __restrict__ gout, long gops) {
     const int Do = 2 * a.Di, Ho = 2 * a.Hi, Wo = 2 * a.Wi;
     const long Vi = (long)a.Di * a.Hi * a.Wi;
-    const long total = (long)a.B * Vi;
+    const int CT = a.ctot;
+    const long total = (long)a.B * Vi * CT;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        long p = e;
+        const int cc = (int)(e % CT);
+        long p = e / CT;
+        const long v = p % Vi;
         const int x = (int)(p % a.Wi); p /= a.Wi;
         const int y = (int)(p % a.Hi); p /= a.Hi;
         const int z = (int)(p % a.Di);
         const int b = (int)(p / a.Di);
-        float acc[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        float acc = 0.f;
         for (int oz = max(2 * z - 1, 0); oz <= min(2 * z + 2, Do - 1); ++oz) {
             const float wz = up2_weight(oz, z, a.Di);
             for (int oy = max(2 * y - 1, 0); oy <= min(2 * y + 2, Ho - 1); ++oy) {
                 const float wzy = wz * up2_weight(oy, y, a.Hi);
-                for (int ox = max(2 * x - 1, 0); ox <= min(2 * x + 2, Wo - 1); ++ox) {
-                    const float w = wzy * up2_weight(ox, x, a.Wi);
-                    const float* g = gout + ((((long)b * Do + oz) * Ho + oy) * Wo + ox) * gops;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        if (k < a.ctot) acc[k] += w * g[k];
-                }
+                for (int ox = max(2 * x - 1, 0); ox <= min(2 * x + 2, Wo - 1); ++ox)
+                    acc += wzy * up2_weight(ox, x, a.Wi) * gout[((((long)b * Do + oz) * Ho + oy) * Wo + ox) * gops + cc];
             }
         }
-        const long v = e - (long)b * Vi;
-        int cc = 0;
-        for (int s = 0; s < a.nsrc; ++s)
-            for (int c = 0; c < a.ch[s]; ++c, ++cc) {
-                float val = 0.f;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) val = (k == cc) ? acc[k] : val;
-                if (a.gsrc[s] != nullptr) a.gsrc[s][((long)b * a.ch[s] + c) * Vi + v] = val;
-            }
+        int s = 0, c = cc;                       // which source / channel within it
+        while (c >= a.ch[s]) { c -= a.ch[s]; ++s; }
+        if (a.gsrc[s] != nullptr) a.gsrc[s][((long)b * a.ch[s] + c) * Vi + v] = acc;
     }
 }
 
@@ -318,6 +309,6 @@ PULPO_API int pulpo_feedback_up2_bwd(const float* gout, int64_t gops, float* con
     a.nsrc = nsrc; a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi;
     for (int i = 0; i < nsrc; ++i) { a.gsrc[i] = gsrcs[i]; a.ch[i] = chans[i]; a.ctot += chans[i]; }
     PULPO_REQUIRE(a.ctot <= 16, "feedback_up2_bwd: more than 16 feedback channels");
-    hipLaunchKernelGGL(feedback_bwd_kernel, dim3(eblocks((long)B * Di * Hi * Wi)), dim3(256), 0, (hipStream_t)stream, a, gout, (long)gops);
+    hipLaunchKernelGGL(feedback_bwd_kernel, dim3(eblocks((long)B * Di * Hi * Wi * a.ctot)), dim3(256), 0, (hipStream_t)stream, a, gout, (long)gops);
     return pulpo::check_launch("feedback_up2_bwd");
 }

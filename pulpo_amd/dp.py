@@ -99,9 +99,14 @@ class DataParallelStepper:
                     dist.broadcast(b, src=0)
 
     def step(self, batch) -> torch.Tensor:
+        from . import ops
         self.arena.zero_grad()
         loss = self.model.training_step(batch, 0)
-        loss.backward()
+        ops.DIRECT_PARAM_GRADS = True          # conv / BN backward kernels add straight into the arena's .grad views
+        try:
+            loss.backward()
+        finally:
+            ops.DIRECT_PARAM_GRADS = False
         allreduce_sum_(self.arena.grad)
         self.opt.step(1.0 / world())
         return loss.detach()

@@ -52,11 +52,10 @@ class ConvUnit(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         conv, bn = self._op[0], self._op[1]
         use_batch_stats = self.training or bn.running_mean is None
-        out = ops.conv_bn_lrelu(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                training=use_batch_stats, momentum=bn.momentum, eps=bn.eps)
-        if self.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-        return out
+        # running statistics and num_batches_tracked are updated inside the BatchNorm finalize kernel
+        return ops.conv_bn_lrelu(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                 training=use_batch_stats, momentum=bn.momentum, eps=bn.eps,
+                                 num_batches_tracked=bn.num_batches_tracked if self.training else None)
 
 
 class ConvSequence(nn.Module):

@@ -79,10 +79,29 @@ def planar(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _colsum(partials: torch.Tensor, nrow: int, ncol: int, scale: float = 1.0) -> torch.Tensor:
+def _colsum(partials: torch.Tensor, nrow: int, ncol: int, scale: float = 1.0, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """column sums of [nrow][ncol] fp32 partials (double accumulation); `into` -> added to that tensor in place, returns None"""
+    if into is not None:
+        lib.call("pulpo_colsum", _ptr(partials), nrow, ncol, _ptr(into), scale, 1, _stream())
+        return None
     out = torch.empty(ncol, device=partials.device, dtype=torch.float32)
-    lib.call("pulpo_colsum", _ptr(partials), nrow, ncol, _ptr(out), scale, _stream())
+    lib.call("pulpo_colsum", _ptr(partials), nrow, ncol, _ptr(out), scale, 0, _stream())
     return out
+
+
+# When True (set by dp.DataParallelStepper, which always drives autograd through .backward() on arena-backed parameters),
+# the conv / BatchNorm backward kernels add parameter gradients straight into the parameters' existing .grad storage and
+# hand `None` to autograd: no per-parameter temporary, no AccumulateGrad add kernel (~170 tiny launches per step).
+DIRECT_PARAM_GRADS = False
+
+
+def _grad_slot(p: torch.Tensor) -> Optional[torch.Tensor]:
+    if not DIRECT_PARAM_GRADS:
+        return None
+    g = getattr(p, "grad", None)
+    if g is None or not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+        return None
+    return g
 
 
 # ------------------------------------------------------------------------------------------------ conv 3x3x3
@@ -128,23 +147,25 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
         _trace_end(t0, f"conv3d_k3_mfma<{cfg // 1000},{cfg % 1000},{'true' if vec else 'false'}>", 54.0 * K * N * B * D * H * W)
 
 
-def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int) -> torch.Tensor:
+def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """weight gradient; `into` -> accumulated into that (Cout,Cin,3,3,3) tensor in place, returns None"""
     B, _, D, H, W = x.shape
-    dw = torch.empty((Cout, Cin, 3, 3, 3), device=x.device, dtype=torch.float32)
+    dw = into if into is not None else torch.empty((Cout, Cin, 3, 3, 3), device=x.device, dtype=torch.float32)
     scratch = torch.empty(lib.query("pulpo_conv3d_k3_wgrad_scratch_floats", Cin, Cout), device=x.device, dtype=torch.float32)
     xb, xp, xc = grid_strides(x)
     db, dp, dc = grid_strides(dy)
     t0 = _trace_begin()
-    lib.call("pulpo_conv3d_k3_wgrad", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), _ptr(scratch), B, D, H, W, Cin, Cout, _stream())
+    lib.call("pulpo_conv3d_k3_wgrad", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), int(into is not None), _ptr(scratch), B, D, H, W,
+             Cin, Cout, _stream())
     _trace_end(t0, "conv3d_k3_wgrad_mfma(+memset,unpack)", 54.0 * Cin * Cout * B * D * H * W)
-    return dw
+    return None if into is not None else dw
 
 
 class _ConvBNLReLU(torch.autograd.Function):
     """ConvUnit: Conv3d(k3,p1,bias) -> BatchNorm3d -> LeakyReLU(0.2)   (reference src/network_blocks.py:22-26)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training: bool, momentum: float, eps: float):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool, momentum: float, eps: float):
         _require_gpu(x, weight, bias, gamma, beta)
         x = as_grid(x)
         B, Cin, D, H, W = x.shape
@@ -157,8 +178,10 @@ class _ConvBNLReLU(torch.autograd.Function):
             ntile = lib.query("pulpo_conv3d_k3_stat_tiles", B, D, H, W)
             stats = torch.empty(ntile * 2 * Cout, device=dev, dtype=torch.float32)
             _conv_raw(x, wp, bias, y, Cin, Cout, stats)
+            nsd = lib.query("pulpo_bn_fwd_finalize_scratch_doubles", ntile, Cout)
+            scratch = torch.empty(nsd, device=dev, dtype=torch.float64) if nsd else None
             lib.call("pulpo_bn_fwd_finalize", _ptr(stats), ntile, Cout, float(B * D * H * W), _ptr(gamma), _ptr(beta), _ptr(running_mean),
-                     _ptr(running_var), momentum, eps, _ptr(coef), _stream())
+                     _ptr(running_var), _ptr(num_batches_tracked), momentum, eps, _ptr(coef), _ptr(scratch), _stream())
         else:
             _conv_raw(x, wp, bias, y, Cin, Cout, None)
             lib.call("pulpo_bn_eval_coef", _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps, Cout, _ptr(coef), _stream())
@@ -166,6 +189,7 @@ class _ConvBNLReLU(torch.autograd.Function):
         lib.call("pulpo_bn_lrelu_apply", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
         ctx.save_for_backward(x, weight, y, coef)
         ctx.training = training
+        ctx.params = (weight, bias, gamma, beta)      # for DIRECT_PARAM_GRADS (their .grad slots)
         return z
 
     @staticmethod
@@ -179,27 +203,35 @@ class _ConvBNLReLU(torch.autograd.Function):
         nblk = lib.query("pulpo_bn_bwd_blocks", npix, Cout)
         part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
         lib.call("pulpo_bn_lrelu_bwd_reduce", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE, _ptr(part), _stream())
-        tot = torch.empty(2 * Cout, device=dev, dtype=torch.float32)           # dbeta | dgamma
+        w_p, b_p, g_p, be_p = ctx.params
+        slot_w, slot_b, slot_g, slot_be = (_grad_slot(t) if need else None
+                                           for t, need in zip((w_p, b_p, g_p, be_p), ctx.needs_input_grad[1:5]))
+        direct_bn = slot_g is not None and slot_be is not None
+        tot = None if direct_bn else torch.empty(2 * Cout, device=dev, dtype=torch.float32)           # dbeta | dgamma
         totd = torch.empty(2 * Cout, device=dev, dtype=torch.float64)          # mean(dbn) | mean(dbn * xhat), kept in double
         # eval-mode BatchNorm is a fixed affine map (dy = scale * dbn): the batch means do not enter
-        lib.call("pulpo_bn_bwd_finalize", _ptr(part), nblk, Cout, float(npix), int(ctx.training), _ptr(tot), _ptr(totd), _stream())
+        lib.call("pulpo_bn_bwd_finalize", _ptr(part), nblk, Cout, float(npix), int(ctx.training),
+                 _ptr(slot_be if direct_bn else tot), _ptr(slot_g) if direct_bn else ctypes.c_void_p(tot.data_ptr() + 4 * Cout), int(direct_bn),
+                 _ptr(totd), _stream())
         dy = new_cl(B, Cout, D, H, W, dev)
         part2 = torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
         lib.call("pulpo_bn_lrelu_bwd_apply", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4), npix, Cout,
                  LRELU_SLOPE, _ptr(part2), _stream())
-        dbias = _colsum(part2, nblk, Cout)
-        dbeta, dgamma = tot[:Cout], tot[Cout:]
-        dw = _wgrad_raw(x, dy, Cin, Cout) if ctx.needs_input_grad[1] else None
+        dbias = _colsum(part2, nblk, Cout, into=slot_b) if ctx.needs_input_grad[2] else None
+        dbeta, dgamma = (None, None) if direct_bn else (tot[:Cout], tot[Cout:])
+        dw = _wgrad_raw(x, dy, Cin, Cout, into=slot_w) if ctx.needs_input_grad[1] else None
         dx = None
         if ctx.needs_input_grad[0]:
             wpt = _pack_weight(weight, dgrad=True)
             dx = torch.empty_like(x) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, dev)
             _conv_raw(dy, wpt, None, dx, Cout, Cin, None)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
-def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5):
-    return _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps))
+def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None):
+    """ConvUnit forward.  In training mode running_mean / running_var / num_batches_tracked are updated in place by the kernel."""
+    return _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
+                              float(eps))
 
 
 class _Conv3dK3(torch.autograd.Function):
