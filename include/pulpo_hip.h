@@ -45,8 +45,10 @@ size_t pulpo_conv3d_k3_packed_floats(int K, int N);
 int pulpo_conv3d_k3_pack_weight(const float* w /*[Cout][Cin][3][3][3]*/, float* wp, int Cin, int Cout, int dgrad, void* stream);
 int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W);
 int pulpo_conv3d_k3_tile_config(int K, int N); /* CH*1000 + NT of the kernel instantiation used (for profiling) */
+size_t pulpo_conv3d_k3_fwd_scratch_floats(int B, int D, int H, int W, int K, int N); /* > 0 for small volumes (deterministic split-K) */
 int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, float* out,
-                        int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W, int K, int N, void* stream);
+                        int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch /*nullable if the query is 0*/, int B,
+                        int D, int H, int W, int K, int N, void* stream);
 /* weight gradient: dw[Cout][Cin][27] = sum_voxels in[v + tap - 1][ci] * dy[v][co]; scratch is overwritten */
 size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
 int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs, int64_t dy_ps,

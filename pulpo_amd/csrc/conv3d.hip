@@ -30,6 +30,8 @@ struct ConvArgs {
     float* stats;                 // nullable: [voxel tile][2][Cout]  (sum, sum of squares of conv+bias)
     int B, D, H, W, Cin, Cout, NPad;
     int ntz, nty, ntx, ncot;
+    int ksplit;                   // > 1: the Cin chunks are split over ksplit workgroups, each storing a partial slab into `part`
+    float* part;                  // [ksplit][B*V][Cout] dense partial outputs (reduced in fixed order by splitk_reduce_kernel)
 };
 
 // 64 bytes of zeros: source address of out-of-volume / out-of-channel lanes of an LDS-DMA piece
@@ -99,7 +101,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(ConvArgs a) {
     float* ws = smem + XS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
+    const int lid0 = pulpo::xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid0 % a.ksplit;          // splits of one tile are neighbours: they share the halo in L2
+    const int lid = lid0 / a.ksplit;
     const int cot = lid % a.ncot;
     const int tile_lin = lid / a.ncot;
     int t = tile_lin;
@@ -109,8 +113,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(ConvArgs a) {
     const int b = t / a.ntz;
     const int z0 = tz_ * TZ, y0 = ty_ * TY, x0 = tx_ * TX;
     const int co0 = cot * NT;
-    const int nchunk = (a.Cin + CH - 1) / CH;
-    const int niter = nchunk * 27;
+    const int nchunk_all = (a.Cin + CH - 1) / CH;
+    const int cper = (nchunk_all + a.ksplit - 1) / a.ksplit;
+    const int chunk0 = split * cper, chunk1 = min(nchunk_all, chunk0 + cper);
+    const int it0 = chunk0 * 27, niter = chunk1 * 27;
     const float* in_b = a.in + (long)b * a.in_bs;
 
     // weight slab prefetch registers
@@ -143,9 +149,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
-    load_w(0);
-    int buf = 0, it = 0;
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
+    if (chunk0 < chunk1) load_w(it0);
+    int buf = 0, it = it0;
+    for (int chunk = chunk0; chunk < chunk1; ++chunk) {
         __syncthreads();   // every wave is done reading xs (previous chunk)
         stage_halo<CH, VEC>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
         for (int tap = 0; tap < 27; ++tap, ++it) {
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(ConvArgs a) {
     for (int n = 0; n < NN; ++n) {
         const int co = co0 + n * 32 + i;
         const bool cok = co < a.Cout;
-        const float bv = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
+        const float bv = (a.bias != nullptr && cok && split == 0) ? a.bias[co] : 0.f;
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -185,7 +191,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(ConvArgs a) {
             const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
             if (cok && gz < a.D && gy < a.H && gx < a.W) {
                 const float val = acc[n][r] + bv;
-                out_b[((long)(gz * a.H + gy) * a.W + gx) * a.out_ps + (long)co * a.out_cs] = val;
+                const long vox = (long)(gz * a.H + gy) * a.W + gx;
+                if (a.ksplit > 1) a.part[(((long)split * a.B + b) * a.D * a.H * a.W + vox) * a.Cout + co] = val;   // this split's partial sum
+                else out_b[vox * a.out_ps + (long)co * a.out_cs] = val;
                 s += val;
                 q += val * val;
             }
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(ConvArgs a) {
         ssum[n] = s + __shfl_xor(s, 32, 64);
         ssq[n] = q + __shfl_xor(q, 32, 64);
     }
-    if (a.stats != nullptr) {
+    if (a.stats != nullptr && a.ksplit == 1) {
         __syncthreads();               // ws no longer read by any wave
         float* red = ws;               // [4 waves][2][NT]
         if (lane < 32) {
@@ -211,6 +219,40 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(ConvArgs a) {
                                   red[(3 * 2 + which) * NT + c];
                 a.stats[((long)tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
             }
+        }
+    }
+}
+
+// split-K finish: out = sum_s part[s] in fixed order (deterministic), plus the per-row (sum, sum of squares) BatchNorm partials.
+// Row r of stats covers voxels [r*V/nrow, (r+1)*V/nrow): any partition is fine for the double-precision finalize.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, float* __restrict__ out, long obs, long ops,
+                                                              long ocs, int B, long V, int C, int nrow, float* __restrict__ stats) {
+    // grid = (nrow, ceil(C/32)): one workgroup per (voxel slice, 32-channel group); 32 channels x 8 voxel lanes
+    __shared__ float red[2][256];
+    const int r = blockIdx.x, c0 = blockIdx.y * 32;
+    const long npix = (long)B * V;
+    const long p0 = npix * r / nrow, p1 = npix * (r + 1) / nrow;
+    const int c = c0 + (threadIdx.x & 31), prow = threadIdx.x >> 5;
+    float s = 0.f, q = 0.f;
+    if (c < C)
+        for (long p = p0 + prow; p < p1; p += 8) {
+            float v = 0.f;
+            for (int k = 0; k < ksplit; ++k) v += part[((long)k * npix + p) * C + c];
+            const long b = p / V, vox = p - b * V;
+            out[b * obs + vox * ops + (long)c * ocs] = v;
+            s += v;
+            q += v * v;
+        }
+    if (stats != nullptr) {
+        red[0][threadIdx.x] = s;
+        red[1][threadIdx.x] = q;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int which = threadIdx.x >> 5, cc = threadIdx.x & 31;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[which][k * 32 + cc];
+            if (c0 + cc < C) stats[((long)r * 2 + which) * C + c0 + cc] = t;
         }
     }
 }
@@ -476,15 +518,33 @@ PULPO_API int pulpo_conv3d_k3_pack_weight(const float* w, float* wp, int Cin, in
 
 // which kernel instantiation pulpo_conv3d_k3_fwd dispatches to: CH * 1000 + NT (vector/scalar staging is decided by the strides)
 PULPO_API int pulpo_conv3d_k3_tile_config(int K, int N) {
-    const int NT = (N % 64 == 0 || N > 96) ? 64 : 32;
+    const int NT = (N % 64 == 0) ? 64 : 32;        // 64-wide cout tiles only when none would be half empty
     return pick_ch(K) * 1000 + NT;
+}
+
+PULPO_API int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W);
+
+// small volumes (the 20^3 / 10^3 pyramid levels) have too few tiles to fill 256 CUs x 4 workgroups: split the Cin chunks
+// over several workgroups per tile (deterministic: partial slabs + ordered reduce)
+int conv_ksplit(int B, int D, int H, int W, int K, int N) {
+    const int cfg = pulpo_conv3d_k3_tile_config(K, N);
+    const int CH = cfg / 1000, NT = cfg % 1000;
+    const long nblk = (long)B * pulpo::cdiv(D, TZ) * pulpo::cdiv(H, TY) * pulpo::cdiv(W, TX) * pulpo::cdiv(N, NT);
+    const int nchunk = (K + CH - 1) / CH;
+    if (nblk >= 512 || nchunk <= 1) return 1;
+    return (int)std::max<long>(1, std::min<long>(std::min(nchunk, 8), 1024 / nblk));   // one resident round of <= 1024 workgroups
+}
+
+PULPO_API size_t pulpo_conv3d_k3_fwd_scratch_floats(int B, int D, int H, int W, int K, int N) {
+    const int ks = conv_ksplit(B, D, H, W, K, N);
+    return ks > 1 ? (size_t)ks * B * D * H * W * N : 0;
 }
 
 // Generic entry: computes out[b][vox][n] = sum_{tap,k} in[b][vox+tap-1][k] * wp[...] (+ bias[n]).
 // K / N are the GEMM's reduction / output channel counts (forward: Cin/Cout; dgrad: Cout/Cin with dgrad-packed wp).
 PULPO_API int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
-                                  float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W,
-                                  int K, int N, void* stream) {
+                                  float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, int B, int D, int H,
+                                  int W, int K, int N, void* stream) {
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd: null pointer");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd: bad dims");
     ConvArgs a;
@@ -499,12 +559,23 @@ PULPO_API int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps,
     a.ncot = pulpo::cdiv(N, NT);
     const long nblk_l = (long)B * a.ntz * a.nty * a.ntx * a.ncot;
     PULPO_REQUIRE(nblk_l < (1L << 31), "conv3d_k3_fwd: grid too large");
-    const int nblk = (int)nblk_l;
+    a.ksplit = conv_ksplit(B, D, H, W, K, N);
+    a.part = scratch;
+    PULPO_REQUIRE(a.ksplit == 1 || scratch != nullptr, "conv3d_k3_fwd: scratch of pulpo_conv3d_k3_fwd_scratch_floats() floats required");
+    const int nblk = (int)nblk_l * a.ksplit;
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0) && CH >= 16;
     hipStream_t st = (hipStream_t)stream;
-    if (CH == 4) return NT == 64 ? launch_conv<4, 64, false>(a, nblk, st) : launch_conv<4, 32, false>(a, nblk, st);
-    if (vec) return NT == 64 ? launch_conv<16, 64, true>(a, nblk, st) : launch_conv<16, 32, true>(a, nblk, st);
-    return NT == 64 ? launch_conv<16, 64, false>(a, nblk, st) : launch_conv<16, 32, false>(a, nblk, st);
+    int rc;
+    if (CH == 4) rc = NT == 64 ? launch_conv<4, 64, false>(a, nblk, st) : launch_conv<4, 32, false>(a, nblk, st);
+    else if (vec) rc = NT == 64 ? launch_conv<16, 64, true>(a, nblk, st) : launch_conv<16, 32, true>(a, nblk, st);
+    else rc = NT == 64 ? launch_conv<16, 64, false>(a, nblk, st) : launch_conv<16, 32, false>(a, nblk, st);
+    if (rc == 0 && a.ksplit > 1) {
+        const int nrow = pulpo_conv3d_k3_stat_tiles(B, D, H, W);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nrow, pulpo::cdiv(N, 32)), dim3(256), 0, st, scratch, a.ksplit, out, (long)out_bs, (long)out_ps, (long)out_cs, B,
+                           (long)D * H * W, N, nrow, stats);
+        rc = pulpo::check_launch("splitk_reduce");
+    }
+    return rc;
 }
 
 PULPO_API int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W) {

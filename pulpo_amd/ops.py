@@ -139,8 +139,11 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
     B, _, D, H, W = x.shape
     xb, xp, xc = grid_strides(x)
     ob, op, oc = grid_strides(out)
+    nscr = lib.query("pulpo_conv3d_k3_fwd_scratch_floats", B, D, H, W, K, N)
+    scratch = torch.empty(nscr, device=x.device, dtype=torch.float32) if nscr else None
     t0 = _trace_begin()
-    lib.call("pulpo_conv3d_k3_fwd", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc, _ptr(stats), B, D, H, W, K, N, _stream())
+    lib.call("pulpo_conv3d_k3_fwd", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc, _ptr(stats), _ptr(scratch), B, D, H, W, K, N,
+             _stream())
     if t0 is not None:
         cfg = lib.query("pulpo_conv3d_k3_tile_config", K, N)
         vec = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0 and cfg // 1000 >= 16

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
 def test_bad_arguments_return_error_codes_not_crashes():
     from pulpo_amd._lib import lib
     lib.load()
-    rc = lib.raw("pulpo_conv3d_k3_fwd")(None, 0, 0, 0, None, None, None, 0, 0, 0, None, 1, 8, 8, 8, 4, 4, None)
+    rc = lib.raw("pulpo_conv3d_k3_fwd")(None, 0, 0, 0, None, None, None, 0, 0, 0, None, None, 1, 8, 8, 8, 4, 4, None)
     assert rc != 0 and b"null pointer" in lib.raw("pulpo_last_error")()
     rc = lib.raw("pulpo_ncc_fwd")(None, None, None, None, None, 1, 8, 8, 8, 4, None)
     assert rc != 0
