@@ -290,7 +290,7 @@ struct WgradArgs {
 constexpr int WG_CH = 32, WG_NT = 32, WG_CP = WG_CH + 1;
 
 // NTW = row tiles (32 (tap,ci) pairs each) per wave: 7 for a full 32-channel ci tile (27 tiles over 4 waves), fewer for
-// narrow inputs.  The MFMAs of the hot loop are unconditional (rows beyond the matrix are fed zeros), so the loop
+// narrow inputs.  The MFMAs of the hot loop are unconditional (rows beyond the matrix compute garbage that is never flushed), so the loop
 // body is one basic block and the compiler can run the LDS reads ahead of the matrix pipe.
 template <bool VEC, int NTW>
 __global__ __launch_bounds__(256, VEC ? 1 : 2) void conv3d_k3_wgrad_mfma(WgradArgs a) {
@@ -420,21 +420,51 @@ __global__ __launch_bounds__(256, VEC ? 1 : 2) void conv3d_k3_wgrad_mfma(WgradAr
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the (zero-sourced) pieces issued during the last tile
     } else {
+        // scalar-staging path (planar / narrow inputs: the 2- and 3-channel first layers).  Only the Cc real channels of the
+        // halo are staged (rows of other channels are never flushed); dY goes through float4 when it is channels-last.
         float* xs = smem;
         float* dys = smem + XS;
+        const bool dyvec = (a.dy_cs == 1) && (a.dy_ps % 4 == 0) && (a.dy_bs % 4 == 0) && (a.Cout % 4 == 0) && (((uintptr_t)a.dy & 15) == 0);
         for (int tl = t_begin; tl < t_end; ++tl) {
             int b, z0, y0, x0;
             decode(tl, b, z0, y0, x0);
             __syncthreads();
-            stage_halo<WG_CH, false>(xs, a.in + (long)b * a.in_bs, a.in_ps, a.in_cs, ci0, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+            const float* in_b = a.in + (long)b * a.in_bs;
+            for (int j = tid; j < HV * Cc; j += 256) {
+                const int c = j / HV, hv = j - c * HV;              // voxel fastest: coalesced for planar inputs
+                const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+                const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                float v = 0.f;
+                if ((unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                    v = in_b[((long)(gz * a.H + gy) * a.W + gx) * a.in_ps + (long)(ci0 + c) * a.in_cs];
+                xs[hv * WG_CP + c] = v;
+            }
             const float* dyb = a.dy + (long)b * a.dy_bs;
-            for (int j = tid; j < MV * WG_NT; j += 256) {
-                const int vv = j >> 5, c = j & 31;
-                const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
-                float val = 0.f;
-                if (gz < a.D && gy < a.H && gx < a.W && co0 + c < a.Cout)
-                    val = dyb[((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + (long)(co0 + c) * a.dy_cs];
-                dys[vv * WG_NT + c] = val;
+            if (dyvec) {
+                float4 val[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = tid + u * 256;
+                    const int vv = j >> 3, q = j & 7;
+                    const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
+                    val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gz < a.D && gy < a.H && gx < a.W && co0 + 4 * q < a.Cout)
+                        val[u] = *reinterpret_cast<const float4*>(dyb + ((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + co0 + 4 * q);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = tid + u * 256;
+                    *reinterpret_cast<float4*>(dys + (j >> 3) * WG_NT + 4 * (j & 7)) = val[u];
+                }
+            } else {
+                for (int j = tid; j < MV * WG_NT; j += 256) {
+                    const int vv = j >> 5, c = j & 31;
+                    const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
+                    float val = 0.f;
+                    if (gz < a.D && gy < a.H && gx < a.W && co0 + c < a.Cout)
+                        val = dyb[((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + (long)(co0 + c) * a.dy_cs];
+                    dys[vv * WG_NT + c] = val;
+                }
             }
             __syncthreads();
             load_body(A0, B0, xs, dys, 0);
