@@ -130,6 +130,22 @@ int pulpo_kl_bwd(const float* mu, const float* sigma, const float* mu1, const fl
 int pulpo_l2reg_fwd(const float* df, int64_t nplanes, int D, int H, int W, float* partial, void* stream);
 int pulpo_l2reg_bwd(const float* df, const float* gscale, float coef, float* gdf, int64_t nplanes, int D, int H, int W, void* stream);
 
+/* ------------------------------------------------------------------- alternative losses / evaluation metrics
+ *   sqdiff: L2_loss (src/losses.py:79-83); dice: Soft_dice_loss (:137-145);
+ * jacdet: jacobian_det (:172-199, 3-D); jdetstd: JDetStd (:202-204).  Scalars finish on the device. */
+int pulpo_metric_blocks(int64_t n);
+int pulpo_sqdiff_fwd(const float* a, const float* b, int64_t n, float* partial, void* stream);
+int pulpo_sqdiff_bwd(const float* a, const float* b, const float* gscale, float coef, float* ga, int64_t n, void* stream);
+int pulpo_dice_blocks(int64_t V);
+int pulpo_dice_fwd(const float* inp, const float* tgt, int nplanes, int64_t V, float dice_factor, float* partial, double* numden, float* loss,
+                   void* stream);
+int pulpo_dice_bwd(const float* inp, const float* tgt, const double* numden, const float* gscale, int nplanes, int64_t V, float dice_factor,
+                   float* ginp, void* stream);
+int pulpo_jacdet_fwd(const float* df, float* out, float* partial /*nullable*/, int B, int D, int H, int W, int normalize, void* stream);
+int pulpo_jdetstd_finalize(const float* partial, int64_t n, float lamb, double* stat, float* loss, void* stream);
+int pulpo_jdetstd_bwd(const float* df, const float* jdet, const double* stat, const float* gscale, float lamb, float* gdf, int B, int D, int H, int W,
+                      int normalize, void* stream);
+
 /* --------------------------------------------------------------------------------------------------- optimizer
  * torch.optim.Adam(lr) defaults (src/models.py:398-400) over a flat fp32 arena; gscale pre-multiplies the gradient. */
 int pulpo_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float gscale,

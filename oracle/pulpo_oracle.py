@@ -262,6 +262,46 @@ def l2_reg(df: Tensor, lamb: float) -> Tensor:
     return d.mean() * lamb * H * W * D
 
 
+# =============================================================================== alternative losses / evaluation metrics
+def l2_loss(inp: Tensor, tgt: Tensor) -> Tensor:
+    """spatial sum of squared differences, mean over batch and channels   losses.py:79-83"""
+    return ((inp - tgt) ** 2).flatten(2).sum(dim=2).mean()
+
+
+def soft_dice(inp: Tensor, tgt: Tensor, dice_factor: float = 1) -> Tensor:
+    """mean_(b,c) (1 - (2<t,i> + eps)/(|t|^2 + |i|^2 + eps)) * voxels / dice_factor, eps 1e-6   losses.py:137-145"""
+    eps = 1e-6
+    num = 2.0 * (tgt * inp).flatten(2).sum(dim=2) + eps
+    den = (tgt ** 2).flatten(2).sum(dim=2) + (inp ** 2).flatten(2).sum(dim=2) + eps
+    return (1 - num / den).mean() * float(math.prod(inp.shape[2:])) / dice_factor
+
+
+def jacobian_det(df: Tensor, normalize: bool = True) -> Tensor:
+    """determinant of (I + grad u) with central differences on a replicate-padded field   losses.py:172-199.
+    Reference quirks kept: with normalize the channels are first scaled by 2/S_i; the field is then channel-FLIPPED and its
+    (flipped) channel c scaled by ((D-1, H-1, W-1)[c] - 1)/2."""
+    B, _, D, H, W = df.shape
+    S = (D, H, W)
+    u = torch.stack([df[:, i] * 2 / S[i] for i in range(3)], dim=1) if normalize else df
+    scale = torch.tensor([(D - 1 - 1) / 2, (H - 1 - 1) / 2, (W - 1 - 1) / 2], dtype=df.dtype).view(1, 3, 1, 1, 1)
+    uf = u.flip(1) * scale
+    J = [[None] * 3 for _ in range(3)]
+    for a in range(3):                                   # derivative axis: 0 = D, 1 = H, 2 = W
+        idx = torch.arange(S[a])
+        plus = uf.index_select(2 + a, (idx + 1).clamp(max=S[a] - 1))
+        minus = uf.index_select(2 + a, (idx - 1).clamp(min=0))
+        g = 0.5 * (plus - minus)
+        for c in range(3):
+            J[a][c] = g[:, c] + (1.0 if a == c else 0.0)
+    return (J[0][0] * (J[1][1] * J[2][2] - J[2][1] * J[1][2]) - J[0][1] * (J[1][0] * J[2][2] - J[2][0] * J[1][2])
+            + J[0][2] * (J[1][0] * J[2][1] - J[2][0] * J[1][1]))
+
+
+def jdet_std(df: Tensor, lamb: float = 0.0, normalize: bool = True) -> Tensor:
+    """lamb * (unbiased) standard deviation of the Jacobian determinant   losses.py:202-204"""
+    return lamb * jacobian_det(df, normalize).std()
+
+
 # =============================================================================== network
 OUT_NAMES = ("mus", "sigmas", "samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed")
 

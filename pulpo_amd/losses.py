@@ -3,9 +3,10 @@
 On the hot path (BASELINE configs: recon_loss=['ncc'], regularizer='L2', diagonal KL):
     KL_two_gauss_with_diag_cov (:47-76), NCC_loss (:85-135), L2_reg (:208-222) and the three Hierarchical*
     wrappers (:225-355).
-Named by the reference's importers but NOT on the hot path (alternative hyper-parameters / evaluation metrics,
-SURVEY.md §8(f) rows 3-4): KL_nondiagonal, L2_loss, Soft_dice_loss, jacobian_det, JDetStd.  They are declared so
-that `from src.losses import ...` keeps working and raise NotImplementedError until their kernels land.
+Alternative hyper-parameters / evaluation metrics, also on HIP kernels (metrics.hip):
+    L2_loss (:79-83, `--recon_loss mse`), Soft_dice_loss (:137-145, `--recon_loss dice`), jacobian_det (:172-199),
+    JDetStd (:202-204, `--regularizer jdet`) - the 3-D forms.
+Still declared only (raise NotImplementedError): KL_nondiagonal (`--nondiagonal`) and the 2-D variants.
 """
 from __future__ import annotations
 
@@ -29,19 +30,27 @@ class KL_nondiagonal:
 
 
 def L2_loss(input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-    _off_path("L2_loss")
+    """spatial sum of squared differences, mean over batch and channels (reference losses.py:79-83)"""
+    return ops.l2_loss(input, target)
 
 
 def Soft_dice_loss(input: torch.Tensor, target: torch.Tensor, dice_factor=1) -> torch.Tensor:
-    _off_path("Soft_dice_loss")
+    """mean over (batch, channel) of (1 - soft dice), times voxels / dice_factor (reference losses.py:137-145)"""
+    return ops.soft_dice_loss(input, target, dice_factor)
 
 
 def jacobian_det(deformation_field: torch.Tensor, lamb=None, normalize=True) -> torch.Tensor:
-    _off_path("jacobian_det")
+    """(B,3,D,H,W) -> (B,D,H,W) Jacobian determinant (reference losses.py:172-199); the 2-D form has no HIP path"""
+    if deformation_field.dim() != 5:
+        _off_path("jacobian_det (2-D)")
+    return ops.jacobian_det(deformation_field, normalize)
 
 
 def JDetStd(deformation_field: torch.Tensor, lamb=0, normalize=True) -> torch.Tensor:
-    _off_path("JDetStd")
+    """lamb * std of the Jacobian determinant (reference losses.py:202-204), differentiable"""
+    if deformation_field.dim() != 5:
+        _off_path("JDetStd (2-D)")
+    return ops.jdet_std(deformation_field, lamb, normalize)
 
 
 def _is_std_normal(mu1, sigma1) -> bool:
@@ -109,11 +118,6 @@ class HierarchicalReconstructionLoss(nn.Module):
         self.window_size = window_size
         self.ndims = ndims
         self.mode = "trilinear" if ndims == 3 else "bilinear"
-        for name in recon_loss:
-            if name not in ("ncc", "mse", "dice"):
-                continue
-            if name != "ncc":
-                _off_path(f"recon_loss '{name}'")
 
     def forward(self, y_hat, y, y_hat_seg=None, seg_y=None, gamma: float = 0.05, dice_factor: int = 1):
         loss = 0.0
@@ -123,8 +127,14 @@ class HierarchicalReconstructionLoss(nn.Module):
             # F.interpolate(y, size) of the reference; the identity resize at full resolution is skipped
             y_target = y if tuple(size) == tuple(y.shape[2:]) else ops.resize_trilinear(y, size)
             term = 0.0
+            if "mse" in self.recon_loss:
+                term = term + w * L2_loss(y_hat[l], y_target)
             if "ncc" in self.recon_loss:
                 term = term + w * NCC_loss(y_hat[l], y_target, gamma=gamma, win_size=self.window_size[l])
+            if "dice" in self.recon_loss:
+                seg_size = y_hat_seg[l].shape[2:]
+                seg_target = seg_y if tuple(seg_size) == tuple(seg_y.shape[2:]) else ops.resize_trilinear(seg_y, seg_size)
+                term = term + w * Soft_dice_loss(y_hat_seg[l], seg_target, dice_factor=dice_factor)
             all_levels[l] = term / len(self.recon_loss)
             loss = loss + all_levels[l]
         return loss, all_levels

@@ -572,6 +572,106 @@ def l2_reg(df, lamb: float = 0.0):
     return _L2Reg.apply(df, float(lamb))
 
 
+# ------------------------------------------------------------------------------------------------ alternative losses / metrics
+class _SqDiff(torch.autograd.Function):
+    """L2_loss: spatial sum of squared differences, mean over batch and channels"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_gpu(a, b)
+        a, b = planar(a), planar(b)
+        n = a.numel()
+        nblk = lib.query("pulpo_metric_blocks", n)
+        part = torch.empty(nblk, device=a.device, dtype=torch.float32)
+        lib.call("pulpo_sqdiff_fwd", _ptr(a), _ptr(b), n, _ptr(part), _stream())
+        ctx.save_for_backward(a, b)
+        ctx.coef = 1.0 / (a.shape[0] * a.shape[1])
+        return _colsum(part, nblk, 1, ctx.coef).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = torch.empty_like(a)
+        lib.call("pulpo_sqdiff_bwd", _ptr(a), _ptr(b), _ptr(g.contiguous()), ctx.coef, _ptr(ga), a.numel(), _stream())
+        return ga, None
+
+
+def l2_loss(inp, target):
+    return _SqDiff.apply(inp, target)
+
+
+class _Dice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, tgt, dice_factor: float):
+        _require_gpu(inp, tgt)
+        inp, tgt = planar(inp), planar(tgt)
+        nplanes = inp.shape[0] * inp.shape[1]
+        V = inp.numel() // nplanes
+        nb = lib.query("pulpo_dice_blocks", V)
+        part = torch.empty(nplanes * nb * 3, device=inp.device, dtype=torch.float32)
+        numden = torch.empty(2 * nplanes, device=inp.device, dtype=torch.float64)
+        loss = torch.empty((), device=inp.device, dtype=torch.float32)
+        lib.call("pulpo_dice_fwd", _ptr(inp), _ptr(tgt), nplanes, V, dice_factor, _ptr(part), _ptr(numden), _ptr(loss), _stream())
+        ctx.save_for_backward(inp, tgt, numden)
+        ctx.meta = (nplanes, V, dice_factor)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        inp, tgt, numden = ctx.saved_tensors
+        nplanes, V, df = ctx.meta
+        ginp = torch.empty_like(inp)
+        lib.call("pulpo_dice_bwd", _ptr(inp), _ptr(tgt), _ptr(numden), _ptr(g.contiguous()), nplanes, V, df, _ptr(ginp), _stream())
+        return ginp, None, None
+
+
+def soft_dice_loss(inp, target, dice_factor=1):
+    return _Dice.apply(inp, target, float(dice_factor))
+
+
+def jacobian_det(df, normalize: bool = True):
+    """determinant of the Jacobian of x + u(x), (B,3,D,H,W) -> (B,D,H,W); evaluation metric, not differentiable here"""
+    _require_gpu(df)
+    d = planar(df.detach())
+    B, C, D, H, W = d.shape
+    if C != 3:
+        raise PulpoHipError("jacobian_det: 3-D displacement field (B,3,D,H,W) expected")
+    out = torch.empty((B, D, H, W), device=d.device, dtype=torch.float32)
+    lib.call("pulpo_jacdet_fwd", _ptr(d), _ptr(out), None, B, D, H, W, int(bool(normalize)), _stream())
+    return out
+
+
+class _JDetStd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, df, lamb: float, normalize: bool):
+        _require_gpu(df)
+        df = planar(df)
+        B, C, D, H, W = df.shape
+        n = B * D * H * W
+        jd = torch.empty((B, D, H, W), device=df.device, dtype=torch.float32)
+        part = torch.empty(2 * lib.query("pulpo_metric_blocks", n), device=df.device, dtype=torch.float32)
+        stat = torch.empty(2, device=df.device, dtype=torch.float64)
+        loss = torch.empty((), device=df.device, dtype=torch.float32)
+        lib.call("pulpo_jacdet_fwd", _ptr(df), _ptr(jd), _ptr(part), B, D, H, W, int(normalize), _stream())
+        lib.call("pulpo_jdetstd_finalize", _ptr(part), n, lamb, _ptr(stat), _ptr(loss), _stream())
+        ctx.save_for_backward(df, jd, stat)
+        ctx.meta = (lamb, normalize)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        df, jd, stat = ctx.saved_tensors
+        lamb, normalize = ctx.meta
+        B, _, D, H, W = df.shape
+        gdf = torch.empty_like(df)
+        lib.call("pulpo_jdetstd_bwd", _ptr(df), _ptr(jd), _ptr(stat), _ptr(g.contiguous()), lamb, _ptr(gdf), B, D, H, W, int(normalize), _stream())
+        return gdf, None, None
+
+
+def jdet_std(df, lamb: float = 0.0, normalize: bool = True):
+    return _JDetStd.apply(df, float(lamb), bool(normalize))
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, gscale: float = 1.0):
     _require_gpu(p, g, m, v)

@@ -355,6 +355,36 @@ def gen_step(name, T, L, size, n0, B, seed, with_grads=True, smooth=False):
     return float(total)
 
 
+# --------------------------------------------------------------------------- 12. alternative losses / evaluation metrics
+def gen_metrics():
+    g = torch.Generator().manual_seed(130)
+    out = {}
+    # L2_loss (losses.py:79-83): mean over (B,C) of the spatial sum of squared differences
+    a = torch.rand(2, 1, 5, 6, 7, generator=g).requires_grad_(True)
+    b = torch.rand(2, 1, 5, 6, 7, generator=g)
+    l = ls.L2_loss(a, b)
+    ga, = torch.autograd.grad(l, [a])
+    out.update(l2_in=npy(a), l2_tgt=npy(b), l2_loss=npy(l), l2_gin=npy(ga))
+    # Soft_dice_loss (losses.py:137-145) on soft "segmentations" with 3 channels
+    a = torch.rand(2, 3, 6, 5, 4, generator=g).requires_grad_(True)
+    b = (torch.rand(2, 3, 6, 5, 4, generator=g) > 0.6).float()
+    for df_ in (1, 4):
+        l = ls.Soft_dice_loss(a, b, dice_factor=df_)
+        ga, = torch.autograd.grad(l, [a])
+        out.update({f"dice{df_}_loss": npy(l), f"dice{df_}_gin": npy(ga)})
+    out.update(dice_in=npy(a), dice_tgt=npy(b))
+    # jacobian_det / JDetStd (losses.py:147-204), 3-D, normalize True and False
+    d = (torch.randn(2, 3, 6, 7, 8, generator=g) * 0.8).requires_grad_(True)
+    for norm in (True, False):
+        jd = ls.jacobian_det(d, normalize=norm)
+        out[f"jdet_norm{int(norm)}"] = npy(jd)
+        s_ = ls.JDetStd(d, lamb=0.3, normalize=norm)
+        gd, = torch.autograd.grad(s_, [d])
+        out.update({f"jstd_norm{int(norm)}": npy(s_), f"jstd_gd_norm{int(norm)}": npy(gd)})
+    out["jdet_df"] = npy(d)
+    save("metrics", **out)
+
+
 def gen_init_tables():
     """models.py:104-123 evaluated for the (T, L) pairs SURVEY.md §8(c).11 lists"""
     out = {}
@@ -399,5 +429,6 @@ if __name__ == "__main__":
     print("   total loss", t)
     t = gen_step("step_T4L3_n2_16x24x16", T=4, L=3, size=[16, 24, 16], n0=2, B=1, seed=120, smooth=True)
     print("   total loss", t)
+    gen_metrics()
     gen_init_tables()
     gen_state_keys()

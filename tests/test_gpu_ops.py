@@ -284,3 +284,38 @@ def test_cpu_tensor_is_refused(ops):
     from pulpo_amd._lib import PulpoHipError
     with pytest.raises(PulpoHipError):
         ops.warp3d(torch.zeros(1, 3, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
+
+
+# ================================================================================================ alternative losses / metrics
+def test_alternative_losses_and_metrics_golden(ops, golden):
+    g = golden("metrics")
+    a = dev(g["l2_in"]).requires_grad_(True)
+    l = ops.l2_loss(a, dev(g["l2_tgt"]))
+    close(l, g["l2_loss"], rtol=1e-5)
+    close(torch.autograd.grad(l * 0.7, [a])[0], 0.7 * g["l2_gin"], atol=1e-7, rtol=1e-5)
+    a = dev(g["dice_in"]).requires_grad_(True)
+    for df_ in (1, 4):
+        l = ops.soft_dice_loss(a, dev(g["dice_tgt"]), df_)
+        close(l, g[f"dice{df_}_loss"], rtol=1e-5)
+        close(torch.autograd.grad(l, [a])[0], g[f"dice{df_}_gin"], atol=1e-6, rtol=1e-4)
+    d = dev(g["jdet_df"]).requires_grad_(True)
+    for norm in (1, 0):
+        close(ops.jacobian_det(d, bool(norm)), g[f"jdet_norm{norm}"], atol=1e-5, rtol=1e-5)
+        s_ = ops.jdet_std(d, 0.3, bool(norm))
+        close(s_, g[f"jstd_norm{norm}"], rtol=1e-4)
+        close(torch.autograd.grad(s_, [d])[0], g[f"jstd_gd_norm{norm}"], atol=1e-6, rtol=1e-3)
+
+
+def test_recon_loss_options_through_the_model_api(ops):
+    """--recon_loss mse dice / --regularizer jdet construct and step (reference train.py:29-32 options)"""
+    from src.models import PULPo
+    FB = list(O.FEEDBACK_DEFAULT)
+    torch.manual_seed(0)
+    m = PULPo(3, 2, 0.1, [16, 16, 16], feedback=FB, n0=4, recon_loss=["ncc", "mse", "dice"], regularizer="jdet", segs=True).cuda().train()
+    x, y = torch.rand(1, 1, 16, 16, 16).cuda(), torch.rand(1, 1, 16, 16, 16).cuda()
+    seg = (torch.rand(1, 1, 16, 16, 16) > 0.5).float().cuda()
+    e = torch.empty((0,), device="cuda")
+    loss = m.training_step((x, y, seg, seg, e, e, e, e), 0)
+    loss.backward()
+    assert bool(torch.isfinite(loss))
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in m.parameters())

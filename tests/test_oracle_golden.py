@@ -149,6 +149,25 @@ def test_kl_and_l2reg(golden):
     close(torch.autograd.grad(r, [df])[0], g["reg_gdf"], atol=1e-7, rtol=1e-5)
 
 
+def test_alternative_losses_and_metrics(golden):
+    g = golden("metrics")
+    a = T(g["l2_in"]).requires_grad_(True)
+    l = O.l2_loss(a, T(g["l2_tgt"]))
+    close(l, g["l2_loss"], rtol=1e-6)
+    close(torch.autograd.grad(l, [a])[0], g["l2_gin"], atol=1e-7, rtol=1e-5)
+    a = T(g["dice_in"]).requires_grad_(True)
+    for df_ in (1, 4):
+        l = O.soft_dice(a, T(g["dice_tgt"]), df_)
+        close(l, g[f"dice{df_}_loss"], rtol=1e-6)
+        close(torch.autograd.grad(l, [a])[0], g[f"dice{df_}_gin"], atol=1e-7, rtol=1e-5)
+    d = T(g["jdet_df"]).requires_grad_(True)
+    for norm in (1, 0):
+        close(O.jacobian_det(d, bool(norm)), g[f"jdet_norm{norm}"], atol=1e-6, rtol=1e-5)
+        s_ = O.jdet_std(d, 0.3, bool(norm))
+        close(s_, g[f"jstd_norm{norm}"], rtol=1e-5)
+        close(torch.autograd.grad(s_, [d])[0], g[f"jstd_gd_norm{norm}"], atol=1e-7, rtol=1e-4)
+
+
 # ------------------------------------------------------------------------------------------------ tables / keys
 def test_weight_tables(golden):
     g = golden("init_tables")
