@@ -48,6 +48,7 @@ class Cfg:
     beta: float = 0.1
     gamma: float = 0.05
     lamb: float = 0.025
+    df_resolution: str = "level_res"
 
     @property
     def offset(self) -> int:                       # lk_offset, pulpo.py:22,86
@@ -73,8 +74,12 @@ def weight_tables(cfg: Cfg) -> Tuple[Dict[int, int], Dict[int, float], Dict[int,
         window = {0: 9}
     scale = {l: float((2.0 ** nd) ** l) for l in range(L)}
     kl_w, rec_w, reg_w = dict(scale), dict(scale), dict(scale)
-    rec_w[0] = scale[0] / (2 ** (nd * o))
-    reg_w[0] = scale[0] / (2 ** (nd * o))
+    if cfg.df_resolution == "full_res":               # every level is evaluated at full resolution (models.py:112-115)
+        rec_w = {l: 1.0 for l in range(L)}
+        reg_w = {l: 1.0 for l in range(L)}
+    else:
+        rec_w[0] = scale[0] / (2 ** (nd * o))
+        reg_w[0] = scale[0] / (2 ** (nd * o))
     rec_w[0] *= 4
     return window, kl_w, rec_w, reg_w
 
@@ -333,12 +338,16 @@ def autoencoder(sd, cfg: Cfg, x: Tensor, acts: Dict[int, Tensor], eps: Optional[
     L, o = cfg.latent_levels, cfg.offset
     sizes = cfg.level_sizes()
     # level_x: pulpo.py:171-179
-    lx = {0: x}
-    for _ in range(o):
-        lx[0] = pool2(lx[0])
-    for l in range(1, L):
-        lx[l] = pool2(lx[l - 1])
-    lx[0] = x
+    full = cfg.df_resolution == "full_res"
+    if full:                                          # pulpo.py:168-169
+        lx = {l: x for l in range(L)}
+    else:
+        lx = {0: x}
+        for _ in range(o):
+            lx[0] = pool2(lx[0])
+        for l in range(1, L):
+            lx[l] = pool2(lx[l - 1])
+        lx[0] = x
     out = {n: {} for n in OUT_NAMES}
     for l in reversed(range(L)):
         k = l + o
@@ -360,7 +369,7 @@ def autoencoder(sd, cfg: Cfg, x: Tensor, acts: Dict[int, Tensor], eps: Optional[
             z = mu + sg * torch.randn_like(sg, dtype=torch.float32)
         else:
             z = mu + sg * eps[l]
-        out_ratio = (cfg.input_size[0] / sizes[k][0]) if l == 0 else 1.0          # pulpo.py:146,290
+        out_ratio = (cfg.input_size[0] / sizes[k][0]) if (l == 0 or full) else 1.0          # pulpo.py:146,290
         res = svf_decoder(sd, cfg, f"{prefix}.decoders.{l}", mu if deterministic else z, lx[l],
                           None if l == L - 1 else out["combined_dfs"][l + 1], out_ratio, training)
         out["mus"][l], out["sigmas"][l], out["samples"][l] = mu, sg, z
@@ -399,7 +408,7 @@ def combine_dfs(individual: Dict[int, Tensor], cfg: Cfg):
             comb[l] = individual[l]
     for l in reversed(range(L)):
         f = vecint(comb[l], 7)
-        tgt = cfg.input_size if l == 0 else comb[l].shape[2:]
+        tgt = cfg.input_size if (l == 0 or cfg.df_resolution == "full_res") else comb[l].shape[2:]
         fin[l] = resize_field(f, 1.0 / (tgt[0] / f.shape[2]))
     return comb, fin
 
@@ -449,7 +458,7 @@ def init_state_dict(cfg: Cfg, seed: int = 0) -> Dict[str, Tensor]:
             unit(d + f".velocity_field._op.{i}", cfg.n0, cfg.n0)
         conv(d + f".velocity_field._op.{cfg.cp_depth - 1}", cfg.n0, 3, 1)
         sd[d + ".integrate.transformer.grid"] = identity_grid(sizes[k])
-        sd[d + ".spatial_transform.grid"] = identity_grid(cfg.input_size if l == 0 else sizes[k])
+        sd[d + ".spatial_transform.grid"] = identity_grid(cfg.input_size if (l == 0 or cfg.df_resolution == "full_res") else sizes[k])
     return sd
 
 

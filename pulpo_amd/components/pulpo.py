@@ -132,8 +132,8 @@ class Autoencoder(nn.Module):
         ndims = len(input_size)
         if ndims != 3:
             raise NotImplementedError("Autoencoder: only 3-D volumes have a HIP path")
-        if df_resolution != "level_res":
-            raise NotImplementedError("Autoencoder: df_resolution='full_res' is not on the HIP path (SURVEY.md §8f)")
+        if df_resolution not in ("level_res", "full_res"):
+            raise ValueError(f"df_resolution is {df_resolution}. Not a known option.")
 
         self.level_sizes = {0: [int(d) for d in input_size]}
         for k in range(total_levels - 1):
@@ -166,7 +166,8 @@ class Autoencoder(nn.Module):
         self.decoders = ModuleIntDict()
         for l in range(latent_levels):
             k = self.lk_offset + l
-            self.decoders[l] = SVFDecoder(zdim=zdim, insize=self.level_sizes[k], outsize=input_size if l == 0 else self.level_sizes[k],
+            full = df_resolution == "full_res"
+            self.decoders[l] = SVFDecoder(zdim=zdim, insize=self.level_sizes[k], outsize=input_size if (l == 0 or full) else self.level_sizes[k],
                                           df_resolution=df_resolution, n0=n0, cp_depth=cp_depth)
         self.mode = "trilinear"
 
@@ -178,21 +179,25 @@ class Autoencoder(nn.Module):
             if name not in store:
                 raise ValueError(f"Feedback list contains {item}. Not a known option.")
             srcs.append(store[name][level])
-        coarse = srcs[0].shape[2:]
-        if all(int(o) == 2 * int(i) for o, i in zip(size, coarse)) and sum(s.shape[1] for s in srcs) <= 16 and len(srcs) <= 8:
+        exact_x2 = all(all(int(o) == 2 * int(i) for o, i in zip(size, s.shape[2:])) for s in srcs)
+        if exact_x2 and sum(s.shape[1] for s in srcs) <= 16 and len(srcs) <= 8:
             return ops.feedback_up2(srcs)
-        # ragged pyramid (a size not divisible by 2^(T-1)): generic resize per tensor, then concatenate
+        # ragged pyramid (a size not divisible by 2^(T-1)) or df_resolution='full_res' (final_dfs / transformed arrive at full
+        # resolution and are down-sampled): generic resize per tensor, then concatenate
         return torch.cat([ops.resize_trilinear(s, size) for s in srcs], dim=1).contiguous(memory_format=torch.channels_last_3d)
 
     def forward(self, x: torch.Tensor, down_activations, deterministic: bool = False):
         L, o = self.latent_levels, self.lk_offset
         # moving image on every latent level (pulpo.py:171-179): level 0 keeps the full-resolution image
-        level_x = {0: x}
-        for _ in range(o):
-            level_x[0] = ops.avg_pool2(level_x[0])
-        for l in range(1, L):
-            level_x[l] = ops.avg_pool2(level_x[l - 1])
-        level_x[0] = x
+        if self.df_resolution == "full_res":
+            level_x = {l: x for l in range(L)}
+        else:
+            level_x = {0: x}
+            for _ in range(o):
+                level_x[0] = ops.avg_pool2(level_x[0])
+            for l in range(1, L):
+                level_x[l] = ops.avg_pool2(level_x[l - 1])
+            level_x[0] = x
 
         names = ("mus", "sigmas", "samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed")
         store: Dict[str, Dict[int, torch.Tensor]] = {n: {} for n in names}

@@ -248,13 +248,17 @@ def weight_dicts(T, L, ndims=3):
 class Step:
     """The reference's training_step assembled from its own component modules (no Lightning)."""
 
-    def __init__(self, T, L, size, n0, seed):
+    def __init__(self, T, L, size, n0, seed, df_resolution="level_res"):
         torch.manual_seed(seed)
         self.T, self.L = T, L
         self.down = cp.DownPath(T, L, list(size), 2, n0)
-        self.ae = cp.Autoencoder(nb.gauss_sampler, "SVF", T, L, 3, list(size), list(FEEDBACK), "level_res", n0, 3)
+        self.ae = cp.Autoencoder(nb.gauss_sampler, "SVF", T, L, 3, list(size), list(FEEDBACK), df_resolution, n0, 3)
         self.prior = cp.PULPoPrior()
         window, kl_w, rec_w, reg_w = weight_dicts(T, L)
+        if df_resolution == "full_res":          # models.py:112-115,123
+            rec_w = {l: 1.0 for l in range(L)}
+            reg_w = {l: 1.0 for l in range(L)}
+            rec_w[0] *= 4
         self.kl = ls.HierarchicalKLLoss(ls.KL_two_gauss_with_diag_cov, kl_w, False, None)
         self.rec = ls.HierarchicalReconstructionLoss(["ncc"], rec_w, False, 3, window)
         self.reg = ls.HierarchicalRegularization(ls.L2_reg, reg_w, False)
@@ -300,8 +304,8 @@ class Step:
 OUT_NAMES = ["mus", "sigmas", "samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed"]
 
 
-def gen_step(name, T, L, size, n0, B, seed, with_grads=True, smooth=False):
-    st = Step(T, L, size, n0, seed)
+def gen_step(name, T, L, size, n0, B, seed, with_grads=True, smooth=False, df_resolution="level_res"):
+    st = Step(T, L, size, n0, seed, df_resolution)
     g = torch.Generator().manual_seed(seed + 2)
     if smooth:
         y = smooth_volume(g, tuple(size), B)
@@ -428,6 +432,8 @@ if __name__ == "__main__":
     t = gen_step("step_T3L2_n4_16", T=3, L=2, size=[16, 16, 16], n0=4, B=2, seed=110)
     print("   total loss", t)
     t = gen_step("step_T4L3_n2_16x24x16", T=4, L=3, size=[16, 24, 16], n0=2, B=1, seed=120, smooth=True)
+    print("   total loss", t)
+    t = gen_step("step_fullres_T3L2_n2_16", T=3, L=2, size=[16, 16, 16], n0=2, B=1, seed=140, df_resolution="full_res")
     print("   total loss", t)
     gen_metrics()
     gen_init_tables()

@@ -35,9 +35,9 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def build_from_golden(models, nb, g, key="sd0."):
+def build_from_golden(models, nb, g, key="sd0.", case=""):
     Tl, L, n0, B, *size = [int(v) for v in g["cfg"]]
-    model = models.PULPo(Tl, L, 0.1, size, feedback=FB, n0=n0)
+    model = models.PULPo(Tl, L, 0.1, size, feedback=FB, n0=n0, df_resolution="full_res" if "fullres" in case else "level_res")
     sd = model.state_dict()
     loaded = 0
     for k, v in g.items():
@@ -62,14 +62,14 @@ def check_outputs(outs, g, prefix, atol=1e-4):
             assert err <= atol * max(1.0, np.abs(ref).max()), (name, l, err)
 
 
-STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16"]
+STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16", "step_fullres_T3L2_n2_16"]
 
 
 @pytest.mark.parametrize("case", STEP_CASES)
 def test_training_step_matches_reference_golden(api, golden, case):
     models, nb = api
     g = golden(case)
-    model, (Tl, L, n0, B, size) = build_from_golden(models, nb, g)
+    model, (Tl, L, n0, B, size) = build_from_golden(models, nb, g, case=case)
     model.train()
     x, y = T(g["x"]).cuda(), T(g["y"]).cuda()
     outs, priors, (total, kl, rec, reg), levels = model._forward_and_losses(x, y)
@@ -111,7 +111,7 @@ def test_training_step_matches_reference_golden(api, golden, case):
 def test_eval_deterministic_and_inference_api(api, golden, case):
     models, nb = api
     g = golden(case)
-    model, (Tl, L, n0, B, size) = build_from_golden(models, nb, g)
+    model, (Tl, L, n0, B, size) = build_from_golden(models, nb, g, case=case)
     sd = model.state_dict()
     for k, v in g.items():                     # eval goldens were taken after one training forward
         if k.startswith("sd1."):
@@ -144,7 +144,8 @@ def test_eval_deterministic_and_inference_api(api, golden, case):
             np.testing.assert_allclose(o_s[l][:, 0].cpu().numpy(), g[f"eval.transformed.{l}"], atol=1e-4)
             np.testing.assert_allclose(d_s[l][:, 1].cpu().numpy(), g[f"eval.individual_dfs.{l}"], atol=1e-4)
         avg_out, avg_dfs = model.predict(x, y, N=2)
-        _, fin_o = O.combine_dfs({l: T(g[f"eval.individual_dfs.{l}"]) for l in range(L)}, O.Cfg(Tl, L, size, n0=n0))
+        _, fin_o = O.combine_dfs({l: T(g[f"eval.individual_dfs.{l}"]) for l in range(L)},
+                                 O.Cfg(Tl, L, size, n0=n0, df_resolution="full_res" if "fullres" in case else "level_res"))
         for l in avg_out:
             ref = O.warp(fin_o[l], T(g["x"]))
             np.testing.assert_allclose(avg_out[l].cpu().numpy(), ref.numpy(), atol=1e-4)

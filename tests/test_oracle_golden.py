@@ -211,12 +211,12 @@ def test_unknown_feedback_item_raises():
 
 
 # ------------------------------------------------------------------------------------------------ full step
-STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16"]
+STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16", "step_fullres_T3L2_n2_16"]
 
 
-def _load_step(g):
+def _load_step(g, case=""):
     Tl, L, n0, B, *size = [int(v) for v in g["cfg"]]
-    cfg = O.Cfg(Tl, L, size, n0=n0)
+    cfg = O.Cfg(Tl, L, size, n0=n0, df_resolution="full_res" if "fullres" in case else "level_res")
     sd = O.init_state_dict(cfg)                       # supplies the (deterministic) grid buffers
     for k, v in g.items():
         if k.startswith("sd0."):
@@ -229,7 +229,7 @@ def _load_step(g):
 @pytest.mark.parametrize("case", STEP_CASES)
 def test_full_training_step(golden, case):
     g = golden(case)
-    cfg, sd, x, y, eps = _load_step(g)
+    cfg, sd, x, y, eps = _load_step(g, case)
     sd = O.clone_sd(sd, requires_grad=True)
     ls, grads, outs = O.train_step(sd, cfg, x, y, eps)
     for name, d in zip(O.OUT_NAMES, outs):
@@ -259,7 +259,7 @@ def test_full_training_step(golden, case):
 @pytest.mark.parametrize("case", STEP_CASES)
 def test_eval_and_deterministic_modes(golden, case):
     g = golden(case)
-    cfg, sd, x, y, eps = _load_step(g)
+    cfg, sd, x, y, eps = _load_step(g, case)
     # eval-mode goldens were produced after one training forward: bring the running stats to that state
     for k, v in g.items():
         if k.startswith("sd1."):
