@@ -143,6 +143,11 @@ int pulpo_dice_bwd(const float* inp, const float* tgt, const double* numden, con
                    float* ginp, void* stream);
 int pulpo_jacdet_fwd(const float* df, float* out, float* partial /*nullable*/, int B, int D, int H, int W, int normalize, void* stream);
 int pulpo_jdetstd_finalize(const float* partial, int64_t n, float lamb, double* stat, float* loss, void* stream);
+/* KL_nondiagonal.loss (src/losses.py:8-44, 3-D): mu, sigma planar (B,3,D,H,W), nplanes = B*3 */
+int pulpo_kl_nondiag_fwd(const float* mu, const float* sigma, int64_t nplanes, int D, int H, int W, float prior_lambda, float* partial, float* loss,
+                         void* stream);
+int pulpo_kl_nondiag_bwd(const float* mu, const float* sigma, const float* gscale, int64_t nplanes, int D, int H, int W, float prior_lambda,
+                         float* gmu, float* gsigma, void* stream);
 int pulpo_jdetstd_bwd(const float* df, const float* jdet, const double* stat, const float* gscale, float lamb, float* gdf, int B, int D, int H, int W,
                       int normalize, void* stream);
 

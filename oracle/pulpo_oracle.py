@@ -307,6 +307,22 @@ def jdet_std(df: Tensor, lamb: float = 0.0, normalize: bool = True) -> Tensor:
     return lamb * jacobian_det(df, normalize).std()
 
 
+def kl_nondiagonal(mu: Tensor, sigma: Tensor, prior_lambda: float = 20.0) -> Tensor:
+    """KL_nondiagonal.loss(prior_mu, prior_sigma, mu, sigma)   losses.py:8-44 (the prior arguments are unused there).
+    D = (number of in-volume voxels of the 3x3x3 neighbourhood) - 1; precision term = mean squared forward differences."""
+    S = mu.shape[2:]
+    nd = len(S)
+    D = box_sum(torch.ones(1, 1, *S, dtype=mu.dtype), 3) - 1
+    s2 = sigma ** 2
+    sigma_term = prior_lambda * D * s2 - torch.log(s2)
+    sm = 0
+    for a in range(nd):
+        d = mu.narrow(2 + a, 1, S[a] - 1) - mu.narrow(2 + a, 0, S[a] - 1)
+        sm = sm + (d * d).mean()
+    precision = 0.5 * sm / nd
+    return (sigma_term.mean() + (prior_lambda / 2) * precision) * nd * 0.5 * float(math.prod(S))
+
+
 # =============================================================================== network
 OUT_NAMES = ("mus", "sigmas", "samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed")
 

@@ -253,3 +253,89 @@ PULPO_API int pulpo_jdetstd_bwd(const float* df, const float* jdet, const double
     hipLaunchKernelGGL(jdetstd_bwd_kernel, dim3(eblocks(n)), dim3(256), 0, st, df, make_geom(B, D, H, W, normalize), jdet, stat, gscale, lamb, (double)n, gdf);
     return pulpo::check_launch("jdetstd_bwd");
 }
+
+// ------------------------------------------------------------------------------------------------ KL_nondiagonal
+// src/losses.py:8-44.  loss = (mean(lambda*D*sigma^2 - log sigma^2) + lambda/2 * (0.5/3) * sum_axes mean(fwd diff of mu)^2) * 3 * 0.5 * V
+// D(v) = number of in-volume voxels of the 3x3x3 neighbourhood minus one.
+namespace {
+
+__device__ __forceinline__ float degree_of(int z, int y, int x, int D, int H, int W) {
+    const int nz = min(z + 1, D - 1) - max(z - 1, 0) + 1, ny = min(y + 1, H - 1) - max(y - 1, 0) + 1, nx = min(x + 1, W - 1) - max(x - 1, 0) + 1;
+    return (float)(nz * ny * nx - 1);
+}
+
+// partial[blk][4] = sum sigma-term, sum dz^2, sum dy^2, sum dx^2
+__global__ __launch_bounds__(256) void kln_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma, long nplanes, int D, int H, int W,
+                                                        float lambda, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    const long V = (long)D * H * W, total = nplanes * V, sz = (long)H * W;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long v = e % V;
+        const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / sz);
+        const float sg2 = sigma[e] * sigma[e], m = mu[e];
+        s0 += lambda * degree_of(z, y, x, D, H, W) * sg2 - logf(sg2);
+        if (z >= 1) { const float d = m - mu[e - sz]; s1 += d * d; }
+        if (y >= 1) { const float d = m - mu[e - W]; s2 += d * d; }
+        if (x >= 1) { const float d = m - mu[e - 1]; s3 += d * d; }
+    }
+    const float t0 = block_sum_256(s0, sh), t1 = block_sum_256(s1, sh), t2 = block_sum_256(s2, sh), t3 = block_sum_256(s3, sh);
+    if (threadIdx.x == 0) { float* p = partial + 4 * blockIdx.x; p[0] = t0; p[1] = t1; p[2] = t2; p[3] = t3; }
+}
+
+__global__ void kln_finalize_kernel(const float* __restrict__ partial, int nblk, double nplanes, int D, int H, int W, double lambda, float* __restrict__ loss) {
+    double s[4] = {0, 0, 0, 0};
+    for (int k = 0; k < nblk; ++k)
+        for (int j = 0; j < 4; ++j) s[j] += partial[4 * k + j];
+    const double V = (double)D * H * W;
+    const double cnt[3] = {nplanes * (D - 1) * H * W, nplanes * D * (H - 1) * W, nplanes * D * H * (W - 1)};
+    const double precision = 0.5 * (s[1] / cnt[0] + s[2] / cnt[1] + s[3] / cnt[2]) / 3.0;
+    loss[0] = (float)((s[0] / (nplanes * V) + lambda / 2 * precision) * 3.0 * 0.5 * V);
+}
+
+__global__ __launch_bounds__(256) void kln_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ gscale,
+                                                        long nplanes, int D, int H, int W, float lambda, float* __restrict__ gmu, float* __restrict__ gsigma) {
+    const long V = (long)D * H * W, total = nplanes * V, sz = (long)H * W;
+    const float g = gscale != nullptr ? gscale[0] : 1.f;
+    const float outer = 1.5f * (float)V * g;                        // ndims * 0.5 * V
+    const float ks = outer / (float)(nplanes * V);
+    const float kp = outer * (lambda * 0.5f) * (0.5f / 3.f) * 2.f;      // d(diff^2) = 2 diff
+    const float cz = kp / (float)(nplanes * (D - 1) * (long)H * W), cy = kp / (float)(nplanes * D * (long)(H - 1) * W),
+                cx = kp / (float)(nplanes * D * (long)H * (W - 1));
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long v = e % V;
+        const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / sz);
+        const float sg = sigma[e], m = mu[e];
+        gsigma[e] = ks * (2.f * lambda * degree_of(z, y, x, D, H, W) * sg - 2.f / sg);
+        float gm = 0.f;
+        if (z >= 1) gm += cz * (m - mu[e - sz]);
+        if (z + 1 < D) gm -= cz * (mu[e + sz] - m);
+        if (y >= 1) gm += cy * (m - mu[e - W]);
+        if (y + 1 < H) gm -= cy * (mu[e + W] - m);
+        if (x >= 1) gm += cx * (m - mu[e - 1]);
+        if (x + 1 < W) gm -= cx * (mu[e + 1] - m);
+        gmu[e] = gm;
+    }
+}
+
+}  // namespace
+
+// mu, sigma planar (B,3,D,H,W); nplanes = B*3; partial: 4*pulpo_metric_blocks(nplanes*D*H*W) floats
+PULPO_API int pulpo_kl_nondiag_fwd(const float* mu, const float* sigma, int64_t nplanes, int D, int H, int W, float prior_lambda, float* partial,
+                                   float* loss, void* stream) {
+    PULPO_REQUIRE(mu && sigma && partial && loss && nplanes > 0 && D > 1 && H > 1 && W > 1, "kl_nondiag_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = pulpo_metric_blocks(nplanes * D * H * W);
+    hipLaunchKernelGGL(kln_fwd_kernel, dim3(nblk), dim3(256), 0, st, mu, sigma, (long)nplanes, D, H, W, prior_lambda, partial);
+    int rc = pulpo::check_launch("kl_nondiag_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(kln_finalize_kernel, dim3(1), dim3(1), 0, st, partial, nblk, (double)nplanes, D, H, W, (double)prior_lambda, loss);
+    return pulpo::check_launch("kl_nondiag_finalize");
+}
+PULPO_API int pulpo_kl_nondiag_bwd(const float* mu, const float* sigma, const float* gscale, int64_t nplanes, int D, int H, int W, float prior_lambda,
+                                   float* gmu, float* gsigma, void* stream) {
+    PULPO_REQUIRE(mu && sigma && gmu && gsigma && nplanes > 0 && D > 1 && H > 1 && W > 1, "kl_nondiag_bwd: bad arguments");
+    hipLaunchKernelGGL(kln_bwd_kernel, dim3(eblocks(nplanes * D * H * W)), dim3(256), 0, (hipStream_t)stream, mu, sigma, gscale, (long)nplanes, D, H, W,
+                       prior_lambda, gmu, gsigma);
+    return pulpo::check_launch("kl_nondiag_bwd");
+}

@@ -6,7 +6,7 @@ On the hot path (BASELINE configs: recon_loss=['ncc'], regularizer='L2', diagona
 Alternative hyper-parameters / evaluation metrics, also on HIP kernels (metrics.hip):
     L2_loss (:79-83, `--recon_loss mse`), Soft_dice_loss (:137-145, `--recon_loss dice`), jacobian_det (:172-199),
     JDetStd (:202-204, `--regularizer jdet`) - the 3-D forms.
-Still declared only (raise NotImplementedError): KL_nondiagonal (`--nondiagonal`) and the 2-D variants.
+KL_nondiagonal (:8-44, `--nondiagonal`) likewise.  Only the 2-D variants still raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -25,8 +25,18 @@ def _off_path(name: str):
 
 
 class KL_nondiagonal:
+    """KL against a prior with a non-diagonal (graph-Laplacian) precision, reference losses.py:8-44: the degree matrix is
+    computed inside the kernel instead of being materialised."""
+
     def __init__(self, inshape, prior_lambda=20) -> None:
-        _off_path("KL_nondiagonal")
+        self.prior_lambda = prior_lambda
+        self.inshape = [int(s) for s in inshape]
+        self.ndims = len(self.inshape)
+        if self.ndims != 3:
+            _off_path("KL_nondiagonal (2-D)")
+
+    def loss(self, prior_mean, prior_sigma, flow_mean, flow_sigma):
+        return ops.kl_nondiagonal(flow_mean, flow_sigma, self.prior_lambda)
 
 
 def L2_loss(input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
@@ -94,8 +104,8 @@ class HierarchicalKLLoss(nn.Module):
         super().__init__()
         self.weight_dict = _apply_pyramid(weight_dict, similarity_pyramid)
         self.KL_divergence = KL_divergence
-        if KL_divergence == KL_nondiagonal:
-            _off_path("KL_nondiagonal")
+        if KL_divergence == KL_nondiagonal:          # one instance per level (reference losses.py:242-243)
+            self.KL_divergence = {key: KL_nondiagonal(inshape=level_sizes[key]).loss for key in level_sizes.keys()}
 
     def forward(self, prior_mus, prior_sigmas, posterior_mus, posterior_sigmas):
         assert self.weight_dict.keys() == prior_mus.keys()
@@ -103,7 +113,10 @@ class HierarchicalKLLoss(nn.Module):
         kl_loss = 0.0
         all_levels = {}
         for l, w in self.weight_dict.items():
-            all_levels[l] = w * self.KL_divergence(posterior_mus[l], posterior_sigmas[l], prior_mus[l], prior_sigmas[l])
+            if isinstance(self.KL_divergence, dict):   # argument order of the reference for the non-diagonal class (losses.py:267-269)
+                all_levels[l] = w * self.KL_divergence[l](prior_mus[l], prior_sigmas[l], posterior_mus[l], posterior_sigmas[l])
+            else:
+                all_levels[l] = w * self.KL_divergence(posterior_mus[l], posterior_sigmas[l], prior_mus[l], prior_sigmas[l])
             kl_loss = kl_loss + all_levels[l]
         return kl_loss, all_levels
 

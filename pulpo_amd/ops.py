@@ -672,6 +672,32 @@ def jdet_std(df, lamb: float = 0.0, normalize: bool = True):
     return _JDetStd.apply(df, float(lamb), bool(normalize))
 
 
+class _KLNonDiag(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, sigma, prior_lambda: float):
+        _require_gpu(mu, sigma)
+        mu, sigma = planar(mu), planar(sigma)
+        B, C, D, H, W = mu.shape
+        part = torch.empty(4 * lib.query("pulpo_metric_blocks", mu.numel()), device=mu.device, dtype=torch.float32)
+        loss = torch.empty((), device=mu.device, dtype=torch.float32)
+        lib.call("pulpo_kl_nondiag_fwd", _ptr(mu), _ptr(sigma), B * C, D, H, W, prior_lambda, _ptr(part), _ptr(loss), _stream())
+        ctx.save_for_backward(mu, sigma)
+        ctx.lam = prior_lambda
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, sigma = ctx.saved_tensors
+        B, C, D, H, W = mu.shape
+        gmu, gsg = torch.empty_like(mu), torch.empty_like(sigma)
+        lib.call("pulpo_kl_nondiag_bwd", _ptr(mu), _ptr(sigma), _ptr(g.contiguous()), B * C, D, H, W, ctx.lam, _ptr(gmu), _ptr(gsg), _stream())
+        return gmu, gsg, None
+
+
+def kl_nondiagonal(mu, sigma, prior_lambda: float = 20.0):
+    return _KLNonDiag.apply(mu, sigma, float(prior_lambda))
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, gscale: float = 1.0):
     _require_gpu(p, g, m, v)

@@ -386,6 +386,15 @@ def gen_metrics():
         gd, = torch.autograd.grad(s_, [d])
         out.update({f"jstd_norm{int(norm)}": npy(s_), f"jstd_gd_norm{int(norm)}": npy(gd)})
     out["jdet_df"] = npy(d)
+    # KL_nondiagonal (losses.py:8-44) as HierarchicalKLLoss calls it: loss(prior_mu, prior_sigma, posterior_mu, posterior_sigma)
+    shape = (5, 6, 7)
+    kln = ls.KL_nondiagonal(inshape=torch.tensor(shape), prior_lambda=20)
+    kln.D = kln.D.cpu()
+    mu = torch.randn(2, 3, *shape, generator=g).requires_grad_(True)
+    sg = (F.softplus(torch.randn(2, 3, *shape, generator=g)) + 0.05).requires_grad_(True)
+    l = kln.loss(torch.zeros_like(mu), torch.ones_like(sg), mu, sg)
+    gm, gs = torch.autograd.grad(l, [mu, sg])
+    out.update(kln_mu=npy(mu), kln_sigma=npy(sg), kln_loss=npy(l), kln_gmu=npy(gm), kln_gsigma=npy(gs), kln_D=npy(kln.D))
     save("metrics", **out)
 
 

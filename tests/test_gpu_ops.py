@@ -307,11 +307,12 @@ def test_alternative_losses_and_metrics_golden(ops, golden):
 
 
 def test_recon_loss_options_through_the_model_api(ops):
-    """--recon_loss mse dice / --regularizer jdet construct and step (reference train.py:29-32 options)"""
+    """--recon_loss mse dice / --regularizer jdet / --nondiagonal construct and step (reference train.py:29-32,157-166 options)"""
     from src.models import PULPo
     FB = list(O.FEEDBACK_DEFAULT)
     torch.manual_seed(0)
-    m = PULPo(3, 2, 0.1, [16, 16, 16], feedback=FB, n0=4, recon_loss=["ncc", "mse", "dice"], regularizer="jdet", segs=True).cuda().train()
+    m = PULPo(3, 2, 0.1, [16, 16, 16], feedback=FB, n0=4, recon_loss=["ncc", "mse", "dice"], regularizer="jdet", segs=True,
+              nondiagonal=True).cuda().train()
     x, y = torch.rand(1, 1, 16, 16, 16).cuda(), torch.rand(1, 1, 16, 16, 16).cuda()
     seg = (torch.rand(1, 1, 16, 16, 16) > 0.5).float().cuda()
     e = torch.empty((0,), device="cuda")
@@ -319,3 +320,15 @@ def test_recon_loss_options_through_the_model_api(ops):
     loss.backward()
     assert bool(torch.isfinite(loss))
     assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+def test_kl_nondiagonal_golden(ops, golden):
+    g = golden("metrics")
+    mu, sg = dev(g["kln_mu"]).requires_grad_(True), dev(g["kln_sigma"]).requires_grad_(True)
+    from src.losses import KL_nondiagonal
+    kl = KL_nondiagonal(inshape=torch.tensor([5, 6, 7]), prior_lambda=20)
+    l = kl.loss(torch.zeros_like(mu), torch.ones_like(sg), mu, sg)
+    close(l, g["kln_loss"], rtol=1e-5)
+    gm, gs = torch.autograd.grad(l, [mu, sg])
+    close(gm, g["kln_gmu"], atol=1e-5, rtol=1e-4)
+    close(gs, g["kln_gsigma"], atol=1e-4, rtol=1e-4)

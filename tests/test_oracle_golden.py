@@ -166,6 +166,11 @@ def test_alternative_losses_and_metrics(golden):
         s_ = O.jdet_std(d, 0.3, bool(norm))
         close(s_, g[f"jstd_norm{norm}"], rtol=1e-5)
         close(torch.autograd.grad(s_, [d])[0], g[f"jstd_gd_norm{norm}"], atol=1e-7, rtol=1e-4)
+    mu, sg = T(g["kln_mu"]).requires_grad_(True), T(g["kln_sigma"]).requires_grad_(True)
+    l = O.kl_nondiagonal(mu, sg, 20.0)
+    close(l, g["kln_loss"], rtol=1e-5)
+    gm, gs = torch.autograd.grad(l, [mu, sg])
+    close(gm, g["kln_gmu"], atol=1e-5, rtol=1e-4); close(gs, g["kln_gsigma"], atol=1e-4, rtol=1e-4)
 
 
 # ------------------------------------------------------------------------------------------------ tables / keys
