@@ -47,10 +47,11 @@ __device__ __forceinline__ int tap_halo_offset(int tap) {
 }
 
 // stage the halo tile of channels [c0, c0+CH) into xs[HV][CH+1]; zero outside the volume / beyond Cin
-template <int CH, bool VEC>
+template <int CH, bool VEC, int TZv = TZ>
 __device__ __forceinline__ void stage_halo(float* xs, const float* __restrict__ in, long in_ps, long in_cs, int c0, int Cin,
                                            int z0, int y0, int x0, int D, int H, int W, int tid) {
     constexpr int CP = CH + 1;
+    constexpr int HV = (TZv + 2) * HY * HX;          // halo voxels of a TZv x 8 x 8 tile (shadows the 2x8x8 constant)
     if constexpr (VEC) {
         // all loads of the tile are issued back to back (NIT float4 per thread in flight), then written to LDS:
         // one exposed memory latency per chunk instead of one per loop iteration
@@ -89,10 +90,12 @@ __device__ __forceinline__ void stage_halo(float* xs, const float* __restrict__ 
     }
 }
 
-template <int CH, int NT, bool VEC>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(ConvArgs a) {
+template <int CH, int NT, bool VEC, int TZv>
+__global__ __launch_bounds__(256, TZv == 4 ? 3 : 2) void conv3d_k3_mfma(ConvArgs a) {
     constexpr int CP = CH + 1;
     constexpr int NN = NT / 32;
+    constexpr int MT = TZv / 2;                      // 32-voxel row tiles per wave: the workgroup tile is TZv x 8 x 8 voxels
+    constexpr int HV = (TZv + 2) * HY * HX;
     constexpr int XS = (HV * CP + 3) & ~3;
     constexpr int WF4 = CH * NT / 4;               // float4 per weight slab
     constexpr int NW = (WF4 + 255) / 256;          // float4 per thread per slab
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(ConvArgs a) {
     const int ty_ = t % a.nty; t /= a.nty;
     const int tz_ = t % a.ntz;
     const int b = t / a.ntz;
-    const int z0 = tz_ * TZ, y0 = ty_ * TY, x0 = tx_ * TX;
+    const int z0 = tz_ * TZv, y0 = ty_ * TY, x0 = tx_ * TX;
     const int co0 = cot * NT;
     const int nchunk_all = (a.Cin + CH - 1) / CH;
     const int cper = (nchunk_all + a.ksplit - 1) / a.ksplit;
@@ -140,35 +143,46 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(ConvArgs a) {
     };
 
     const int i = lane & 31, kk = lane >> 5;
-    const int v = wave * 32 + i;
-    const int hb = ((v >> 6) * HY + ((v >> 3) & 7)) * HX + (v & 7);
+    int hb[MT];                                       // halo index of this lane's voxel in each of the wave's row tiles
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int v = (wave * MT + m) * 32 + i;
+        hb[m] = ((v >> 6) * HY + ((v >> 3) & 7)) * HX + (v & 7);
+    }
 
-    f32x16 acc[NN];
+    f32x16 acc[MT][NN];
 #pragma unroll
-    for (int n = 0; n < NN; ++n)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     if (chunk0 < chunk1) load_w(it0);
     int buf = 0, it = it0;
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
         __syncthreads();   // every wave is done reading xs (previous chunk)
-        stage_halo<CH, VEC>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+        stage_halo<CH, VEC, TZv>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
         for (int tap = 0; tap < 27; ++tap, ++it) {
             store_w(buf);
             __syncthreads();
             if (it + 1 < niter) load_w(it + 1);
-            const float* xa = xs + (hb + tap_halo_offset(tap)) * CP + kk;
+            const float* xa[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xa[m] = xs + (hb[m] + tap_halo_offset(tap)) * CP + kk;
             const float* wb = ws + buf * CH * NT + kk * NT + i;
-            // (fragment reads are left to hipcc's placement here: with 4 waves per SIMD the other waves cover each read's
+            // (fragment reads are left to hipcc's placement here: with several waves per SIMD the other waves cover each read's
             //  latency, and forcing all reads of the tap ahead of its MFMAs measured ~8 % slower)
 #pragma unroll
             for (int s = 0; s < CH / 2; ++s) {
-                const float av = xa[2 * s];
+                float av[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[m] = xa[m][2 * s];
 #pragma unroll
                 for (int n = 0; n < NN; ++n) {
                     const float bv = wb[2 * s * NT + n * 32];
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv, acc[m][n], 0, 0, 0);
                 }
             }
             buf ^= 1;
@@ -185,17 +199,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(ConvArgs a) {
         const float bv = (a.bias != nullptr && cok && split == 0) ? a.bias[co] : 0.f;
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-            const int vv = wave * 32 + row;
-            const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
-            if (cok && gz < a.D && gy < a.H && gx < a.W) {
-                const float val = acc[n][r] + bv;
-                const long vox = (long)(gz * a.H + gy) * a.W + gx;
-                if (a.ksplit > 1) a.part[(((long)split * a.B + b) * a.D * a.H * a.W + vox) * a.Cout + co] = val;   // this split's partial sum
-                else out_b[vox * a.out_ps + (long)co * a.out_cs] = val;
-                s += val;
-                q += val * val;
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const int vv = (wave * MT + m) * 32 + row;
+                const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
+                if (cok && gz < a.D && gy < a.H && gx < a.W) {
+                    const float val = acc[m][n][r] + bv;
+                    const long vox = (long)(gz * a.H + gy) * a.W + gx;
+                    if (a.ksplit > 1) a.part[(((long)split * a.B + b) * a.D * a.H * a.W + vox) * a.Cout + co] = val;   // this split's partial sum
+                    else out_b[vox * a.out_ps + (long)co * a.out_cs] = val;
+                    s += val;
+                    q += val * val;
+                }
             }
         }
         ssum[n] = s + __shfl_xor(s, 32, 64);
@@ -514,18 +531,33 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
 int pick_ch(int K) { return K <= 4 ? 4 : 16; }
 int npad(int N) { return (N + 63) & ~63; }
 
-template <int CH, int NT, bool VEC>
-int launch_conv(const ConvArgs& a, int nblk, hipStream_t st) {
-    constexpr size_t lds = (size_t)(((HV * (CH + 1) + 3) & ~3) + 2 * CH * NT) * sizeof(float);
+// z extent of the forward voxel tile: 4 (each wave = two 32-voxel MFMA row tiles, every weight fragment feeds two MFMAs,
+// halo read amplification 2.3x instead of 3.1x) when the volume's depth divides evenly and there are enough tiles
+int conv_tz(int D, int H, int W) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("PULPO_CONV_TZ"); force = e ? atoi(e) : 0; }
+    if (force == 2 || force == 4) return (force == 4 && D % 4 == 0) ? 4 : 2;
+    return (D % 4 == 0 && (long)D * H * W >= 64L * 64 * 64) ? 4 : 2;
+}
+
+template <int CH, int NT, bool VEC, int TZv>
+int launch_conv_tz(const ConvArgs& a, int nblk, hipStream_t st) {
+    constexpr size_t lds = (size_t)((((TZv + 2) * HY * HX * (CH + 1) + 3) & ~3) + 2 * CH * NT) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma<CH, NT, VEC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma<CH, NT, VEC, TZv>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(conv3d): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3d_k3_mfma<CH, NT, VEC>), dim3(nblk), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3d_k3_mfma<CH, NT, VEC, TZv>), dim3(nblk), dim3(256), lds, st, a);
     return pulpo::check_launch("conv3d_k3_mfma");
+}
+
+template <int CH, int NT, bool VEC>
+int launch_conv(const ConvArgs& a, int nblk, hipStream_t st, int tz) {
+    if (tz == 4) return launch_conv_tz<CH, NT, VEC, 4>(a, nblk, st);
+    return launch_conv_tz<CH, NT, VEC, 2>(a, nblk, st);
 }
 
 }  // namespace
@@ -559,7 +591,7 @@ PULPO_API int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W);
 int conv_ksplit(int B, int D, int H, int W, int K, int N) {
     const int cfg = pulpo_conv3d_k3_tile_config(K, N);
     const int CH = cfg / 1000, NT = cfg % 1000;
-    const long nblk = (long)B * pulpo::cdiv(D, TZ) * pulpo::cdiv(H, TY) * pulpo::cdiv(W, TX) * pulpo::cdiv(N, NT);
+    const long nblk = (long)B * pulpo::cdiv(D, conv_tz(D, H, W)) * pulpo::cdiv(H, TY) * pulpo::cdiv(W, TX) * pulpo::cdiv(N, NT);
     const int nchunk = (K + CH - 1) / CH;
     if (nblk >= 512 || nchunk <= 1) return 1;
     return (int)std::max<long>(1, std::min<long>(std::min(nchunk, 8), 1024 / nblk));   // one resident round of <= 1024 workgroups
@@ -583,9 +615,10 @@ PULPO_API int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps,
     a.out = out; a.out_bs = out_bs; a.out_ps = out_ps; a.out_cs = out_cs;
     a.stats = stats;
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
-    a.ntz = pulpo::cdiv(D, TZ); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
     const int cfg = pulpo_conv3d_k3_tile_config(K, N);
     const int CH = cfg / 1000, NT = cfg % 1000;
+    const int tz = conv_tz(D, H, W);
+    a.ntz = pulpo::cdiv(D, tz); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
     a.ncot = pulpo::cdiv(N, NT);
     const long nblk_l = (long)B * a.ntz * a.nty * a.ntx * a.ncot;
     PULPO_REQUIRE(nblk_l < (1L << 31), "conv3d_k3_fwd: grid too large");
@@ -596,9 +629,9 @@ PULPO_API int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps,
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0) && CH >= 16;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (CH == 4) rc = NT == 64 ? launch_conv<4, 64, false>(a, nblk, st) : launch_conv<4, 32, false>(a, nblk, st);
-    else if (vec) rc = NT == 64 ? launch_conv<16, 64, true>(a, nblk, st) : launch_conv<16, 32, true>(a, nblk, st);
-    else rc = NT == 64 ? launch_conv<16, 64, false>(a, nblk, st) : launch_conv<16, 32, false>(a, nblk, st);
+    if (CH == 4) rc = NT == 64 ? launch_conv<4, 64, false>(a, nblk, st, tz) : launch_conv<4, 32, false>(a, nblk, st, tz);
+    else if (vec) rc = NT == 64 ? launch_conv<16, 64, true>(a, nblk, st, tz) : launch_conv<16, 32, true>(a, nblk, st, tz);
+    else rc = NT == 64 ? launch_conv<16, 64, false>(a, nblk, st, tz) : launch_conv<16, 32, false>(a, nblk, st, tz);
     if (rc == 0 && a.ksplit > 1) {
         const int nrow = pulpo_conv3d_k3_stat_tiles(B, D, H, W);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nrow, pulpo::cdiv(N, 32)), dim3(256), 0, st, scratch, a.ksplit, out, (long)out_bs, (long)out_ps, (long)out_cs, B,
@@ -609,7 +642,7 @@ PULPO_API int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps,
 }
 
 PULPO_API int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W) {
-    return B * pulpo::cdiv(D, TZ) * pulpo::cdiv(H, TY) * pulpo::cdiv(W, TX);
+    return B * pulpo::cdiv(D, conv_tz(D, H, W)) * pulpo::cdiv(H, TY) * pulpo::cdiv(W, TX);
 }
 
 PULPO_API size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout) { return (size_t)27 * Cin * npad(Cout); }
