@@ -83,6 +83,23 @@ def cpu_baseline(size, T, L, B):
                       f"oracle/pulpo_oracle.py on torch-CPU, {dt:.1f} s"}
 
 
+def pmc_traffic(kernel: str) -> dict:
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of this same command
+    (profiles/r1_bench160_pmc_traffic.json, made by scripts/pmc_traffic.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs;
+    counters cannot be read from inside the process).  Launch-weighted over the kernel's tile variants."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_bench160_pmc_traffic.json")
+    if not os.path.exists(path):
+        return {"traffic": None}
+    rows = json.load(open(path))["per_launch"]
+    stem = kernel.replace(" ", "").rstrip(">")
+    hit = [r for k, r in rows.items() if k.replace(" ", "").startswith(stem)]
+    n = sum(r["launches"] for r in hit)
+    if n == 0:
+        return {"traffic": None}
+    return {"traffic": sum(r["traffic_bytes"] * r["launches"] for r in hit) / n, "traffic_unit": "bytes/launch",
+            "traffic_source": "profiles/r1_bench160_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE raw for 64-B gathers + WRITE_SIZE)"}
+
+
 def main():
     args = parse()
     from pulpo_amd import dp, ops
@@ -136,6 +153,7 @@ def main():
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / dt
+        is160_cfg = size == [160, 160, 160] and (T, L) == (5, 4) and B == 1
         # ---- dominant kernel from the live HIP-event trace
         roof = None
         per_kernel = {}
@@ -150,7 +168,9 @@ def main():
             roof = {"bound": "mfma", "kernel": dom[0], "achieved": fl / sec / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "launches": n, "avg_launch_ms": sec / n * 1e3,
                     "flop_per_launch": fl / n}
-        is160 = size == [160, 160, 160] and (T, L) == (5, 4)
+            if is160_cfg:
+                roof.update(pmc_traffic(dom[0]))
+        is160 = is160_cfg
         out = {
             "metric": "volume-pairs/sec fwd+bwd, 160^3 fp32",
             "value": value, "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -1,0 +1,68 @@
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py -> per-kernel HBM-side bytes per launch (JSON + markdown).
+
+usage: python scripts/pmc_traffic.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> <out prefix under profiles/>
+
+The two counters do not fit one pass on gfx950 (TCC has 4 slots: FETCH_SIZE costs 3, WRITE_SIZE 2), so they come from two runs of
+the same command.  Units: rocprofv3 reports both in KiB.  Correction applied as MI355X_MICROARCH.md prescribes: FETCH_SIZE reads
+one half of the bytes of fully coalesced 16 B/lane streams - that applies to the LDS-DMA wgrad kernel and the elementwise
+float4 kernels (factor 2 below); the forward/dgrad convolution gathers 64-byte runs per voxel, an access width the guide calls
+uncalibrated, so its FETCH_SIZE is reported raw (factor 1) and is a lower bound.
+"""
+import csv, glob, json, re, sys
+from collections import defaultdict
+
+csv.field_size_limit(1 << 30)
+
+
+def short(name: str) -> str:
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    if n.startswith("at::"):
+        return n[:60]
+    return n.split("(")[0]
+
+
+def collect(d: str, counter: str):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = short(r["Kernel_Name"])
+            tot[k] += float(r["Counter_Value"])
+            cnt[k] += 1
+    return tot, cnt
+
+
+FETCH_FACTOR = [(re.compile(r"conv3d_k3_wgrad_mfma<true"), 2.0), (re.compile(r"conv3d_k3_mfma"), 1.0), (re.compile(r"conv3d_k3_wgrad_mfma<false"), 1.0)]
+
+
+def main():
+    fdir, wdir, out = sys.argv[1:4]
+    ft, fc = collect(fdir, "FETCH_SIZE")
+    wt, wc = collect(wdir, "WRITE_SIZE")
+    rows = {}
+    for k in ft:
+        if k not in wt or fc[k] != wc[k]:
+            continue
+        factor = 2.0
+        for pat, fac in FETCH_FACTOR:
+            if pat.search(k):
+                factor = fac
+                break
+        fetch = ft[k] * 1024 / fc[k]
+        write = wt[k] * 1024 / wc[k]
+        rows[k] = {"launches": fc[k], "fetch_raw_bytes": fetch, "fetch_factor": factor, "write_bytes": write,
+                   "traffic_bytes": fetch * factor + write}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-trace",
+               "per_launch": rows}, open(out + ".json", "w"), indent=1)
+    top = sorted(rows.items(), key=lambda kv: -kv[1]["traffic_bytes"] * kv[1]["launches"])[:25]
+    with open(out + ".md", "w") as f:
+        f.write("# HBM-side traffic per launch (PMC), bench.py 160^3 step\n\n" + __doc__.split("\n\n", 2)[2] + "\n")
+        f.write("| kernel | launches | FETCH raw MiB | factor | WRITE MiB | traffic MiB/launch |\n|---|---|---|---|---|---|\n")
+        for k, r in top:
+            f.write(f"| `{k}` | {r['launches']} | {r['fetch_raw_bytes']/2**20:.1f} | {r['fetch_factor']:.0f} | {r['write_bytes']/2**20:.1f} | {r['traffic_bytes']/2**20:.1f} |\n")
+    print(open(out + ".md").read())
+
+
+if __name__ == "__main__":
+    main()
