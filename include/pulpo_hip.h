@@ -55,6 +55,20 @@ int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t
                           int64_t dy_cs, float* dw, int accumulate /*dw += instead of dw =*/, float* scratch, int B, int D, int H, int W, int Cin,
                           int Cout, void* stream);
 
+/* bf16-operand variant (BASELINE configs 4-5; no counterpart in the reference, whose arithmetic is fp32 throughout - SURVEY.md 8(d)):
+ * the same convolution with both operands rounded to bf16 (round-to-nearest-even) as they are staged, products and sums in
+ * fp32 on v_mfma_f32_32x32x16_bf16.  Activations, gradients, bias, outputs and `stats` stay fp32; same tiling, same
+ * pulpo_conv3d_k3_stat_tiles().  wp holds bf16 bit patterns. */
+size_t pulpo_conv3d_k3_packed_bf16_elems(int K, int N);
+int pulpo_conv3d_k3_pack_weight_bf16(const float* w /*[Cout][Cin][3][3][3]*/, uint16_t* wp, int Cin, int Cout, int dgrad, void* stream);
+size_t pulpo_conv3d_k3_fwd_bf16_scratch_floats(int B, int D, int H, int W, int K, int N);
+int pulpo_conv3d_k3_fwd_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias, float* out,
+                             int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, int B, int D, int H, int W, int K,
+                             int N, void* stream);
+int pulpo_conv3d_k3_wgrad_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs, int64_t dy_ps,
+                               int64_t dy_cs, float* dw, int accumulate, float* scratch /*pulpo_conv3d_k3_wgrad_scratch_floats*/, int B, int D,
+                               int H, int W, int Cin, int Cout, void* stream);
+
 /* ------------------------------------------------------------- ConvUnit: BatchNorm3d + LeakyReLU(0.2, inplace)
  * replaces nn.BatchNorm3d / nn.LeakyReLU (src/network_blocks.py:24-25) = aten::native_batch_norm(+_backward),
  * aten::leaky_relu_(+_backward).  coef = 8*C floats: [4][C] floats (mean, rstd, scale = gamma*rstd, shift = beta - mean*scale)

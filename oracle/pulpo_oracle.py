@@ -85,12 +85,51 @@ def weight_tables(cfg: Cfg) -> Tuple[Dict[int, int], Dict[int, float], Dict[int,
 
 
 # =============================================================================== elementary operators
+# bf16-operand mode (BASELINE configs 4-5).  The reference has no reduced-precision mode, so this is a
+# DEFINITION, not a restatement - "parity unpinned" against the reference: each 3x3x3 convolution product (forward, data
+# gradient, weight gradient) takes its two operands rounded to bf16 (round-to-nearest-even) and accumulates in fp32;
+# GEMMs with <= 4 reduction channels (the image / latent inputs) stay fp32.  Everything else is fp32 as in the reference.
+CONV_PRECISION = "fp32"
+
+
+def _rb(t: Tensor) -> Tensor:
+    return t.bfloat16().to(t.dtype)
+
+
+class _ConvBf16Operands(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        xin, win = (_rb(x), _rb(w)) if w.shape[1] > 4 else (x, w)
+        return F.conv3d(xin, win, b, stride=1, padding=1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dyr = _rb(dy)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:                      # data gradient: K = Cout channels
+            gx = torch.nn.grad.conv3d_input(x.shape, _rb(w) if w.shape[0] > 4 else w, dyr if w.shape[0] > 4 else dy, stride=1, padding=1)
+        if ctx.needs_input_grad[1]:                      # weight gradient: bf16 operands when Cin > 4
+            big = w.shape[1] > 4
+            gw = torch.nn.grad.conv3d_weight(_rb(x) if big else x, w.shape, dyr if big else dy, stride=1, padding=1)
+        gb = dy.sum(dim=(0, 2, 3, 4)) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def conv3_k3(h: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """the padded 3x3x3 convolution of ConvUnit in the active operand precision"""
+    if CONV_PRECISION == "bf16":
+        return _ConvBf16Operands.apply(h, w, b)
+    return F.conv3d(h, w, b, stride=1, padding=1)
+
+
 def conv_unit(h: Tensor, sd: Dict[str, Tensor], prefix: str, training: bool) -> Tensor:
     """Conv3d(k3,p1,bias) -> BatchNorm3d(eps 1e-5, momentum 0.1) -> LeakyReLU(0.2)   network_blocks.py:22-26.
     `prefix` names the ConvUnit ('..._op.0'); its children are '_op.0' (conv) and '_op.1' (bn).
     In training mode the running statistics in `sd` are updated in place, as nn.BatchNorm3d does."""
     w, b = sd[prefix + "._op.0.weight"], sd[prefix + "._op.0.bias"]
-    h = F.conv3d(h, w, b, stride=1, padding=1)
+    h = conv3_k3(h, w, b)
     rm, rv = sd[prefix + "._op.1.running_mean"], sd[prefix + "._op.1.running_var"]
     if training:
         nbt = sd.get(prefix + "._op.1.num_batches_tracked")

@@ -10,15 +10,17 @@
 // the (4x10x10)-voxel halo of a 16-channel input chunk is staged once in LDS ([voxel][CH+1], odd stride ->
 // conflict-free ds_read_b32 for the A fragment; all global loads of the tile issued back to back) and re-used by all
 // 27 taps; the 27 weight slabs stream through a double-buffered LDS tile, prefetched global->registers one tap ahead.
-#include "common.h"
+#include "conv_shared.h"
 #include <stdlib.h>
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 namespace {
 
-constexpr int TZ = 2, TY = 8, TX = 8, MV = TZ * TY * TX;          // output voxel tile
-constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;  // halo tile
+using pulpo_conv::TY; using pulpo_conv::TX; using pulpo_conv::HY; using pulpo_conv::HX;
+using pulpo_conv::conv_tz; using pulpo_conv::npad;
+constexpr int TZ = 2, MV = TZ * TY * TX;          // base output voxel tile (wgrad; forward uses conv_tz())
+constexpr int HZ = TZ + 2, HV = HZ * HY * HX;     // halo tile
 
 struct ConvArgs {
     const float* in;
@@ -529,16 +531,6 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
 // Cin chunk staged per pass: 16 channels (27 KB halo tile + 8 KB weight double buffer => 4 workgroups per CU; measured
 // faster than 32- and 8-channel chunks on MI355X), 4 for the 2-/3-channel input layers
 int pick_ch(int K) { return K <= 4 ? 4 : 16; }
-int npad(int N) { return (N + 63) & ~63; }
-
-// z extent of the forward voxel tile: 4 (each wave = two 32-voxel MFMA row tiles, every weight fragment feeds two MFMAs,
-// halo read amplification 2.3x instead of 3.1x) when the volume's depth divides evenly and there are enough tiles
-int conv_tz(int D, int H, int W) {
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("PULPO_CONV_TZ"); force = e ? atoi(e) : 0; }
-    if (force == 2 || force == 4) return (force == 4 && D % 4 == 0) ? 4 : 2;
-    return (D % 4 == 0 && (long)D * H * W >= 64L * 64 * 64) ? 4 : 2;
-}
 
 template <int CH, int NT, bool VEC, int TZv>
 int launch_conv_tz(const ConvArgs& a, int nblk, hipStream_t st) {
@@ -561,6 +553,25 @@ int launch_conv(const ConvArgs& a, int nblk, hipStream_t st, int tz) {
 }
 
 }  // namespace
+
+// z extent of the forward voxel tile: 4 (each wave = two 32-voxel MFMA row tiles, every weight fragment feeds two MFMAs,
+// halo read amplification 2.3x instead of 3.1x) when the volume's depth divides evenly and there are enough tiles
+int pulpo_conv::conv_tz(int D, int H, int W) {
+    return (D % 4 == 0 && (long)D * H * W >= 64L * 64 * 64) ? 4 : 2;
+}
+
+int pulpo_conv::launch_splitk_reduce(const float* part, int ksplit, float* out, long obs, long ops, long ocs, int B, long V, int C, int nrow,
+                                     float* stats, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nrow, pulpo::cdiv(C, 32)), dim3(256), 0, st, part, ksplit, out, obs, ops, ocs, B, V, C, nrow, stats);
+    return pulpo::check_launch("splitk_reduce");
+}
+
+int pulpo_conv::launch_unpack_wgrad(const float* packed, float* dw, int Cin, int Cout, int accumulate, hipStream_t st) {
+    const long total = (long)Cout * Cin * 27;
+    const int ub = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ub), dim3(256), 0, st, packed, dw, Cin, Cout, npad(Cout), total, accumulate);
+    return pulpo::check_launch("unpack_wgrad");
+}
 
 // ================================================================================================ C ABI
 PULPO_API size_t pulpo_conv3d_k3_packed_floats(int K, int N) {
@@ -633,10 +644,8 @@ PULPO_API int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps,
     else if (vec) rc = NT == 64 ? launch_conv<16, 64, true>(a, nblk, st, tz) : launch_conv<16, 32, true>(a, nblk, st, tz);
     else rc = NT == 64 ? launch_conv<16, 64, false>(a, nblk, st, tz) : launch_conv<16, 32, false>(a, nblk, st, tz);
     if (rc == 0 && a.ksplit > 1) {
-        const int nrow = pulpo_conv3d_k3_stat_tiles(B, D, H, W);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nrow, pulpo::cdiv(N, 32)), dim3(256), 0, st, scratch, a.ksplit, out, (long)out_bs, (long)out_ps, (long)out_cs, B,
-                           (long)D * H * W, N, nrow, stats);
-        rc = pulpo::check_launch("splitk_reduce");
+        rc = pulpo_conv::launch_splitk_reduce(scratch, a.ksplit, out, (long)out_bs, (long)out_ps, (long)out_cs, B, (long)D * H * W, N,
+                                              pulpo_conv3d_k3_stat_tiles(B, D, H, W), stats, st);
     }
     return rc;
 }
@@ -699,8 +708,5 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
 #undef PULPO_WGRAD
     rc = pulpo::check_launch("conv3d_k3_wgrad_mfma");
     if (rc) return rc;
-    const long total = (long)Cout * Cin * 27;
-    const int ub = (int)std::min<long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ub), dim3(256), 0, st, scratch, dw, Cin, Cout, a.NPad, total, accumulate);
-    return pulpo::check_launch("unpack_wgrad");
+    return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
 }

@@ -126,9 +126,30 @@ def _trace_end(start, name: str, flops: float):
     CONV_TRACE.append((name, flops, start, end))
 
 
+# Operand precision of the 3x3x3 convolutions: "fp32" (the reference's arithmetic; exact-fp32 MFMA) or "bf16" (BASELINE configs
+# 4-5: operands rounded to bf16 while staged, fp32 accumulation; activations, statistics, losses and gradients stay fp32).
+# Layers with <= 4 reduction channels (the 2-channel image input) always run the fp32 kernel.
+CONV_PRECISION = "fp32"
+
+
+def set_conv_precision(precision: str) -> None:
+    global CONV_PRECISION
+    if precision not in ("fp32", "bf16"):
+        raise ValueError(f"conv precision is {precision}. Not a known option.")
+    CONV_PRECISION = precision
+
+
+def _use_bf16(K: int) -> bool:
+    return CONV_PRECISION == "bf16" and K > 4
+
+
 def _pack_weight(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
     Cout, Cin = w.shape[0], w.shape[1]
     K, N = (Cout, Cin) if dgrad else (Cin, Cout)
+    if _use_bf16(K):
+        wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_bf16_elems", K, N), device=w.device, dtype=torch.int16)
+        lib.call("pulpo_conv3d_k3_pack_weight_bf16", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
+        return wp
     wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_floats", K, N), device=w.device, dtype=torch.float32)
     lib.call("pulpo_conv3d_k3_pack_weight", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
     return wp
@@ -139,15 +160,21 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
     B, _, D, H, W = x.shape
     xb, xp, xc = grid_strides(x)
     ob, op, oc = grid_strides(out)
-    nscr = lib.query("pulpo_conv3d_k3_fwd_scratch_floats", B, D, H, W, K, N)
+    bf16 = wp.dtype == torch.int16
+    sfx = "_bf16" if bf16 else ""
+    nscr = lib.query(f"pulpo_conv3d_k3_fwd{sfx}_scratch_floats", B, D, H, W, K, N)
     scratch = torch.empty(nscr, device=x.device, dtype=torch.float32) if nscr else None
     t0 = _trace_begin()
-    lib.call("pulpo_conv3d_k3_fwd", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc, _ptr(stats), _ptr(scratch), B, D, H, W, K, N,
-             _stream())
+    lib.call(f"pulpo_conv3d_k3_fwd{sfx}", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc, _ptr(stats), _ptr(scratch), B, D, H, W,
+             K, N, _stream())
     if t0 is not None:
-        cfg = lib.query("pulpo_conv3d_k3_tile_config", K, N)
-        vec = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0 and cfg // 1000 >= 16
-        _trace_end(t0, f"conv3d_k3_mfma<{cfg // 1000},{cfg % 1000},{'true' if vec else 'false'}>", 54.0 * K * N * B * D * H * W)
+        vec_ok = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0
+        if bf16:
+            name = f"conv3d_k3_mfma_bf16<{64 if N % 64 == 0 else 32},{'true' if vec_ok else 'false'}>"
+        else:
+            cfg = lib.query("pulpo_conv3d_k3_tile_config", K, N)
+            name = f"conv3d_k3_mfma<{cfg // 1000},{cfg % 1000},{'true' if vec_ok and cfg // 1000 >= 16 else 'false'}>"
+        _trace_end(t0, name, 54.0 * K * N * B * D * H * W)
 
 
 def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -158,9 +185,10 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
     xb, xp, xc = grid_strides(x)
     db, dp, dc = grid_strides(dy)
     t0 = _trace_begin()
-    lib.call("pulpo_conv3d_k3_wgrad", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), int(into is not None), _ptr(scratch), B, D, H, W,
+    sfx = "_bf16" if _use_bf16(Cin) else ""
+    lib.call(f"pulpo_conv3d_k3_wgrad{sfx}", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), int(into is not None), _ptr(scratch), B, D, H, W,
              Cin, Cout, _stream())
-    _trace_end(t0, "conv3d_k3_wgrad_mfma(+memset,unpack)", 54.0 * Cin * Cout * B * D * H * W)
+    _trace_end(t0, f"conv3d_k3_wgrad{sfx or '_mfma'}(+memset,unpack)", 54.0 * Cin * Cout * B * D * H * W)
     return None if into is not None else dw
 
 

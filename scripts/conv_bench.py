@@ -1,5 +1,5 @@
 """Micro-benchmark of the MFMA convolution kernels on the layer shapes of the 160^3 / T5 / L4 training step.
-usage: python scripts/conv_bench.py [--reps 10] [--only fwd|dgrad|wgrad]"""
+usage: python scripts/conv_bench.py [--reps 10] [--only fwd|dgrad|wgrad] [--precision fp32|bf16]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,8 +23,10 @@ def timeit(fn, reps):
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=10); ap.add_argument("--only", default="")
     ap.add_argument("--shapes", type=int, nargs="*", default=None)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="conv operand precision (bf16 = BASELINE configs 4-5)")
     a = ap.parse_args()
     lib.load()
+    ops.set_conv_precision(a.precision)
     tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
     print(f"{'shape':>22s} {'GFLOP':>8s} | {'fwd ms':>8s} {'TF/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s}")
     for idx, (ci, co, S, cnt) in enumerate(SHAPES):

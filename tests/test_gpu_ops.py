@@ -191,6 +191,37 @@ def test_conv3d_vs_oracle(ops, B, Cin, Cout, size, cl):
     assert rel_l2(gb, gref[2]) < 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,size,cl", [c for c in CONV_CASES if c[1] > 4] + [(1, 32, 64, (16, 64, 64), True), (1, 96, 96, (64, 64, 64), True)])
+def test_conv3d_bf16_operands_vs_oracle(ops, B, Cin, Cout, size, cl):
+    """bf16-operand mode (BASELINE configs 4-5): the kernel against the oracle's definition (operands rounded to bf16, exact
+    products, wide accumulation) - bf16 x bf16 products are exact in fp32, so the fp32 tolerances of the fp32 test apply.
+    Also bounds the distance to the fp32 convolution (stated: relative L2 <= 1e-2 for N(0,1) data)."""
+    gen = torch.Generator().manual_seed(B * 1000 + Cin * 10 + Cout)
+    x = torch.randn(B, Cin, *size, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (27 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    up = torch.randn(B, Cout, *size, generator=gen)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    O.CONV_PRECISION = "bf16"
+    ops.set_conv_precision("bf16")
+    try:
+        ref = O.conv3_k3(xr, wr, br)
+        gref = torch.autograd.grad((ref * up.double()).sum(), [xr, wr, br])
+        xd = x.cuda().contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        out = ops.conv3d_k3(xd, wd, bd)
+        gx, gw, gb = torch.autograd.grad((out * up.cuda()).sum(), [xd, wd, bd])
+    finally:
+        O.CONV_PRECISION = "fp32"
+        ops.set_conv_precision("fp32")
+    assert rel_l2(out, ref) < 2e-6
+    assert rel_l2(gx, gref[0]) < 2e-6
+    assert rel_l2(gw, gref[1]) < 1e-5
+    assert rel_l2(gb, gref[2]) < 1e-5
+    full = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    assert rel_l2(out, full) < 1e-2
+
+
 def test_conv_linearity_at_full_channel_width(ops):
     """size-independent property at a BASELINE layer shape (32->32 @ 48^3): conv(a*x1 + x2) = a*conv(x1) + conv(x2) (no bias)"""
     gen = torch.Generator().manual_seed(3)
