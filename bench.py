@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FEEDBACK = ["samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed"]
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 matrix peak
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
 FLOP_ALG_PER_PAIR_160 = 5.708e12       # conv FLOPs fwd+bwd per pair at 160^3 / T5 / L4
 BYTES_ALG_PER_PAIR_160 = 41.98e9       # fused-kernel compulsory bytes per pair
@@ -40,6 +41,9 @@ def parse():
     ap.add_argument("--size", type=int, nargs=3, default=[160, 160, 160])
     ap.add_argument("--levels", type=int, nargs=2, default=[5, 4], help="total_levels latent_levels")
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="conv operand precision: fp32 (the metric's configuration, default) or bf16 operands / fp32 accumulate "
+                         "(BASELINE configs 4-5; reported under its own metric name, never as the fp32 headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="do not bracket conv launches with HIP events")
     return ap.parse_args()
@@ -114,6 +118,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib.load()
+    ops.set_conv_precision(args.precision)
+    bf16 = args.precision == "bf16"
 
     from src.models import PULPo
     T, L = args.levels
@@ -165,17 +171,18 @@ def main():
                 k[2] += s.elapsed_time(e) * 1e-3
             dom = max(per_kernel.items(), key=lambda kv: kv[1][2])
             n, fl, sec = dom[1]
-            roof = {"bound": "mfma", "kernel": dom[0], "achieved": fl / sec / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "launches": n, "avg_launch_ms": sec / n * 1e3,
+            peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom[0] else PEAK_FP32_MFMA_TFLOPS
+            roof = {"bound": "mfma", "kernel": dom[0], "achieved": fl / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
+                    "frac": fl / sec / 1e12 / peak, "traffic": None, "launches": n, "avg_launch_ms": sec / n * 1e3,
                     "flop_per_launch": fl / n}
-            if is160_cfg:
+            if is160_cfg and not bf16:
                 roof.update(pmc_traffic(dom[0]))
         is160 = is160_cfg
         out = {
-            "metric": "volume-pairs/sec fwd+bwd, 160^3 fp32",
+            "metric": "volume-pairs/sec fwd+bwd, 160^3 " + ("bf16 conv operands (fp32 accumulate, fp32 activations)" if bf16 else "fp32"),
             "value": value, "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic U[0,1) volumes, default-initialised weights (manual_seed 0)",
+            "dtype": "bf16xbf16->f32 convs, f32 elsewhere" if bf16 else "f32", "data": "synthetic U[0,1) volumes, default-initialised weights (manual_seed 0)",
             "config": {"workload": f"{size[0]}x{size[1]}x{size[2]} synthetic pair, {L}-level pyramid (total_levels {T}), fp32, batch {B} per GPU, "
                                    "fwd+bwd+grad all-reduce+Adam", "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roof,
@@ -184,9 +191,10 @@ def main():
         }
         if is160:
             per_gpu = value / world
-            out["step_rooflines"] = {"conv_flop_frac_of_157.3TF": FLOP_ALG_PER_PAIR_160 * per_gpu / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            mpeak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+            out["step_rooflines"] = {f"conv_flop_frac_of_{mpeak:g}TF": FLOP_ALG_PER_PAIR_160 * per_gpu / 1e12 / mpeak,
                                      "alg_bytes_frac_of_8TBps": BYTES_ALG_PER_PAIR_160 * per_gpu / 8.0e12}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not bf16:
             out["cpu_baseline"] = cpu_baseline(size, T, L, B)
         else:
             out["cpu_baseline"] = None
