@@ -165,6 +165,13 @@ int pulpo_kl_nondiag_bwd(const float* mu, const float* sigma, const float* gscal
 int pulpo_jdetstd_bwd(const float* df, const float* jdet, const double* stat, const float* gscale, float lamb, float* gdf, int B, int D, int H, int W,
                       int normalize, void* stream);
 
+/* ------------------------------------------------------------------------------- Monte-Carlo uncertainty statistics
+ * evaluate.py:222-251 stacks N sampled volumes / fields per level and takes torch.std(axis=0) (unbiased) then torch.mean over the
+ * channel axis.  Streaming form: fold sample k (1-based count) into running (mean, M2) images of the sample's shape, then
+ * out[b][v] = mean_c sqrt(M2[b][c][v] / (k - 1)) (* |scale[b][v]| when scale != NULL: the warped mask of evaluate.py:249). */
+int pulpo_mc_moments_update(const float* sample, float* mean, float* m2, int64_t n, int k, void* stream);
+int pulpo_mc_moments_std(const float* m2, const float* scale /*nullable (B,V)*/, float* out /*(B,V)*/, int B, int C, int64_t V, int k, void* stream);
+
 /* --------------------------------------------------------------------------------------------------- optimizer
  * torch.optim.Adam(lr) defaults (src/models.py:398-400) over a flat fp32 arena; gscale pre-multiplies the gradient. */
 int pulpo_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float gscale,

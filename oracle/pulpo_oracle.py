@@ -535,3 +535,12 @@ def train_step(sd, cfg: Cfg, x: Tensor, y: Tensor, eps):
     params = {k: v for k, v in sd.items() if v.requires_grad}
     gl = torch.autograd.grad(ls[0], list(params.values()), allow_unused=True)
     return ls, {k: g for k, g in zip(params, gl)}, outs
+
+
+# =============================================================================== Monte-Carlo uncertainty maps
+def mc_std_map(stack: Tensor, scale: Optional[Tensor] = None) -> Tensor:
+    """(N, C, D, H, W) samples -> (D, H, W): torch.mean(torch.std(stack * scale, axis=0), axis=0)   evaluate.py:243-251
+    (torch.std is the unbiased estimator; `scale` is the warped mask of evaluate.py:249, broadcast over N and C)"""
+    if scale is not None:
+        stack = stack * scale
+    return torch.mean(torch.std(stack, axis=0), axis=0)

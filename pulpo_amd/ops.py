@@ -727,6 +727,45 @@ def kl_nondiagonal(mu, sigma, prior_lambda: float = 20.0):
 
 
 # ------------------------------------------------------------------------------------------------ optimizer
+# ------------------------------------------------------------------------------------------------ MC uncertainty
+class StreamingMoments:
+    """running per-voxel mean / unbiased std over Monte-Carlo samples (evaluate.py:222-251 keeps all N samples instead).
+    update() folds one (B, C, D, H, W) sample in; std_map() = torch.mean(torch.std(stack, axis=0), axis=<channel>) -> (B, D, H, W)."""
+
+    def __init__(self) -> None:
+        self.count = 0
+        self._mean = None
+        self._m2 = None
+
+    def update(self, sample: torch.Tensor) -> None:
+        _require_gpu(sample)
+        s = sample.detach().contiguous()
+        if self._mean is None:
+            self._mean, self._m2 = torch.empty_like(s), torch.empty_like(s)
+        elif s.shape != self._mean.shape:
+            raise ValueError(f"StreamingMoments: sample shape {tuple(s.shape)} differs from {tuple(self._mean.shape)}")
+        self.count += 1
+        lib.call("pulpo_mc_moments_update", _ptr(s), _ptr(self._mean), _ptr(self._m2), s.numel(), self.count, _stream())
+
+    def mean(self) -> torch.Tensor:
+        if self._mean is None:
+            raise ValueError("StreamingMoments: no samples")
+        return self._mean
+
+    def std_map(self, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self._m2 is None:
+            raise ValueError("StreamingMoments: no samples")
+        B, C = self._m2.shape[0], self._m2.shape[1]
+        V = self._m2[0, 0].numel()
+        out = torch.empty((B,) + tuple(self._m2.shape[2:]), device=self._m2.device, dtype=torch.float32)
+        sc = None
+        if scale is not None:
+            _require_gpu(scale)
+            sc = scale.detach().expand((B, 1) + tuple(self._m2.shape[2:])).contiguous()
+        lib.call("pulpo_mc_moments_std", _ptr(self._m2), _ptr(sc), _ptr(out), B, C, V, self.count, _stream())
+        return out
+
+
 def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, gscale: float = 1.0):
     _require_gpu(p, g, m, v)
     lib.call("pulpo_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, int(step), gscale, _stream())

@@ -363,3 +363,26 @@ def test_kl_nondiagonal_golden(ops, golden):
     gm, gs = torch.autograd.grad(l, [mu, sg])
     close(gm, g["kln_gmu"], atol=1e-5, rtol=1e-4)
     close(gs, g["kln_gsigma"], atol=1e-4, rtol=1e-4)
+
+
+# ================================================================================================ MC uncertainty statistics
+@pytest.mark.parametrize("N,C,size", [(8, 3, (6, 7, 9)), (2, 1, (5, 5, 5)), (5, 3, (16, 16, 16))])
+def test_streaming_mc_moments_vs_oracle(ops, N, C, size):
+    """the streaming (mean, M2) kernel against evaluate.py's stack + torch.std + torch.mean (oracle.mc_std_map)"""
+    gen = torch.Generator().manual_seed(N * 10 + C)
+    stack = torch.randn(N, C, *size, generator=gen) * 3 + 1.5
+    mask = (torch.rand(1, 1, *size, generator=gen) > 0.3).float() * torch.rand(1, 1, *size, generator=gen)
+    sm = ops.StreamingMoments()
+    for i in range(N):
+        sm.update(stack[i:i + 1].cuda())
+    close(sm.mean()[0], stack.mean(dim=0), atol=1e-5)
+    close(sm.std_map()[0], O.mc_std_map(stack), atol=1e-5, rtol=1e-5)
+    close(sm.std_map(scale=mask.cuda())[0], O.mc_std_map(stack, mask), atol=1e-5, rtol=1e-5)
+
+
+def test_streaming_mc_moments_single_sample_is_nan_like_torch_std(ops):
+    sm = ops.StreamingMoments()
+    sm.update(torch.ones(1, 3, 4, 4, 4, device="cuda"))
+    assert bool(torch.isnan(sm.std_map()).all())          # torch.std over one sample is NaN (unbiased estimator), evaluate.py:243
+    with pytest.raises(ValueError):
+        sm.update(torch.ones(1, 3, 4, 4, 5, device="cuda"))
