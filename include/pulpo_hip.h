@@ -49,6 +49,11 @@ size_t pulpo_conv3d_k3_fwd_scratch_floats(int B, int D, int H, int W, int K, int
 int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, float* out,
                         int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch /*nullable if the query is 0*/, int B,
                         int D, int H, int W, int K, int N, void* stream);
+/* eval-mode ConvUnit in ONE kernel (inference: predict / predict_deterministic / evaluate.py): out = LeakyReLU_slope(conv * scale + shift)
+ * with coef from pulpo_bn_eval_coef (running statistics folded) - the store of the convolution applies what pulpo_bn_lrelu_apply would */
+int pulpo_conv3d_k3_fwd_bn_lrelu(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
+                                 const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* scratch, int B,
+                                 int D, int H, int W, int K, int N, void* stream);
 /* weight gradient: dw[Cout][Cin][27] = sum_voxels in[v + tap - 1][ci] * dy[v][co]; scratch is overwritten */
 size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
 int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs, int64_t dy_ps,
@@ -65,6 +70,9 @@ size_t pulpo_conv3d_k3_fwd_bf16_scratch_floats(int B, int D, int H, int W, int K
 int pulpo_conv3d_k3_fwd_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias, float* out,
                              int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, int B, int D, int H, int W, int K,
                              int N, void* stream);
+int pulpo_conv3d_k3_fwd_bn_lrelu_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias,
+                                      const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* scratch,
+                                      int B, int D, int H, int W, int K, int N, void* stream);
 int pulpo_conv3d_k3_wgrad_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs, int64_t dy_ps,
                                int64_t dy_cs, float* dw, int accumulate, float* scratch /*pulpo_conv3d_k3_wgrad_scratch_floats*/, int B, int D,
                                int H, int W, int Cin, int Cout, void* stream);

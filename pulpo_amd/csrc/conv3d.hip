@@ -34,6 +34,8 @@ struct ConvArgs {
     int ntz, nty, ntx, ncot;
     int ksplit;                   // > 1: the Cin chunks are split over ksplit workgroups, each storing a partial slab into `part`
     float* part;                  // [ksplit][B*V][Cout] dense partial outputs (reduced in fixed order by splitk_reduce_kernel)
+    const float* coef;            // nullable: eval-mode BatchNorm coefficients (scale at [2C], shift at [3C]) + LeakyReLU fused into the store
+    float slope;
 };
 
 // 64 bytes of zeros: source address of out-of-volume / out-of-channel lanes of an LDS-DMA piece
@@ -199,6 +201,8 @@ __global__ __launch_bounds__(256, TZv == 4 ? 3 : 2) void conv3d_k3_mfma(ConvArgs
         const int co = co0 + n * 32 + i;
         const bool cok = co < a.Cout;
         const float bv = (a.bias != nullptr && cok && split == 0) ? a.bias[co] : 0.f;
+        const bool fuse = a.coef != nullptr && cok;
+        const float fsc = fuse ? a.coef[2 * a.Cout + co] : 1.f, fsh = fuse ? a.coef[3 * a.Cout + co] : 0.f;
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -208,10 +212,16 @@ __global__ __launch_bounds__(256, TZv == 4 ? 3 : 2) void conv3d_k3_mfma(ConvArgs
                 const int vv = (wave * MT + m) * 32 + row;
                 const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
                 if (cok && gz < a.D && gy < a.H && gx < a.W) {
-                    const float val = acc[m][n][r] + bv;
+                    float val = acc[m][n][r] + bv;
                     const long vox = (long)(gz * a.H + gy) * a.W + gx;
                     if (a.ksplit > 1) a.part[(((long)split * a.B + b) * a.D * a.H * a.W + vox) * a.Cout + co] = val;   // this split's partial sum
-                    else out_b[vox * a.out_ps + (long)co * a.out_cs] = val;
+                    else {
+                        if (fuse) {                       // the arithmetic of bn_lrelu_apply_kernel
+                            const float t = val * fsc + fsh;
+                            val = t > 0.f ? t : t * a.slope;
+                        }
+                        out_b[vox * a.out_ps + (long)co * a.out_cs] = val;
+                    }
                     s += val;
                     q += val * val;
                 }
@@ -245,7 +255,8 @@ __global__ __launch_bounds__(256, TZv == 4 ? 3 : 2) void conv3d_k3_mfma(ConvArgs
 // split-K finish: out = sum_s part[s] in fixed order (deterministic), plus the per-row (sum, sum of squares) BatchNorm partials.
 // Row r of stats covers voxels [r*V/nrow, (r+1)*V/nrow): any partition is fine for the double-precision finalize.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, float* __restrict__ out, long obs, long ops,
-                                                              long ocs, int B, long V, int C, int nrow, float* __restrict__ stats) {
+                                                              long ocs, int B, long V, int C, int nrow, float* __restrict__ stats,
+                                                              const float* __restrict__ coef, float slope) {
     // grid = (nrow, ceil(C/32)): one workgroup per (voxel slice, 32-channel group); 32 channels x 8 voxel lanes
     __shared__ float red[2][256];
     const int r = blockIdx.x, c0 = blockIdx.y * 32;
@@ -253,11 +264,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const long p0 = npix * r / nrow, p1 = npix * (r + 1) / nrow;
     const int c = c0 + (threadIdx.x & 31), prow = threadIdx.x >> 5;
     float s = 0.f, q = 0.f;
+    const bool fuse = coef != nullptr && c < C;
+    const float fsc = fuse ? coef[2 * C + c] : 1.f, fsh = fuse ? coef[3 * C + c] : 0.f;
     if (c < C)
         for (long p = p0 + prow; p < p1; p += 8) {
             float v = 0.f;
             for (int k = 0; k < ksplit; ++k) v += part[((long)k * npix + p) * C + c];
             const long b = p / V, vox = p - b * V;
+            if (fuse) {
+                const float t = v * fsc + fsh;
+                v = t > 0.f ? t : t * slope;
+            }
             out[b * obs + vox * ops + (long)c * ocs] = v;
             s += v;
             q += v * v;
@@ -561,8 +578,9 @@ int pulpo_conv::conv_tz(int D, int H, int W) {
 }
 
 int pulpo_conv::launch_splitk_reduce(const float* part, int ksplit, float* out, long obs, long ops, long ocs, int B, long V, int C, int nrow,
-                                     float* stats, hipStream_t st) {
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nrow, pulpo::cdiv(C, 32)), dim3(256), 0, st, part, ksplit, out, obs, ops, ocs, B, V, C, nrow, stats);
+                                     float* stats, const float* coef, float slope, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nrow, pulpo::cdiv(C, 32)), dim3(256), 0, st, part, ksplit, out, obs, ops, ocs, B, V, C, nrow, stats,
+                       coef, slope);
     return pulpo::check_launch("splitk_reduce");
 }
 
@@ -615,16 +633,18 @@ PULPO_API size_t pulpo_conv3d_k3_fwd_scratch_floats(int B, int D, int H, int W, 
 
 // Generic entry: computes out[b][vox][n] = sum_{tap,k} in[b][vox+tap-1][k] * wp[...] (+ bias[n]).
 // K / N are the GEMM's reduction / output channel counts (forward: Cin/Cout; dgrad: Cout/Cin with dgrad-packed wp).
-PULPO_API int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
-                                  float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, int B, int D, int H,
-                                  int W, int K, int N, void* stream) {
+static int conv_fwd_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, float* out,
+                         int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, const float* coef, float slope, int B,
+                         int D, int H, int W, int K, int N, void* stream) {
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd: null pointer");
+    PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd: batch statistics are not available from the fused eval-mode epilogue");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd: bad dims");
     ConvArgs a;
     a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
     a.wp = wp; a.bias = bias;
     a.out = out; a.out_bs = out_bs; a.out_ps = out_ps; a.out_cs = out_cs;
     a.stats = stats;
+    a.coef = coef; a.slope = slope;
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
     const int cfg = pulpo_conv3d_k3_tile_config(K, N);
     const int CH = cfg / 1000, NT = cfg % 1000;
@@ -645,9 +665,23 @@ PULPO_API int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps,
     else rc = NT == 64 ? launch_conv<16, 64, false>(a, nblk, st, tz) : launch_conv<16, 32, false>(a, nblk, st, tz);
     if (rc == 0 && a.ksplit > 1) {
         rc = pulpo_conv::launch_splitk_reduce(scratch, a.ksplit, out, (long)out_bs, (long)out_ps, (long)out_cs, B, (long)D * H * W, N,
-                                              pulpo_conv3d_k3_stat_tiles(B, D, H, W), stats, st);
+                                              pulpo_conv3d_k3_stat_tiles(B, D, H, W), stats, coef, slope, st);
     }
     return rc;
+}
+
+PULPO_API int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
+                                  float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, int B, int D, int H,
+                                  int W, int K, int N, void* stream) {
+    return conv_fwd_impl(in, in_bs, in_ps, in_cs, wp, bias, out, out_bs, out_ps, out_cs, stats, scratch, nullptr, 0.f, B, D, H, W, K, N, stream);
+}
+
+// eval-mode ConvUnit in one kernel: out = LeakyReLU(BatchNorm_eval(conv + bias)) with coef from pulpo_bn_eval_coef
+PULPO_API int pulpo_conv3d_k3_fwd_bn_lrelu(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
+                                           const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs,
+                                           float* scratch, int B, int D, int H, int W, int K, int N, void* stream) {
+    PULPO_REQUIRE(coef, "conv3d_k3_fwd_bn_lrelu: null coef");
+    return conv_fwd_impl(in, in_bs, in_ps, in_cs, wp, bias, out, out_bs, out_ps, out_cs, nullptr, scratch, coef, slope, B, D, H, W, K, N, stream);
 }
 
 PULPO_API int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W) {

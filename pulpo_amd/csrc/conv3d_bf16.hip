@@ -34,6 +34,8 @@ struct ConvArgsH {
     int ntz, nty, ntx, ncot;
     int ksplit;
     float* part;
+    const float* coef;            // nullable: fused eval-mode BatchNorm + LeakyReLU (see conv3d.hip)
+    float slope;
 };
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
@@ -183,6 +185,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16(ConvArgsH a) {
         const int co = co0 + n * 32 + i;
         const bool cok = co < a.Cout;
         const float bias = (a.bias != nullptr && cok && split == 0) ? a.bias[co] : 0.f;
+        const bool fuse = a.coef != nullptr && cok;
+        const float fsc = fuse ? a.coef[2 * a.Cout + co] : 1.f, fsh = fuse ? a.coef[3 * a.Cout + co] : 0.f;
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -192,10 +196,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16(ConvArgsH a) {
                 const int vv = (wave * MT + m) * 32 + row;
                 const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
                 if (cok && gz < a.D && gy < a.H && gx < a.W) {
-                    const float val = acc[m][n][r] + bias;
+                    float val = acc[m][n][r] + bias;
                     const long vox = (long)(gz * a.H + gy) * a.W + gx;
                     if (a.ksplit > 1) a.part[(((long)split * a.B + b) * a.D * a.H * a.W + vox) * a.Cout + co] = val;
-                    else out_b[vox * a.out_ps + (long)co * a.out_cs] = val;
+                    else {
+                        if (fuse) {
+                            const float t = val * fsc + fsh;
+                            val = t > 0.f ? t : t * a.slope;
+                        }
+                        out_b[vox * a.out_ps + (long)co * a.out_cs] = val;
+                    }
                     s += val;
                     q += val * val;
                 }
@@ -443,16 +453,18 @@ PULPO_API size_t pulpo_conv3d_k3_fwd_bf16_scratch_floats(int B, int D, int H, in
 
 PULPO_API int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W);
 
-PULPO_API int pulpo_conv3d_k3_fwd_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias,
-                                       float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, int B, int D,
-                                       int H, int W, int K, int N, void* stream) {
+static int conv_fwd_bf16_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias, float* out,
+                              int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, const float* coef, float slope,
+                              int B, int D, int H, int W, int K, int N, void* stream) {
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_bf16: null pointer");
+    PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd_bf16: batch statistics are not available from the fused eval-mode epilogue");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd_bf16: bad dims");
     ConvArgsH a;
     a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
     a.wp = wp; a.bias = bias;
     a.out = out; a.out_bs = out_bs; a.out_ps = out_ps; a.out_cs = out_cs;
     a.stats = stats;
+    a.coef = coef; a.slope = slope;
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
     const int tz = conv_tz(D, H, W), NT = nt_for(N);
     a.ntz = pulpo::cdiv(D, tz); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
@@ -472,8 +484,23 @@ PULPO_API int pulpo_conv3d_k3_fwd_bf16(const float* in, int64_t in_bs, int64_t i
 #undef PULPO_BF16
     if (rc == 0 && a.ksplit > 1)
         rc = pulpo_conv::launch_splitk_reduce(scratch, a.ksplit, out, (long)out_bs, (long)out_ps, (long)out_cs, B, (long)D * H * W, N,
-                                              pulpo_conv3d_k3_stat_tiles(B, D, H, W), stats, st);
+                                              pulpo_conv3d_k3_stat_tiles(B, D, H, W), stats, coef, slope, st);
     return rc;
+}
+
+PULPO_API int pulpo_conv3d_k3_fwd_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias,
+                                       float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, int B, int D,
+                                       int H, int W, int K, int N, void* stream) {
+    return conv_fwd_bf16_impl(in, in_bs, in_ps, in_cs, wp, bias, out, out_bs, out_ps, out_cs, stats, scratch, nullptr, 0.f, B, D, H, W, K, N,
+                              stream);
+}
+
+PULPO_API int pulpo_conv3d_k3_fwd_bn_lrelu_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp,
+                                                const float* bias, const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps,
+                                                int64_t out_cs, float* scratch, int B, int D, int H, int W, int K, int N, void* stream) {
+    PULPO_REQUIRE(coef, "conv3d_k3_fwd_bn_lrelu_bf16: null coef");
+    return conv_fwd_bf16_impl(in, in_bs, in_ps, in_cs, wp, bias, out, out_bs, out_ps, out_cs, nullptr, scratch, coef, slope, B, D, H, W, K, N,
+                              stream);
 }
 
 /* weight gradient with bf16 operands: dw[Cout][Cin][27] (+)= sum_voxels bf16(in[v + tap - 1][ci]) * bf16(dy[v][co]), fp32 accumulation */

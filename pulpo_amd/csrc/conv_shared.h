@@ -14,8 +14,9 @@ int conv_tz(int D, int H, int W);
 inline int npad(int N) { return (N + 63) & ~63; }
 
 // out = sum over the ksplit partial slabs (fixed order) + per-row BatchNorm partials; see splitk_reduce_kernel in conv3d.hip
+// (coef != nullptr: eval-mode BatchNorm + LeakyReLU applied to the reduced value, see ConvArgs::coef)
 int launch_splitk_reduce(const float* part, int ksplit, float* out, long obs, long ops, long ocs, int B, long V, int C, int nrow, float* stats,
-                         hipStream_t st);
+                         const float* coef, float slope, hipStream_t st);
 
 // dw[Cout][Cin][27] (+)= packed[27][Cin][NPad]; see unpack_wgrad_kernel in conv3d.hip
 int launch_unpack_wgrad(const float* packed, float* dw, int Cin, int Cout, int accumulate, hipStream_t st);

@@ -156,7 +156,8 @@ def _pack_weight(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
 
 
 def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, K: int, N: int,
-              stats: Optional[torch.Tensor]):
+              stats: Optional[torch.Tensor], coef: Optional[torch.Tensor] = None):
+    """coef: eval-mode BatchNorm coefficients -> BatchNorm + LeakyReLU are applied by the convolution's store (one kernel per ConvUnit)"""
     B, _, D, H, W = x.shape
     xb, xp, xc = grid_strides(x)
     ob, op, oc = grid_strides(out)
@@ -165,8 +166,12 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
     nscr = lib.query(f"pulpo_conv3d_k3_fwd{sfx}_scratch_floats", B, D, H, W, K, N)
     scratch = torch.empty(nscr, device=x.device, dtype=torch.float32) if nscr else None
     t0 = _trace_begin()
-    lib.call(f"pulpo_conv3d_k3_fwd{sfx}", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc, _ptr(stats), _ptr(scratch), B, D, H, W,
-             K, N, _stream())
+    if coef is None:
+        lib.call(f"pulpo_conv3d_k3_fwd{sfx}", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc, _ptr(stats), _ptr(scratch), B, D, H,
+                 W, K, N, _stream())
+    else:
+        lib.call(f"pulpo_conv3d_k3_fwd_bn_lrelu{sfx}", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc,
+                 _ptr(scratch), B, D, H, W, K, N, _stream())
     if t0 is not None:
         vec_ok = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0
         if bf16:
@@ -214,8 +219,12 @@ class _ConvBNLReLU(torch.autograd.Function):
             lib.call("pulpo_bn_fwd_finalize", _ptr(stats), ntile, Cout, float(B * D * H * W), _ptr(gamma), _ptr(beta), _ptr(running_mean),
                      _ptr(running_var), _ptr(num_batches_tracked), momentum, eps, _ptr(coef), _ptr(scratch), _stream())
         else:
-            _conv_raw(x, wp, bias, y, Cin, Cout, None)
             lib.call("pulpo_bn_eval_coef", _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps, Cout, _ptr(coef), _stream())
+            if not any(ctx.needs_input_grad):
+                # inference: conv + folded BatchNorm + LeakyReLU in one kernel, the pre-norm tensor is never written
+                _conv_raw(x, wp, bias, y, Cin, Cout, None, coef=coef)
+                return y
+            _conv_raw(x, wp, bias, y, Cin, Cout, None)
         z = new_cl(B, Cout, D, H, W, dev)
         lib.call("pulpo_bn_lrelu_apply", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
         ctx.save_for_backward(x, weight, y, coef)

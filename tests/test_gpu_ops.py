@@ -222,6 +222,39 @@ def test_conv3d_bf16_operands_vs_oracle(ops, B, Cin, Cout, size, cl):
     assert rel_l2(out, full) < 1e-2
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("Cin,Cout,size", [(32, 64, (8, 16, 16)), (192, 192, (5, 6, 4)), (3, 32, (9, 8, 8)), (16, 12, (7, 6, 5))])
+def test_eval_mode_fused_epilogue_equals_separate_passes(ops, precision, Cin, Cout, size):
+    """inference runs conv + folded BatchNorm + LeakyReLU as one kernel (also through the split-K reduce of small volumes);
+    with a gradient requested the pre-norm tensor is kept and the normalisation is a separate pass: same bits either way,
+    and the eval-mode gradient matches the oracle."""
+    gen = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(2, Cin, *size, generator=gen)
+    sd = {"u._op.0.weight": torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (27 * Cin) ** 0.5, "u._op.0.bias": torch.randn(Cout, generator=gen),
+          "u._op.1.weight": torch.rand(Cout, generator=gen) + 0.5, "u._op.1.bias": torch.randn(Cout, generator=gen),
+          "u._op.1.running_mean": torch.randn(Cout, generator=gen) * 0.1, "u._op.1.running_var": torch.rand(Cout, generator=gen) + 0.5}
+    d = {k: v.cuda() for k, v in sd.items()}
+    args = (d["u._op.0.weight"], d["u._op.0.bias"], d["u._op.1.weight"], d["u._op.1.bias"], d["u._op.1.running_mean"], d["u._op.1.running_var"])
+    ops.set_conv_precision(precision)
+    O.CONV_PRECISION = precision
+    try:
+        xg = x.cuda().requires_grad_(True)
+        sep = ops.conv_bn_lrelu(xg, *args, training=False)
+        fused = ops.conv_bn_lrelu(x.cuda(), *args, training=False)
+        assert torch.equal(sep.detach(), fused)
+        xr = x.double().requires_grad_(True)
+        ref = O.conv_unit(xr, {k: v.double() for k, v in sd.items()}, "u", training=False)
+        assert rel_l2(fused, ref) < 5e-6
+        up = torch.randn(ref.shape, generator=gen)
+        gx, = torch.autograd.grad((sep * up.cuda()).sum(), [xg])
+        gr, = torch.autograd.grad((ref * up.double()).sum(), [xr])
+        # bf16 mode: the gradient operand dy is itself rounded to bf16 - fp32-vs-fp64 differences in dy flip a few roundings
+        assert rel_l2(gx, gr) < (5e-6 if precision == "fp32" else 2e-4)
+    finally:
+        ops.set_conv_precision("fp32")
+        O.CONV_PRECISION = "fp32"
+
+
 def test_conv_linearity_at_full_channel_width(ops):
     """size-independent property at a BASELINE layer shape (32->32 @ 48^3): conv(a*x1 + x2) = a*conv(x1) + conv(x2) (no bias)"""
     gen = torch.Generator().manual_seed(3)
