@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="conv operand precision: fp32 (the metric's configuration, default) or bf16 operands / fp32 accumulate "
                          "(BASELINE configs 4-5; reported under its own metric name, never as the fp32 headline)")
+    ap.add_argument("--data", default="uniform", choices=["uniform", "oasis"],
+                    help="uniform: U[0,1) volumes (configs 1-3); oasis: masked smooth anatomy + smooth random deformation (configs 4-5)")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train (the metric: fwd+bwd+all-reduce+Adam) or infer (eval-mode predict_deterministic, reported under its own metric name)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="do not bracket conv launches with HIP events")
     return ap.parse_args()
@@ -127,9 +131,8 @@ def main():
     torch.manual_seed(0)
     model = PULPo(T, L, 0.1, size, feedback=FEEDBACK, n0=32).to(dev).train()
     stepper = dp.DataParallelStepper(model)
-    g = torch.Generator().manual_seed(1234 + rank)
-    x = torch.rand(B, 1, *size, generator=g).to(dev)
-    y = torch.rand(B, 1, *size, generator=g).to(dev)
+    from pulpo_amd import synthetic
+    x, y = (synthetic.oasis_like_pair if args.data == "oasis" else synthetic.uniform_pair)(size, B, 1234 + rank, dev)
     empty = torch.empty((0,), device=dev)
     batch = (x, y, empty, empty, empty, empty, empty, empty)
 
@@ -138,14 +141,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    infer = args.mode == "infer"
+    if infer:
+        model.eval()
+
+        def one_step():
+            with torch.no_grad():
+                out, _ = model.predict_deterministic(x, y)
+            return out[0].sum()
+    else:
+        def one_step():
+            return stepper.step(batch)
+
     for _ in range(args.warmup):
-        stepper.step(batch)
+        one_step()
     barrier()
     if not args.no_trace:
         ops.CONV_TRACE = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = stepper.step(batch)
+        loss = one_step()
     barrier()
     dt = time.perf_counter() - t0
     trace, ops.CONV_TRACE = ops.CONV_TRACE, None
@@ -179,22 +194,23 @@ def main():
                 roof.update(pmc_traffic(dom[0]))
         is160 = is160_cfg
         out = {
-            "metric": "volume-pairs/sec fwd+bwd, 160^3 " + ("bf16 conv operands (fp32 accumulate, fp32 activations)" if bf16 else "fp32"),
+            "metric": ("volume-pairs/sec inference (predict_deterministic), 160^3 " if infer else "volume-pairs/sec fwd+bwd, 160^3 ") + ("bf16 conv operands (fp32 accumulate, fp32 activations)" if bf16 else "fp32"),
             "value": value, "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16xbf16->f32 convs, f32 elsewhere" if bf16 else "f32", "data": "synthetic U[0,1) volumes, default-initialised weights (manual_seed 0)",
-            "config": {"workload": f"{size[0]}x{size[1]}x{size[2]} synthetic pair, {L}-level pyramid (total_levels {T}), fp32, batch {B} per GPU, "
-                                   "fwd+bwd+grad all-reduce+Adam", "global_batch": world * B, "parallelism": f"dp{world}"},
+            "dtype": "bf16xbf16->f32 convs, f32 elsewhere" if bf16 else "f32", "data": ("synthetic OASIS-style pair (masked smooth anatomy, smooth random deformation)" if args.data == "oasis" else "synthetic U[0,1) volumes")
+            + ", default-initialised weights (manual_seed 0)",
+            "config": {"workload": f"{size[0]}x{size[1]}x{size[2]} synthetic pair, {L}-level pyramid (total_levels {T}), {'bf16 conv operands' if bf16 else 'fp32'}, batch {B} per GPU, "
+                                   + ("eval-mode forward (mu path, no sampling)" if infer else "fwd+bwd+grad all-reduce+Adam"), "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roof,
             "conv_kernels": {k: {"launches": v[0], "TFLOP/s": v[1] / v[2] / 1e12, "ms_total_per_step": v[2] / args.steps * 1e3}
                              for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][2])},
         }
-        if is160:
+        if is160 and not infer:
             per_gpu = value / world
             mpeak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
             out["step_rooflines"] = {f"conv_flop_frac_of_{mpeak:g}TF": FLOP_ALG_PER_PAIR_160 * per_gpu / 1e12 / mpeak,
                                      "alg_bytes_frac_of_8TBps": BYTES_ALG_PER_PAIR_160 * per_gpu / 8.0e12}
-        if world == 1 and not args.no_cpu_baseline and not bf16:
+        if world == 1 and not args.no_cpu_baseline and not bf16 and not infer:
             out["cpu_baseline"] = cpu_baseline(size, T, L, B)
         else:
             out["cpu_baseline"] = None
