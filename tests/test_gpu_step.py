@@ -366,6 +366,46 @@ def test_full_resolution_properties_96(api):
         assert bool((a == b).all())        # the forward path has no atomics: bitwise reproducible
 
 
+def test_config5_shape_bf16_train_step_and_mc_uncertainty(api):
+    """BASELINE config 5: 192 x 224 x 160 pair, 5-level pyramid (T6/L5, n0 = 32), bf16 conv operands, OASIS-style synthetic data, one
+    training step through the data-parallel stepper plus the 8-sample Monte-Carlo uncertainty maps.  No oracle at this size in the test
+    budget (a CPU step takes minutes): size-independent properties - shapes of every level (deepest 6 x 7 x 5), finite values, loss
+    decrease over three Adam steps on one pair, std maps finite, non-negative and zero outside the head mask for the warped image."""
+    models, nb = api
+    from pulpo_amd import dp, ops, synthetic
+    from pulpo_amd.uncertainty import mc_uncertainty
+    size = [192, 224, 160]
+    torch.manual_seed(0)
+    model = models.PULPo(6, 5, 0.1, size, feedback=FB, n0=32).cuda().train()
+    x, y = synthetic.oasis_like_pair(size, 1, 7, "cuda")
+    assert 0.2 < float((y > 0).float().mean()) < 0.35            # ellipsoid with semi-axes 0.4: 4/3 pi 0.4^3 = 0.27 of the box
+    empty = torch.empty((0,), device="cuda")
+    ops.set_conv_precision("bf16")
+    try:
+        stepper = dp.DataParallelStepper(model)
+        losses = [float(stepper.step((x, y, empty, empty, empty, empty, empty, empty))) for _ in range(3)]
+        assert all(np.isfinite(losses)) and losses[2] < losses[0], losses
+        model.eval()
+        with torch.no_grad():
+            outs = model.autoencoder(x, model.downpath(x, y))
+        for l in range(5):
+            k = l + 1
+            lvl = tuple(s // 2 ** k for s in size)
+            assert tuple(outs[0][l].shape) == (1, 3) + lvl                                       # mus
+            assert tuple(outs[7][l].shape) == (1, 1) + (tuple(size) if l == 0 else lvl)            # transformed
+        assert tuple(outs[0][4].shape[2:]) == (6, 7, 5)
+        res = mc_uncertainty(model, x, y, 8)
+        for l in range(5):
+            for key in ("output_std", "individual_df_std", "final_df_std"):
+                v = res[key][l]
+                assert bool(torch.isfinite(v).all()) and float(v.min()) >= 0.0, (key, l)
+            assert float(res["individual_df_std"][l].max()) > 0.0
+        corner = res["output_std"][0][:8, :8, :8]
+        assert float(corner.abs().max()) < 1e-6          # background stays background under small deformations
+    finally:
+        ops.set_conv_precision("fp32")
+
+
 def test_mc_uncertainty_matches_stacked_statistics(api, golden):
     """pulpo_amd.uncertainty.mc_uncertainty (streaming moments) against the reference's procedure (evaluate.py:222-251) carried out
     with stacked samples on the same latent noise: the sampler is replaced by one that replays a recorded noise sequence."""
