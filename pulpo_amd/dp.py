@@ -1,5 +1,6 @@
-"""Data-parallel training over volume pairs: one process per GPU, flat fp32 parameter / gradient arenas, one RCCL
-all-reduce (sum) of the gradient arena per step over xGMI, fused Adam over the arenas.
+"""Data-parallel training over volume pairs: one process per GPU, flat fp32 parameter / gradient arenas, the gradient arena
+summed over ranks by RCCL over xGMI in up to three contiguous buckets that are launched while the backward pass is still
+running, fused Adam over the arenas.
 
 The reference has no distributed code: pairs are independent, the only exchange is the gradient
 sum.  BatchNorm statistics stay per replica, exactly as un-synchronised DDP over the reference would behave.
@@ -24,8 +25,13 @@ class FlatArena:
 
     ALIGN = 4   # floats (16 bytes)
 
-    def __init__(self, module: nn.Module):
-        params = [p for p in module.parameters() if p.requires_grad]
+    def __init__(self, module: nn.Module, params: Optional[List[nn.Parameter]] = None):
+        """params: optional explicit order of the module's trainable parameters inside the arena (bucketed all-reduce keeps
+        every bucket contiguous); default = module.parameters() order"""
+        if params is None:
+            params = [p for p in module.parameters() if p.requires_grad]
+        elif {id(p) for p in params} != {id(p) for p in module.parameters() if p.requires_grad}:
+            raise ValueError("FlatArena: `params` must be a permutation of the module's trainable parameters")
         if not params:
             raise ValueError("FlatArena: module has no trainable parameters")
         dev, dt = params[0].device, params[0].dtype
@@ -85,12 +91,62 @@ class FusedAdam:
         ops.adam_step(self.arena.data, self.arena.grad, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1], self.eps, grad_scale)
 
 
-class DataParallelStepper:
-    """forward + backward + gradient all-reduce + Adam for one batch of volume pairs per rank (weak scaling)."""
+def _gradient_buckets(model: nn.Module):
+    """Order the parameters by the time their gradient completes in the backward pass of PULPo and cut the order into buckets:
 
-    def __init__(self, model: nn.Module, lr: Optional[float] = None):
+        0: autoencoder.*                 complete when the gradient of the coarsest DownPath activation has been accumulated
+        1: downpath.down_blocks[k >= 2]  complete when the gradient of down_blocks[1]'s output has been accumulated
+        2: everything else (down_blocks[0..1]: 0.3 M of the 14.7 M parameters at T5/L4) - complete when backward() returns
+
+    The full-resolution blocks 0 and 1 carry ~45 % of the backward time and almost no parameters, so buckets 0 and 1 (98 % of
+    the bytes) travel over xGMI underneath them.  Returns (ordered params, [(start, stop) index ranges], trigger modules)."""
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    down = getattr(model, "downpath", None)
+    if down is None or not hasattr(down, "down_blocks") or not hasattr(model, "autoencoder"):
+        return [p for _, p in named], [(0, len(named))], []
+    T = down.total_levels
+
+    def bucket(name: str) -> int:
+        if name.startswith("autoencoder."):
+            return 0
+        if name.startswith("downpath.down_blocks."):
+            return 1 if int(name.split(".")[2]) >= 2 else 2
+        return 2
+
+    order = sorted(range(len(named)), key=lambda i: (bucket(named[i][0]), i))
+    params = [named[i][1] for i in order]
+    ids = [bucket(named[i][0]) for i in order]
+    ranges, triggers = [], []
+    for b, trig in ((0, down.down_blocks[T - 1]), (1, down.down_blocks[1] if T >= 3 else None), (2, None)):
+        idx = [j for j, v in enumerate(ids) if v == b]
+        if idx:
+            ranges.append((idx[0], idx[-1] + 1))
+            triggers.append(trig)
+    return params, ranges, triggers
+
+
+class DataParallelStepper:
+    """forward + backward + gradient all-reduce + Adam for one batch of volume pairs per rank (weak scaling).
+
+    overlap=True (default, world_size > 1): the gradient arena is reduced in the buckets of _gradient_buckets(); a bucket's
+    all-reduce is issued from a tensor hook the moment autograd has finished accumulating the gradient that precedes the
+    remaining, parameter-poor part of the backward pass.  RCCL orders the collective after the kernels already enqueued on
+    the compute stream, and the Adam step waits for all buckets."""
+
+    def __init__(self, model: nn.Module, lr: Optional[float] = None, overlap: bool = True):
         self.model = model
-        self.arena = FlatArena(model)
+        params, ranges, triggers = _gradient_buckets(model)
+        self.arena = FlatArena(model, params)
+        off = self.arena.offsets + [self.arena.numel]
+        self.buckets = [(off[a], off[b]) for a, b in ranges]            # float ranges of the arena, in completion order
+        self.overlap = bool(overlap) and len(self.buckets) > 1
+        self._works: List = []
+        self._launched = 0
+        self._armed = False
+        if self.overlap:
+            for i, trig in enumerate(triggers):
+                if trig is not None:
+                    trig.register_forward_hook(self._make_forward_hook(i))
         self.opt = FusedAdam(self.arena, lr=lr if lr is not None else float(model.hparams.lr))
         if world() > 1:     # start from identical weights: broadcast rank 0's arena (and BN buffers)
             dist.broadcast(self.arena.data, src=0)
@@ -98,16 +154,42 @@ class DataParallelStepper:
                 if b.is_floating_point():
                     dist.broadcast(b, src=0)
 
+    # bucket i is complete once the gradient of trigger module i's OUTPUT has been accumulated (see _gradient_buckets)
+    def _make_forward_hook(self, i: int):
+        def fwd_hook(_module, _inputs, output):
+            if self._armed and isinstance(output, torch.Tensor) and output.requires_grad:
+                output.register_hook(lambda g, i=i: self._launch_upto(i))
+        return fwd_hook
+
+    def _launch_upto(self, i: int) -> None:
+        """issue the all-reduce of every not yet launched bucket up to and including i (buckets complete in index order)"""
+        while self._launched <= i:
+            a, b = self.buckets[self._launched]
+            if world() > 1:
+                self._works.append(dist.all_reduce(self.arena.grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
+            self._launched += 1
+        return None
+
     def step(self, batch) -> torch.Tensor:
         from . import ops
         self.arena.zero_grad()
-        loss = self.model.training_step(batch, 0)
-        ops.DIRECT_PARAM_GRADS = True          # conv / BN backward kernels add straight into the arena's .grad views
+        self._works, self._launched = [], 0
+        self._armed = self.overlap and world() > 1
         try:
-            loss.backward()
+            loss = self.model.training_step(batch, 0)
+            ops.DIRECT_PARAM_GRADS = True          # conv / BN backward kernels add straight into the arena's .grad views
+            try:
+                loss.backward()
+            finally:
+                ops.DIRECT_PARAM_GRADS = False
         finally:
-            ops.DIRECT_PARAM_GRADS = False
-        allreduce_sum_(self.arena.grad)
+            self._armed = False
+        if self.overlap and world() > 1:
+            self._launch_upto(len(self.buckets) - 1)
+            for w in self._works:
+                w.wait()
+        else:
+            allreduce_sum_(self.arena.grad)
         self.opt.step(1.0 / world())
         return loss.detach()
 

@@ -454,3 +454,76 @@ def test_mc_uncertainty_matches_stacked_statistics(api, golden):
     for l in range(L):
         ref = torch.stack(inds[l]).mean(dim=0)
         assert float((res2["individual_dfs"][l][0].cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pulpo_amd import dp
+import src.models as models, src.network_blocks as nb
+dp.init_from_env("gloo")                     # two ranks share the one GPU of the test box: gloo moves CUDA tensors, RCCL would refuse
+rank = dist.get_rank()
+dev = torch.device("cuda", 0)
+FB = ["samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed"]
+size = [32, 32, 32]
+
+def build():
+    torch.manual_seed(0)
+    m = models.PULPo(4, 3, 0.1, size, feedback=FB, n0=8).to(dev).train()
+    g = torch.Generator().manual_seed(3)
+    for l in range(3):
+        s = 32 // 2 ** (l + 1)
+        m.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(torch.randn(1, 3, s, s, s, generator=g).to(dev))
+    return m
+
+g = torch.Generator().manual_seed(50 + rank)           # a different pair on every rank
+x, y = torch.rand(1, 1, *size, generator=g).to(dev), torch.rand(1, 1, *size, generator=g).to(dev)
+e = torch.empty((0,), device=dev)
+batch = (x, y, e, e, e, e, e, e)
+ref = build()
+ref.training_step(batch, 0).backward()
+exp = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+for t in exp.values():
+    dist.all_reduce(t)
+net = build()
+stepper = dp.DataParallelStepper(net, overlap=True)
+assert len(stepper.buckets) == 3 and stepper.overlap
+stepper.opt.step = lambda scale: None
+launches = []
+orig = stepper._launch_upto
+def spy(i):
+    launches.append(i)
+    return orig(i)
+stepper._launch_upto = spy
+stepper.step(batch)
+torch.cuda.synchronize()
+assert launches == [0, 1, 2], launches
+worst = 0.0
+for n, p in net.named_parameters():
+    if n in exp:
+        err = float((p.grad - exp[n]).norm() / (exp[n].norm() + 1e-12))
+        if not (n.endswith("_op.0.bias") and "velocity_field._op.2" not in n):      # zero-mean gradients in front of a BatchNorm: noise
+            worst = max(worst, err)
+            assert err < 1e-3, (n, err)
+    else:
+        assert float(p.grad.abs().max()) == 0.0, n
+print(f"rank {rank} dp ok worst {worst:.2e}")
+dist.destroy_process_group()
+'''
+
+
+def test_bucketed_allreduce_with_the_real_model_two_ranks_one_gpu(tmp_path):
+    """the overlapped, bucketed gradient exchange of DataParallelStepper with the real PULPo model: two ranks (gloo over CUDA tensors,
+    both on the single GPU of the test box) with different pairs; every parameter's gradient after the step equals the sum of the two
+    ranks' plain local gradients, i.e. no bucket was reduced before its last contribution had been enqueued."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29647", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=420)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o[-3000:]
+        assert f"rank {r} dp ok" in o

@@ -167,3 +167,81 @@ def test_data_parallel_plumbing_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok world 2" in o
+
+
+BUCKET_WORKER = r'''
+import os, sys, types, torch, torch.nn as nn, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pulpo_amd import dp
+from pulpo_amd.utils import ModuleIntDict
+dp.init_from_env("gloo")
+rank = dist.get_rank()
+
+class Down(nn.Module):                       # PULPo's module structure (downpath.down_blocks[k], autoencoder) on plain CPU ops
+    def __init__(self, T):
+        super().__init__()
+        self.total_levels = T
+        self.down_blocks = ModuleIntDict()
+        for k in range(T):
+            self.down_blocks[k] = nn.Sequential(nn.Linear(8, 8), nn.Tanh())
+    def forward(self, h):
+        acts = {}
+        for k in range(self.total_levels):
+            h = self.down_blocks[k](h)
+            acts[k] = h
+        return acts
+
+class Net(nn.Module):
+    def __init__(self, T=4):
+        super().__init__()
+        self.downpath = Down(T)
+        self.autoencoder = nn.ModuleList([nn.Linear(8, 8) for _ in range(T)])
+        self.extra = nn.Linear(8, 1)
+        self.hparams = types.SimpleNamespace(lr=1e-3)
+    def training_step(self, batch, idx):
+        acts = self.downpath(batch)
+        h = 0
+        for k in reversed(range(len(self.autoencoder))):       # coarse to fine, every level feeds the finer ones
+            h = torch.tanh(self.autoencoder[k](acts[k] + h))
+        return self.extra(h).pow(2).mean()
+
+torch.manual_seed(0)
+net = Net()
+launches = []
+stepper = dp.DataParallelStepper(net, overlap=True)
+assert len(stepper.buckets) == 3 and stepper.overlap
+names = {id(p): n for n, p in net.named_parameters()}
+order = [names[id(p)] for p in stepper.arena.params]
+assert order[0].startswith("autoencoder.") and order[-1].startswith(("downpath.down_blocks.0", "downpath.down_blocks.1", "extra"))
+stepper.opt.step = lambda scale: None        # the fused Adam is a GPU kernel; this test is about the gradient exchange
+orig = stepper._launch_upto
+def spy(i):
+    launches.append((i, stepper._launched))
+    return orig(i)
+stepper._launch_upto = spy
+x = torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + rank))
+# expected: sum over ranks of the local gradients, from a plain backward without the stepper
+ref = Net(); ref.load_state_dict(net.state_dict())
+ref.training_step(x, 0).backward()
+exp = {n: p.grad.clone() for n, p in ref.named_parameters()}
+for t in exp.values():
+    dist.all_reduce(t)
+stepper.step(x)
+assert [i for i, _ in launches] == [0, 1, 2], launches      # two hooks during backward, the rest after it
+for n, p in net.named_parameters():
+    assert torch.allclose(p.grad, exp[n], rtol=1e-6, atol=1e-7), n
+print(f"rank {rank} buckets ok")
+dist.destroy_process_group()
+'''
+
+
+def test_bucketed_overlapped_allreduce_gloo_world2(tmp_path):
+    script = tmp_path / "bucket_worker.py"
+    script.write_text(BUCKET_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29643", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} buckets ok" in o
