@@ -54,6 +54,15 @@ int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps, int64_t i
 int pulpo_conv3d_k3_fwd_bn_lrelu(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
                                  const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* scratch, int B,
                                  int D, int H, int W, int K, int N, void* stream);
+/* Winograd F(2,3)-along-x variant of the same convolution for large volumes (1.5x fewer matrix instructions, all fp32; results
+ * differ from the direct kernel by fp32 rounding only).  pulpo_conv3d_k3_algo() = 1 where it applies; it has its own weight packing;
+ * coef (nullable) selects the fused eval-mode BatchNorm + LeakyReLU store, stats (nullable) the BatchNorm partials (same tiles). */
+int pulpo_conv3d_k3_algo(int B, int D, int H, int W, int K, int N);
+size_t pulpo_conv3d_k3_packed_wino_floats(int K, int N);
+int pulpo_conv3d_k3_pack_weight_wino(const float* w /*[Cout][Cin][3][3][3]*/, float* wp, int Cin, int Cout, int dgrad, void* stream);
+int pulpo_conv3d_k3_fwd_wino(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
+                             float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W,
+                             int K, int N, void* stream);
 /* weight gradient: dw[Cout][Cin][27] = sum_voxels in[v + tap - 1][ci] * dy[v][co]; scratch is overwritten */
 size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
 int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs, int64_t dy_ps,

@@ -293,6 +293,242 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ Winograd F(2,3) along x
+// Large volumes: the 3 x-taps of the 3x3x3 stencil are evaluated with the minimal-filtering identity F(2,3) (two neighbouring
+// outputs from four transformed inputs and four transformed weights instead of 2 x 3 products): 36 instead of 54 MFMA row
+// products per output pair = 1.5x fewer matrix instructions, all arithmetic still fp32.
+//   input  (staging)  : v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3        per (z, y, x-pair, channel)
+//   weights (packing) : u0 = g0, u1 = (g0 + g1 + g2)/2, u2 = (g0 - g1 + g2)/2, u3 = g2  per (dz, dy, cin, cout)
+//   output (registers): y_even = m0 + m1 + m2, y_odd = m1 - m2 - m3                     the four m live in the same lane
+// Workgroup = 4 x 8 x 8 output voxels = 4 z-planes (one per wave) x 32 (y, x-pair) blocks; the MFMA rows are the blocks, one
+// accumulator set per transformed point.  8-channel chunks: 960 transformed halo rows x 9 floats (34.5 KB) + the double-buffered
+// (dz, dy) weight slabs [4 points][8][NT] (16 KB at NT = 64) => 3 workgroups per CU.
+constexpr int WN_CH = 8, WN_CP = WN_CH + 1, WN_HZ = 6, WN_ROWS = WN_HZ * HY * 4 * 4;
+
+template <bool VEC>
+__device__ __forceinline__ void stage_halo_wino(float* xs, const float* __restrict__ in, long in_ps, long in_cs, int c0, int Cin, int z0, int y0,
+                                                int x0, int D, int H, int W, int tid) {
+    if constexpr (VEC) {
+        constexpr int Q = WN_CH / 4;
+        constexpr int NITEM = WN_HZ * HY * 4 * Q;              // (hz, hy, x-pair, channel quad)
+        constexpr int NIT = (NITEM + 255) / 256;
+        float4 d[NIT][4];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int j = tid + u * 256;
+            const int q = j % Q, xb = (j / Q) & 3, hrow = j / (4 * Q);
+            const int hz = hrow / HY, hy = hrow - hz * HY;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy;
+            const bool rowok = j < NITEM && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && c0 + 4 * q < Cin;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int gx = x0 - 1 + 2 * xb + t;
+                d[u][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rowok && (unsigned)gx < (unsigned)W) d[u][t] = *reinterpret_cast<const float4*>(in + ((long)(gz * H + gy) * W + gx) * in_ps + c0 + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int j = tid + u * 256;
+            if (j < NITEM) {
+                const int q = j % Q, rb = j / Q;                // rb = (hz*HY + hy)*4 + xb
+                float* o = xs + (rb * 4) * WN_CP + 4 * q;
+                const float4 d0 = d[u][0], d1 = d[u][1], d2 = d[u][2], d3 = d[u][3];
+                o[0] = d0.x - d2.x; o[1] = d0.y - d2.y; o[2] = d0.z - d2.z; o[3] = d0.w - d2.w;
+                o += WN_CP;
+                o[0] = d1.x + d2.x; o[1] = d1.y + d2.y; o[2] = d1.z + d2.z; o[3] = d1.w + d2.w;
+                o += WN_CP;
+                o[0] = d2.x - d1.x; o[1] = d2.y - d1.y; o[2] = d2.z - d1.z; o[3] = d2.w - d1.w;
+                o += WN_CP;
+                o[0] = d1.x - d3.x; o[1] = d1.y - d3.y; o[2] = d1.z - d3.z; o[3] = d1.w - d3.w;
+            }
+        }
+    } else {
+        for (int j = tid; j < WN_HZ * HY * 4 * WN_CH; j += 256) {
+            const int c = j % WN_CH, rb = j / WN_CH;
+            const int xb = rb & 3, hrow = rb >> 2;
+            const int hz = hrow / HY, hy = hrow - hz * HY;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy;
+            float d[4] = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && c0 + c < Cin) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int gx = x0 - 1 + 2 * xb + t;
+                    if ((unsigned)gx < (unsigned)W) d[t] = in[((long)(gz * H + gy) * W + gx) * in_ps + (long)(c0 + c) * in_cs];
+                }
+            }
+            float* o = xs + (rb * 4) * WN_CP + c;
+            o[0] = d[0] - d[2];
+            o[WN_CP] = d[1] + d[2];
+            o[2 * WN_CP] = d[2] - d[1];
+            o[3 * WN_CP] = d[1] - d[3];
+        }
+    }
+}
+
+template <int NT, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_wino_mfma(ConvArgs a) {
+    constexpr int CH = WN_CH, CP = WN_CP;
+    constexpr int NN = NT / 32;
+    constexpr int XS = (WN_ROWS * CP + 3) & ~3;
+    constexpr int WSL = 4 * CH * NT;                 // floats of one (dz, dy) weight slab set: [point][k][NT]
+    constexpr int WF4 = WSL / 4;
+    constexpr int NW = WF4 / 256;                    // float4 per thread per slab set (1 at NT = 32, 2 at NT = 64)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* ws = smem + XS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
+    const int cot = lid % a.ncot;
+    const int tile_lin = lid / a.ncot;
+    int t = tile_lin;
+    const int tx_ = t % a.ntx; t /= a.ntx;
+    const int ty_ = t % a.nty; t /= a.nty;
+    const int tz_ = t % a.ntz;
+    const int b = t / a.ntz;
+    const int z0 = tz_ * 4, y0 = ty_ * TY, x0 = tx_ * TX;
+    const int co0 = cot * NT;
+    const int nchunk = (a.Cin + CH - 1) / CH;
+    const int niter = nchunk * 9;
+    const float* in_b = a.in + (long)b * a.in_bs;
+
+    float4 wreg[NW];
+    auto load_w = [&](int it) {
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int j = tid + u * 256;
+            const int row = j / (NT / 4), c4 = j - row * (NT / 4);              // row = point * CH + k
+            wreg[u] = *reinterpret_cast<const float4*>(a.wp + ((long)it * 4 * CH + row) * a.NPad + co0 + c4 * 4);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NW; ++u) *reinterpret_cast<float4*>(ws + buf * WSL + (tid + u * 256) * 4) = wreg[u];
+    };
+
+    const int i = lane & 31, kk = lane >> 5;
+    // MFMA row i of wave w = block (z = w, y = i >> 2, x-pair = i & 3); its transformed rows start at rowbase (+ point)
+    const int rowbase = ((wave * HY + (i >> 2)) * 4 + (i & 3)) * 4;
+
+    f32x16 acc[4][NN];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][n][r] = 0.f;
+
+    load_w(0);
+    int buf = 0, it = 0;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        __syncthreads();
+        stage_halo_wino<VEC>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+        for (int zy = 0; zy < 9; ++zy, ++it) {
+            store_w(buf);
+            __syncthreads();
+            if (it + 1 < niter) load_w(it + 1);
+            const float* xa = xs + (rowbase + ((zy / 3) * HY + zy % 3) * 16) * CP + kk;
+            const float* wb = ws + buf * WSL + kk * NT + i;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                for (int s = 0; s < CH / 2; ++s) {
+                    const float av = xa[p * CP + 2 * s];
+#pragma unroll
+                    for (int n = 0; n < NN; ++n) {
+                        const float bv = wb[(p * CH + 2 * s) * NT + n * 32];
+                        acc[p][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p][n], 0, 0, 0);
+                    }
+                }
+            }
+            buf ^= 1;
+        }
+    }
+
+    // ---- epilogue: inverse transform in registers, bias, [BatchNorm + LeakyReLU], store, per-tile BatchNorm partial statistics
+    float* out_b = a.out + (long)b * a.out_bs;
+    float ssum[NN], ssq[NN];
+    const int gz = z0 + wave;
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        const int co = co0 + n * 32 + i;
+        const bool cok = co < a.Cout;
+        const float bv = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
+        const bool fuse = a.coef != nullptr && cok;
+        const float fsc = fuse ? a.coef[2 * a.Cout + co] : 1.f, fsh = fuse ? a.coef[3 * a.Cout + co] : 0.f;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int gy = y0 + (row >> 2), gx = x0 + 2 * (row & 3);
+            const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[3][n][r];
+            float ve = m0 + m1 + m2 + bv, vo = m1 - m2 - m3 + bv;
+            if (cok && gz < a.D && gy < a.H) {
+                const long vox = (long)(gz * a.H + gy) * a.W + gx;
+                if (gx < a.W) {
+                    s += ve; q += ve * ve;
+                    if (fuse) { const float tt = ve * fsc + fsh; ve = tt > 0.f ? tt : tt * a.slope; }
+                    out_b[vox * a.out_ps + (long)co * a.out_cs] = ve;
+                }
+                if (gx + 1 < a.W) {
+                    s += vo; q += vo * vo;
+                    if (fuse) { const float tt = vo * fsc + fsh; vo = tt > 0.f ? tt : tt * a.slope; }
+                    out_b[(vox + 1) * a.out_ps + (long)co * a.out_cs] = vo;
+                }
+            }
+        }
+        ssum[n] = s + __shfl_xor(s, 32, 64);
+        ssq[n] = q + __shfl_xor(q, 32, 64);
+    }
+    if (a.stats != nullptr) {
+        __syncthreads();
+        float* red = ws;               // [4 waves][2][NT]
+        if (lane < 32) {
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                red[(wave * 2 + 0) * NT + n * 32 + i] = ssum[n];
+                red[(wave * 2 + 1) * NT + n * 32 + i] = ssq[n];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * NT) {
+            const int which = tid / NT, c = tid - which * NT;
+            if (co0 + c < a.Cout) {
+                const float tot = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] + red[(2 * 2 + which) * NT + c] +
+                                  red[(3 * 2 + which) * NT + c];
+                a.stats[((long)tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
+            }
+        }
+    }
+}
+
+// Winograd weight packing: wp[k/8][dz*3+dy][point][k%8][n]  (forward: K = Cin, N = Cout, g_t = w[n][k][dz][dy][t];
+// dgrad: K = Cout, N = Cin, g_t = w[k][n][2-dz][2-dy][2-t])
+__global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int NPad, int dgrad, long total) {
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(e % NPad);
+        long r = e / NPad;
+        const int kc = (int)(r % WN_CH); r /= WN_CH;
+        const int pt = (int)(r % 4); r /= 4;
+        const int zy = (int)(r % 9);
+        const int chunk = (int)(r / 9);
+        const int k = chunk * WN_CH + kc;
+        float val = 0.f;
+        if (k < K && n < N) {
+            float g[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int tap = zy * 3 + t;
+                g[t] = dgrad ? w[((long)k * Cin + n) * 27 + (26 - tap)] : w[((long)n * Cin + k) * 27 + tap];
+            }
+            val = pt == 0 ? g[0] : pt == 1 ? 0.5f * (g[0] + g[1] + g[2]) : pt == 2 ? 0.5f * (g[0] - g[1] + g[2]) : g[2];
+        }
+        wp[e] = val;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight packing
 // w: PyTorch layout [Cout][Cin][27].  forward : K = Cin,  N = Cout, wp[k/CH][tap][k%CH][n] = w[n][k][tap]
 //                                     dgrad   : K = Cout, N = Cin,  wp[k/CH][tap][k%CH][n] = w[k][n][26 - tap]
@@ -743,4 +979,66 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
     rc = pulpo::check_launch("conv3d_k3_wgrad_mfma");
     if (rc) return rc;
     return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
+}
+
+// 1 = Winograd F(2,3)-along-x kernel (large volumes, > 4 reduction channels), 0 = direct implicit GEMM
+PULPO_API int pulpo_conv3d_k3_algo(int B, int D, int H, int W, int K, int N) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("PULPO_CONV_WINOGRAD"); force = e ? atoi(e) + 1 : 0; }     // unset: policy; 0 / 1: force off / on
+    if (force == 1) return 0;
+    const bool shape_ok = K > 4 && conv_tz(D, H, W) == 4;
+    if (force == 2) return shape_ok ? 1 : 0;
+    return shape_ok ? 1 : 0;
+}
+
+PULPO_API size_t pulpo_conv3d_k3_packed_wino_floats(int K, int N) { return (size_t)((K + WN_CH - 1) / WN_CH) * 9 * 4 * WN_CH * npad(N); }
+
+PULPO_API int pulpo_conv3d_k3_pack_weight_wino(const float* w, float* wp, int Cin, int Cout, int dgrad, void* stream) {
+    PULPO_REQUIRE(w && wp && Cin > 0 && Cout > 0, "conv3d_k3_pack_weight_wino: bad arguments");
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    const long total = (long)pulpo_conv3d_k3_packed_wino_floats(K, N);
+    const int nb = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wp, Cin, Cout, npad(N), dgrad, total);
+    return pulpo::check_launch("pack_weight_wino");
+}
+
+template <int NT, bool VEC>
+static int launch_wino(const ConvArgs& a, int nblk, hipStream_t st) {
+    constexpr size_t lds = (size_t)(((WN_ROWS * WN_CP + 3) & ~3) + 2 * 4 * WN_CH * NT) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino_mfma<NT, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(conv3d wino): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3d_k3_wino_mfma<NT, VEC>), dim3(nblk), dim3(256), lds, st, a);
+    return pulpo::check_launch("conv3d_k3_wino_mfma");
+}
+
+// same contract as pulpo_conv3d_k3_fwd / _fwd_bn_lrelu (coef nullable) with weights from pulpo_conv3d_k3_pack_weight_wino;
+// only for shapes where pulpo_conv3d_k3_algo() returns 1
+PULPO_API int pulpo_conv3d_k3_fwd_wino(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
+                                       const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats,
+                                       int B, int D, int H, int W, int K, int N, void* stream) {
+    PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_wino: null pointer");
+    PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd_wino: bad dims");
+    PULPO_REQUIRE(conv_tz(D, H, W) == 4, "conv3d_k3_fwd_wino: volume %dx%dx%d is not tiled 4x8x8 (see pulpo_conv3d_k3_algo)", D, H, W);
+    PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd_wino: batch statistics are not available from the fused eval-mode epilogue");
+    ConvArgs a;
+    a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
+    a.wp = wp; a.bias = bias;
+    a.out = out; a.out_bs = out_bs; a.out_ps = out_ps; a.out_cs = out_cs;
+    a.stats = stats;
+    a.coef = coef; a.slope = slope;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
+    a.ntz = pulpo::cdiv(D, 4); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
+    const int NT = (N % 64 == 0) ? 64 : 32;
+    a.ncot = pulpo::cdiv(N, NT);
+    a.ksplit = 1; a.part = nullptr;
+    const long nblk_l = (long)B * a.ntz * a.nty * a.ntx * a.ncot;
+    PULPO_REQUIRE(nblk_l < (1L << 31), "conv3d_k3_fwd_wino: grid too large");
+    const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) return NT == 64 ? launch_wino<64, true>(a, (int)nblk_l, st) : launch_wino<32, true>(a, (int)nblk_l, st);
+    return NT == 64 ? launch_wino<64, false>(a, (int)nblk_l, st) : launch_wino<32, false>(a, (int)nblk_l, st);
 }

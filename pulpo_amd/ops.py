@@ -143,15 +143,25 @@ def _use_bf16(K: int) -> bool:
     return CONV_PRECISION == "bf16" and K > 4
 
 
-def _pack_weight(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+def _pack_weight(w: torch.Tensor, dgrad: bool, shape=None) -> torch.Tensor:
+    """GEMM-ordered copy of a (Cout, Cin, 3, 3, 3) weight for the forward (dgrad=False) or data-gradient (True) convolution.
+    shape = (B, D, H, W) of the volume it will be applied to: large volumes use the Winograd-x kernel, which has its own packing
+    (the returned tensor carries the choice in `_pulpo_algo`)."""
     Cout, Cin = w.shape[0], w.shape[1]
     K, N = (Cout, Cin) if dgrad else (Cin, Cout)
     if _use_bf16(K):
         wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_bf16_elems", K, N), device=w.device, dtype=torch.int16)
         lib.call("pulpo_conv3d_k3_pack_weight_bf16", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
+        wp._pulpo_algo = "bf16"
+        return wp
+    if shape is not None and lib.query("pulpo_conv3d_k3_algo", *shape, K, N) == 1:
+        wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_wino_floats", K, N), device=w.device, dtype=torch.float32)
+        lib.call("pulpo_conv3d_k3_pack_weight_wino", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
+        wp._pulpo_algo = "wino"
         return wp
     wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_floats", K, N), device=w.device, dtype=torch.float32)
     lib.call("pulpo_conv3d_k3_pack_weight", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
+    wp._pulpo_algo = "direct"
     return wp
 
 
@@ -161,7 +171,15 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
     B, _, D, H, W = x.shape
     xb, xp, xc = grid_strides(x)
     ob, op, oc = grid_strides(out)
-    bf16 = wp.dtype == torch.int16
+    algo = getattr(wp, "_pulpo_algo", "bf16" if wp.dtype == torch.int16 else "direct")
+    bf16 = algo == "bf16"
+    vec_ok = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0
+    if algo == "wino":
+        t0 = _trace_begin()
+        lib.call("pulpo_conv3d_k3_fwd_wino", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc, _ptr(stats),
+                 B, D, H, W, K, N, _stream())
+        _trace_end(t0, f"conv3d_k3_wino_mfma<{64 if N % 64 == 0 else 32},{'true' if vec_ok else 'false'}>", 54.0 * K * N * B * D * H * W)
+        return
     sfx = "_bf16" if bf16 else ""
     nscr = lib.query(f"pulpo_conv3d_k3_fwd{sfx}_scratch_floats", B, D, H, W, K, N)
     scratch = torch.empty(nscr, device=x.device, dtype=torch.float32) if nscr else None
@@ -173,7 +191,6 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
         lib.call(f"pulpo_conv3d_k3_fwd_bn_lrelu{sfx}", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc,
                  _ptr(scratch), B, D, H, W, K, N, _stream())
     if t0 is not None:
-        vec_ok = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0
         if bf16:
             name = f"conv3d_k3_mfma_bf16<{64 if N % 64 == 0 else 32},{'true' if vec_ok else 'false'}>"
         else:
@@ -207,7 +224,7 @@ class _ConvBNLReLU(torch.autograd.Function):
         B, Cin, D, H, W = x.shape
         Cout = weight.shape[0]
         dev = x.device
-        wp = _pack_weight(weight, dgrad=False)
+        wp = _pack_weight(weight, dgrad=False, shape=(B, D, H, W))
         y = new_cl(B, Cout, D, H, W, dev)
         coef = torch.empty(8 * Cout, device=dev, dtype=torch.float32)      # [4][C] floats + [2][C] doubles
         if training:
@@ -262,7 +279,7 @@ class _ConvBNLReLU(torch.autograd.Function):
         dw = _wgrad_raw(x, dy, Cin, Cout, into=slot_w) if ctx.needs_input_grad[1] else None
         dx = None
         if ctx.needs_input_grad[0]:
-            wpt = _pack_weight(weight, dgrad=True)
+            wpt = _pack_weight(weight, dgrad=True, shape=(B, D, H, W))
             dx = torch.empty_like(x) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, dev)
             _conv_raw(dy, wpt, None, dx, Cout, Cin, None)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
@@ -284,7 +301,7 @@ class _Conv3dK3(torch.autograd.Function):
         B, Cin, D, H, W = x.shape
         Cout = weight.shape[0]
         y = new_cl(B, Cout, D, H, W, x.device)
-        _conv_raw(x, _pack_weight(weight, False), bias, y, Cin, Cout, None)
+        _conv_raw(x, _pack_weight(weight, False, shape=(B, D, H, W)), bias, y, Cin, Cout, None)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
@@ -300,7 +317,7 @@ class _Conv3dK3(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, x.device)
-            _conv_raw(dy, _pack_weight(weight, True), None, dx, Cout, Cin, None)
+            _conv_raw(dy, _pack_weight(weight, True, shape=(B, D, H, W)), None, dx, Cout, Cin, None)
         return dx, dw, db
 
 

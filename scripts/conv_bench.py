@@ -36,7 +36,7 @@ def main():
         w = torch.randn(co, ci, 3, 3, 3, device="cuda") * 0.05
         y = ops.new_cl(1, co, S, S, S, x.device); dx = ops.new_cl(1, ci, S, S, S, x.device)
         stats = torch.empty(lib.query("pulpo_conv3d_k3_stat_tiles", 1, S, S, S) * 2 * co, device="cuda")
-        wp, wpt = ops._pack_weight(w, False), ops._pack_weight(w, True)
+        wp, wpt = ops._pack_weight(w, False, shape=(1, S, S, S)), ops._pack_weight(w, True, shape=(1, S, S, S))
         fl = 54.0 * ci * co * S ** 3
         res = []
         for name, fn in (("fwd", lambda: ops._conv_raw(x, wp, None, y, ci, co, stats)), ("dgrad", lambda: ops._conv_raw(dy, wpt, None, dx, co, ci, None)),

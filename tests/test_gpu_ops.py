@@ -255,6 +255,31 @@ def test_eval_mode_fused_epilogue_equals_separate_passes(ops, precision, Cin, Co
         O.CONV_PRECISION = "fp32"
 
 
+@pytest.mark.parametrize("B,Cin,Cout,size", [(1, 32, 32, (64, 64, 64)), (1, 64, 64, (64, 64, 64)), (2, 16, 96, (64, 56, 80)), (1, 20, 12, (64, 64, 70)),
+                                            (1, 96, 32, (68, 61, 67))])
+def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size):
+    """volumes of >= 64^3 voxels take the Winograd F(2,3)-along-x kernel for forward and data gradient (pulpo_conv3d_k3_algo):
+    same fp32 tolerance against the fp64 convolution as the direct kernel, ragged H / W (odd W: half-filled x pairs) included"""
+    from pulpo_amd._lib import lib
+    assert lib.query("pulpo_conv3d_k3_algo", B, *size, Cin, Cout) == 1
+    gen = torch.Generator().manual_seed(B * 1000 + Cin * 10 + Cout)
+    x = torch.randn(B, Cin, *size, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (27 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    up = torch.randn(B, Cout, *size, generator=gen)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv3d(xr.double(), wr.double(), br.double(), padding=1)
+    gref = torch.autograd.grad((ref * up.double()).sum(), [xr, wr, br])
+    xd = x.cuda().contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    out = ops.conv3d_k3(xd, wd, bd)
+    assert rel_l2(out, ref) < 2e-6
+    gx, gw, gb = torch.autograd.grad((out * up.cuda()).sum(), [xd, wd, bd])
+    assert rel_l2(gx, gref[0]) < 2e-6
+    assert rel_l2(gw, gref[1]) < 1e-5
+    assert rel_l2(gb, gref[2]) < 1e-5
+
+
 def test_conv_linearity_at_full_channel_width(ops):
     """size-independent property at a BASELINE layer shape (32->32 @ 48^3): conv(a*x1 + x2) = a*conv(x1) + conv(x2) (no bias)"""
     gen = torch.Generator().manual_seed(3)
