@@ -303,7 +303,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // Workgroup = 4 x 8 x 8 output voxels = 4 z-planes (one per wave) x 32 (y, x-pair) blocks; the MFMA rows are the blocks, one
 // accumulator set per transformed point.  8-channel chunks: 960 transformed halo rows x 9 floats (34.5 KB) + the double-buffered
 // (dz, dy) weight slabs [4 points][8][NT] (16 KB at NT = 64) => 3 workgroups per CU.
-constexpr int WN_CH = 8, WN_CP = WN_CH + 1, WN_HZ = 6, WN_ROWS = WN_HZ * HY * 4 * 4;
+// LDS rows are ordered (hz, point, hy, x-pair): the 32 (y, x-pair) blocks an A fragment reads are 32 consecutive rows of 9 floats
+// (odd stride => one bank per lane), a (dz, dy) tap moves the window by dz * 4 * WN_PL + dy * 4 rows
+constexpr int WN_CH = 8, WN_CP = WN_CH + 1, WN_HZ = 6, WN_PL = HY * 4, WN_ROWS = WN_HZ * 4 * WN_PL;
 
 template <bool VEC>
 __device__ __forceinline__ void stage_halo_wino(float* xs, const float* __restrict__ in, long in_ps, long in_cs, int c0, int Cin, int z0, int y0,
@@ -332,14 +334,15 @@ __device__ __forceinline__ void stage_halo_wino(float* xs, const float* __restri
             const int j = tid + u * 256;
             if (j < NITEM) {
                 const int q = j % Q, rb = j / Q;                // rb = (hz*HY + hy)*4 + xb
-                float* o = xs + (rb * 4) * WN_CP + 4 * q;
+                const int hz = rb / (HY * 4), yx = rb - hz * (HY * 4);
+                float* o = xs + (hz * 4 * WN_PL + yx) * WN_CP + 4 * q;      // row (hz, point 0, hy, xb); points are WN_PL rows apart
                 const float4 d0 = d[u][0], d1 = d[u][1], d2 = d[u][2], d3 = d[u][3];
                 o[0] = d0.x - d2.x; o[1] = d0.y - d2.y; o[2] = d0.z - d2.z; o[3] = d0.w - d2.w;
-                o += WN_CP;
+                o += WN_PL * WN_CP;
                 o[0] = d1.x + d2.x; o[1] = d1.y + d2.y; o[2] = d1.z + d2.z; o[3] = d1.w + d2.w;
-                o += WN_CP;
+                o += WN_PL * WN_CP;
                 o[0] = d2.x - d1.x; o[1] = d2.y - d1.y; o[2] = d2.z - d1.z; o[3] = d2.w - d1.w;
-                o += WN_CP;
+                o += WN_PL * WN_CP;
                 o[0] = d1.x - d3.x; o[1] = d1.y - d3.y; o[2] = d1.z - d3.z; o[3] = d1.w - d3.w;
             }
         }
@@ -357,11 +360,11 @@ __device__ __forceinline__ void stage_halo_wino(float* xs, const float* __restri
                     if ((unsigned)gx < (unsigned)W) d[t] = in[((long)(gz * H + gy) * W + gx) * in_ps + (long)(c0 + c) * in_cs];
                 }
             }
-            float* o = xs + (rb * 4) * WN_CP + c;
+            float* o = xs + (hz * 4 * WN_PL + hrow * 4 - hz * (HY * 4) + xb) * WN_CP + c;
             o[0] = d[0] - d[2];
-            o[WN_CP] = d[1] + d[2];
-            o[2 * WN_CP] = d[2] - d[1];
-            o[3 * WN_CP] = d[1] - d[3];
+            o[WN_PL * WN_CP] = d[1] + d[2];
+            o[2 * WN_PL * WN_CP] = d[2] - d[1];
+            o[3 * WN_PL * WN_CP] = d[1] - d[3];
         }
     }
 }
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino_mfma(ConvArgs a) {
 
     const int i = lane & 31, kk = lane >> 5;
     // MFMA row i of wave w = block (z = w, y = i >> 2, x-pair = i & 3); its transformed rows start at rowbase (+ point)
-    const int rowbase = ((wave * HY + (i >> 2)) * 4 + (i & 3)) * 4;
+    const int rowbase = wave * 4 * WN_PL + i;          // + point * WN_PL
 
     f32x16 acc[4][NN];
 #pragma unroll
@@ -428,13 +431,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino_mfma(ConvArgs a) {
             store_w(buf);
             __syncthreads();
             if (it + 1 < niter) load_w(it + 1);
-            const float* xa = xs + (rowbase + ((zy / 3) * HY + zy % 3) * 16) * CP + kk;
+            const float* xa = xs + (rowbase + (zy / 3) * 4 * WN_PL + (zy % 3) * 4) * CP + kk;
             const float* wb = ws + buf * WSL + kk * NT + i;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
 #pragma unroll
                 for (int s = 0; s < CH / 2; ++s) {
-                    const float av = xa[p * CP + 2 * s];
+                    const float av = xa[p * WN_PL * CP + 2 * s];
 #pragma unroll
                     for (int n = 0; n < NN; ++n) {
                         const float bv = wb[(p * CH + 2 * s) * NT + n * 32];
@@ -807,10 +810,10 @@ int launch_conv(const ConvArgs& a, int nblk, hipStream_t st, int tz) {
 
 }  // namespace
 
-// z extent of the forward voxel tile: 4 (each wave = two 32-voxel MFMA row tiles, every weight fragment feeds two MFMAs,
-// halo read amplification 2.3x instead of 3.1x) when the volume's depth divides evenly and there are enough tiles
+// z extent of the forward voxel tile: 4 (the Winograd kernel's tile; in the direct kernel each wave = two 32-voxel MFMA row tiles)
+// when the volume's depth divides evenly and there are enough tiles (measured: pays from 40^3 up, not at 20^3)
 int pulpo_conv::conv_tz(int D, int H, int W) {
-    return (D % 4 == 0 && (long)D * H * W >= 64L * 64 * 64) ? 4 : 2;
+    return (D % 4 == 0 && (long)D * H * W >= 40L * 40 * 40) ? 4 : 2;
 }
 
 int pulpo_conv::launch_splitk_reduce(const float* part, int ksplit, float* out, long obs, long ops, long ocs, int B, long V, int C, int nrow,
@@ -1032,13 +1035,12 @@ PULPO_API int pulpo_conv3d_k3_fwd_wino(const float* in, int64_t in_bs, int64_t i
     a.coef = coef; a.slope = slope;
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
     a.ntz = pulpo::cdiv(D, 4); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
-    const int NT = (N % 64 == 0) ? 64 : 32;
+    const int NT = 32;                 // 64-wide tiles need 128 accumulator registers and measured slower (2 instead of 3 waves per SIMD)
     a.ncot = pulpo::cdiv(N, NT);
     a.ksplit = 1; a.part = nullptr;
     const long nblk_l = (long)B * a.ntz * a.nty * a.ntx * a.ncot;
     PULPO_REQUIRE(nblk_l < (1L << 31), "conv3d_k3_fwd_wino: grid too large");
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (vec) return NT == 64 ? launch_wino<64, true>(a, (int)nblk_l, st) : launch_wino<32, true>(a, (int)nblk_l, st);
-    return NT == 64 ? launch_wino<64, false>(a, (int)nblk_l, st) : launch_wino<32, false>(a, (int)nblk_l, st);
+    return vec ? launch_wino<32, true>(a, (int)nblk_l, st) : launch_wino<32, false>(a, (int)nblk_l, st);
 }
