@@ -684,12 +684,13 @@ __global__ __launch_bounds__(256, VEC ? 1 : 2) void conv3d_k3_wgrad_mfma(WgradAr
             for (int sb = 0; sb < 16; sb += 2) {            // fully unrolled: 16 bodies of 4 steps, fragments one body ahead
                 load_body(A1, B1, xs_c, dys_c, sb + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                issue_piece(sb, xnext);
+                // the next tile's 17 DMA pieces go out during the first nine bodies, so they have half a tile of MFMAs to land
+                if (sb < 8) { issue_piece(2 * sb, xnext); issue_piece(2 * sb + 1, xnext); }
+                if (sb == 8) issue_piece(16, xnext);
                 mma_body(A0, B0);
                 load_body(A0, B0, xs_c, dys_c, (sb + 2) & 15);   // (wraps to body 0 on the last trip: harmless re-read)
                 __builtin_amdgcn_sched_barrier(0);
-                issue_piece(sb + 1, xnext);
-                if (sb == 14) issue_piece(16, xnext);
+                if (sb < 8) { issue_piece(2 * sb + 2, xnext); issue_piece(2 * sb + 3, xnext); }
                 mma_body(A1, B1);
             }
         }
@@ -767,6 +768,197 @@ __global__ __launch_bounds__(256, VEC ? 1 : 2) void conv3d_k3_wgrad_mfma(WgradAr
                     if (rg < rows) {
                         const int tap = rg / Cc, ci = rg - tap * Cc;
                         atomicAdd(a.dwp + ((long)tap * a.Cin + ci0 + ci) * a.NPad + co, acc[u][r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient, Winograd along x
+// The transpose of the forward identity: with V = B^T d (four transformed inputs per x-pair) and E = A dy (four combinations of the
+// pair's two output gradients), M_p[(dz,dy,ci)][co] = sum over x-pairs V_p * E_p and dw[.., t] = G^T M - 36 instead of 54 matrix
+// products per x-pair.  Wave p of the workgroup owns transformed point p (all nine (dz, dy) row tiles of its 32-channel slice), so
+// both operand transforms are wave-uniform two-term combinations formed from the raw LDS-DMA images as the fragments are read
+// (A: two ds_read + one fma, B: two ds_read + two fma per nine MFMAs), and every wave adds its share of G^T M at the flush.
+// Same persistent one-workgroup-per-CU LDS-DMA pipeline as conv3d_k3_wgrad_mfma<true, NTW>.
+template <int NTW>
+__global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
+    const int npair = a.ncit * a.ncot;
+    const int pair = lid % npair, split = lid / npair;
+    const int cit = pair / a.ncot, cot = pair - cit * a.ncot;
+    const int ci0 = cit * WG_CH, co0 = cot * WG_NT;
+    const int Cc = min(WG_CH, a.Cin - ci0);
+    const int rows = 9 * Cc;
+    const int nrt = (rows + 31) >> 5;                 // host guarantees nrt <= NTW
+    const int i = lane & 31, kk = lane >> 5;
+    const int pt = __builtin_amdgcn_readfirstlane(wave);
+    // A = X[x + ta] + sa * X[x + tb];  B = c0 * dY[x] + c1 * dY[x + 1]
+    const int ta = pt == 0 ? 0 : pt == 2 ? 2 : 1;
+    const int tb = pt == 2 ? 1 : pt == 3 ? 3 : 2;
+    const float sa = pt == 1 ? 1.f : -1.f;
+    const float c0 = pt == 3 ? 0.f : 1.f;
+    const float c1 = pt == 0 ? 0.f : pt == 1 ? 1.f : -1.f;
+
+    int rowoff[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        const int r = 32 * u + i;
+        const int zy = r < rows ? r / Cc : 0, ci = r < rows ? r - zy * Cc : 0;
+        rowoff[u] = ((zy / 3) * HY + zy % 3) * HX * 32 + ci;
+    }
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+
+    const int ntile = a.B * a.ntz * a.nty * a.ntx;
+    const int per = (ntile + a.nsplit - 1) / a.nsplit;
+    const int t_begin = split * per, t_end = min(ntile, t_begin + per);
+    auto decode = [&](int tl, int& b, int& z0, int& y0, int& x0) {
+        int t = tl;
+        const int tx_ = t % a.ntx; t /= a.ntx;
+        const int ty_ = t % a.nty; t /= a.nty;
+        const int tz_ = t % a.ntz;
+        b = t / a.ntz;
+        z0 = tz_ * TZ; y0 = ty_ * TY; x0 = tx_ * TX;
+    };
+    // one body = 2 K-steps of two x-pairs each; x-pair b = (z, y, xb) with xb fastest: 64 per 2x8x8 tile = 16 bodies.
+    // The RAW operand pairs are fetched one body ahead; the two-term combinations are formed right in front of the MFMA that
+    // consumes them (a VALU op in the shadow of the previous MFMA), so no LDS latency is exposed between bodies.
+    constexpr int NQ = 2;
+    // per-lane LDS addresses are loop invariant (row offset, the lane's half of the x-pair couple, the point's two taps); the position
+    // of the K-step inside the tile is a compile-time constant of the unrolled body => every ds_read is base register + immediate
+    int offa[NTW], offb[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        offa[u] = rowoff[u] + kk * 64 + ta * 32;
+        offb[u] = rowoff[u] + kk * 64 + tb * 32;
+    }
+    const int offy = kk * 2 * WG_NT + i;
+    auto load_body = [&](float (&Ra)[NQ][NTW], float (&Rb)[NQ][NTW], float (&Y0)[NQ], float (&Y1)[NQ], const float* xs_c, const float* dys_c, int sb) {
+#pragma unroll
+        for (int q4 = 0; q4 < NQ; ++q4) {
+            const int blk = 2 * (sb * NQ + q4);                 // even x-pair of the couple; the odd one is 2 voxels further along x
+            const int z = blk >> 5, y = (blk >> 2) & 7, xb = blk & 3;
+            const int hbk = ((z * HY + y) * HX + 2 * xb) * 32;
+            const int v0 = ((z * 8 + y) * 8 + 2 * xb) * WG_NT;
+            Y0[q4] = dys_c[offy + v0];
+            Y1[q4] = dys_c[offy + v0 + WG_NT];
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+                Ra[q4][u] = xs_c[offa[u] + hbk];
+                Rb[q4][u] = xs_c[offb[u] + hbk];
+            }
+        }
+    };
+    auto mma_body = [&](const float (&Ra)[NQ][NTW], const float (&Rb)[NQ][NTW], const float (&Y0)[NQ], const float (&Y1)[NQ]) {
+#pragma unroll
+        for (int q4 = 0; q4 < NQ; ++q4) {
+            const float bv = fmaf(c1, Y1[q4], c0 * Y0[q4]);
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+                const float av = fmaf(sa, Rb[q4][u], Ra[q4][u]);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u], 0, 0, 0);
+            }
+        }
+    };
+    float Ra0[NQ][NTW], Rb0[NQ][NTW], Ra1[NQ][NTW], Rb1[NQ][NTW], Ya0[NQ], Yb0[NQ], Ya1[NQ], Yb1[NQ];
+
+    const int wave_u = pt;
+    const float* zero = reinterpret_cast<const float*>(g_zero_page);
+    constexpr int XIMG = 13 * 4 * 256;
+    constexpr int SET = XIMG + MV * WG_NT;
+    int nb = 0, nz0 = 0, ny0 = 0, nx0 = 0;
+    bool more = false;
+    auto issue_piece = [&](int pc, float* xd) {
+        if (pc < 13) {
+            const int j = tid + pc * 256;
+            const int hv = j >> 3, q = j & 7;
+            const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = nz0 - 1 + hz, gy = ny0 - 1 + hy, gx = nx0 - 1 + hx;
+            const bool ok = more && hv < HV && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
+                            ci0 + 4 * q < a.Cin;
+            const float* src = ok ? a.in + (long)nb * a.in_bs + ((long)(gz * a.H + gy) * a.W + gx) * a.in_ps + ci0 + 4 * q : zero;
+            dma16(src, xd + (wave_u + 4 * pc) * 256);
+        } else {
+            const int u = pc - 13;
+            const int j = tid + u * 256;
+            const int vv = j >> 3, q = j & 7;
+            const int gz = nz0 + (vv >> 6), gy = ny0 + ((vv >> 3) & 7), gx = nx0 + (vv & 7);
+            const bool ok = more && gz < a.D && gy < a.H && gx < a.W && co0 + 4 * q < a.Cout;
+            const float* src = ok ? a.dy + (long)nb * a.dy_bs + ((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + co0 + 4 * q : zero;
+            dma16(src, xd + XIMG + (wave_u + 4 * u) * 256);
+        }
+    };
+    if (t_begin < t_end) {
+        more = true;
+        decode(t_begin, nb, nz0, ny0, nx0);
+#pragma unroll
+        for (int pc = 0; pc < 17; ++pc) issue_piece(pc, smem);
+    }
+    int cur = 0;
+    for (int tl = t_begin; tl < t_end; ++tl, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        more = tl + 1 < t_end;
+        if (more) decode(tl + 1, nb, nz0, ny0, nx0);
+        const float* xs_c = smem + cur * SET;
+        const float* dys_c = xs_c + XIMG;
+        float* xnext = smem + (cur ^ 1) * SET;
+        load_body(Ra0, Rb0, Ya0, Yb0, xs_c, dys_c, 0);
+#pragma unroll
+        for (int sb = 0; sb < 16; sb += 2) {            // 16 bodies; one DMA piece of the next tile per body (+ the 17th on the last trip)
+            // the raw reads of the next body are threaded through the MFMAs of the current one (1 MFMA : 3 LDS reads : 2 VALU), so
+            // neither their issue slots nor their latency stall the matrix pipe of this single-wave-per-SIMD kernel
+            load_body(Ra1, Rb1, Ya1, Yb1, xs_c, dys_c, sb + 1);
+            if (sb < 8) { issue_piece(2 * sb, xnext); issue_piece(2 * sb + 1, xnext); }     // all 17 pieces in the first nine bodies
+            if (sb == 8) issue_piece(16, xnext);
+            mma_body(Ra0, Rb0, Ya0, Yb0);
+#pragma unroll
+            for (int g = 0; g < NQ * NTW; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_body(Ra0, Rb0, Ya0, Yb0, xs_c, dys_c, (sb + 2) & 15);
+            if (sb < 8) { issue_piece(2 * sb + 2, xnext); issue_piece(2 * sb + 3, xnext); }
+            mma_body(Ra1, Rb1, Ya1, Yb1);
+#pragma unroll
+            for (int g = 0; g < NQ * NTW; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // flush: this wave's share of G^T M.  point 0 -> tap 0; 1 -> (1/2, 1/2, 1/2); 2 -> (1/2, -1/2, 1/2); 3 -> tap 2
+    const int co = co0 + i;
+    if (co < a.Cout) {
+        const float g0 = pt == 0 ? 1.f : pt == 3 ? 0.f : 0.5f;
+        const float g1 = pt == 1 ? 0.5f : pt == 2 ? -0.5f : 0.f;
+        const float g2 = pt == 0 ? 0.f : pt == 3 ? 1.f : 0.5f;
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) {
+            if (u < nrt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rg = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    if (rg < rows) {
+                        const int zy = rg / Cc, ci = rg - zy * Cc;
+                        float* d = a.dwp + ((long)(zy * 3) * a.Cin + ci0 + ci) * a.NPad + co;
+                        const float m = acc[u][r];
+                        if (g0 != 0.f) atomicAdd(d, g0 * m);
+                        if (g1 != 0.f) atomicAdd(d + (long)a.Cin * a.NPad, g1 * m);
+                        if (g2 != 0.f) atomicAdd(d + 2L * a.Cin * a.NPad, g2 * m);
                     }
                 }
             }
@@ -973,7 +1165,25 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
         }                                                                                                                         \
         hipLaunchKernelGGL((conv3d_k3_wgrad_mfma<VECV, NTWV>), dim3(nblk), dim3(256), bytes, st, a);                              \
     }
-    if (vec) {
+    static int wino = -1;
+    if (wino < 0) { const char* e = getenv("PULPO_WGRAD_WINOGRAD"); wino = e ? atoi(e) : 1; }
+    if (vec && wino && Cin >= 8) {
+        // Winograd-x variant: wave = transformed point, nine (dz, dy) row tiles of <= 32 channels
+        const int nrt9 = (9 * std::min(Cin, WG_CH) + 31) / 32;
+#define PULPO_WGRAD_W(NTWV)                                                                                                       \
+    {                                                                                                                             \
+        static bool attr = false;                                                                                                 \
+        if (!attr) {                                                                                                              \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_wino<NTWV>),                       \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);                      \
+            if (ea != hipSuccess) return pulpo::fail((int)ea, "hipFuncSetAttribute(wgrad wino): %s", hipGetErrorString(ea));      \
+            attr = true;                                                                                                          \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((conv3d_k3_wgrad_wino<NTWV>), dim3(nblk), dim3(256), lds_dma, st, a);                                  \
+    }
+        if (nrt9 <= 3) PULPO_WGRAD_W(3) else if (nrt9 <= 5) PULPO_WGRAD_W(5) else PULPO_WGRAD_W(9)
+#undef PULPO_WGRAD_W
+    } else if (vec) {
         if (ntw <= 1) PULPO_WGRAD(true, 1) else if (ntw <= 2) PULPO_WGRAD(true, 2) else if (ntw <= 4) PULPO_WGRAD(true, 4) else PULPO_WGRAD(true, 7)
     } else {
         if (ntw <= 1) PULPO_WGRAD(false, 1) else if (ntw <= 2) PULPO_WGRAD(false, 2) else if (ntw <= 4) PULPO_WGRAD(false, 4) else PULPO_WGRAD(false, 7)
