@@ -1167,7 +1167,7 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
     }
     static int wino = -1;
     if (wino < 0) { const char* e = getenv("PULPO_WGRAD_WINOGRAD"); wino = e ? atoi(e) : 1; }
-    if (vec && wino && Cin >= 8) {
+    if (vec && wino && Cin >= 8 && (long)D * H * W >= 32L * 32 * 32) {      // (measured: no gain on the 20^3 / 10^3 pyramid levels)
         // Winograd-x variant: wave = transformed point, nine (dz, dy) row tiles of <= 32 channels
         const int nrt9 = (9 * std::min(Cin, WG_CH) + 31) / 32;
 #define PULPO_WGRAD_W(NTWV)                                                                                                       \

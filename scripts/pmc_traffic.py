@@ -5,7 +5,7 @@ usage: python scripts/pmc_traffic.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE
 The two counters do not fit one pass on gfx950 (TCC has 4 slots: FETCH_SIZE costs 3, WRITE_SIZE 2), so they come from two runs of
 the same command.  Units: rocprofv3 reports both in KiB.  Correction applied as MI355X_MICROARCH.md prescribes: FETCH_SIZE reads
 one half of the bytes of fully coalesced 16 B/lane streams - that applies to the LDS-DMA wgrad kernel and the elementwise
-float4 kernels (factor 2 below); the forward/dgrad convolution gathers 64-byte runs per voxel, an access width the guide calls
+float4 kernels (factor 2 below); the forward/dgrad convolutions gather 32- or 64-byte runs per voxel, an access width the guide calls
 uncalibrated, so its FETCH_SIZE is reported raw (factor 1) and is a lower bound.
 """
 import csv, glob, json, re, sys
@@ -33,7 +33,8 @@ def collect(d: str, counter: str):
     return tot, cnt
 
 
-FETCH_FACTOR = [(re.compile(r"conv3d_k3_wgrad_mfma<true"), 2.0), (re.compile(r"conv3d_k3_mfma"), 1.0), (re.compile(r"conv3d_k3_wgrad_mfma<false"), 1.0)]
+FETCH_FACTOR = [(re.compile(r"conv3d_k3_wgrad_mfma<true|conv3d_k3_wgrad_wino"), 2.0), (re.compile(r"conv3d_k3_(wino_)?mfma"), 1.0),
+                (re.compile(r"conv3d_k3_wgrad_mfma<false"), 1.0)]
 
 
 def main():
