@@ -191,10 +191,13 @@ def main():
                     "frac": fl / sec / 1e12 / peak, "traffic": None, "launches": n, "avg_launch_ms": sec / n * 1e3,
                     "flop_per_launch": fl / n}
             if "wino" in dom[0]:
-                # algorithmic FLOP are those of the direct convolution; the Winograd F(2,3)-along-x kernel issues 2/3 of them
-                roof["matrix_pipe_TFLOPs"] = roof["achieved"] * 2.0 / 3.0
+                # algorithmic FLOP are those of the direct convolution; the Winograd kernels issue 2/3 (F(2,3) along x) or
+                # 4/9 (F(2x2,3x3) in y and x) of them
+                issued = 4.0 / 9.0 if "wino2" in dom[0] else 2.0 / 3.0
+                roof["matrix_pipe_TFLOPs"] = roof["achieved"] * issued
                 roof["matrix_pipe_frac"] = roof["matrix_pipe_TFLOPs"] / peak
-                roof["note"] = "achieved/frac count the direct convolution's 54*K*N*V FLOP; the kernel evaluates the x taps with F(2,3) and issues 36*K*N*V"
+                roof["note"] = ("achieved/frac count the direct convolution's 54*K*N*V FLOP; the kernel evaluates the "
+                                + ("y and x taps with F(2x2,3x3) and issues 24*K*N*V" if "wino2" in dom[0] else "x taps with F(2,3) and issues 36*K*N*V"))
             if is160_cfg and not bf16:
                 roof.update(pmc_traffic(dom[0]))
         is160 = is160_cfg

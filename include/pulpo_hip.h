@@ -63,6 +63,12 @@ int pulpo_conv3d_k3_pack_weight_wino(const float* w /*[Cout][Cin][3][3][3]*/, fl
 int pulpo_conv3d_k3_fwd_wino(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
                              float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W,
                              int K, int N, void* stream);
+/* F(2x2,3x3) in (y, x): pulpo_conv3d_k3_algo() = 2; same contract as the _wino entry points, own packing */
+size_t pulpo_conv3d_k3_packed_wino2_floats(int K, int N);
+int pulpo_conv3d_k3_pack_weight_wino2(const float* w /*[Cout][Cin][3][3][3]*/, float* wp, int Cin, int Cout, int dgrad, void* stream);
+int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
+                              float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W,
+                              int K, int N, void* stream);
 /* weight gradient: dw[Cout][Cin][27] = sum_voxels in[v + tap - 1][ci] * dy[v][co]; scratch is overwritten */
 size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
 int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs, int64_t dy_ps,

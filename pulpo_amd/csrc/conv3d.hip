@@ -532,6 +532,202 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------ Winograd F(2x2,3x3) in (y, x)
+// The y taps get the same treatment as the x taps: 16 transformed points per 2x2 output block, 3 (dz) x 16 matrix products per four
+// outputs = 2.25x fewer than the direct kernel (1.5x fewer than F(2,3) along x alone).  The halo is staged x-transformed exactly as
+// for the x-only kernel; WAVE py OWNS THE FOUR POINTS (py, px = 0..3) and forms the y combination of its A fragments as they are
+// read (two ds_read + one fma per MFMA, wave-uniform tap pair), for all 64 blocks of the 4x8x8 tile (two MFMA row tiles of
+// 2 z-planes x 4 x 4 blocks).  The x inverse transform is in-lane; the y inverse transform sums over the four waves through LDS
+// once per tile, after which wave w finishes row tile w >> 1, x parity w & 1 (bias, BatchNorm partials, store).
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
+    constexpr int CH = WN_CH, CP = WN_CP, NT = 32;
+    constexpr int XS = (WN_ROWS * CP + 3) & ~3;
+    constexpr int WSL = 16 * CH * NT;                // floats of one dz weight slab set: [py][px][k][NT]
+    constexpr int RED = 4 * 2 * 2 * 16 * 64;         // floats of the cross-wave exchange buffer (reuses xs / ws)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* ws = smem + XS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
+    const int cot = lid % a.ncot;
+    const int tile_lin = lid / a.ncot;
+    int t = tile_lin;
+    const int tx_ = t % a.ntx; t /= a.ntx;
+    const int ty_ = t % a.nty; t /= a.nty;
+    const int tz_ = t % a.ntz;
+    const int b = t / a.ntz;
+    const int z0 = tz_ * 4, y0 = ty_ * TY, x0 = tx_ * TX;
+    const int co0 = cot * NT;
+    const int nchunk = (a.Cin + CH - 1) / CH;
+    const int niter = nchunk * 3;
+    const float* in_b = a.in + (long)b * a.in_bs;
+
+    // weight slab prefetch: 16 KB per dz = four float4 per thread (scalars, not an array: the array form ended up in scratch)
+    float4 w0, w1, w2, w3;
+    const float* wsrc = a.wp + (long)(tid >> 3) * a.NPad + co0 + (tid & 7) * 4;      // row = (py * 4 + px) * CH + k; 32 rows per 256 threads
+    auto load_w = [&](int it) {
+        const float* p = wsrc + (long)it * 16 * CH * a.NPad;
+        w0 = *reinterpret_cast<const float4*>(p);
+        w1 = *reinterpret_cast<const float4*>(p + 32L * a.NPad);
+        w2 = *reinterpret_cast<const float4*>(p + 64L * a.NPad);
+        w3 = *reinterpret_cast<const float4*>(p + 96L * a.NPad);
+    };
+    auto store_w = [&](int buf) {
+        float* d = ws + buf * WSL + tid * 4;
+        *reinterpret_cast<float4*>(d) = w0;
+        *reinterpret_cast<float4*>(d + 1024) = w1;
+        *reinterpret_cast<float4*>(d + 2048) = w2;
+        *reinterpret_cast<float4*>(d + 3072) = w3;
+    };
+
+    const int i = lane & 31, kk = lane >> 5;
+    const int py = __builtin_amdgcn_readfirstlane(wave);
+    // y combination of this wave's point row: v = X[2 yb + ta] + sa * X[2 yb + tb]   (same table as the x transform)
+    const int ta = py == 0 ? 0 : py == 2 ? 2 : 1;
+    const int tb = py == 2 ? 1 : py == 3 ? 3 : 2;
+    const float sa = py == 1 ? 1.f : -1.f;
+    // MFMA row i of row tile m = block (z = 2 m + (i >> 4), yb = (i >> 2) & 3, xb = i & 3); LDS rows are (hz, px, hy, xb)
+    const int lrow = (i >> 4) * 4 * WN_PL + ((i >> 2) & 3) * 8 + (i & 3);
+    const float* pa = xs + (lrow + ta * 4) * CP + kk;
+    const float* pb = xs + (lrow + tb * 4) * CP + kk;
+    const float* wbase = ws + (py * 4 * CH + kk) * NT + i;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][p][r] = 0.f;
+
+    load_w(0);
+    int buf = 0, it = 0;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        __syncthreads();
+        stage_halo_wino<VEC>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+        for (int dz = 0; dz < 3; ++dz, ++it) {
+            store_w(buf);
+            __syncthreads();
+            if (it + 1 < niter) load_w(it + 1);
+            const float* xa = pa + dz * 4 * WN_PL * CP;
+            const float* xb_ = pb + dz * 4 * WN_PL * CP;
+            const float* wb = wbase + buf * WSL;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+#pragma unroll
+                for (int s = 0; s < CH / 2; ++s) {
+                    const float bv = wb[(px * CH + 2 * s) * NT];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int off = ((2 * m * 4 + px) * WN_PL) * CP + 2 * s;
+                        const float av = fmaf(sa, xb_[off], xa[off]);
+                        acc[m][px] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][px], 0, 0, 0);
+                    }
+                }
+            }
+            buf ^= 1;
+        }
+    }
+
+    // ---- x inverse transform in registers, y inverse transform across the four waves through LDS
+    __syncthreads();                                   // every wave has left xs / ws
+    float* R = smem;                                   // [py][m][ox][r][lane]
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0 = acc[m][0][r], m1 = acc[m][1][r], m2 = acc[m][2][r], m3 = acc[m][3][r];
+            R[(((py * 2 + m) * 2 + 0) * 16 + r) * 64 + lane] = m0 + m1 + m2;
+            R[(((py * 2 + m) * 2 + 1) * 16 + r) * 64 + lane] = m1 - m2 - m3;
+        }
+    }
+    __syncthreads();
+    const int fm = wave >> 1, fox = wave & 1;           // this wave finishes row tile fm, x parity fox
+    float* out_b = a.out + (long)b * a.out_bs;
+    const int co = co0 + i;
+    const bool cok = co < a.Cout;
+    const float bias = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
+    const bool fuse = a.coef != nullptr && cok;
+    const float fsc = fuse ? a.coef[2 * a.Cout + co] : 1.f, fsh = fuse ? a.coef[3 * a.Cout + co] : 0.f;
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float tq[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) tq[p] = R[(((p * 2 + fm) * 2 + fox) * 16 + r) * 64 + lane];
+        float v0 = tq[0] + tq[1] + tq[2] + bias, v1 = tq[1] - tq[2] - tq[3] + bias;
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const int gz = z0 + 2 * fm + (row >> 4), gy = y0 + 2 * ((row >> 2) & 3), gx = x0 + 2 * (row & 3) + fox;
+        if (cok && gz < a.D && gx < a.W) {
+            const long vox = (long)(gz * a.H + gy) * a.W + gx;
+            if (gy < a.H) {
+                ssum += v0; ssq += v0 * v0;
+                if (fuse) { const float tt = v0 * fsc + fsh; v0 = tt > 0.f ? tt : tt * a.slope; }
+                out_b[vox * a.out_ps + (long)co * a.out_cs] = v0;
+            }
+            if (gy + 1 < a.H) {
+                ssum += v1; ssq += v1 * v1;
+                if (fuse) { const float tt = v1 * fsc + fsh; v1 = tt > 0.f ? tt : tt * a.slope; }
+                out_b[(vox + a.W) * a.out_ps + (long)co * a.out_cs] = v1;
+            }
+        }
+    }
+    ssum += __shfl_xor(ssum, 32, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (a.stats != nullptr) {
+        float* red = smem + RED;                        // [4 waves][2][NT], behind the exchange buffer
+        if (lane < 32) {
+            red[(wave * 2 + 0) * NT + i] = ssum;
+            red[(wave * 2 + 1) * NT + i] = ssq;
+        }
+        __syncthreads();
+        if (tid < 2 * NT) {
+            const int which = tid / NT, c = tid - which * NT;
+            if (co0 + c < a.Cout) {
+                const float tot = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] + red[(2 * 2 + which) * NT + c] +
+                                  red[(3 * 2 + which) * NT + c];
+                a.stats[((long)tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
+            }
+        }
+    }
+}
+
+// packing for the (y, x) Winograd kernel: wp[k/8][dz][py][px][k%8][n] = sum_dy sum_dx G[py][dy] G[px][dx] g[dz][dy][dx]
+__global__ void pack_weight_wino2_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int NPad, int dgrad, long total) {
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(e % NPad);
+        long r = e / NPad;
+        const int kc = (int)(r % WN_CH); r /= WN_CH;
+        const int px = (int)(r % 4); r /= 4;
+        const int py = (int)(r % 4); r /= 4;
+        const int dz = (int)(r % 3);
+        const int chunk = (int)(r / 3);
+        const int k = chunk * WN_CH + kc;
+        float val = 0.f;
+        if (k < K && n < N) {
+            // first along x (exactly the x-only kernel's weights), then along y
+            float ux[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                float g[3];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int tap = (dz * 3 + dy) * 3 + dx;
+                    g[dx] = dgrad ? w[((long)k * Cin + n) * 27 + (26 - tap)] : w[((long)n * Cin + k) * 27 + tap];
+                }
+                ux[dy] = px == 0 ? g[0] : px == 1 ? 0.5f * (g[0] + g[1] + g[2]) : px == 2 ? 0.5f * (g[0] - g[1] + g[2]) : g[2];
+            }
+            val = py == 0 ? ux[0] : py == 1 ? 0.5f * (ux[0] + ux[1] + ux[2]) : py == 2 ? 0.5f * (ux[0] - ux[1] + ux[2]) : ux[2];
+            (void)G;
+        }
+        wp[e] = val;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight packing
 // w: PyTorch layout [Cout][Cin][27].  forward : K = Cin,  N = Cout, wp[k/CH][tap][k%CH][n] = w[n][k][tap]
 //                                     dgrad   : K = Cout, N = Cin,  wp[k/CH][tap][k%CH][n] = w[k][n][26 - tap]
@@ -1200,8 +1396,9 @@ PULPO_API int pulpo_conv3d_k3_algo(int B, int D, int H, int W, int K, int N) {
     if (force < 0) { const char* e = getenv("PULPO_CONV_WINOGRAD"); force = e ? atoi(e) + 1 : 0; }     // unset: policy; 0 / 1: force off / on
     if (force == 1) return 0;
     const bool shape_ok = K > 4 && conv_tz(D, H, W) == 4;
-    if (force == 2) return shape_ok ? 1 : 0;
-    return shape_ok ? 1 : 0;
+    static int two = -1;
+    if (two < 0) { const char* e = getenv("PULPO_CONV_WINOGRAD_2D"); two = e ? atoi(e) : 1; }      // default: the (y, x) kernel
+    return shape_ok ? (two ? 2 : 1) : 0;
 }
 
 PULPO_API size_t pulpo_conv3d_k3_packed_wino_floats(int K, int N) { return (size_t)((K + WN_CH - 1) / WN_CH) * 9 * 4 * WN_CH * npad(N); }
@@ -1253,4 +1450,54 @@ PULPO_API int pulpo_conv3d_k3_fwd_wino(const float* in, int64_t in_bs, int64_t i
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
     return vec ? launch_wino<32, true>(a, (int)nblk_l, st) : launch_wino<32, false>(a, (int)nblk_l, st);
+}
+
+// ---- (y, x) Winograd variant: same contract as the x-only entry points
+PULPO_API size_t pulpo_conv3d_k3_packed_wino2_floats(int K, int N) { return (size_t)((K + WN_CH - 1) / WN_CH) * 3 * 16 * WN_CH * npad(N); }
+
+PULPO_API int pulpo_conv3d_k3_pack_weight_wino2(const float* w, float* wp, int Cin, int Cout, int dgrad, void* stream) {
+    PULPO_REQUIRE(w && wp && Cin > 0 && Cout > 0, "conv3d_k3_pack_weight_wino2: bad arguments");
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    const long total = (long)pulpo_conv3d_k3_packed_wino2_floats(K, N);
+    const int nb = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_weight_wino2_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wp, Cin, Cout, npad(N), dgrad, total);
+    return pulpo::check_launch("pack_weight_wino2");
+}
+
+template <bool VEC>
+static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
+    constexpr size_t lds = (size_t)(((WN_ROWS * WN_CP + 3) & ~3) + 2 * 16 * WN_CH * 32) * sizeof(float);
+    static_assert(lds >= (size_t)(4 * 2 * 2 * 16 * 64 + 4 * 2 * 32) * sizeof(float), "exchange buffer must fit");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino2_mfma<VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(conv3d wino2): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3d_k3_wino2_mfma<VEC>), dim3(nblk), dim3(256), lds, st, a);
+    return pulpo::check_launch("conv3d_k3_wino2_mfma");
+}
+
+PULPO_API int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
+                                        const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats,
+                                        int B, int D, int H, int W, int K, int N, void* stream) {
+    PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_wino2: null pointer");
+    PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd_wino2: bad dims");
+    PULPO_REQUIRE(conv_tz(D, H, W) == 4, "conv3d_k3_fwd_wino2: volume %dx%dx%d is not tiled 4x8x8 (see pulpo_conv3d_k3_algo)", D, H, W);
+    PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd_wino2: batch statistics are not available from the fused eval-mode epilogue");
+    ConvArgs a;
+    a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
+    a.wp = wp; a.bias = bias;
+    a.out = out; a.out_bs = out_bs; a.out_ps = out_ps; a.out_cs = out_cs;
+    a.stats = stats;
+    a.coef = coef; a.slope = slope;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
+    a.ntz = pulpo::cdiv(D, 4); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
+    a.ncot = pulpo::cdiv(N, 32);
+    a.ksplit = 1; a.part = nullptr;
+    const long nblk_l = (long)B * a.ntz * a.nty * a.ntx * a.ncot;
+    PULPO_REQUIRE(nblk_l < (1L << 31), "conv3d_k3_fwd_wino2: grid too large");
+    const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    return vec ? launch_wino2<true>(a, (int)nblk_l, st) : launch_wino2<false>(a, (int)nblk_l, st);
 }

@@ -154,10 +154,12 @@ def _pack_weight(w: torch.Tensor, dgrad: bool, shape=None) -> torch.Tensor:
         lib.call("pulpo_conv3d_k3_pack_weight_bf16", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
         wp._pulpo_algo = "bf16"
         return wp
-    if shape is not None and lib.query("pulpo_conv3d_k3_algo", *shape, K, N) == 1:
-        wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_wino_floats", K, N), device=w.device, dtype=torch.float32)
-        lib.call("pulpo_conv3d_k3_pack_weight_wino", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
-        wp._pulpo_algo = "wino"
+    algo = lib.query("pulpo_conv3d_k3_algo", *shape, K, N) if shape is not None else 0
+    if algo in (1, 2):
+        name = "wino" if algo == 1 else "wino2"
+        wp = torch.empty(lib.query(f"pulpo_conv3d_k3_packed_{name}_floats", K, N), device=w.device, dtype=torch.float32)
+        lib.call(f"pulpo_conv3d_k3_pack_weight_{name}", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
+        wp._pulpo_algo = name
         return wp
     wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_floats", K, N), device=w.device, dtype=torch.float32)
     lib.call("pulpo_conv3d_k3_pack_weight", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
@@ -174,11 +176,11 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
     algo = getattr(wp, "_pulpo_algo", "bf16" if wp.dtype == torch.int16 else "direct")
     bf16 = algo == "bf16"
     vec_ok = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0
-    if algo == "wino":
+    if algo in ("wino", "wino2"):
         t0 = _trace_begin()
-        lib.call("pulpo_conv3d_k3_fwd_wino", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc, _ptr(stats),
+        lib.call(f"pulpo_conv3d_k3_fwd_{algo}", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc, _ptr(stats),
                  B, D, H, W, K, N, _stream())
-        _trace_end(t0, f"conv3d_k3_wino_mfma<32,{'true' if vec_ok else 'false'}>", 54.0 * K * N * B * D * H * W)
+        _trace_end(t0, f"conv3d_k3_{algo}_mfma<32,{'true' if vec_ok else 'false'}>", 54.0 * K * N * B * D * H * W)
         return
     sfx = "_bf16" if bf16 else ""
     nscr = lib.query(f"pulpo_conv3d_k3_fwd{sfx}_scratch_floats", B, D, H, W, K, N)
