@@ -1199,9 +1199,9 @@ int launch_conv(const ConvArgs& a, int nblk, hipStream_t st, int tz) {
 }  // namespace
 
 // z extent of the forward voxel tile: 4 (the Winograd kernel's tile; in the direct kernel each wave = two 32-voxel MFMA row tiles)
-// when the volume's depth divides evenly and there are enough tiles (measured: pays from 40^3 up, not at 20^3)
+// when the volume's depth divides evenly and there are enough tiles (measured: the (y, x) Winograd kernel pays from 20^3 up)
 int pulpo_conv::conv_tz(int D, int H, int W) {
-    return (D % 4 == 0 && (long)D * H * W >= 40L * 40 * 40) ? 4 : 2;
+    return (D % 4 == 0 && (long)D * H * W >= 20L * 20 * 20) ? 4 : 2;
 }
 
 int pulpo_conv::launch_splitk_reduce(const float* part, int ksplit, float* out, long obs, long ops, long ocs, int B, long V, int C, int nrow,

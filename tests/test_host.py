@@ -31,10 +31,11 @@ def test_library_exports_every_declared_symbol():
     # pure host-side size queries (no device work)
     assert lib.query("pulpo_conv3d_k3_packed_floats", 32, 32) == 27 * 32 * 64
     assert lib.query("pulpo_conv3d_k3_packed_floats", 2, 32) == 27 * 4 * 64
-    assert lib.query("pulpo_conv3d_k3_stat_tiles", 1, 160, 160, 160) == 40 * 20 * 20      # 4x8x8 voxel tiles from 40^3 up
-    assert lib.query("pulpo_conv3d_k3_stat_tiles", 2, 32, 32, 32) == 2 * 16 * 4 * 4        # 2x8x8 below
+    assert lib.query("pulpo_conv3d_k3_stat_tiles", 1, 160, 160, 160) == 40 * 20 * 20      # 4x8x8 voxel tiles from 20^3 up (depth % 4 == 0)
+    assert lib.query("pulpo_conv3d_k3_stat_tiles", 2, 32, 32, 32) == 2 * 8 * 4 * 4
+    assert lib.query("pulpo_conv3d_k3_stat_tiles", 1, 10, 10, 10) == 5 * 2 * 2             # 2x8x8 otherwise
     assert lib.query("pulpo_conv3d_k3_packed_bf16_elems", 48, 32) == 2 * 27 * 64 * 32
-    assert lib.query("pulpo_conv3d_k3_algo", 1, 40, 40, 40, 64, 128) in (1, 2) and lib.query("pulpo_conv3d_k3_algo", 1, 20, 20, 20, 192, 192) == 0
+    assert lib.query("pulpo_conv3d_k3_algo", 1, 40, 40, 40, 64, 128) in (1, 2) and lib.query("pulpo_conv3d_k3_algo", 1, 10, 10, 10, 192, 192) == 0
     assert lib.query("pulpo_conv3d_k3_algo", 1, 160, 160, 160, 2, 32) == 0                  # image input layers: direct kernel
     assert lib.query("pulpo_conv3d_k3_packed_wino_floats", 20, 12) == 3 * 9 * 4 * 8 * 64
     assert lib.query("pulpo_conv3d_k3_wgrad_scratch_floats", 160, 64) == 27 * 160 * 64
