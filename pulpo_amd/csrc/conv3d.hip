@@ -306,6 +306,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // LDS rows are ordered (hz, point, hy, x-pair): the 32 (y, x-pair) blocks an A fragment reads are 32 consecutive rows of 9 floats
 // (odd stride => one bank per lane), a (dz, dy) tap moves the window by dz * 4 * WN_PL + dy * 4 rows
 constexpr int WN_CH = 8, WN_CP = WN_CH + 1, WN_HZ = 6, WN_PL = HY * 4, WN_ROWS = WN_HZ * 4 * WN_PL;
+// floats per hz plane: 160 rows + 4 floats, so that blocks of neighbouring z-planes (the (y, x) kernel's row tiles span two) fall on
+// disjoint LDS banks
+constexpr int WN_PS = 4 * WN_PL * WN_CP + 4;
 
 template <bool VEC>
 __device__ __forceinline__ void stage_halo_wino(float* xs, const float* __restrict__ in, long in_ps, long in_cs, int c0, int Cin, int z0, int y0,
@@ -335,7 +338,7 @@ __device__ __forceinline__ void stage_halo_wino(float* xs, const float* __restri
             if (j < NITEM) {
                 const int q = j % Q, rb = j / Q;                // rb = (hz*HY + hy)*4 + xb
                 const int hz = rb / (HY * 4), yx = rb - hz * (HY * 4);
-                float* o = xs + (hz * 4 * WN_PL + yx) * WN_CP + 4 * q;      // row (hz, point 0, hy, xb); points are WN_PL rows apart
+                float* o = xs + hz * WN_PS + yx * WN_CP + 4 * q;      // row (hz, point 0, hy, xb); points are WN_PL rows apart
                 const float4 d0 = d[u][0], d1 = d[u][1], d2 = d[u][2], d3 = d[u][3];
                 o[0] = d0.x - d2.x; o[1] = d0.y - d2.y; o[2] = d0.z - d2.z; o[3] = d0.w - d2.w;
                 o += WN_PL * WN_CP;
@@ -360,7 +363,7 @@ __device__ __forceinline__ void stage_halo_wino(float* xs, const float* __restri
                     if ((unsigned)gx < (unsigned)W) d[t] = in[((long)(gz * H + gy) * W + gx) * in_ps + (long)(c0 + c) * in_cs];
                 }
             }
-            float* o = xs + (hz * 4 * WN_PL + hrow * 4 - hz * (HY * 4) + xb) * WN_CP + c;
+            float* o = xs + hz * WN_PS + (hrow * 4 - hz * (HY * 4) + xb) * WN_CP + c;
             o[0] = d[0] - d[2];
             o[WN_PL * WN_CP] = d[1] + d[2];
             o[2 * WN_PL * WN_CP] = d[2] - d[1];
@@ -369,11 +372,52 @@ __device__ __forceinline__ void stage_halo_wino(float* xs, const float* __restri
     }
 }
 
+// the VEC staging of stage_halo_wino split into its two halves, so that a kernel can issue the raw loads of the next chunk early
+constexpr int WN_Q = WN_CH / 4, WN_NITEM = WN_HZ * HY * 4 * WN_Q, WN_NIT = (WN_NITEM + 255) / 256;
+
+__device__ __forceinline__ void wino_load_raw(float4 (&d)[WN_NIT][4], const float* __restrict__ in, long in_ps, int c0, int Cin, int z0, int y0, int x0,
+                                              int D, int H, int W, int tid) {
+#pragma unroll
+    for (int u = 0; u < WN_NIT; ++u) {
+        const int j = tid + u * 256;
+        const int q = j % WN_Q, xb = (j / WN_Q) & 3, hrow = j / (4 * WN_Q);
+        const int hz = hrow / HY, hy = hrow - hz * HY;
+        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy;
+        const bool rowok = j < WN_NITEM && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && c0 + 4 * q < Cin;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int gx = x0 - 1 + 2 * xb + t;
+            d[u][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rowok && (unsigned)gx < (unsigned)W) d[u][t] = *reinterpret_cast<const float4*>(in + ((long)(gz * H + gy) * W + gx) * in_ps + c0 + 4 * q);
+        }
+    }
+}
+
+__device__ __forceinline__ void wino_store_transformed(float* xs, const float4 (&d)[WN_NIT][4], int tid) {
+#pragma unroll
+    for (int u = 0; u < WN_NIT; ++u) {
+        const int j = tid + u * 256;
+        if (j < WN_NITEM) {
+            const int q = j % WN_Q, rb = j / WN_Q;                // rb = (hz*HY + hy)*4 + xb
+            const int hz = rb / (HY * 4), yx = rb - hz * (HY * 4);
+            float* o = xs + hz * WN_PS + yx * WN_CP + 4 * q;
+            const float4 d0 = d[u][0], d1 = d[u][1], d2 = d[u][2], d3 = d[u][3];
+            o[0] = d0.x - d2.x; o[1] = d0.y - d2.y; o[2] = d0.z - d2.z; o[3] = d0.w - d2.w;
+            o += WN_PL * WN_CP;
+            o[0] = d1.x + d2.x; o[1] = d1.y + d2.y; o[2] = d1.z + d2.z; o[3] = d1.w + d2.w;
+            o += WN_PL * WN_CP;
+            o[0] = d2.x - d1.x; o[1] = d2.y - d1.y; o[2] = d2.z - d1.z; o[3] = d2.w - d1.w;
+            o += WN_PL * WN_CP;
+            o[0] = d1.x - d3.x; o[1] = d1.y - d3.y; o[2] = d1.z - d3.z; o[3] = d1.w - d3.w;
+        }
+    }
+}
+
 template <int NT, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wino_mfma(ConvArgs a) {
     constexpr int CH = WN_CH, CP = WN_CP;
     constexpr int NN = NT / 32;
-    constexpr int XS = (WN_ROWS * CP + 3) & ~3;
+    constexpr int XS = WN_HZ * WN_PS;
     constexpr int WSL = 4 * CH * NT;                 // floats of one (dz, dy) weight slab set: [point][k][NT]
     constexpr int WF4 = WSL / 4;
     constexpr int NW = WF4 / 256;                    // float4 per thread per slab set (1 at NT = 32, 2 at NT = 64)
@@ -412,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino_mfma(ConvArgs a) {
 
     const int i = lane & 31, kk = lane >> 5;
     // MFMA row i of wave w = block (z = w, y = i >> 2, x-pair = i & 3); its transformed rows start at rowbase (+ point)
-    const int rowbase = wave * 4 * WN_PL + i;          // + point * WN_PL
+    const int rowbase = wave * WN_PS + i * WN_CP;       // float offset of (hz = wave, point 0, block i); + point * WN_PL * CP
 
     f32x16 acc[4][NN];
 #pragma unroll
@@ -431,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino_mfma(ConvArgs a) {
             store_w(buf);
             __syncthreads();
             if (it + 1 < niter) load_w(it + 1);
-            const float* xa = xs + (rowbase + (zy / 3) * 4 * WN_PL + (zy % 3) * 4) * CP + kk;
+            const float* xa = xs + rowbase + (zy / 3) * WN_PS + (zy % 3) * 4 * CP + kk;
             const float* wb = ws + buf * WSL + kk * NT + i;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -542,7 +586,7 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __re
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
     constexpr int CH = WN_CH, CP = WN_CP, NT = 32;
-    constexpr int XS = (WN_ROWS * CP + 3) & ~3;
+    constexpr int XS = WN_HZ * WN_PS;
     constexpr int WSL = 16 * CH * NT;                // floats of one dz weight slab set: [py][px][k][NT]
     constexpr int RED = 4 * 2 * 2 * 16 * 64;         // floats of the cross-wave exchange buffer (reuses xs / ws)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -589,9 +633,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
     const int tb = py == 2 ? 1 : py == 3 ? 3 : 2;
     const float sa = py == 1 ? 1.f : -1.f;
     // MFMA row i of row tile m = block (z = 2 m + (i >> 4), yb = (i >> 2) & 3, xb = i & 3); LDS rows are (hz, px, hy, xb)
-    const int lrow = (i >> 4) * 4 * WN_PL + ((i >> 2) & 3) * 8 + (i & 3);
-    const float* pa = xs + (lrow + ta * 4) * CP + kk;
-    const float* pb = xs + (lrow + tb * 4) * CP + kk;
+    const int lrow = ((i >> 2) & 3) * 8 + (i & 3);
+    const float* pa = xs + (i >> 4) * WN_PS + (lrow + ta * 4) * CP + kk;
+    const float* pb = xs + (i >> 4) * WN_PS + (lrow + tb * 4) * CP + kk;
     const float* wbase = ws + (py * 4 * CH + kk) * NT + i;
 
     f32x16 acc[2][4];
@@ -604,28 +648,50 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
 
     load_w(0);
     int buf = 0, it = 0;
+    // (VEC) the raw halo loads of chunk c+1 are issued in front of the last dz iteration of chunk c: their latency hides behind
+    // its 32 MFMAs, and the registers are only live for that third of the loop
+    float4 raw[VEC ? WN_NIT : 1][4];
+    if constexpr (VEC) wino_load_raw(raw, in_b, a.in_ps, 0, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         __syncthreads();
-        stage_halo_wino<VEC>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+        if constexpr (VEC) wino_store_transformed(xs, raw, tid);
+        else stage_halo_wino<false>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+#pragma unroll
         for (int dz = 0; dz < 3; ++dz, ++it) {
             store_w(buf);
             __syncthreads();
             if (it + 1 < niter) load_w(it + 1);
-            const float* xa = pa + dz * 4 * WN_PL * CP;
-            const float* xb_ = pb + dz * 4 * WN_PL * CP;
+            if constexpr (VEC) {
+                if (dz == 2 && chunk + 1 < nchunk) wino_load_raw(raw, in_b, a.in_ps, (chunk + 1) * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+            }
+            const float* xa = pa + dz * WN_PS;
+            const float* xb_ = pb + dz * WN_PS;
             const float* wb = wbase + buf * WSL;
+            // 16 steps (px, s) of two MFMAs (row tiles m = 0, 1).  The five LDS words of step n+2 are requested before the MFMAs of step
+            // n are issued (three-slot register ring, pinned by sched_barrier), so no ds_read -> s_waitcnt -> v_mfma chain is exposed.
+            float ra[3][2], rb[3][2], rw[3];
+            auto fetch = [&](int st, int slot) {
+                const int px = st >> 2, s2 = st & 3;
+                rw[slot] = wb[(px * CH + 2 * s2) * NT];
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
-#pragma unroll
-                for (int s = 0; s < CH / 2; ++s) {
-                    const float bv = wb[(px * CH + 2 * s) * NT];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const int off = ((2 * m * 4 + px) * WN_PL) * CP + 2 * s;
-                        const float av = fmaf(sa, xb_[off], xa[off]);
-                        acc[m][px] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][px], 0, 0, 0);
-                    }
+                for (int m = 0; m < 2; ++m) {
+                    const int off = 2 * m * WN_PS + px * WN_PL * CP + 2 * s2;
+                    ra[slot][m] = xa[off];
+                    rb[slot][m] = xb_[off];
                 }
+            };
+            fetch(0, 0);
+            fetch(1, 1);
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                if (st + 2 < 16) fetch(st + 2, (st + 2) % 3);         // two steps (four MFMAs) of slack for the LDS round trip (three measured slower)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const float av = fmaf(sa, rb[st % 3][m], ra[st % 3][m]);
+                    acc[m][st >> 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, rw[st % 3], acc[m][st >> 2], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             buf ^= 1;
         }
@@ -1414,7 +1480,7 @@ PULPO_API int pulpo_conv3d_k3_pack_weight_wino(const float* w, float* wp, int Ci
 
 template <int NT, bool VEC>
 static int launch_wino(const ConvArgs& a, int nblk, hipStream_t st) {
-    constexpr size_t lds = (size_t)(((WN_ROWS * WN_CP + 3) & ~3) + 2 * 4 * WN_CH * NT) * sizeof(float);
+    constexpr size_t lds = (size_t)(WN_HZ * WN_PS + 2 * 4 * WN_CH * NT) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino_mfma<NT, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1466,7 +1532,7 @@ PULPO_API int pulpo_conv3d_k3_pack_weight_wino2(const float* w, float* wp, int C
 
 template <bool VEC>
 static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
-    constexpr size_t lds = (size_t)(((WN_ROWS * WN_CP + 3) & ~3) + 2 * 16 * WN_CH * 32) * sizeof(float);
+    constexpr size_t lds = (size_t)(WN_HZ * WN_PS + 2 * 16 * WN_CH * 32) * sizeof(float);
     static_assert(lds >= (size_t)(4 * 2 * 2 * 16 * 64 + 4 * 2 * 32) * sizeof(float), "exchange buffer must fit");
     static bool attr_set = false;
     if (!attr_set) {
