@@ -762,35 +762,37 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
 
 // packing for the (y, x) Winograd kernel: wp[k/8][dz][py][px][k%8][n] = sum_dy sum_dx G[py][dy] G[px][dx] g[dz][dy][dx]
 __global__ void pack_weight_wino2_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int NPad, int dgrad, long total) {
+    // one thread per (chunk, dz, k, n): nine taps in, sixteen transformed points out
     const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
-    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int n = (int)(e % NPad);
         long r = e / NPad;
         const int kc = (int)(r % WN_CH); r /= WN_CH;
-        const int px = (int)(r % 4); r /= 4;
-        const int py = (int)(r % 4); r /= 4;
         const int dz = (int)(r % 3);
         const int chunk = (int)(r / 3);
         const int k = chunk * WN_CH + kc;
-        float val = 0.f;
-        if (k < K && n < N) {
-            // first along x (exactly the x-only kernel's weights), then along y
-            float ux[3];
+        float ux[3][4];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                float g[3];
+        for (int dy = 0; dy < 3; ++dy) {
+            float g[3] = {0.f, 0.f, 0.f};
+            if (k < K && n < N) {
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const int tap = (dz * 3 + dy) * 3 + dx;
                     g[dx] = dgrad ? w[((long)k * Cin + n) * 27 + (26 - tap)] : w[((long)n * Cin + k) * 27 + tap];
                 }
-                ux[dy] = px == 0 ? g[0] : px == 1 ? 0.5f * (g[0] + g[1] + g[2]) : px == 2 ? 0.5f * (g[0] - g[1] + g[2]) : g[2];
             }
-            val = py == 0 ? ux[0] : py == 1 ? 0.5f * (ux[0] + ux[1] + ux[2]) : py == 2 ? 0.5f * (ux[0] - ux[1] + ux[2]) : ux[2];
-            (void)G;
+            ux[dy][0] = g[0]; ux[dy][1] = 0.5f * (g[0] + g[1] + g[2]); ux[dy][2] = 0.5f * (g[0] - g[1] + g[2]); ux[dy][3] = g[2];
         }
-        wp[e] = val;
+        float* o = wp + (((long)(chunk * 3 + dz) * 16) * WN_CH + kc) * NPad + n;          // + (py * 4 + px) * WN_CH * NPad
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const float u0 = ux[0][px], u1 = ux[1][px], u2 = ux[2][px];
+            o[(long)(0 * 4 + px) * WN_CH * NPad] = u0;
+            o[(long)(1 * 4 + px) * WN_CH * NPad] = 0.5f * (u0 + u1 + u2);
+            o[(long)(2 * 4 + px) * WN_CH * NPad] = 0.5f * (u0 - u1 + u2);
+            o[(long)(3 * 4 + px) * WN_CH * NPad] = u2;
+        }
     }
 }
 
@@ -1524,8 +1526,8 @@ PULPO_API size_t pulpo_conv3d_k3_packed_wino2_floats(int K, int N) { return (siz
 PULPO_API int pulpo_conv3d_k3_pack_weight_wino2(const float* w, float* wp, int Cin, int Cout, int dgrad, void* stream) {
     PULPO_REQUIRE(w && wp && Cin > 0 && Cout > 0, "conv3d_k3_pack_weight_wino2: bad arguments");
     const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
-    const long total = (long)pulpo_conv3d_k3_packed_wino2_floats(K, N);
-    const int nb = (int)std::min<long>((total + 255) / 256, 4096);
+    const long total = (long)pulpo_conv3d_k3_packed_wino2_floats(K, N) / 16;          // threads: one per (chunk, dz, k, n)
+    const int nb = (int)std::min<long>((total + 255) / 256, 8192);
     hipLaunchKernelGGL(pack_weight_wino2_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wp, Cin, Cout, npad(N), dgrad, total);
     return pulpo::check_launch("pack_weight_wino2");
 }
