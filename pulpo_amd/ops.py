@@ -130,6 +130,9 @@ def _trace_end(start, name: str, flops: float):
 # 4-5: operands rounded to bf16 while staged, fp32 accumulation; activations, statistics, losses and gradients stay fp32).
 # Layers with <= 4 reduction channels (the 2-channel image input) always run the fp32 kernel.
 CONV_PRECISION = "fp32"
+# None: the library's choice per shape (pulpo_conv3d_k3_algo); "direct" | "wino" | "wino2": force that forward / data-gradient kernel
+# wherever a Winograd kernel would be eligible (A/B runs and the full-size consistency test)
+CONV_ALGO = None
 
 
 def set_conv_precision(precision: str) -> None:
@@ -155,6 +158,8 @@ def _pack_weight(w: torch.Tensor, dgrad: bool, shape=None) -> torch.Tensor:
         wp._pulpo_algo = "bf16"
         return wp
     algo = lib.query("pulpo_conv3d_k3_algo", *shape, K, N) if shape is not None else 0
+    if CONV_ALGO is not None and algo != 0:            # diagnostic override; only among the kernels valid for this shape
+        algo = {"direct": 0, "wino": 1, "wino2": 2}[CONV_ALGO]
     if algo in (1, 2):
         name = "wino" if algo == 1 else "wino2"
         wp = torch.empty(lib.query(f"pulpo_conv3d_k3_packed_{name}_floats", K, N), device=w.device, dtype=torch.float32)

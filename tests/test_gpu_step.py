@@ -406,6 +406,52 @@ def test_config5_shape_bf16_train_step_and_mc_uncertainty(api):
         ops.set_conv_precision("fp32")
 
 
+def test_headline_config_160_direct_and_winograd_kernels_agree(api):
+    """BASELINE config 3 / the metric's workload at FULL size (160^3, T5/L4, n0 = 32, B = 1): no oracle run fits the test budget
+    (11 s per CPU step), so the size-independent property is the agreement of independent kernels - the direct implicit-GEMM
+    convolution (pinned against the reference goldens at small sizes) and the two Winograd kernels - on every output dictionary and the
+    loss terms of one training-mode forward, plus finite gradients and a bitwise reproducible forward."""
+    models, nb = api
+    from pulpo_amd import ops
+    size = [160, 160, 160]
+    torch.manual_seed(0)
+    model = models.PULPo(5, 4, 0.1, size, feedback=FB, n0=32).cuda().train()
+    gen = torch.Generator().manual_seed(11)
+    x, y = torch.rand(1, 1, *size, generator=gen).cuda(), torch.rand(1, 1, *size, generator=gen).cuda()
+    for l in range(4):
+        s_ = 160 // 2 ** (l + 1)
+        model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(torch.randn(1, 3, s_, s_, s_, generator=gen).cuda())
+    bn_state = {k: v.clone() for k, v in model.state_dict().items()}
+    res = {}
+    try:
+        for algo in ("direct", "wino", "wino2"):
+            ops.CONV_ALGO = algo
+            model.load_state_dict(bn_state)                 # same BatchNorm running statistics going in
+            with torch.no_grad():
+                outs, _, losses, _ = model._forward_and_losses(x, y)
+            res[algo] = ([{l: v.clone() for l, v in d.items()} for d in outs], [float(v) for v in losses])
+        ops.CONV_ALGO = None
+        for algo in ("wino", "wino2"):
+            for name, d0, d1 in zip(OUT, res["direct"][0], res[algo][0]):
+                for l in d0:
+                    err = float((d0[l] - d1[l]).abs().max()) / max(1.0, float(d0[l].abs().max()))
+                    assert err <= 1e-4, (algo, name, l, err)
+            np.testing.assert_allclose(res[algo][1], res["direct"][1], rtol=1e-4)
+        model.load_state_dict(bn_state)
+        outs, _, (total, kl, rec, reg), _ = model._forward_and_losses(x, y)
+        total.backward()
+        for k, p in model.named_parameters():
+            if "encoders.3.sample_merge_block" in k:
+                assert p.grad is None
+            else:
+                assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+        model.eval()
+        with torch.no_grad():
+            assert bool((model(x, y) == model(x, y)).all())
+    finally:
+        ops.CONV_ALGO = None
+
+
 def test_mc_uncertainty_matches_stacked_statistics(api, golden):
     """pulpo_amd.uncertainty.mc_uncertainty (streaming moments) against the reference's procedure (evaluate.py:222-251) carried out
     with stacked samples on the same latent noise: the sampler is replaced by one that replays a recorded noise sequence."""
