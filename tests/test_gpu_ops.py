@@ -255,14 +255,16 @@ def test_eval_mode_fused_epilogue_equals_separate_passes(ops, precision, Cin, Co
         O.CONV_PRECISION = "fp32"
 
 
+@pytest.mark.parametrize("algo", ["wino2", "wino"])
 @pytest.mark.parametrize("B,Cin,Cout,size", [(1, 32, 32, (64, 64, 64)), (1, 64, 64, (64, 64, 64)), (2, 16, 96, (64, 56, 80)), (1, 20, 12, (64, 64, 70)),
-                                            (1, 96, 32, (68, 61, 67))])
-def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size):
+                                            (1, 96, 32, (68, 61, 67)), (2, 192, 192, (20, 20, 20)), (1, 8, 40, (24, 20, 17))])
+def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size, algo):
     """volumes of >= 40^3 voxels take a Winograd kernel for forward and data gradient (pulpo_conv3d_k3_algo: 2 = F(2x2,3x3) in (y, x),
     1 = F(2,3) along x only) and the Winograd-x weight-gradient kernel: same fp32 tolerance against the fp64 convolution as the
     direct kernels; ragged H / W (odd sizes: half-filled blocks) included"""
     from pulpo_amd._lib import lib
     assert lib.query("pulpo_conv3d_k3_algo", B, *size, Cin, Cout) in (1, 2)
+    ops.CONV_ALGO = algo                      # "wino2" is the library's default choice; "wino" (x only) stays selectable
     gen = torch.Generator().manual_seed(B * 1000 + Cin * 10 + Cout)
     x = torch.randn(B, Cin, *size, generator=gen)
     w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (27 * Cin) ** 0.5
