@@ -133,8 +133,12 @@ class DataParallelStepper:
     remaining, parameter-poor part of the backward pass.  RCCL orders the collective after the kernels already enqueued on
     the compute stream, and the Adam step waits for all buckets."""
 
-    def __init__(self, model: nn.Module, lr: Optional[float] = None, overlap: bool = True):
+    def __init__(self, model: nn.Module, lr: Optional[float] = None, overlap: bool = True, async_wgrad: bool = True):
         self.model = model
+        # weight gradients on a second stream (ops.ASYNC_WGRAD_STREAM): overlaps them with the BatchNorm backward passes
+        dev0 = next(model.parameters()).device
+        self.async_wgrad = bool(async_wgrad) and dev0.type == "cuda" and os.environ.get("PULPO_ASYNC_WGRAD", "1") != "0"
+        self._side = torch.cuda.Stream(device=dev0) if self.async_wgrad else None
         params, ranges, triggers = _gradient_buckets(model)
         self.arena = FlatArena(model, params)
         off = self.arena.offsets + [self.arena.numel]
@@ -163,6 +167,9 @@ class DataParallelStepper:
 
     def _launch_upto(self, i: int) -> None:
         """issue the all-reduce of every not yet launched bucket up to and including i (buckets complete in index order)"""
+        if self._launched <= i and world() > 1:
+            from . import ops
+            ops.join_async_wgrad()           # weight gradients of the bucket may still be running on the side stream
         while self._launched <= i:
             a, b = self.buckets[self._launched]
             if world() > 1:
@@ -178,10 +185,13 @@ class DataParallelStepper:
         try:
             loss = self.model.training_step(batch, 0)
             ops.DIRECT_PARAM_GRADS = True          # conv / BN backward kernels add straight into the arena's .grad views
+            ops.ASYNC_WGRAD_STREAM = self._side if self.async_wgrad else None
             try:
                 loss.backward()
             finally:
                 ops.DIRECT_PARAM_GRADS = False
+                ops.join_async_wgrad()
+                ops.ASYNC_WGRAD_STREAM = None
         finally:
             self._armed = False
         if self.overlap and world() > 1:

@@ -221,6 +221,30 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
     return None if into is not None else dw
 
 
+# Weight gradients off the critical path.  Inside a data-parallel step the weight gradient goes straight into the gradient arena and
+# nothing reads it before the all-reduce, so it need not finish before the backward pass moves on: it is queued on a second HIP
+# stream BEHIND this unit's data-gradient kernel, where the matrix-bound persistent kernel (one workgroup per CU) runs next to the
+# HBM-bound BatchNorm / LeakyReLU backward passes of the preceding unit on the main stream.  Joined before the gradient exchange
+# (dp.DataParallelStepper).  None = disabled (plain autograd use: gradients are returned on the caller's stream).
+ASYNC_WGRAD_STREAM = None
+
+
+def _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w):
+    main = torch.cuda.current_stream()
+    side = ASYNC_WGRAD_STREAM
+    side.wait_stream(main)                       # after everything queued so far: dy, this unit's data gradient, zero_grad
+    with torch.cuda.stream(side):
+        _wgrad_raw(x, dy, Cin, Cout, into=slot_w)
+    x.record_stream(side)                        # keep both operands' memory out of the allocator's hands until the side stream is done
+    dy.record_stream(side)
+
+
+def join_async_wgrad():
+    """make the current stream wait for every weight gradient queued on the side stream"""
+    if ASYNC_WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(ASYNC_WGRAD_STREAM)
+
+
 class _ConvBNLReLU(torch.autograd.Function):
     """ConvUnit: Conv3d(k3,p1,bias) -> BatchNorm3d -> LeakyReLU(0.2)   (reference src/network_blocks.py:22-26)"""
 
@@ -283,12 +307,15 @@ class _ConvBNLReLU(torch.autograd.Function):
                  LRELU_SLOPE, _ptr(part2), _stream())
         dbias = _colsum(part2, nblk, Cout, into=slot_b) if ctx.needs_input_grad[2] else None
         dbeta, dgamma = (None, None) if direct_bn else (tot[:Cout], tot[Cout:])
-        dw = _wgrad_raw(x, dy, Cin, Cout, into=slot_w) if ctx.needs_input_grad[1] else None
+        defer_w = ctx.needs_input_grad[1] and slot_w is not None and ASYNC_WGRAD_STREAM is not None
+        dw = _wgrad_raw(x, dy, Cin, Cout, into=slot_w) if (ctx.needs_input_grad[1] and not defer_w) else None
         dx = None
         if ctx.needs_input_grad[0]:
             wpt = _pack_weight(weight, dgrad=True, shape=(B, D, H, W))
             dx = torch.empty_like(x) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, dev)
             _conv_raw(dy, wpt, None, dx, Cout, Cin, None)
+        if defer_w:
+            _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
