@@ -105,7 +105,7 @@ def pmc_traffic(kernel: str) -> dict:
     if n == 0:
         return {"traffic": None}
     return {"traffic": sum(r["traffic_bytes"] * r["launches"] for r in hit) / n, "traffic_unit": "bytes/launch",
-            "traffic_source": "profiles/r1_bench160_pmc_traffic.json (rocprofv3 --pmc, FETCH_SIZE raw for 64-B gathers + WRITE_SIZE)"}
+            "traffic_source": "profiles/r1_bench160_pmc_traffic.json (rocprofv3 --pmc passes of this command: FETCH_SIZE raw for the conv kernels' short gathers + WRITE_SIZE)"}
 
 
 def main():
@@ -164,6 +164,20 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     trace, ops.CONV_TRACE = ops.CONV_TRACE, None
+    # Inside the timed region the weight gradients run on a second stream next to the main stream's kernels, so a kernel's HIP-event
+    # bracket there includes the time it shares the CUs.  Two extra, untimed steps with that overlap switched off give the same
+    # kernels' stand-alone durations (reported as roofline["serialized"]; the throughput value is NOT taken from these steps).
+    trace_serial = None
+    if trace is not None and not infer and world == 1 and stepper.async_wgrad:
+        stepper.async_wgrad = False
+        one_step()
+        torch.cuda.synchronize()
+        ops.CONV_TRACE = []
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        trace_serial, ops.CONV_TRACE = ops.CONV_TRACE, None
+        stepper.async_wgrad = True
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -198,6 +212,13 @@ def main():
                 roof["matrix_pipe_frac"] = roof["matrix_pipe_TFLOPs"] / peak
                 roof["note"] = ("achieved/frac count the direct convolution's 54*K*N*V FLOP; the kernel evaluates the "
                                 + ("y and x taps with F(2x2,3x3) and issues 24*K*N*V" if "wino2" in dom[0] else "x taps with F(2,3) and issues 36*K*N*V"))
+            if trace_serial:
+                ts = [(fl_, s_.elapsed_time(e_) * 1e-3) for name_, fl_, s_, e_ in trace_serial if name_ == dom[0]]
+                if ts:
+                    fls, secs = sum(a_ for a_, _ in ts), sum(b_ for _, b_ in ts)
+                    roof["serialized"] = {"achieved": fls / secs / 1e12, "frac": fls / secs / 1e12 / peak, "avg_launch_ms": secs / len(ts) * 1e3,
+                                          "launches": len(ts), "note": "same kernel, weight-gradient stream overlap switched off (2 untimed steps)"}
+                roof["overlap_note"] = "timed-region brackets include CU sharing with the weight-gradient kernels on the second stream"
             if is160_cfg and not bf16:
                 roof.update(pmc_traffic(dom[0]))
         is160 = is160_cfg

@@ -185,7 +185,8 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
         t0 = _trace_begin()
         lib.call(f"pulpo_conv3d_k3_fwd_{algo}", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc, _ptr(stats),
                  B, D, H, W, K, N, _stream())
-        _trace_end(t0, f"conv3d_k3_{algo}_mfma<32,{'true' if vec_ok else 'false'}>", 54.0 * K * N * B * D * H * W)
+        tmpl = f"<32,{'true' if vec_ok else 'false'}>" if algo == "wino" else f"<{'true' if vec_ok else 'false'}>"
+        _trace_end(t0, f"conv3d_k3_{algo}_mfma{tmpl}", 54.0 * K * N * B * D * H * W)
         return
     sfx = "_bf16" if bf16 else ""
     nscr = lib.query(f"pulpo_conv3d_k3_fwd{sfx}_scratch_floats", B, D, H, W, K, N)
