@@ -158,6 +158,8 @@ def main():
     barrier()
     if not args.no_trace:
         ops.CONV_TRACE = []
+        ops.CONV_TRACE_STRIDE = 7        # every 7th conv launch of the timed region is bracketed (the launch count per step is not a multiple of 7)
+    ops.CONV_TRACE_STRIDE_USED = ops.CONV_TRACE_STRIDE
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
@@ -173,6 +175,7 @@ def main():
         one_step()
         torch.cuda.synchronize()
         ops.CONV_TRACE = []
+        ops.CONV_TRACE_STRIDE = 1
         for _ in range(2):
             one_step()
         torch.cuda.synchronize()
@@ -202,7 +205,8 @@ def main():
             n, fl, sec = dom[1]
             peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom[0] else PEAK_FP32_MFMA_TFLOPS
             roof = {"bound": "mfma", "kernel": dom[0], "achieved": fl / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
-                    "frac": fl / sec / 1e12 / peak, "traffic": None, "launches": n, "avg_launch_ms": sec / n * 1e3,
+                    "frac": fl / sec / 1e12 / peak, "traffic": None, "launches": n, "launch_sampling": f"every {ops.CONV_TRACE_STRIDE_USED}th conv launch of the timed region",
+                    "avg_launch_ms": sec / n * 1e3,
                     "flop_per_launch": fl / n}
             if "wino" in dom[0]:
                 # algorithmic FLOP are those of the direct convolution; the Winograd kernels issue 2/3 (F(2,3) along x) or
@@ -231,7 +235,8 @@ def main():
             "config": {"workload": f"{size[0]}x{size[1]}x{size[2]} synthetic pair, {L}-level pyramid (total_levels {T}), {'bf16 conv operands' if bf16 else 'fp32'}, batch {B} per GPU, "
                                    + ("eval-mode forward (mu path, no sampling)" if infer else "fwd+bwd+grad all-reduce+Adam"), "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roof,
-            "conv_kernels": {k: {"launches": v[0], "TFLOP/s": v[1] / v[2] / 1e12, "ms_total_per_step": v[2] / args.steps * 1e3}
+            "conv_kernels": {k: {"launches_sampled": v[0], "TFLOP/s": v[1] / v[2] / 1e12,
+                                 "ms_total_per_step_est": v[2] * ops.CONV_TRACE_STRIDE_USED / args.steps * 1e3}
                              for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][2])},
         }
         if is160 and not infer:

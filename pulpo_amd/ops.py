@@ -108,10 +108,16 @@ def _grad_slot(p: torch.Tensor) -> Optional[torch.Tensor]:
 # Optional live kernel timing (bench.py): when CONV_TRACE is a list, every conv / wgrad launch is bracketed by HIP events
 # recorded on the launch stream and (kernel name, algorithmic FLOPs, start, end) is appended.  No synchronisation here.
 CONV_TRACE = None
+CONV_TRACE_STRIDE = 1          # > 1: bracket only every n-th launch (a stride co-prime with the launches per step samples every layer)
+_trace_counter = 0
 
 
 def _trace_begin():
+    global _trace_counter
     if CONV_TRACE is None:
+        return None
+    _trace_counter += 1
+    if _trace_counter % CONV_TRACE_STRIDE:
         return None
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()
