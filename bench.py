@@ -46,8 +46,9 @@ def parse():
                          "(BASELINE configs 4-5; reported under its own metric name, never as the fp32 headline)")
     ap.add_argument("--data", default="uniform", choices=["uniform", "oasis"],
                     help="uniform: U[0,1) volumes (configs 1-3); oasis: masked smooth anatomy + smooth random deformation (configs 4-5)")
-    ap.add_argument("--mode", default="train", choices=["train", "infer"],
-                    help="train (the metric: fwd+bwd+all-reduce+Adam) or infer (eval-mode predict_deterministic, reported under its own metric name)")
+    ap.add_argument("--mode", default="train", choices=["train", "infer", "mc8"],
+                    help="train (the metric: fwd+bwd+all-reduce+Adam), infer (eval-mode predict_deterministic) or mc8 (8-sample Monte-Carlo "
+                         "uncertainty maps of one pair, BASELINE config 5) - the latter two are reported under their own metric names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="do not bracket conv launches with HIP events")
     return ap.parse_args()
@@ -141,8 +142,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    infer = args.mode == "infer"
-    if infer:
+    infer = args.mode in ("infer", "mc8")
+    if args.mode == "mc8":
+        from pulpo_amd.uncertainty import mc_uncertainty
+        model.eval()
+
+        def one_step():
+            res = mc_uncertainty(model, x[:1], y[:1], 8)
+            return res["output_std"][0].sum()
+    elif infer:
         model.eval()
 
         def one_step():
@@ -227,7 +235,8 @@ def main():
                 roof.update(pmc_traffic(dom[0]))
         is160 = is160_cfg
         out = {
-            "metric": ("volume-pairs/sec inference (predict_deterministic), 160^3 " if infer else "volume-pairs/sec fwd+bwd, 160^3 ") + ("bf16 conv operands (fp32 accumulate, fp32 activations)" if bf16 else "fp32"),
+            "metric": ("volume-pairs/sec, 8-sample MC uncertainty maps per pair, " if args.mode == "mc8" else "volume-pairs/sec inference (predict_deterministic), " if infer
+                       else "volume-pairs/sec fwd+bwd, ") + f"{size[0]}x{size[1]}x{size[2]} " + ("bf16 conv operands (fp32 accumulate, fp32 activations)" if bf16 else "fp32"),
             "value": value, "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16xbf16->f32 convs, f32 elsewhere" if bf16 else "f32", "data": ("synthetic OASIS-style pair (masked smooth anatomy, smooth random deformation)" if args.data == "oasis" else "synthetic U[0,1) volumes")

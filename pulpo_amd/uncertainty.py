@@ -30,9 +30,19 @@ def mc_uncertainty(model, x: torch.Tensor, y: torch.Tensor, num_samples: int, ma
     m_ind = {l: ops.StreamingMoments() for l in range(L)}
     m_fin = {l: ops.StreamingMoments() for l in range(L)}
     individual = None
+    # In eval mode the encoder pyramid is a deterministic function of (x, y): BatchNorm uses its running statistics and the latent
+    # noise only enters the autoencoder.  evaluate.py recomputes it for every sample; here it is computed once and each sample runs
+    # only the stochastic half (identical results, ~40 % less work per sample).  In training mode fall back to model.predict().
+    down = model.downpath(x, y) if not model.training else None
     for _ in range(num_samples):
-        outputs, individual = model.predict(x, y, N=1)
-        _, final = model.combine_dfs(individual)
+        if down is not None:
+            outs = model.autoencoder(x, down)
+            individual = outs[4]                               # predict(N=1): the mean over one sample is the sample
+            _, final = model.combine_dfs(individual)
+            outputs = {l: model.autoencoder.decoders[l].spatial_transform(final[l], x) for l in final}
+        else:
+            outputs, individual = model.predict(x, y, N=1)
+            _, final = model.combine_dfs(individual)
         for l in range(L):
             m_out[l].update(outputs[l])
             m_ind[l].update(individual[l])
