@@ -77,11 +77,12 @@ int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t
 
 /* bf16-operand variant (BASELINE configs 4-5; no counterpart in the reference, whose arithmetic is fp32 throughout - SURVEY.md 8(d)):
  * the same convolution with both operands rounded to bf16 (round-to-nearest-even) as they are staged, products and sums in
- * fp32 on v_mfma_f32_32x32x16_bf16.  Activations, gradients, bias, outputs and `stats` stay fp32; same tiling, same
- * pulpo_conv3d_k3_stat_tiles().  wp holds bf16 bit patterns. */
+ * fp32 on v_mfma_f32_32x32x16_bf16.  Activations, gradients, bias, outputs and `stats` stay fp32; `stats` has
+ * pulpo_conv3d_k3_fwd_bf16_stat_tiles() rows.  wp holds bf16 bit patterns. */
 size_t pulpo_conv3d_k3_packed_bf16_elems(int K, int N);
 int pulpo_conv3d_k3_pack_weight_bf16(const float* w /*[Cout][Cin][3][3][3]*/, uint16_t* wp, int Cin, int Cout, int dgrad, void* stream);
 size_t pulpo_conv3d_k3_fwd_bf16_scratch_floats(int B, int D, int H, int W, int K, int N);
+int pulpo_conv3d_k3_fwd_bf16_stat_tiles(int B, int D, int H, int W); /* rows of `stats` this kernel writes (its own tiling policy) */
 int pulpo_conv3d_k3_fwd_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias, float* out,
                              int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, int B, int D, int H, int W, int K,
                              int N, void* stream);

@@ -17,7 +17,10 @@ using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 namespace {
 
 using pulpo_conv::TY; using pulpo_conv::TX; using pulpo_conv::HY; using pulpo_conv::HX;
-using pulpo_conv::conv_tz; using pulpo_conv::npad;
+using pulpo_conv::npad;
+
+// z extent of this kernel's voxel tile (its own policy: the 4x8x8 tile pays from 64^3 up; pulpo_conv3d_k3_fwd_bf16_stat_tiles follows it)
+inline int conv_tz(int D, int H, int W) { return (D % 4 == 0 && (long)D * H * W >= 64L * 64 * 64) ? 4 : 2; }
 
 constexpr int CH = 32;            // channels per staged chunk = two K=16 MFMA steps
 constexpr int CP = CH + 8;        // LDS row length in bf16 elements
@@ -99,10 +102,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16(ConvArgsH a) {
     constexpr int NN = NT / 32;
     constexpr int MT = TZv / 2;
     constexpr int HV = (TZv + 2) * HY * HX;
-    constexpr int WSLAB = NT * CP;                      // bf16 elements of one LDS weight slab [NT][CP]
+    constexpr int TPB = (TZv == 4 && NT == 64) ? 3 : 1;  // taps (one dx row) per barrier: 3 on the big 64-cout tiles = 24 MFMAs per wave between
+                                                          // barriers (on the 32-cout tiles the extra registers cost the third wave per SIMD: measured slower)
+    constexpr int WSLAB = TPB * NT * CP;                // bf16 elements of one LDS weight slab set [TPB][NT][CP]
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_h[];
     uint16_t* xs = smem_h;                              // [HV][CP]
-    uint16_t* ws = smem_h + HV * CP;                    // [2][NT][CP]
+    uint16_t* ws = smem_h + HV * CP;                    // [2][TPB][NT][CP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lid0 = pulpo::xcd_remap(blockIdx.x, gridDim.x);
@@ -120,18 +125,33 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16(ConvArgsH a) {
     const int nchunk_all = (a.Cin + CH - 1) / CH;
     const int cper = (nchunk_all + a.ksplit - 1) / a.ksplit;
     const int chunk0 = split * cper, chunk1 = min(nchunk_all, chunk0 + cper);
-    const int it0 = chunk0 * 27, niter = chunk1 * 27;
+    constexpr int NIT = 27 / TPB;                       // barrier iterations per chunk
+    const int it0 = chunk0 * NIT, niter = chunk1 * NIT;
     const float* in_b = a.in + (long)b * a.in_bs;
 
-    // weight slab: NT rows (cout) x 32 k bf16 = NT*4 pieces of 16 bytes; one piece per thread (NT = 64) or per low thread (NT = 32)
+    // weight slab of one tap: NT rows (cout) x 32 k bf16 = NT*4 pieces of 16 bytes; one piece per thread (NT = 64) or per low thread (NT = 32)
     const int wrow = tid >> 2, wpiece = tid & 3;
     const bool wact = wrow < NT;
-    uint4 wreg = make_uint4(0, 0, 0, 0);
+    uint4 wr0 = make_uint4(0, 0, 0, 0), wr1 = wr0, wr2 = wr0;      // (scalars: an array indexed in the lambdas ends up in scratch)
     auto load_w = [&](int it) {
-        if (wact) wreg = *reinterpret_cast<const uint4*>(a.wp + ((long)it * a.NPad + co0 + wrow) * CH + wpiece * 8);
+        if (wact) {
+            const uint16_t* p = a.wp + (((long)it * TPB) * a.NPad + co0 + wrow) * CH + wpiece * 8;
+            wr0 = *reinterpret_cast<const uint4*>(p);
+            if constexpr (TPB == 3) {
+                wr1 = *reinterpret_cast<const uint4*>(p + (long)a.NPad * CH);
+                wr2 = *reinterpret_cast<const uint4*>(p + 2L * a.NPad * CH);
+            }
+        }
     };
     auto store_w = [&](int buf) {
-        if (wact) *reinterpret_cast<uint4*>(ws + buf * WSLAB + wrow * CP + wpiece * 8) = wreg;
+        if (wact) {
+            uint16_t* d = ws + buf * WSLAB + wrow * CP + wpiece * 8;
+            *reinterpret_cast<uint4*>(d) = wr0;
+            if constexpr (TPB == 3) {
+                *reinterpret_cast<uint4*>(d + NT * CP) = wr1;
+                *reinterpret_cast<uint4*>(d + 2 * NT * CP) = wr2;
+            }
+        }
     };
 
     const int i = lane & 31, kk = lane >> 5;
@@ -155,23 +175,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16(ConvArgsH a) {
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
         __syncthreads();
         stage_halo_bf16<VEC, TZv>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
-        for (int tap = 0; tap < 27; ++tap, ++it) {
+        for (int itc = 0; itc < NIT; ++itc, ++it) {
             store_w(buf);
             __syncthreads();
             if (it + 1 < niter) load_w(it + 1);
-            const int off = tap_halo_offset(tap);
             const uint16_t* wb = ws + buf * WSLAB + i * CP + kk * 8;
+            // steps = (tap of this iteration, K half); the fragments of step n + (SLOTS - 1) are requested before the MFMAs of step n
+            constexpr int STEPS = TPB * (CH / 16);
+            constexpr int SLOTS = STEPS < 3 ? STEPS : 3;
+            bf16x8 av[SLOTS][MT], bv[SLOTS][NN];
+            auto fetch = [&](int st, int slot) {
+                const int d = st / (CH / 16), ks = st % (CH / 16);
+                const int off = tap_halo_offset(itc * TPB + d);
 #pragma unroll
-            for (int ks = 0; ks < CH / 16; ++ks) {
-                bf16x8 av[MT], bv[NN];
+                for (int m = 0; m < MT; ++m) av[slot][m] = *reinterpret_cast<const bf16x8*>(xs + (hb[m] + off) * CP + ks * 16 + kk * 8);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const bf16x8*>(xs + (hb[m] + off) * CP + ks * 16 + kk * 8);
+                for (int n = 0; n < NN; ++n) bv[slot][n] = *reinterpret_cast<const bf16x8*>(wb + (d * NT + n * 32) * CP + ks * 16);
+            };
 #pragma unroll
-                for (int n = 0; n < NN; ++n) bv[n] = *reinterpret_cast<const bf16x8*>(wb + n * 32 * CP + ks * 16);
+            for (int st = 0; st < SLOTS - 1; ++st) fetch(st, st);
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                if (st + SLOTS - 1 < STEPS) fetch(st + SLOTS - 1, (st + SLOTS - 1) % SLOTS);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int n = 0; n < NN; ++n)
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bv[n], acc[m][n], 0, 0, 0);
+                    for (int m = 0; m < MT; ++m)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[st % SLOTS][m], bv[st % SLOTS][n], acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             buf ^= 1;
         }
@@ -420,7 +452,7 @@ int conv_ksplit_bf16(int B, int D, int H, int W, int K, int N) {
 
 template <int NT, bool VEC, int TZv>
 int launch_bf16(const ConvArgsH& a, int nblk, hipStream_t st) {
-    constexpr size_t lds = (size_t)((TZv + 2) * HY * HX * CP + 2 * NT * CP) * sizeof(uint16_t);
+    constexpr size_t lds = (size_t)((TZv + 2) * HY * HX * CP + 2 * ((TZv == 4 && NT == 64) ? 3 : 1) * NT * CP) * sizeof(uint16_t);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma_bf16<NT, VEC, TZv>),
@@ -451,7 +483,9 @@ PULPO_API size_t pulpo_conv3d_k3_fwd_bf16_scratch_floats(int B, int D, int H, in
     return ks > 1 ? (size_t)ks * B * D * H * W * N : 0;
 }
 
-PULPO_API int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W);
+PULPO_API int pulpo_conv3d_k3_fwd_bf16_stat_tiles(int B, int D, int H, int W) {
+    return B * pulpo::cdiv(D, conv_tz(D, H, W)) * pulpo::cdiv(H, TY) * pulpo::cdiv(W, TX);
+}
 
 static int conv_fwd_bf16_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias, float* out,
                               int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, const float* coef, float slope,
@@ -484,7 +518,7 @@ static int conv_fwd_bf16_impl(const float* in, int64_t in_bs, int64_t in_ps, int
 #undef PULPO_BF16
     if (rc == 0 && a.ksplit > 1)
         rc = pulpo_conv::launch_splitk_reduce(scratch, a.ksplit, out, (long)out_bs, (long)out_ps, (long)out_cs, B, (long)D * H * W, N,
-                                              pulpo_conv3d_k3_stat_tiles(B, D, H, W), stats, coef, slope, st);
+                                              pulpo_conv3d_k3_fwd_bf16_stat_tiles(B, D, H, W), stats, coef, slope, st);
     return rc;
 }
 

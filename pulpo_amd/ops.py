@@ -266,7 +266,7 @@ class _ConvBNLReLU(torch.autograd.Function):
         y = new_cl(B, Cout, D, H, W, dev)
         coef = torch.empty(8 * Cout, device=dev, dtype=torch.float32)      # [4][C] floats + [2][C] doubles
         if training:
-            ntile = lib.query("pulpo_conv3d_k3_stat_tiles", B, D, H, W)
+            ntile = lib.query("pulpo_conv3d_k3_fwd_bf16_stat_tiles" if wp._pulpo_algo == "bf16" else "pulpo_conv3d_k3_stat_tiles", B, D, H, W)
             stats = torch.empty(ntile * 2 * Cout, device=dev, dtype=torch.float32)
             _conv_raw(x, wp, bias, y, Cin, Cout, stats)
             nsd = lib.query("pulpo_bn_fwd_finalize_scratch_doubles", ntile, Cout)

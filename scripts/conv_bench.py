@@ -37,7 +37,7 @@ def main():
         dy = torch.randn(1, co, S, S, S, device="cuda").contiguous(memory_format=torch.channels_last_3d)
         w = torch.randn(co, ci, 3, 3, 3, device="cuda") * 0.05
         y = ops.new_cl(1, co, S, S, S, x.device); dx = ops.new_cl(1, ci, S, S, S, x.device)
-        stats = torch.empty(lib.query("pulpo_conv3d_k3_stat_tiles", 1, S, S, S) * 2 * co, device="cuda")
+        stats = torch.empty(lib.query("pulpo_conv3d_k3_stat_tiles", 1, S, S, S) * 2 * co * 2, device="cuda")     # (x2: room for either precision's tiling)
         wp, wpt = ops._pack_weight(w, False, shape=(1, S, S, S)), ops._pack_weight(w, True, shape=(1, S, S, S))
         fl = 54.0 * ci * co * S ** 3
         res = []
