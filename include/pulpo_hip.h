@@ -55,7 +55,8 @@ int pulpo_conv3d_k3_fwd_bn_lrelu(const float* in, int64_t in_bs, int64_t in_ps, 
                                  const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* scratch, int B,
                                  int D, int H, int W, int K, int N, void* stream);
 /* Winograd F(2,3)-along-x variant of the same convolution for large volumes (1.5x fewer matrix instructions, all fp32; results
- * differ from the direct kernel by fp32 rounding only).  pulpo_conv3d_k3_algo() = 1 where it applies; it has its own weight packing;
+ * differ from the direct kernel by fp32 rounding only).  pulpo_conv3d_k3_algo() says which kernel family to use for a shape (0 direct,
+ * 1 this one, 2 the (y, x) variant below); each has its own weight packing;
  * coef (nullable) selects the fused eval-mode BatchNorm + LeakyReLU store, stats (nullable) the BatchNorm partials (same tiles). */
 int pulpo_conv3d_k3_algo(int B, int D, int H, int W, int K, int N);
 size_t pulpo_conv3d_k3_packed_wino_floats(int K, int N);

@@ -1458,7 +1458,8 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
     return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
 }
 
-// 1 = Winograd F(2,3)-along-x kernel (large volumes, > 4 reduction channels), 0 = direct implicit GEMM
+// forward / data-gradient kernel for a shape: 2 = Winograd F(2x2,3x3) in (y, x) (default where a Winograd kernel applies: 4x8x8-tiled
+// volumes, > 4 reduction channels), 1 = Winograd F(2,3) along x only, 0 = direct implicit GEMM
 PULPO_API int pulpo_conv3d_k3_algo(int B, int D, int H, int W, int K, int N) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("PULPO_CONV_WINOGRAD"); force = e ? atoi(e) + 1 : 0; }     // unset: policy; 0 / 1: force off / on
