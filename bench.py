@@ -236,7 +236,7 @@ def main():
         is160 = is160_cfg
         out = {
             "metric": ("volume-pairs/sec, 8-sample MC uncertainty maps per pair, " if args.mode == "mc8" else "volume-pairs/sec inference (predict_deterministic), " if infer
-                       else "volume-pairs/sec fwd+bwd, ") + f"{size[0]}x{size[1]}x{size[2]} " + ("bf16 conv operands (fp32 accumulate, fp32 activations)" if bf16 else "fp32"),
+                       else "volume-pairs/sec fwd+bwd, ") + ("160^3 " if size == [160, 160, 160] else f"{size[0]}x{size[1]}x{size[2]} ") + ("bf16 conv operands (fp32 accumulate, fp32 activations)" if bf16 else "fp32"),
             "value": value, "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16xbf16->f32 convs, f32 elsewhere" if bf16 else "f32", "data": ("synthetic OASIS-style pair (masked smooth anatomy, smooth random deformation)" if args.data == "oasis" else "synthetic U[0,1) volumes")
