@@ -166,6 +166,7 @@ def main():
     barrier()
     if not args.no_trace:
         ops.CONV_TRACE = []
+        ops.HBM_TRACE = []
         ops.CONV_TRACE_STRIDE = 7        # every 7th conv launch of the timed region is bracketed (the launch count per step is not a multiple of 7)
     ops.CONV_TRACE_STRIDE_USED = ops.CONV_TRACE_STRIDE
     t0 = time.perf_counter()
@@ -174,6 +175,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     trace, ops.CONV_TRACE = ops.CONV_TRACE, None
+    hbm_trace, ops.HBM_TRACE = ops.HBM_TRACE, None
     # Inside the timed region the weight gradients run on a second stream next to the main stream's kernels, so a kernel's HIP-event
     # bracket there includes the time it shares the CUs.  Two extra, untimed steps with that overlap switched off give the same
     # kernels' stand-alone durations (reported as roofline["serialized"]; the throughput value is NOT taken from these steps).
@@ -233,6 +235,17 @@ def main():
                 roof["overlap_note"] = "timed-region brackets include CU sharing with the weight-gradient kernels on the second stream"
             if is160_cfg and not bf16:
                 roof.update(pmc_traffic(dom[0]))
+        # ---- the HBM-bound family (BatchNorm / LeakyReLU passes): algorithmic bytes over the same live brackets, against 8 TB/s
+        hbm_roof = None
+        if hbm_trace:
+            fam = {}
+            for name, nbytes, s_, e_ in hbm_trace:
+                k = fam.setdefault(name, [0, 0.0, 0.0])
+                k[0] += 1
+                k[1] += nbytes
+                k[2] += s_.elapsed_time(e_) * 1e-3
+            hbm_roof = {name: {"bound": "hbm", "achieved": v[1] / v[2] / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": v[1] / v[2] / 8.0e12,
+                               "launches_sampled": v[0], "avg_launch_ms": v[2] / v[0] * 1e3} for name, v in fam.items()}
         is160 = is160_cfg
         out = {
             "metric": ("volume-pairs/sec, 8-sample MC uncertainty maps per pair, " if args.mode == "mc8" else "volume-pairs/sec inference (predict_deterministic), " if infer
@@ -244,6 +257,7 @@ def main():
             "config": {"workload": f"{size[0]}x{size[1]}x{size[2]} synthetic pair, {L}-level pyramid (total_levels {T}), {'bf16 conv operands' if bf16 else 'fp32'}, batch {B} per GPU, "
                                    + ("eval-mode forward (mu path, no sampling)" if infer else "fwd+bwd+grad all-reduce+Adam"), "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roof,
+            "hbm_rooflines": hbm_roof,
             "conv_kernels": {k: {"launches_sampled": v[0], "TFLOP/s": v[1] / v[2] / 1e12,
                                  "ms_total_per_step_est": v[2] * ops.CONV_TRACE_STRIDE_USED / args.steps * 1e3}
                              for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][2])},

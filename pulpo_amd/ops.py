@@ -124,6 +124,30 @@ def _trace_begin():
     return ev
 
 
+# HBM-bound kernels (BatchNorm / LeakyReLU passes): same bracket, algorithmic BYTES instead of FLOP
+HBM_TRACE = None
+
+
+def _hbm_begin():
+    global _trace_counter
+    if HBM_TRACE is None:
+        return None
+    _trace_counter += 1
+    if _trace_counter % CONV_TRACE_STRIDE:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _hbm_end(start, name: str, nbytes: float):
+    if start is None:
+        return
+    end = torch.cuda.Event(enable_timing=True)
+    end.record()
+    HBM_TRACE.append((name, nbytes, start, end))
+
+
 def _trace_end(start, name: str, flops: float):
     if start is None:
         return
@@ -281,7 +305,9 @@ class _ConvBNLReLU(torch.autograd.Function):
                 return y
             _conv_raw(x, wp, bias, y, Cin, Cout, None)
         z = new_cl(B, Cout, D, H, W, dev)
+        t0 = _hbm_begin()
         lib.call("pulpo_bn_lrelu_apply", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
+        _hbm_end(t0, "bn_lrelu_apply", 8.0 * Cout * B * D * H * W)            # read y, write z
         ctx.save_for_backward(x, weight, y, coef)
         ctx.training = training
         ctx.params = (weight, bias, gamma, beta)      # for DIRECT_PARAM_GRADS (their .grad slots)
@@ -297,7 +323,9 @@ class _ConvBNLReLU(torch.autograd.Function):
         dz = to_cl(dz)
         nblk = lib.query("pulpo_bn_bwd_blocks", npix, Cout)
         part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
+        t0 = _hbm_begin()
         lib.call("pulpo_bn_lrelu_bwd_reduce", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE, _ptr(part), _stream())
+        _hbm_end(t0, "bn_lrelu_bwd_reduce", 8.0 * Cout * npix)                # read dz, y
         w_p, b_p, g_p, be_p = ctx.params
         slot_w, slot_b, slot_g, slot_be = (_grad_slot(t) if need else None
                                            for t, need in zip((w_p, b_p, g_p, be_p), ctx.needs_input_grad[1:5]))
@@ -310,8 +338,10 @@ class _ConvBNLReLU(torch.autograd.Function):
                  _ptr(totd), _stream())
         dy = new_cl(B, Cout, D, H, W, dev)
         part2 = torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
+        t0 = _hbm_begin()
         lib.call("pulpo_bn_lrelu_bwd_apply", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4), npix, Cout,
                  LRELU_SLOPE, _ptr(part2), _stream())
+        _hbm_end(t0, "bn_lrelu_bwd_apply", 12.0 * Cout * npix)                # read dz, y; write dy
         dbias = _colsum(part2, nblk, Cout, into=slot_b) if ctx.needs_input_grad[2] else None
         dbeta, dgamma = (None, None) if direct_bn else (tot[:Cout], tot[Cout:])
         defer_w = ctx.needs_input_grad[1] and slot_w is not None and ASYNC_WGRAD_STREAM is not None
