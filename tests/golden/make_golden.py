@@ -432,6 +432,13 @@ def gen_state_keys():
 
 
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "step32":
+        # a step large enough (32^3) for the Winograd forward / data-gradient and weight-gradient kernels to be the ones compared
+        # with the real reference (the 16^3 cases below run the direct kernels)
+        t = gen_step("step_T3L2_n8_32", T=3, L=2, size=[32, 32, 32], n0=8, B=1, seed=150, smooth=True)
+        print("   total loss", t)
+        raise SystemExit(0)
     gen_warp()
     gen_vecint()
     gen_resample()

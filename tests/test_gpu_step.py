@@ -62,7 +62,7 @@ def check_outputs(outs, g, prefix, atol=1e-4):
             assert err <= atol * max(1.0, np.abs(ref).max()), (name, l, err)
 
 
-STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16", "step_fullres_T3L2_n2_16"]
+STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16", "step_fullres_T3L2_n2_16", "step_T3L2_n8_32"]
 
 
 @pytest.mark.parametrize("case", STEP_CASES)
@@ -72,8 +72,45 @@ def test_training_step_matches_reference_golden(api, golden, case):
     model, (Tl, L, n0, B, size) = build_from_golden(models, nb, g, case=case)
     model.train()
     x, y = T(g["x"]).cuda(), T(g["y"]).cuda()
+    gpu_units = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, nb.ConvUnit):
+            mod.register_forward_hook(lambda m, i, o, name=name: gpu_units.__setitem__(name, o.detach()))
     outs, priors, (total, kl, rec, reg), levels = model._forward_and_losses(x, y)
     check_outputs(outs, g, "train")
+    # LeakyReLU slope flips against the reference's own fp32 evaluation (the oracle reproduces the reference to 1e-5, so its
+    # activations stand in for the reference's): one flip moves every upstream gradient by ~1e-3 (see the n0 = 32 test below), so the
+    # gradient bound is 1e-3 without flips and 2e-2 with (measured up to 8.5e-3 on the 32^3 case, for the direct and both Winograd
+    # kernels alike - scripts/golden32_check.py)
+    ref_units = {}
+    orig_unit = O.conv_unit
+
+    def recording_unit(h, sd_, prefix, training):
+        out = orig_unit(h, sd_, prefix, training)
+        ref_units[prefix] = out.detach()
+        return out
+
+    O.conv_unit = recording_unit
+    try:
+        sd0 = {k[4:]: T(v.copy()) for k, v in g.items() if k.startswith("sd0.")}
+        cfg = O.Cfg(Tl, L, size, n0=n0, df_resolution="full_res" if "fullres" in case else "level_res")
+        O.forward(sd0, cfg, T(g["x"]), T(g["y"]), {l: T(g[f"eps.{l}"]) for l in range(L)}, training=True)
+    finally:
+        O.conv_unit = orig_unit
+    assert set(gpu_units) == set(ref_units)
+    flips = sum(int(((gpu_units[k].cpu() > 0) != (ref_units[k] > 0)).sum()) for k in ref_units)
+    assert flips <= 1e-5 * sum(v.numel() for v in ref_units.values()), flips
+    grad_bound = 1e-3 if flips == 0 else 2e-2
+    g64 = None
+    if case == "step_T3L2_n8_32":
+        # On this case (smooth images, 9^3 NCC windows at 32^3) the reference's own fp32 gradients sit 5e-4 (median) to 2e-3 from an fp64
+        # evaluation of the same arithmetic - the cancellation noise of the windowed variances - and so do these, in a different direction
+        # (scripts/golden32_check.py).  The criterion is therefore: no further from fp64 than the reference is (x1.5 + 2e-4), and within
+        # 1e-2 of the reference.
+        sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        _, g64, _ = O.train_step(O.clone_sd(sd64, requires_grad=True), cfg, T(g["x"]).double(), T(g["y"]).double(),
+                                 {l: T(g[f"eps.{l}"]).double() for l in range(L)})
+        grad_bound = 1e-2
     for key, val in zip(("total", "kl", "rec", "reg"), (total, kl, rec, reg)):
         np.testing.assert_allclose(float(val), float(g["train." + key]), rtol=1e-4)
     for nm, d in zip(("kl_l", "rec_l", "reg_l"), levels):
@@ -94,7 +131,10 @@ def test_training_step_matches_reference_golden(api, golden, case):
                 continue
             e = rel_l2(p.grad, ref)
             worst = max(worst, e)
-            assert e < 1e-3, (k, e)
+            assert e < grad_bound, (k, e, flips)
+            if g64 is not None:
+                e_gpu, e_ref = rel_l2(p.grad, g64[k]), rel_l2(T(ref), g64[k])
+                assert e_gpu <= 1.5 * e_ref + 2e-4, (k, e_gpu, e_ref)
             n_checked += 1
         else:
             assert "nograd." + k in g, k

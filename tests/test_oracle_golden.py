@@ -216,7 +216,7 @@ def test_unknown_feedback_item_raises():
 
 
 # ------------------------------------------------------------------------------------------------ full step
-STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16", "step_fullres_T3L2_n2_16"]
+STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16", "step_fullres_T3L2_n2_16", "step_T3L2_n8_32"]
 
 
 def _load_step(g, case=""):
