@@ -258,6 +258,7 @@ def main():
                                    + ("eval-mode forward (mu path, no sampling)" if infer else "fwd+bwd+grad all-reduce+Adam"), "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roof,
             "hbm_rooflines": hbm_roof,
+            "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
             "conv_kernels": {k: {"launches_sampled": v[0], "TFLOP/s": v[1] / v[2] / 1e12,
                                  "ms_total_per_step_est": v[2] * ops.CONV_TRACE_STRIDE_USED / args.steps * 1e3}
                              for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][2])},
