@@ -44,7 +44,8 @@ class DownPath(nn.Module):
         self.lk_offset = total_levels - latent_levels
         self.input_size = input_size
         chans = _channel_plan(total_levels, n0)
-        self.downsample = nn.AvgPool3d(kernel_size=2, stride=2, padding=0, ceil_mode=True)   # parameter-free; HIP kernel is used
+        AvgPool = nn.AvgPool3d if len(input_size) == 3 else nn.AvgPool2d
+        self.downsample = AvgPool(kernel_size=2, stride=2, padding=0, ceil_mode=True)        # parameter-free; HIP kernel is used
         self.down_blocks = ModuleIntDict()
         for k in range(total_levels):
             cin = input_channels if k == 0 else chans[k - 1]
@@ -76,8 +77,7 @@ class PULPoEncoder(nn.Module):
             h = self.sample_merge_block(torch.cat([feedback, down_activation], dim=1))
         sampler = self.sampler
         if sampler is gauss_sampler:                         # fused: noise drawn once, sample formed in the head kernel
-            B, _, D, H, W = h.shape
-            eps = torch.randn((B, self.zdim, D, H, W), device=h.device, dtype=torch.float32)
+            eps = torch.randn((h.shape[0], self.zdim) + tuple(h.shape[2:]), device=h.device, dtype=torch.float32)
             return self.mu_sigma.sample(h, eps)
         if isinstance(sampler, FixedNoiseSampler):
             return self.mu_sigma.sample(h, sampler.fixed_eps)
@@ -130,8 +130,8 @@ class Autoencoder(nn.Module):
         self.df_resolution = df_resolution
         self.cp_depth = cp_depth
         ndims = len(input_size)
-        if ndims != 3:
-            raise NotImplementedError("Autoencoder: only 3-D volumes have a HIP path")
+        if ndims not in (2, 3):
+            raise NotImplementedError("Autoencoder: volumes (ndims 3) or slices (ndims 2) expected")
         if df_resolution not in ("level_res", "full_res"):
             raise ValueError(f"df_resolution is {df_resolution}. Not a known option.")
 
@@ -169,7 +169,7 @@ class Autoencoder(nn.Module):
             full = df_resolution == "full_res"
             self.decoders[l] = SVFDecoder(zdim=zdim, insize=self.level_sizes[k], outsize=input_size if (l == 0 or full) else self.level_sizes[k],
                                           df_resolution=df_resolution, n0=n0, cp_depth=cp_depth)
-        self.mode = "trilinear"
+        self.mode = "trilinear" if ndims == 3 else "bilinear"
 
     # ------------------------------------------------------------------------------------------------------------
     def _gather_feedback(self, store: Dict[str, Dict[int, torch.Tensor]], level: int, size) -> torch.Tensor:
@@ -180,11 +180,12 @@ class Autoencoder(nn.Module):
                 raise ValueError(f"Feedback list contains {item}. Not a known option.")
             srcs.append(store[name][level])
         exact_x2 = all(all(int(o) == 2 * int(i) for o, i in zip(size, s.shape[2:])) for s in srcs)
-        if exact_x2 and sum(s.shape[1] for s in srcs) <= 16 and len(srcs) <= 8:
+        if exact_x2 and srcs[0].dim() == 5 and sum(s.shape[1] for s in srcs) <= 16 and len(srcs) <= 8:
             return ops.feedback_up2(srcs)
         # ragged pyramid (a size not divisible by 2^(T-1)) or df_resolution='full_res' (final_dfs / transformed arrive at full
         # resolution and are down-sampled): generic resize per tensor, then concatenate
-        return torch.cat([ops.resize_trilinear(s, size) for s in srcs], dim=1).contiguous(memory_format=torch.channels_last_3d)
+        fmt = torch.channels_last_3d if srcs[0].dim() == 5 else torch.channels_last
+        return torch.cat([ops.resize_trilinear(s, size) for s in srcs], dim=1).contiguous(memory_format=fmt)
 
     def forward(self, x: torch.Tensor, down_activations, deterministic: bool = False):
         L, o = self.latent_levels, self.lk_offset

@@ -181,9 +181,9 @@ __global__ __launch_bounds__(256) void l2reg_fwd_kernel(const float* __restrict_
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long v = e % V;
         const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((long)W * H));
-        if (x >= 1 && y >= 1 && z >= 1) {
+        if (x >= 1 && y >= 1 && (z >= 1 || D == 1)) {          // D == 1: the 2-D form (losses.py:211-215), no difference along depth
             const float c = df[e];
-            const float a = c - df[e - (long)H * W], b = c - df[e - W], d = c - df[e - 1];
+            const float a = D == 1 ? 0.f : c - df[e - (long)H * W], b = c - df[e - W], d = c - df[e - 1];
             local += a * a + b * b + d * d;
         }
     }
@@ -201,10 +201,11 @@ __global__ __launch_bounds__(256) void l2reg_bwd_kernel(const float* __restrict_
         const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / sz);
         const float c = df[e];
         float g = 0.f;
-        if (x >= 1 && y >= 1 && z >= 1) g += (c - df[e - sz]) + (c - df[e - sy]) + (c - df[e - 1]);   // as the centre voxel
+        const bool flat = D == 1;                                                                           // 2-D form: no depth term
+        if (x >= 1 && y >= 1 && (z >= 1 || flat)) g += (flat ? 0.f : c - df[e - sz]) + (c - df[e - sy]) + (c - df[e - 1]);   // as the centre voxel
         if (z + 1 < D && y >= 1 && x >= 1) g -= df[e + sz] - c;                                         // as the -z neighbour
-        if (y + 1 < H && z >= 1 && x >= 1) g -= df[e + sy] - c;
-        if (x + 1 < W && z >= 1 && y >= 1) g -= df[e + 1] - c;
+        if (y + 1 < H && (z >= 1 || flat) && x >= 1) g -= df[e + sy] - c;
+        if (x + 1 < W && (z >= 1 || flat) && y >= 1) g -= df[e + 1] - c;
         gdf[e] = k0 * g;
     }
 }
@@ -212,6 +213,9 @@ __global__ __launch_bounds__(256) void l2reg_bwd_kernel(const float* __restrict_
 }  // namespace
 
 PULPO_API int pulpo_loss_blocks(int64_t n) { return eblocks(n, 1024); }
+
+// win^ndims of losses.py:124: a depth-1 volume is the reference's 2-D case (conv2d with a win x win window)
+static inline float ncc_window_count(int win, int D) { return D == 1 ? (float)(win * win) : (float)(win * win * win); }
 
 // I = y_true, J = y_pred, planar (B,1,D,H,W).  S: 5*N floats (saved for backward), T: 10*N floats scratch (N = B*D*H*W).
 // partial: pulpo_loss_blocks(N) floats.  loss = -gamma/B * sum(partial)  (finish with pulpo_colsum(scale = -gamma/B)).
@@ -230,7 +234,7 @@ PULPO_API int pulpo_ncc_fwd(const float* I, const float* J, float* S, float* T, 
     hipLaunchKernelGGL(box_axis_kernel, dim3(eblocks(N)), dim3(256), 0, st, T1, T2, N, 5, H, (long)W, pad);
     rc = pulpo::check_launch("ncc box_y");
     if (rc) return rc;
-    hipLaunchKernelGGL(ncc_final_kernel, dim3(pulpo_loss_blocks(N)), dim3(256), 0, st, T2, S, N, D, (long)H * W, pad, (float)(win * win * win), partial);
+    hipLaunchKernelGGL(ncc_final_kernel, dim3(pulpo_loss_blocks(N)), dim3(256), 0, st, T2, S, N, D, (long)H * W, pad, ncc_window_count(win, D), partial);
     return pulpo::check_launch("ncc final");
 }
 
@@ -245,7 +249,7 @@ PULPO_API int pulpo_ncc_bwd(const float* I, const float* J, const float* S, floa
     const long nrows = (long)B * D * H;
     float* T1 = T;
     float* T2 = T + 3 * N;
-    hipLaunchKernelGGL(ncc_abc_kernel, dim3(eblocks(N)), dim3(256), 0, st, S, T1, N, (float)(win * win * win));
+    hipLaunchKernelGGL(ncc_abc_kernel, dim3(eblocks(N)), dim3(256), 0, st, S, T1, N, ncc_window_count(win, D));
     int rc = pulpo::check_launch("ncc abc");
     if (rc) return rc;
     hipLaunchKernelGGL(box_x_kernel<1>, dim3(eblocks(nrows * segs * 64)), dim3(256), 0, st, T1, nullptr, T2, N, nrows, W, pad, 3, segs);
@@ -276,13 +280,13 @@ PULPO_API int pulpo_kl_bwd(const float* mu, const float* sigma, const float* mu1
 // sum of squared forward differences on the [1:,1:,1:] block of nplanes = B*3 volumes;
 // finish with pulpo_colsum(scale = lamb*D*H*W / (nplanes*(D-1)*(H-1)*(W-1)))
 PULPO_API int pulpo_l2reg_fwd(const float* df, int64_t nplanes, int D, int H, int W, float* partial, void* stream) {
-    PULPO_REQUIRE(df && partial && nplanes > 0 && D > 1 && H > 1 && W > 1, "l2reg_fwd: bad arguments");
+    PULPO_REQUIRE(df && partial && nplanes > 0 && D >= 1 && H > 1 && W > 1, "l2reg_fwd: bad arguments");
     hipLaunchKernelGGL(l2reg_fwd_kernel, dim3(pulpo_loss_blocks(nplanes * D * H * W)), dim3(256), 0, (hipStream_t)stream, df, (long)nplanes, D, H, W, partial);
     return pulpo::check_launch("l2reg_fwd");
 }
 
 PULPO_API int pulpo_l2reg_bwd(const float* df, const float* gscale, float coef, float* gdf, int64_t nplanes, int D, int H, int W, void* stream) {
-    PULPO_REQUIRE(df && gdf && nplanes > 0 && D > 1 && H > 1 && W > 1, "l2reg_bwd: bad arguments");
+    PULPO_REQUIRE(df && gdf && nplanes > 0 && D >= 1 && H > 1 && W > 1, "l2reg_bwd: bad arguments");
     hipLaunchKernelGGL(l2reg_bwd_kernel, dim3(eblocks(nplanes * D * H * W)), dim3(256), 0, (hipStream_t)stream, df, gscale, coef, gdf, (long)nplanes, D, H, W);
     return pulpo::check_launch("l2reg_bwd");
 }

@@ -86,7 +86,31 @@ struct JacGeom {
     int B, D, H, W;
     float pre[3];     // 2/S_i when normalising, else 1: applied to ORIGINAL channel i
     float post[3];    // ((D-1,H-1,W-1)[c] - 1)/2 applied to FLIPPED channel c (= original channel 2-c)
+    // D == 1: the reference's 2-D form (losses.py:153-170) on a 2-channel field (B,2,H,W): same recipe over (H, W)
+    float pre2[2], post2[2];
 };
+
+// 2-D: J[a][c], a in (y, x), flipped channel c reads original channel 1-c; returns the 2x2 determinant
+__device__ __forceinline__ float jac2_at(const float* __restrict__ df, const JacGeom& g, long b, int y, int x, float (*J)[2]) {
+    const long V = (long)g.H * g.W;
+    const int S[2] = {g.H, g.W};
+    const int p[2] = {y, x};
+    const long st[2] = {g.W, 1};
+    const long v = (long)y * g.W + x;
+    float Jl[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float* u = df + (b * 2 + (1 - c)) * V;
+        const float sc = g.pre2[1 - c] * g.post2[c];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const long ip = v + (p[a] + 1 < S[a] ? st[a] : 0), im = v - (p[a] > 0 ? st[a] : 0);
+            Jl[a][c] = 0.5f * sc * (u[ip] - u[im]) + (a == c ? 1.f : 0.f);
+        }
+    }
+    if (J != nullptr) { J[0][0] = Jl[0][0]; J[0][1] = Jl[0][1]; J[1][0] = Jl[1][0]; J[1][1] = Jl[1][1]; }
+    return Jl[0][0] * Jl[1][1] - Jl[1][0] * Jl[0][1];
+}
 
 // J[a][c] at voxel (z,y,x); returns the determinant, optionally the 9 entries
 __device__ __forceinline__ float jac_at(const float* __restrict__ df, const JacGeom& g, long b, int z, int y, int x, float (*J)[3]) {
@@ -120,7 +144,7 @@ __global__ __launch_bounds__(256) void jacdet_fwd_kernel(const float* __restrict
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long b = e / V, v = e - b * V;
         const int x = (int)(v % g.W), y = (int)((v / g.W) % g.H), z = (int)(v / ((long)g.W * g.H));
-        const float d = jac_at(df, g, b, z, y, x, nullptr);
+        const float d = g.D == 1 ? jac2_at(df, g, b, y, x, nullptr) : jac_at(df, g, b, z, y, x, nullptr);
         out[e] = d;
         s += d; q += d * d;
     }
@@ -154,9 +178,29 @@ __global__ __launch_bounds__(256) void jdetstd_bwd_kernel(const float* __restric
         const long b = e / V, v = e - b * V;
         const int x = (int)(v % g.W), y = (int)((v / g.W) % g.H), z = (int)(v / sz);
         const int p[3] = {z, y, x};
+        const float w = k0 * (float)((double)jdet[e] - mean);
+        if (g.D == 1) {                  // 2-D form: 2x2 cofactors, two channels
+            float J2[2][2];
+            jac2_at(df, g, b, y, x, J2);
+            const float Cf2[2][2] = {{J2[1][1], -J2[1][0]}, {-J2[0][1], J2[0][0]}};
+            const int S2[2] = {g.H, g.W};
+            const int p2[2] = {y, x};
+            const long st2[2] = {sy, 1};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float* gu = gdf + (b * 2 + (1 - c)) * V;
+                const float sc = 0.5f * g.pre2[1 - c] * g.post2[c] * w;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const long ip = v + (p2[a] + 1 < S2[a] ? st2[a] : 0), im = v - (p2[a] > 0 ? st2[a] : 0);
+                    atomicAdd(gu + ip, sc * Cf2[a][c]);
+                    atomicAdd(gu + im, -sc * Cf2[a][c]);
+                }
+            }
+            continue;
+        }
         float J[3][3];
         jac_at(df, g, b, z, y, x, J);
-        const float w = k0 * (float)((double)jdet[e] - mean);
         // cofactor matrix: d det / d J[a][c]
         float Cf[3][3];
         Cf[0][0] = J[1][1] * J[2][2] - J[2][1] * J[1][2];
@@ -189,6 +233,10 @@ JacGeom make_geom(int B, int D, int H, int W, int normalize) {
     for (int i = 0; i < 3; ++i) {
         g.pre[i] = normalize ? 2.f / (float)S[i] : 1.f;
         g.post[i] = ((float)(S[i] - 1) - 1.f) / 2.f;
+    }
+    for (int i = 0; i < 2; ++i) {
+        g.pre2[i] = normalize ? 2.f / (float)S[i + 1] : 1.f;
+        g.post2[i] = ((float)(S[i + 1] - 1) - 1.f) / 2.f;
     }
     return g;
 }
@@ -248,7 +296,7 @@ PULPO_API int pulpo_jdetstd_bwd(const float* df, const float* jdet, const double
     PULPO_REQUIRE(df && jdet && stat && gdf && B > 0 && D > 0 && H > 0 && W > 0, "jdetstd_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const long n = (long)B * D * H * W;
-    hipError_t e = hipMemsetAsync(gdf, 0, sizeof(float) * 3 * n, st);
+    hipError_t e = hipMemsetAsync(gdf, 0, sizeof(float) * (D == 1 ? 2 : 3) * n, st);        // D == 1: two-channel 2-D field
     if (e != hipSuccess) return pulpo::fail((int)e, "jdetstd_bwd memset: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(jdetstd_bwd_kernel, dim3(eblocks(n)), dim3(256), 0, st, df, make_geom(B, D, H, W, normalize), jdet, stat, gscale, lamb, (double)n, gdf);
     return pulpo::check_launch("jdetstd_bwd");
@@ -289,18 +337,20 @@ __global__ void kln_finalize_kernel(const float* __restrict__ partial, int nblk,
         for (int j = 0; j < 4; ++j) s[j] += partial[4 * k + j];
     const double V = (double)D * H * W;
     const double cnt[3] = {nplanes * (D - 1) * H * W, nplanes * D * (H - 1) * W, nplanes * D * H * (W - 1)};
-    const double precision = 0.5 * (s[1] / cnt[0] + s[2] / cnt[1] + s[3] / cnt[2]) / 3.0;
-    loss[0] = (float)((s[0] / (nplanes * V) + lambda / 2 * precision) * 3.0 * 0.5 * V);
+    const double nd = D == 1 ? 2.0 : 3.0;                 // D == 1: the reference's 2-D form (no depth axis)
+    const double precision = 0.5 * ((D == 1 ? 0.0 : s[1] / cnt[0]) + s[2] / cnt[1] + s[3] / cnt[2]) / nd;
+    loss[0] = (float)((s[0] / (nplanes * V) + lambda / 2 * precision) * nd * 0.5 * V);
 }
 
 __global__ __launch_bounds__(256) void kln_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ gscale,
                                                         long nplanes, int D, int H, int W, float lambda, float* __restrict__ gmu, float* __restrict__ gsigma) {
     const long V = (long)D * H * W, total = nplanes * V, sz = (long)H * W;
     const float g = gscale != nullptr ? gscale[0] : 1.f;
-    const float outer = 1.5f * (float)V * g;                        // ndims * 0.5 * V
+    const float nd = D == 1 ? 2.f : 3.f;
+    const float outer = nd * 0.5f * (float)V * g;                   // ndims * 0.5 * V
     const float ks = outer / (float)(nplanes * V);
-    const float kp = outer * (lambda * 0.5f) * (0.5f / 3.f) * 2.f;      // d(diff^2) = 2 diff
-    const float cz = kp / (float)(nplanes * (D - 1) * (long)H * W), cy = kp / (float)(nplanes * D * (long)(H - 1) * W),
+    const float kp = outer * (lambda * 0.5f) * (0.5f / nd) * 2.f;       // d(diff^2) = 2 diff
+    const float cz = D == 1 ? 0.f : kp / (float)(nplanes * (D - 1) * (long)H * W), cy = kp / (float)(nplanes * D * (long)(H - 1) * W),
                 cx = kp / (float)(nplanes * D * (long)H * (W - 1));
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long v = e % V;
@@ -323,7 +373,7 @@ __global__ __launch_bounds__(256) void kln_bwd_kernel(const float* __restrict__ 
 // mu, sigma planar (B,3,D,H,W); nplanes = B*3; partial: 4*pulpo_metric_blocks(nplanes*D*H*W) floats
 PULPO_API int pulpo_kl_nondiag_fwd(const float* mu, const float* sigma, int64_t nplanes, int D, int H, int W, float prior_lambda, float* partial,
                                    float* loss, void* stream) {
-    PULPO_REQUIRE(mu && sigma && partial && loss && nplanes > 0 && D > 1 && H > 1 && W > 1, "kl_nondiag_fwd: bad arguments");
+    PULPO_REQUIRE(mu && sigma && partial && loss && nplanes > 0 && D >= 1 && H > 1 && W > 1, "kl_nondiag_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = pulpo_metric_blocks(nplanes * D * H * W);
     hipLaunchKernelGGL(kln_fwd_kernel, dim3(nblk), dim3(256), 0, st, mu, sigma, (long)nplanes, D, H, W, prior_lambda, partial);
@@ -334,7 +384,7 @@ PULPO_API int pulpo_kl_nondiag_fwd(const float* mu, const float* sigma, int64_t 
 }
 PULPO_API int pulpo_kl_nondiag_bwd(const float* mu, const float* sigma, const float* gscale, int64_t nplanes, int D, int H, int W, float prior_lambda,
                                    float* gmu, float* gsigma, void* stream) {
-    PULPO_REQUIRE(mu && sigma && gmu && gsigma && nplanes > 0 && D > 1 && H > 1 && W > 1, "kl_nondiag_bwd: bad arguments");
+    PULPO_REQUIRE(mu && sigma && gmu && gsigma && nplanes > 0 && D >= 1 && H > 1 && W > 1, "kl_nondiag_bwd: bad arguments");
     hipLaunchKernelGGL(kln_bwd_kernel, dim3(eblocks(nplanes * D * H * W)), dim3(256), 0, (hipStream_t)stream, mu, sigma, gscale, (long)nplanes, D, H, W,
                        prior_lambda, gmu, gsigma);
     return pulpo::check_launch("kl_nondiag_bwd");

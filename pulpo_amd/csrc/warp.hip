@@ -17,6 +17,11 @@ struct Corner {
 };
 
 __device__ __forceinline__ Corner sample_coord(float pos, float disp, int Sg, int Si) {
+    if (Sg == 1) {            // a depth-1 grid is the reference's 2-D case (bilinear grid_sample over H, W): no coordinate along this axis
+        Corner r;
+        r.i0 = 0; r.i1 = 0; r.f = 0.f; r.dscale = 0.f;
+        return r;
+    }
     float t = pos + disp;
     t = t / (float)(Sg - 1);
     t = t - 0.5f;
@@ -129,7 +134,7 @@ inline int eblocks(long items) { return (int)std::max<long>(1, std::min<long>((i
 PULPO_API int pulpo_warp3d_fwd(const float* df, const float* img, float* out, int B, int C, int Dg, int Hg, int Wg, int Di, int Hi, int Wi,
                                void* stream) {
     PULPO_REQUIRE(df && img && out && B > 0 && C > 0, "warp3d_fwd: bad arguments");
-    PULPO_REQUIRE(Dg > 1 && Hg > 1 && Wg > 1 && Di > 0 && Hi > 0 && Wi > 0, "warp3d_fwd: grid dims must be > 1");
+    PULPO_REQUIRE(Dg >= 1 && Hg > 1 && Wg > 1 && Di > 0 && Hi > 0 && Wi > 0 && (Dg > 1 || Di == 1), "warp3d_fwd: grid H, W must be > 1 (depth 1 = 2-D form, with a depth-1 image)");
     const long total = (long)B * Dg * Hg * Wg;
     hipStream_t st = (hipStream_t)stream;
     if (C == 1) hipLaunchKernelGGL(warp_fwd_kernel<1>, dim3(eblocks(total)), dim3(256), 0, st, df, img, nullptr, out, B, Dg, Hg, Wg, Di, Hi, Wi, C);
@@ -142,7 +147,7 @@ PULPO_API int pulpo_warp3d_fwd(const float* df, const float* img, float* out, in
 PULPO_API int pulpo_warp3d_bwd(const float* df, const float* img, const float* gout, float* gdf, float* gimg, int B, int C, int Dg, int Hg, int Wg,
                                int Di, int Hi, int Wi, void* stream) {
     PULPO_REQUIRE(df && img && gout && B > 0 && C > 0, "warp3d_bwd: bad arguments");
-    PULPO_REQUIRE(Dg > 1 && Hg > 1 && Wg > 1, "warp3d_bwd: grid dims must be > 1");
+    PULPO_REQUIRE(Dg >= 1 && Hg > 1 && Wg > 1, "warp3d_bwd: grid H, W must be > 1");
     hipStream_t st = (hipStream_t)stream;
     if (gimg != nullptr) {
         hipError_t e = hipMemsetAsync(gimg, 0, sizeof(float) * (size_t)B * C * Di * Hi * Wi, st);
@@ -155,7 +160,7 @@ PULPO_API int pulpo_warp3d_bwd(const float* df, const float* img, const float* g
 
 // work: (nsteps+1) buffers of B*3*D*H*W floats; work[k] is the field after k squarings, work[nsteps] the result.
 PULPO_API int pulpo_vecint_fwd(const float* v, float* work, int B, int D, int H, int W, int nsteps, void* stream) {
-    PULPO_REQUIRE(v && work && B > 0 && D > 1 && H > 1 && W > 1 && nsteps >= 0, "vecint_fwd: bad arguments");
+    PULPO_REQUIRE(v && work && B > 0 && D >= 1 && H > 1 && W > 1 && nsteps >= 0, "vecint_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const long n = (long)B * 3 * D * H * W, total = (long)B * D * H * W;
     hipLaunchKernelGGL(scale_kernel, dim3(eblocks(n)), dim3(256), 0, st, v, work, 1.0f / (float)(1 << nsteps), n);
@@ -172,7 +177,7 @@ PULPO_API int pulpo_vecint_fwd(const float* v, float* work, int B, int D, int H,
 
 // gin = d loss / d v given gout = d loss / d work[nsteps].  tmp: 2 buffers of B*3*D*H*W floats.
 PULPO_API int pulpo_vecint_bwd(const float* work, const float* gout, float* gin, float* tmp, int B, int D, int H, int W, int nsteps, void* stream) {
-    PULPO_REQUIRE(work && gout && gin && tmp && B > 0 && D > 1 && H > 1 && W > 1 && nsteps >= 0, "vecint_bwd: bad arguments");
+    PULPO_REQUIRE(work && gout && gin && tmp && B > 0 && D >= 1 && H > 1 && W > 1 && nsteps >= 0, "vecint_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const long n = (long)B * 3 * D * H * W, total = (long)B * D * H * W;
     const float* g = gout;

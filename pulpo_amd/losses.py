@@ -6,7 +6,8 @@ On the hot path (BASELINE configs: recon_loss=['ncc'], regularizer='L2', diagona
 Alternative hyper-parameters / evaluation metrics, also on HIP kernels (metrics.hip):
     L2_loss (:79-83, `--recon_loss mse`), Soft_dice_loss (:137-145, `--recon_loss dice`), jacobian_det (:172-199),
     JDetStd (:202-204, `--regularizer jdet`) - the 3-D forms.
-KL_nondiagonal (:8-44, `--nondiagonal`) likewise.  Only the 2-D variants still raise NotImplementedError.
+KL_nondiagonal (:8-44, `--nondiagonal`) likewise.  2-D inputs (train.py --ndims 2) run the reference's 2-D forms through the same
+kernels as depth-1 volumes.
 """
 from __future__ import annotations
 
@@ -32,8 +33,8 @@ class KL_nondiagonal:
         self.prior_lambda = prior_lambda
         self.inshape = [int(s) for s in inshape]
         self.ndims = len(self.inshape)
-        if self.ndims != 3:
-            _off_path("KL_nondiagonal (2-D)")
+        if self.ndims not in (2, 3):
+            _off_path("KL_nondiagonal (ndims %d)" % self.ndims)
 
     def loss(self, prior_mean, prior_sigma, flow_mean, flow_sigma):
         return ops.kl_nondiagonal(flow_mean, flow_sigma, self.prior_lambda)
@@ -51,15 +52,15 @@ def Soft_dice_loss(input: torch.Tensor, target: torch.Tensor, dice_factor=1) -> 
 
 def jacobian_det(deformation_field: torch.Tensor, lamb=None, normalize=True) -> torch.Tensor:
     """(B,3,D,H,W) -> (B,D,H,W) Jacobian determinant (reference losses.py:172-199); the 2-D form has no HIP path"""
-    if deformation_field.dim() != 5:
-        _off_path("jacobian_det (2-D)")
+    if deformation_field.dim() not in (4, 5):
+        _off_path("jacobian_det")
     return ops.jacobian_det(deformation_field, normalize)
 
 
 def JDetStd(deformation_field: torch.Tensor, lamb=0, normalize=True) -> torch.Tensor:
     """lamb * std of the Jacobian determinant (reference losses.py:202-204), differentiable"""
-    if deformation_field.dim() != 5:
-        _off_path("JDetStd (2-D)")
+    if deformation_field.dim() not in (4, 5):
+        _off_path("JDetStd")
     return ops.jdet_std(deformation_field, lamb, normalize)
 
 
@@ -78,15 +79,15 @@ def KL_two_gauss_with_diag_cov(mu0: torch.Tensor, sigma0: torch.Tensor, mu1: tor
 
 def NCC_loss(y_pred: torch.Tensor, y_true: torch.Tensor, win_size: int = 9, gamma: float = 0.05) -> torch.Tensor:
     """-gamma * sum_voxels mean_batch(local squared NCC) with a win_size^3 zero-padded window"""
-    if y_pred.dim() != 5:
-        raise NotImplementedError("NCC_loss: only 3-D volumes have a HIP path")
+    if y_pred.dim() not in (4, 5):
+        raise NotImplementedError("NCC_loss: volumes (B,1,D,H,W) or slices (B,1,H,W) expected")
     return ops.ncc_loss(y_pred, y_true, win_size, gamma)
 
 
 def L2_reg(deformation_field: torch.Tensor, lamb=0) -> torch.Tensor:
     """lamb * H*W*D * mean of squared forward differences over the [1:,1:,1:] block"""
-    if deformation_field.dim() != 5:
-        raise NotImplementedError("L2_reg: only 3-D fields have a HIP path")
+    if deformation_field.dim() not in (4, 5):
+        raise NotImplementedError("L2_reg: fields (B,3,D,H,W) or (B,2,H,W) expected")
     return ops.l2_reg(deformation_field, lamb)
 
 

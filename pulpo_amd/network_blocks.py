@@ -3,7 +3,8 @@
 
 The nn.Conv3d / nn.BatchNorm3d children exist only as parameter + buffer containers so that checkpoints written by the
 reference load unchanged ('_op.0.weight', '_op.1.running_mean', ...); they are never called.
-Only the 3-D configuration (the one every BASELINE config uses) has a HIP path; 2-D inputs raise.
+2-D inputs (train.py --ndims 2) get nn.Conv2d / nn.BatchNorm2d containers, as in the reference, and run as depth-1 volumes through the
+same kernels (pulpo_amd.ops lifts (B,C,H,W) tensors; see the "2-D mode" block there).
 """
 from __future__ import annotations
 
@@ -31,9 +32,11 @@ class FixedNoiseSampler:
         return mu + sigma * self.fixed_eps
 
 
-def _need3d(input_size: Sequence[int], who: str):
-    if len(input_size) != 3:
-        raise NotImplementedError(f"{who}: only 3-D volumes have a HIP path (got ndims={len(input_size)})")
+def _ndims(input_size: Sequence[int], who: str) -> int:
+    nd = len(input_size)
+    if nd not in (2, 3):
+        raise NotImplementedError(f"{who}: volumes (ndims 3) or slices (ndims 2) expected, got ndims={nd}")
+    return nd
 
 
 class ConvUnit(nn.Module):
@@ -41,11 +44,12 @@ class ConvUnit(nn.Module):
 
     def __init__(self, input_size: Sequence[int], in_channels: int, out_channels: int = None) -> None:
         super().__init__()
-        _need3d(input_size, "ConvUnit")
+        nd = _ndims(input_size, "ConvUnit")
         out_channels = out_channels or in_channels
+        Conv, BatchNorm = (nn.Conv3d, nn.BatchNorm3d) if nd == 3 else (nn.Conv2d, nn.BatchNorm2d)
         self._op = nn.Sequential(
-            nn.Conv3d(in_channels, out_channels, kernel_size=3, padding=1),
-            nn.BatchNorm3d(out_channels),
+            Conv(in_channels, out_channels, kernel_size=3, padding=1),
+            BatchNorm(out_channels),
             nn.LeakyReLU(negative_slope=0.2, inplace=True),
         )
 
@@ -78,11 +82,12 @@ class MuSigmaBlock(nn.Module):
 
     def __init__(self, input_size: Sequence[int], in_channels: int, zdim: int) -> None:
         super().__init__()
-        _need3d(input_size, "MuSigmaBlock")
-        if zdim != 3:
-            raise NotImplementedError("MuSigmaBlock: the HIP head kernel produces zdim == 3 latents")
-        self._conv_mu = nn.Conv3d(in_channels, zdim, kernel_size=1)
-        self._conv_sigma = nn.Sequential(nn.Conv3d(in_channels, zdim, kernel_size=1), nn.Softplus())
+        nd = _ndims(input_size, "MuSigmaBlock")
+        if zdim != nd:
+            raise NotImplementedError("MuSigmaBlock: the HIP head kernel produces zdim == ndims latents (the reference's setting, models.py:88)")
+        Conv = nn.Conv3d if nd == 3 else nn.Conv2d
+        self._conv_mu = Conv(in_channels, zdim, kernel_size=1)
+        self._conv_sigma = nn.Sequential(Conv(in_channels, zdim, kernel_size=1), nn.Softplus())
 
     def sample(self, x: torch.Tensor, eps: Optional[torch.Tensor]):
         """fused head: (mu, sigma, z = mu + sigma*eps); eps None -> z = mu"""
@@ -99,16 +104,17 @@ class VelocityField(nn.Module):
 
     def __init__(self, input_size: Sequence[int], zdim: int, max_channels: int, depth: int) -> None:
         super().__init__()
-        _need3d(input_size, "VelocityField")
+        nd = _ndims(input_size, "VelocityField")
+        Conv = nn.Conv3d if nd == 3 else nn.Conv2d
         self.depth = depth
         if depth == 1:
-            layers = [nn.Conv3d(zdim, 3, kernel_size=3)]           # unpadded in the reference (src/network_blocks.py:75)
+            layers = [Conv(zdim, nd, kernel_size=3)]               # unpadded in the reference (src/network_blocks.py:75)
         elif depth == 0:
             layers = [nn.Identity()]
         else:
             layers = [ConvUnit(input_size, zdim, max_channels)]
             layers += [ConvUnit(input_size, max_channels, max_channels) for _ in range(depth - 2)]
-            layers += [nn.Conv3d(max_channels, 3, kernel_size=1)]
+            layers += [Conv(max_channels, nd, kernel_size=1)]
         self._op = nn.Sequential(*layers)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -117,7 +123,7 @@ class VelocityField(nn.Module):
         if self.depth == 1:
             conv = self._op[0]
             full = ops.conv3d_k3(x, conv.weight, conv.bias)         # 'valid' conv = interior of the zero-padded one
-            return full[:, :, 1:-1, 1:-1, 1:-1].contiguous()
+            return (full[:, :, 1:-1, 1:-1, 1:-1] if full.dim() == 5 else full[:, :, 1:-1, 1:-1]).contiguous()
         for unit in list(self._op)[:-1]:
             x = unit(x)
         last = self._op[-1]
@@ -134,7 +140,7 @@ class SpatialTransformer(nn.Module):
         super().__init__()
         self.size = size
         self.mode = mode
-        _need3d(size, "SpatialTransformer")
+        _ndims(size, "SpatialTransformer")
         axes = [torch.arange(0, int(s)) for s in size]
         grid = torch.stack(torch.meshgrid(axes, indexing="ij")).unsqueeze(0).to(torch.float32)
         self.register_buffer("grid", grid, persistent=True)
@@ -150,10 +156,10 @@ class ResizeTransform(nn.Module):
 
     def __init__(self, vel_resize, ndims):
         super().__init__()
-        if ndims != 3:
-            raise NotImplementedError("ResizeTransform: only ndims == 3 has a HIP path")
+        if ndims not in (2, 3):
+            raise NotImplementedError("ResizeTransform: ndims 2 or 3 expected")
         self.factor = 1.0 / vel_resize
-        self.mode = "trilinear"
+        self.mode = "trilinear" if ndims == 3 else "bilinear"
 
     def out_size(self, x: torch.Tensor):
         return [int(s * self.factor) for s in x.shape[2:]]     # floor(in * scale_factor), as F.interpolate

@@ -79,6 +79,33 @@ def planar(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ---------------------------------------------------------------------------------------------- 2-D mode (train.py --ndims 2)
+# Slices are run as depth-1 volumes through the same kernels: (B,C,H,W) -> (B,C,1,H,W); 3x3 weights sit in the middle depth slice of a
+# 3x3x3 kernel (the other two slices multiply zero padding); 2-channel fields / latents get a leading zero depth channel.  The kernels
+# with ndims-dependent arithmetic (warp normalisation, NCC window count, L2_reg, Jacobian, KL_nondiagonal) switch to the reference's
+# 2-D form when the depth is 1.  All lifting is done with differentiable torch views / pads on small tensors.
+def _is2d(t) -> bool:
+    return t is not None and t.dim() == 4
+
+
+def _lift(t):
+    return None if t is None else t.unsqueeze(2)
+
+
+def _lift_field(f):
+    """(B,2,H,W) -> (B,3,1,H,W) with a zero depth component in front"""
+    return None if f is None else torch.cat([torch.zeros_like(f[:, :1]), f], dim=1).unsqueeze(2)
+
+
+def _unlift_field(f5):
+    return f5[:, 1:, 0]
+
+
+def _lift_w3(w):
+    """(Cout,Cin,3,3) -> (Cout,Cin,3,3,3): taps in the middle depth slice"""
+    return torch.nn.functional.pad(w.unsqueeze(2), (0, 0, 0, 0, 1, 1))
+
+
 def _colsum(partials: torch.Tensor, nrow: int, ncol: int, scale: float = 1.0, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """column sums of [nrow][ncol] fp32 partials (double accumulation); `into` -> added to that tensor in place, returns None"""
     if into is not None:
@@ -96,7 +123,7 @@ DIRECT_PARAM_GRADS = False
 
 
 def _grad_slot(p: torch.Tensor) -> Optional[torch.Tensor]:
-    if not DIRECT_PARAM_GRADS:
+    if not DIRECT_PARAM_GRADS or not p.is_leaf:         # (lifted 2-D weights are derived tensors: their gradient goes through autograd)
         return None
     g = getattr(p, "grad", None)
     if g is None or not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
@@ -358,6 +385,9 @@ class _ConvBNLReLU(torch.autograd.Function):
 
 def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None):
     """ConvUnit forward.  In training mode running_mean / running_var / num_batches_tracked are updated in place by the kernel."""
+    if _is2d(x):
+        return conv_bn_lrelu(_lift(x), _lift_w3(weight), bias, gamma, beta, running_mean, running_var, training, momentum, eps,
+                             num_batches_tracked).squeeze(2)
     return _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
                               float(eps))
 
@@ -393,6 +423,8 @@ class _Conv3dK3(torch.autograd.Function):
 
 
 def conv3d_k3(x, weight, bias=None):
+    if _is2d(x):
+        return conv3d_k3(_lift(x), _lift_w3(weight), bias).squeeze(2)
     return _Conv3dK3.apply(x, weight, bias)
 
 
@@ -437,6 +469,14 @@ def mu_sigma_sample(h, w_mu, b_mu, w_sigma, b_sigma, eps):
     """MuSigmaBlock + sampler: returns (mu, sigma, z) planar (B,3,D,H,W); eps=None -> z = mu.
     w_*: (3, C, 1, 1, 1) conv weights (reference src/network_blocks.py:54-57)"""
     C = w_mu.shape[1]
+    if _is2d(h):
+        # 2-D: two latent channels -> rows (0, mu_y, mu_x) / (0, sigma_y, sigma_x) of the three-channel head kernel; the padded channel
+        # (mu 0, sigma softplus(0), noise 0 -> sample 0) is dropped again
+        z1, zb = w_mu.new_zeros(1, C), b_mu.new_zeros(1)
+        Wt = torch.cat([z1, w_mu.reshape(2, C), z1, w_sigma.reshape(2, C)], dim=0)
+        bias = torch.cat([zb, b_mu, zb, b_sigma], dim=0)
+        mu, sigma, z = _Heads.apply(_lift(h), Wt, bias, _lift_field(eps), 6)
+        return _unlift_field(mu), _unlift_field(sigma), _unlift_field(z)
     Wt = torch.cat([w_mu.reshape(3, C), w_sigma.reshape(3, C)], dim=0)
     bias = torch.cat([b_mu, b_sigma], dim=0)
     return _Heads.apply(h, Wt, bias, eps, 6)
@@ -444,6 +484,10 @@ def mu_sigma_sample(h, w_mu, b_mu, w_sigma, b_sigma, eps):
 
 def conv1x1_to3(h, w, b):
     """Conv3d(C, 3, kernel_size=1) with planar output (reference src/network_blocks.py:81)"""
+    if _is2d(h):
+        C = w.shape[1]
+        Wt = torch.cat([w.new_zeros(1, C), w.reshape(2, C)], dim=0)
+        return _unlift_field(_Heads.apply(_lift(h), Wt, torch.cat([b.new_zeros(1), b]), None, 3))
     return _Heads.apply(h, w.reshape(3, w.shape[1]), b, None, 3)
 
 
@@ -471,6 +515,8 @@ class _AvgPool2(torch.autograd.Function):
 
 def avg_pool2(x):
     """AvgPool3d(kernel 2, stride 2, ceil_mode=True)"""
+    if _is2d(x):
+        return avg_pool2(_lift(x)).squeeze(2)
     return _AvgPool2.apply(x)
 
 
@@ -502,6 +548,8 @@ class _Resize(torch.autograd.Function):
 
 def resize_trilinear(x, size, mult: float = 1.0, add=None):
     """mult * F.interpolate(x, size, 'trilinear', align_corners=False) (+ add)"""
+    if _is2d(x):                                       # bilinear = trilinear over a depth-1 volume
+        return resize_trilinear(_lift(x), [1] + [int(v) for v in size], mult, _lift(add)).squeeze(2)
     return _Resize.apply(x, tuple(int(s) for s in size), float(mult), add)
 
 
@@ -567,6 +615,8 @@ class _Warp(torch.autograd.Function):
 
 def warp3d(df, img):
     """SpatialTransformer.forward(df, img)"""
+    if _is2d(df):                                      # 2-D SpatialTransformer: channels (y, x) -> (0, y, x), depth-1 grid and image
+        return warp3d(_lift_field(df), _lift(img)).squeeze(2)
     return _Warp.apply(df, img)
 
 
@@ -594,6 +644,8 @@ class _VecInt(torch.autograd.Function):
 
 
 def vecint(v, nsteps: int = 7):
+    if _is2d(v):
+        return _unlift_field(vecint(_lift_field(v), nsteps))
     return _VecInt.apply(v, int(nsteps))
 
 
@@ -631,6 +683,8 @@ class _NCC(torch.autograd.Function):
 
 
 def ncc_loss(pred, true, win: int = 9, gamma: float = 0.05):
+    if _is2d(pred):                                    # depth 1 selects the win x win window count in the kernel
+        return ncc_loss(_lift(pred), _lift(true), win, gamma)
     return _NCC.apply(pred, true, int(win), float(gamma))
 
 
@@ -661,6 +715,8 @@ class _KL(torch.autograd.Function):
 def kl_diag(mu, sigma, mu1=None, sigma1=None):
     """KL[N(mu, sigma^2) || N(mu1, sigma1^2)] (sum over features, mean over batch); mu1/sigma1 None = N(0,1).
     Gradients flow to (mu, sigma) only: the prior is a constant in the reference (pulpo.py:330-341)."""
+    if _is2d(mu):
+        return kl_diag(_lift(mu), _lift(sigma), _lift(mu1), _lift(sigma1))
     return _KL.apply(mu, sigma, mu1, sigma1)
 
 
@@ -678,7 +734,7 @@ class _L2Reg(torch.autograd.Function):
         nblk = lib.query("pulpo_loss_blocks", n)
         part = torch.empty(nblk, device=df.device, dtype=torch.float32)
         lib.call("pulpo_l2reg_fwd", _ptr(df), B * C, D, H, W, _ptr(part), _stream())
-        coef = lamb * D * H * W / float(B * C * (D - 1) * (H - 1) * (W - 1))
+        coef = lamb * D * H * W / float(B * C * max(D - 1, 1) * (H - 1) * (W - 1))      # D == 1: the 2-D form (no depth difference)
         ctx.save_for_backward(df)
         ctx.coef = coef
         return _colsum(part, nblk, 1, coef).reshape(())
@@ -694,6 +750,8 @@ class _L2Reg(torch.autograd.Function):
 
 
 def l2_reg(df, lamb: float = 0.0):
+    if _is2d(df):
+        return l2_reg(_lift(df), lamb)
     return _L2Reg.apply(df, float(lamb))
 
 
@@ -722,6 +780,8 @@ class _SqDiff(torch.autograd.Function):
 
 
 def l2_loss(inp, target):
+    if _is2d(inp):
+        return l2_loss(_lift(inp), _lift(target))
     return _SqDiff.apply(inp, target)
 
 
@@ -751,16 +811,20 @@ class _Dice(torch.autograd.Function):
 
 
 def soft_dice_loss(inp, target, dice_factor=1):
+    if _is2d(inp):
+        return soft_dice_loss(_lift(inp), _lift(target), dice_factor)
     return _Dice.apply(inp, target, float(dice_factor))
 
 
 def jacobian_det(df, normalize: bool = True):
     """determinant of the Jacobian of x + u(x), (B,3,D,H,W) -> (B,D,H,W); evaluation metric, not differentiable here"""
+    if _is2d(df):                                      # (B,2,H,W) -> (B,H,W)
+        return jacobian_det(_lift(df), normalize)[:, 0]
     _require_gpu(df)
     d = planar(df.detach())
     B, C, D, H, W = d.shape
-    if C != 3:
-        raise PulpoHipError("jacobian_det: 3-D displacement field (B,3,D,H,W) expected")
+    if C != (2 if D == 1 else 3):
+        raise PulpoHipError("jacobian_det: displacement field (B,3,D,H,W) or, for slices, (B,2,1,H,W) expected")
     out = torch.empty((B, D, H, W), device=d.device, dtype=torch.float32)
     lib.call("pulpo_jacdet_fwd", _ptr(d), _ptr(out), None, B, D, H, W, int(bool(normalize)), _stream())
     return out
@@ -794,6 +858,8 @@ class _JDetStd(torch.autograd.Function):
 
 
 def jdet_std(df, lamb: float = 0.0, normalize: bool = True):
+    if _is2d(df):
+        return jdet_std(_lift(df), lamb, normalize)
     return _JDetStd.apply(df, float(lamb), bool(normalize))
 
 
@@ -820,6 +886,8 @@ class _KLNonDiag(torch.autograd.Function):
 
 
 def kl_nondiagonal(mu, sigma, prior_lambda: float = 20.0):
+    if _is2d(mu):
+        return kl_nondiagonal(_lift(mu), _lift(sigma), prior_lambda)
     return _KLNonDiag.apply(mu, sigma, float(prior_lambda))
 
 

@@ -251,21 +251,22 @@ class Step:
     def __init__(self, T, L, size, n0, seed, df_resolution="level_res"):
         torch.manual_seed(seed)
         self.T, self.L = T, L
+        nd = len(size)                           # 3 (volumes) or 2 (slices, train.py --ndims 2): zdim = ndims (models.py:88)
         self.down = cp.DownPath(T, L, list(size), 2, n0)
-        self.ae = cp.Autoencoder(nb.gauss_sampler, "SVF", T, L, 3, list(size), list(FEEDBACK), df_resolution, n0, 3)
+        self.ae = cp.Autoencoder(nb.gauss_sampler, "SVF", T, L, nd, list(size), list(FEEDBACK), df_resolution, n0, 3)
         self.prior = cp.PULPoPrior()
-        window, kl_w, rec_w, reg_w = weight_dicts(T, L)
+        window, kl_w, rec_w, reg_w = weight_dicts(T, L, ndims=nd)
         if df_resolution == "full_res":          # models.py:112-115,123
             rec_w = {l: 1.0 for l in range(L)}
             reg_w = {l: 1.0 for l in range(L)}
             rec_w[0] *= 4
         self.kl = ls.HierarchicalKLLoss(ls.KL_two_gauss_with_diag_cov, kl_w, False, None)
-        self.rec = ls.HierarchicalReconstructionLoss(["ncc"], rec_w, False, 3, window)
+        self.rec = ls.HierarchicalReconstructionLoss(["ncc"], rec_w, False, nd, window)
         self.reg = ls.HierarchicalRegularization(ls.L2_reg, reg_w, False)
         g = torch.Generator().manual_seed(seed + 1)
         with torch.no_grad():  # make BN affine + running stats non-trivial so eval mode is a real test
             for m in list(self.down.modules()) + list(self.ae.modules()):
-                if isinstance(m, torch.nn.BatchNorm3d):
+                if isinstance(m, (torch.nn.BatchNorm3d, torch.nn.BatchNorm2d)):
                     m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.5 + 0.75)
                     m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
                     m.running_mean.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
@@ -315,7 +316,7 @@ def gen_step(name, T, L, size, n0, B, seed, with_grads=True, smooth=False, df_re
         y = torch.rand(B, 1, *size, generator=g)
     o = T - L
     lvl = lambda l: [s // (2 ** (l + o)) for s in size]
-    eps = {l: torch.randn(B, 3, *lvl(l), generator=g) for l in range(L)}
+    eps = {l: torch.randn(B, len(size), *lvl(l), generator=g) for l in range(L)}
     st.set_eps(eps)
     out = {"cfg": np.array([T, L, n0, B] + list(size), dtype=np.int64), "x": npy(x), "y": npy(y)}
     out.update({f"eps.{l}": npy(e) for l, e in eps.items()})
@@ -431,8 +432,81 @@ def gen_state_keys():
         print("default feedback list ->", e)
 
 
+
+# --------------------------------------------------------------------------- 13. 2-D mode (train.py --ndims 2): operators and a full step
+def gen_2d():
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    # SpatialTransformer 2-D: random field, zero field (not the identity), image larger than the grid; VecInt
+    H, W = 10, 14
+    st = nb.SpatialTransformer([H, W])
+    df = (torch.randn(2, 2, H, W, generator=g) * 1.5).requires_grad_(True)
+    img = torch.rand(2, 3, H, W, generator=g).requires_grad_(True)
+    up = torch.randn(2, 3, H, W, generator=g)
+    o = st(df.clone(), img)
+    gd, gi = torch.autograd.grad((o * up).sum(), [df, img])
+    out.update({"w_df": npy(df), "w_img": npy(img), "w_up": npy(up), "w_out": npy(o), "w_gdf": npy(gd), "w_gimg": npy(gi)})
+    out["w_zero"] = npy(st(torch.zeros(1, 2, H, W), img[:1].detach()))
+    big = torch.rand(1, 1, 2 * H, 2 * W, generator=g)
+    out.update({"w_big": npy(big), "w_big_out": npy(st(df[:1].detach().clone(), big))})
+    vi = nb.VecInt([H, W], 7)
+    v = (torch.randn(1, 2, H, W, generator=g) * 2).requires_grad_(True)
+    vo = vi(v)
+    gv, = torch.autograd.grad((vo * up[:1, :2]).sum(), [v])
+    out.update({"vi_in": npy(v), "vi_out": npy(vo), "vi_g": npy(gv)})
+    # pooling / interpolation / ResizeTransform
+    x = torch.rand(2, 5, 9, 12, generator=g)
+    out.update({"r_x": npy(x), "r_pool": npy(F.avg_pool2d(x, 2, 2, 0, ceil_mode=True)), "r_up": npy(F.interpolate(x, size=[18, 24], mode="bilinear", align_corners=False)),
+                "r_down": npy(F.interpolate(x, size=[5, 7], mode="bilinear", align_corners=False))})
+    f2 = torch.randn(1, 2, 6, 8, generator=g)
+    out.update({"r_f": npy(f2), "r_rt_up": npy(nb.ResizeTransform(0.5, 2)(f2)), "r_rt_down": npy(nb.ResizeTransform(2.0, 2)(f2))})
+    # ConvUnit 2-D (train + eval), MuSigmaBlock 2-D
+    torch.manual_seed(5)
+    cu = nb.ConvUnit([12, 10], 6, 10)
+    xc = torch.randn(2, 6, 12, 10, generator=g).requires_grad_(True)
+    upc = torch.randn(2, 10, 12, 10, generator=g)
+    out.update({"cu_sd0." + k: npy(v) for k, v in cu.state_dict().items()})
+    cu.train()
+    oc = cu(xc)
+    grads = torch.autograd.grad((oc * upc).sum(), [xc] + list(cu.parameters()))
+    out.update({"cu_x": npy(xc), "cu_up": npy(upc), "cu_out": npy(oc), "cu_gx": npy(grads[0])})
+    out.update({"cu_g." + k: npy(gv_) for (k, _), gv_ in zip(cu.named_parameters(), grads[1:])})
+    out.update({"cu_sd1." + k: npy(v) for k, v in cu.state_dict().items()})
+    cu.eval()
+    out["cu_out_eval"] = npy(cu(xc.detach()))
+    ms = nb.MuSigmaBlock([12, 10], 6, 2)
+    mu, sg = ms(xc.detach())
+    out.update({"ms_sd." + k: npy(v) for k, v in ms.state_dict().items()})
+    out.update({"ms_mu": npy(mu), "ms_sigma": npy(sg)})
+    # losses: NCC (w = 3, 5, 7), L2_reg, jacobian_det / JDetStd, KL_nondiagonal, all 2-D
+    a = smooth_volume(g, (20, 24), 2)[:, :, 0] if False else torch.rand(2, 1, 20, 24, generator=g)
+    b = (0.5 * a + 0.5 * torch.rand(2, 1, 20, 24, generator=g)).requires_grad_(True)
+    out.update({"l_a": npy(a), "l_b": npy(b)})
+    for w in (3, 5, 7):
+        l = ls.NCC_loss(b, a, win_size=w, gamma=0.05)
+        gb, = torch.autograd.grad(l, [b])
+        out.update({f"l_ncc{w}": npy(l), f"l_ncc{w}_g": npy(gb)})
+    fld = (torch.randn(2, 2, 20, 24, generator=g) * 2).requires_grad_(True)
+    l2 = ls.L2_reg(fld, lamb=0.025)
+    g2, = torch.autograd.grad(l2, [fld])
+    jd = ls.jacobian_det(fld.detach())
+    js = ls.JDetStd(fld, lamb=0.7)
+    gj, = torch.autograd.grad(js, [fld])
+    out.update({"l_fld": npy(fld), "l_l2": npy(l2), "l_l2_g": npy(g2), "l_jdet": npy(jd), "l_jstd": npy(js), "l_jstd_g": npy(gj)})
+    mu2 = torch.randn(2, 2, 12, 10, generator=g).requires_grad_(True)
+    sg2 = (torch.rand(2, 2, 12, 10, generator=g) + 0.3).requires_grad_(True)
+    kn = ls.KL_nondiagonal([12, 10]).loss(None, None, mu2, sg2)
+    gk = torch.autograd.grad(kn, [mu2, sg2])
+    out.update({"l_mu": npy(mu2), "l_sg": npy(sg2), "l_klnd": npy(kn), "l_klnd_gmu": npy(gk[0]), "l_klnd_gsg": npy(gk[1])})
+    save("ops2d", **out)
+    t = gen_step("step2d_T3L2_n4_32x24", T=3, L=2, size=[32, 24], n0=4, B=2, seed=210)
+    print("   total loss", t)
+
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "2d":
+        gen_2d()
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "step32":
         # a step large enough (32^3) for the Winograd forward / data-gradient and weight-gradient kernels to be the ones compared
         # with the real reference (the 16^3 cases below run the direct kernels)

@@ -249,3 +249,18 @@ def test_bucketed_overlapped_allreduce_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} buckets ok" in o
+
+
+def test_2d_model_state_dict_matches_reference_fixture(golden):
+    """train.py --ndims 2: the 2-D model builds on the CPU with the reference's parameter / buffer names and shapes (Conv2d / BatchNorm2d
+    containers), taken from the state dict of the 2-D golden step generated from the real reference"""
+    import src.models as models
+    g = golden("step2d_T3L2_n4_32x24")
+    Tl, L, n0, B, *size = [int(v) for v in g["cfg"]]
+    model = models.PULPo(Tl, L, 0.1, size, feedback=["samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed"], n0=n0)
+    sd = model.state_dict()
+    ref = {k[4:]: v.shape for k, v in g.items() if k.startswith("sd0.")}
+    assert set(ref) == {k for k in sd if not k.endswith(".grid")}
+    for k, shp in ref.items():
+        assert tuple(sd[k].shape) == shp, k
+    assert model.autoencoder.encoders[0].mu_sigma._conv_mu.weight.shape[0] == 2          # zdim = ndims
