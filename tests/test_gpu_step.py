@@ -618,3 +618,27 @@ def test_bucketed_allreduce_with_the_real_model_two_ranks_one_gpu(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o[-3000:]
         assert f"rank {r} dp ok" in o
+
+
+def test_device_prefetcher_delivers_batches_in_order(api):
+    """pulpo_amd.prefetch.DevicePrefetcher (the device half of the input pipeline): every batch arrives on the GPU, bit-identical and in
+    order, empty optional entries (segmentations / landmarks / masks of the reference's 8-tuples) included; a training step consumes it"""
+    models, nb = api
+    from pulpo_amd import dp
+    from pulpo_amd.prefetch import DevicePrefetcher
+    gen = torch.Generator().manual_seed(2)
+    empty = torch.empty((0,))
+    batches = [(torch.rand(1, 1, 16, 16, 16, generator=gen), torch.rand(1, 1, 16, 16, 16, generator=gen), empty, empty, empty, empty, empty, empty)
+               for _ in range(5)]
+    got = list(DevicePrefetcher(batches, "cuda"))
+    assert len(got) == 5
+    for b_cpu, b_gpu in zip(batches, got):
+        assert all(t.is_cuda for t in b_gpu)
+        assert torch.equal(b_gpu[0].cpu(), b_cpu[0]) and torch.equal(b_gpu[1].cpu(), b_cpu[1]) and b_gpu[2].numel() == 0
+    torch.manual_seed(0)
+    model = models.PULPo(3, 2, 0.1, [16, 16, 16], feedback=FB, n0=4).cuda().train()
+    stepper = dp.DataParallelStepper(model)
+    losses = [float(stepper.step(b)) for b in DevicePrefetcher(batches, "cuda")]
+    assert len(losses) == 5 and all(np.isfinite(losses))
+    with pytest.raises(ValueError):
+        DevicePrefetcher(batches, "cpu")
