@@ -24,6 +24,11 @@ from .network_blocks import DFAdder, ResizeTransform, SpatialTransformer, VecInt
 from . import ops
 
 
+class _DoneEvent:
+    def query(self) -> bool:
+        return True
+
+
 class PULPo(ABC, LightningModule):
 
     def __init__(
@@ -106,7 +111,7 @@ class PULPo(ABC, LightningModule):
                                                                       ndims=self.ndims)
         self.hierarchical_regularization = HierarchicalRegularization(regularizer=regularization_loss, weight_dict=reg_w,
                                                                       similarity_pyramid=similarity_pyramid)
-        self._pending_nan_probe: Optional[torch.Tensor] = None
+        self._pending_nan_probe = None          # (pinned flag, event) of an earlier step's NaN test
 
     # ------------------------------------------------------------------------------------------------ steps
     def _forward_and_losses(self, x, y, seg_x=None, seg_y=None):
@@ -126,7 +131,16 @@ class PULPo(ABC, LightningModule):
         total = kl + rec + reg
         return outs, (prior_mus, prior_sigmas), (total, kl, rec, reg), (kl_levels, rec_levels, reg_levels)
 
+    def _logging_active(self) -> bool:
+        """is anybody going to read what log_dict receives?  (a Lightning trainer, or a logger attached to the stand-alone base)"""
+        if getattr(self, "logger", None) is not None:
+            return True
+        tr = getattr(self, "_trainer", None)                       # pl.LightningModule keeps the attached trainer here
+        return tr is not None
+
     def _log_levels(self, stage: str, mus, sigmas, priors, levels, **kw):
+        if not self._logging_active():
+            return                    # the 16 per-level mean reductions are only computed when they have a consumer
         kl_l, rec_l, reg_l = levels
         for level in kl_l.keys():
             with torch.no_grad():
@@ -143,11 +157,33 @@ class PULPo(ABC, LightningModule):
                 **stats}, **kw)
 
     def _check_previous_step_for_nan(self):
-        probe, self._pending_nan_probe = self._pending_nan_probe, None
-        if probe is not None and bool(torch.isnan(probe).any()):
+        """the reference tests the regularisation terms for NaN inside the step with a host synchronisation (models.py:188-192); here the
+        flag of step n travels to pinned host memory asynchronously and is looked at when its copy has completed (normally at step n+1),
+        so the host never waits for the GPU"""
+        pending = self._pending_nan_probe
+        if pending is None:
+            return
+        flag, event = pending
+        if not event.query():
+            return                    # not there yet: look again next step
+        self._pending_nan_probe = None
+        if bool(flag.item()):
             print("NAN IN REGULARIZATION LOSS")
             torch.save(self.state_dict(), "nan_state_dict.pt")
             self.trainer.should_stop = True
+
+    def _arm_nan_probe(self, reg_levels) -> None:
+        if self._pending_nan_probe is not None:
+            return                    # the previous flag has not been consumed yet
+        bad = torch.isnan(torch.stack([v.detach() for v in reg_levels.values()])).any()
+        if bad.is_cuda:
+            flag = torch.empty((), dtype=torch.bool, pin_memory=True)
+            flag.copy_(bad, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+        else:
+            flag, event = bad, _DoneEvent()
+        self._pending_nan_probe = (flag, event)
 
     def training_step(self, batch, batch_idx):
         x, y, seg_x, seg_y, lm1, lm2, mask1, mask2 = batch
@@ -156,7 +192,7 @@ class PULPo(ABC, LightningModule):
         self.log_dict({"train/kl_loss": kl, "train/reconstruction_loss": rec, "train/regularization_loss": reg, "train/total_loss": total},
                       on_step=True, on_epoch=True, prog_bar=True)
         self._log_levels("train", outs[0], outs[1], priors, levels, on_step=False, on_epoch=True)
-        self._pending_nan_probe = torch.stack([v.detach() for v in levels[2].values()])
+        self._arm_nan_probe(levels[2])
         return total
 
     def validation_step(self, batch, batch_idx):
