@@ -116,13 +116,15 @@ def main():
     args = parse()
     from pulpo_amd import dp, ops
     from pulpo_amd._lib import lib
-    local = dp.init_from_env("nccl")
+    local = dp.init_from_env(os.environ.get("PULPO_DIST_BACKEND", "nccl"))     # (gloo: rehearsal of the multi-rank path on a one-GPU box)
     world = dp.world()
     rank = dist.get_rank() if world > 1 else 0
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE is {world}; using {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    if local >= torch.cuda.device_count():           # only in the gloo rehearsal with more ranks than GPUs
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib.load()

@@ -642,3 +642,23 @@ def test_device_prefetcher_delivers_batches_in_order(api):
     assert len(losses) == 5 and all(np.isfinite(losses))
     with pytest.raises(ValueError):
         DevicePrefetcher(batches, "cpu")
+
+
+def test_bench_two_rank_rehearsal(tmp_path):
+    """bench.py's multi-rank path (rendezvous from the torchrun environment, weight broadcast, bucketed exchange, barrier + max-over-ranks
+    timing, one JSON line from rank 0) rehearsed with two ranks on the one GPU of the test box: gloo instead of RCCL, which refuses two
+    ranks per device.  The driver's real N > 1 runs use the identical code with backend nccl."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PULPO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29561",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "32", "32", "32", "--levels", "3", "2",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]                     # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2
+    assert d["value"] > 0 and abs(d["value"] - 2 * 1 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]       # pairs of ALL ranks / time
+    assert d["roofline"] is not None and d["cpu_baseline"] is None
