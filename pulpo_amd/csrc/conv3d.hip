@@ -1204,29 +1204,38 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino(WgradArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // flush: this wave's share of G^T M.  point 0 -> tap 0; 1 -> (1/2, 1/2, 1/2); 2 -> (1/2, -1/2, 1/2); 3 -> tap 2
+    // flush: dw[.., t] = G^T M needs the four points of a (dz, dy, ci, co) entry, which live in the four waves.  They meet in LDS (the image
+    // sets are free now), eight row tiles at a time, and each entry leaves as three float atomics (tap 0: M0 + (M1 + M2)/2, tap 1:
+    // (M1 - M2)/2, tap 2: (M1 + M2)/2 + M3) in 128-byte runs of couts - 2.7x fewer atomics than flushing every wave's share separately.
+    __syncthreads();
+    float* X = smem;                                       // [point][tile slot 0..7][r][lane]
     const int co = co0 + i;
-    if (co < a.Cout) {
-        const float g0 = pt == 0 ? 1.f : pt == 3 ? 0.f : 0.5f;
-        const float g1 = pt == 1 ? 0.5f : pt == 2 ? -0.5f : 0.f;
-        const float g2 = pt == 0 ? 0.f : pt == 3 ? 1.f : 0.5f;
+    constexpr int GRP = 8;
+    for (int g0 = 0; g0 < nrt; g0 += GRP) {
+        const int ng = min(GRP, nrt - g0);
 #pragma unroll
         for (int u = 0; u < NTW; ++u) {
-            if (u < nrt) {
+            if (u >= g0 && u < g0 + ng) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rg = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                    if (rg < rows) {
-                        const int zy = rg / Cc, ci = rg - zy * Cc;
-                        float* d = a.dwp + ((long)(zy * 3) * a.Cin + ci0 + ci) * a.NPad + co;
-                        const float m = acc[u][r];
-                        if (g0 != 0.f) atomicAdd(d, g0 * m);
-                        if (g1 != 0.f) atomicAdd(d + (long)a.Cin * a.NPad, g1 * m);
-                        if (g2 != 0.f) atomicAdd(d + 2L * a.Cin * a.NPad, g2 * m);
-                    }
-                }
+                for (int r = 0; r < 16; ++r) X[((pt * GRP + (u - g0)) * 16 + r) * 64 + lane] = acc[u][r];
             }
         }
+        __syncthreads();
+        for (int j = wave; j < ng * 16; j += 4) {
+            const int tl = j >> 4, r = j & 15;
+            const float m0 = X[((0 * GRP + tl) * 16 + r) * 64 + lane], m1 = X[((1 * GRP + tl) * 16 + r) * 64 + lane];
+            const float m2 = X[((2 * GRP + tl) * 16 + r) * 64 + lane], m3 = X[((3 * GRP + tl) * 16 + r) * 64 + lane];
+            const int rg = 32 * (g0 + tl) + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (rg < rows && co < a.Cout) {
+                const int zy = rg / Cc, ci = rg - zy * Cc;
+                float* d = a.dwp + ((long)(zy * 3) * a.Cin + ci0 + ci) * a.NPad + co;
+                const float hs = 0.5f * (m1 + m2);
+                atomicAdd(d, m0 + hs);
+                atomicAdd(d + (long)a.Cin * a.NPad, 0.5f * (m1 - m2));
+                atomicAdd(d + 2L * a.Cin * a.NPad, hs + m3);
+            }
+        }
+        __syncthreads();
     }
 }
 
