@@ -6,10 +6,13 @@
 //
 // Data layout: activations are channels-last (N,D,H,W,C) with explicit batch/pixel/channel strides, so channel
 // slices of a concatenation buffer and planar 1-3 channel volumes go through the same kernels.
-// One workgroup = 256 threads = 4 waves (one per SIMD), 4 workgroups per CU.  A workgroup owns a 2x8x8 voxel tile;
-// the (4x10x10)-voxel halo of a 16-channel input chunk is staged once in LDS ([voxel][CH+1], odd stride ->
-// conflict-free ds_read_b32 for the A fragment; all global loads of the tile issued back to back) and re-used by all
-// 27 taps; the 27 weight slabs stream through a double-buffered LDS tile, prefetched global->registers one tap ahead.
+// Direct kernel: one workgroup = 256 threads = 4 waves (one per SIMD) owns a 2x8x8 or 4x8x8 voxel tile; the halo of a 16-channel
+// input chunk is staged once in LDS ([voxel][CH+1], odd stride -> conflict-free ds_read_b32 for the A fragment; all global loads of the
+// tile issued back to back) and re-used by all 27 taps; the 27 weight slabs stream through a double-buffered LDS tile, prefetched
+// global->registers one tap ahead.
+// Volumes of >= 20^3 voxels (depth % 4 == 0) run the Winograd forms further down instead: F(2x2,3x3) in (y, x) for forward / data
+// gradient (conv3d_k3_wino2_mfma; conv3d_k3_wino_mfma is the x-only predecessor) and F(2,3) along x for the weight gradient
+// (conv3d_k3_wgrad_wino) - fewer matrix instructions, all arithmetic still fp32.
 #include "conv_shared.h"
 #include <stdlib.h>
 
