@@ -136,6 +136,7 @@ def _grad_slot(p: torch.Tensor) -> Optional[torch.Tensor]:
 # recorded on the launch stream and (kernel name, algorithmic FLOPs, start, end) is appended.  No synchronisation here.
 CONV_TRACE = None
 CONV_TRACE_STRIDE = 1          # > 1: bracket only every n-th launch (a stride co-prime with the launches per step samples every layer)
+CONV_TRACE_STRIDE_USED = 1     # the stride of the last timed trace (bench.py scales sampled totals with it)
 _trace_counter = 0
 
 
