@@ -173,6 +173,19 @@ def main():
         def one_step():
             return stepper.step(batch)
 
+    # insurance for the multi-rank runs, which cannot be rehearsed with RCCL on a one-GPU box: if the first step fails with the overlapped
+    # gradient exchange / second-stream weight gradients, every rank (the failure would be deterministic) falls back to the plain
+    # single-all-reduce stepper and says so on stderr
+    if world > 1 and not infer and args.warmup > 0:
+        try:
+            one_step()
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] rank {rank}: overlapped stepper failed ({type(exc).__name__}: {exc}); falling back to overlap=False, async_wgrad=False",
+                  file=sys.stderr)
+            ops.ASYNC_WGRAD_STREAM = None
+            ops.DIRECT_PARAM_GRADS = False
+            stepper = dp.DataParallelStepper(model, overlap=False, async_wgrad=False)
     for _ in range(args.warmup):
         one_step()
     barrier()
