@@ -1,0 +1,536 @@
+// Weight gradient of the 3x3x3 convolution:  D[(tap,cin)][cout] += A[(tap,cin)][voxel] * B[voxel][cout]  (the GEMM's K is the voxel index).
+// Persistent workgroups (one per CU) fed by LDS-DMA, direct form (conv3d_k3_wgrad_mfma) and Winograd F(2,3)-along-x form
+// (conv3d_k3_wgrad_wino); atomic flush into a packed scratch, then unpack (optionally accumulating into the parameter's .grad).
+#include "conv_shared.h"
+#include <stdlib.h>
+
+namespace {
+
+using namespace pulpo_conv;
+
+// 64 bytes of zeros: source address of out-of-volume / out-of-channel lanes of an LDS-DMA piece
+__device__ float4 g_zero_page[4];
+
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS starting at the WAVE-UNIFORM address lds_piece
+__device__ __forceinline__ void dma16(const float* src, float* lds_piece) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+struct WgradArgs {
+    const float* in;
+    long in_bs, in_ps, in_cs;
+    const float* dy;
+    long dy_bs, dy_ps, dy_cs;
+    float* dwp;                   // zero-initialised scratch [27][Cin][NPad], accumulated with float atomics
+    int B, D, H, W, Cin, Cout, NPad;
+    int ntz, nty, ntx, ncit, ncot, nsplit;
+};
+
+constexpr int WG_CH = 32, WG_NT = 32, WG_CP = WG_CH + 1;
+
+// NTW = row tiles (32 (tap,ci) pairs each) per wave: 7 for a full 32-channel ci tile (27 tiles over 4 waves), fewer for
+// narrow inputs.  The MFMAs of the hot loop are unconditional (rows beyond the matrix compute garbage that is never flushed), so the loop
+// body is one basic block and the compiler can run the LDS reads ahead of the matrix pipe.
+template <bool VEC, int NTW>
+__global__ __launch_bounds__(256, VEC ? 1 : 2) void conv3d_k3_wgrad_mfma(WgradArgs a) {
+    constexpr int XS = (HV * WG_CP + 3) & ~3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
+    const int npair = a.ncit * a.ncot;
+    const int pair = lid % npair, split = lid / npair;
+    const int cit = pair / a.ncot, cot = pair - cit * a.ncot;
+    const int ci0 = cit * WG_CH, co0 = cot * WG_NT;
+    const int Cc = min(WG_CH, a.Cin - ci0);
+    const int rows = 27 * Cc;
+    const int nrt = (rows + 31) >> 5;                 // row tiles of 32 (tap,ci) pairs; host guarantees nrt <= 4 * NTW
+    const int i = lane & 31, kk = lane >> 5;
+    constexpr int STR = VEC ? 32 : WG_CP;             // voxel stride of the halo image (DMA image is unpadded)
+
+    int rowoff[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        const int r = 32 * (wave + 4 * u) + i;
+        const int tap = r < rows ? r / Cc : 0, ci = r < rows ? r - tap * Cc : 0;
+        rowoff[u] = tap_halo_offset(tap) * STR + ci;
+    }
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+
+    const int ntile = a.B * a.ntz * a.nty * a.ntx;
+    const int per = (ntile + a.nsplit - 1) / a.nsplit;
+    const int t_begin = split * per, t_end = min(ntile, t_begin + per);
+
+    auto decode = [&](int tl, int& b, int& z0, int& y0, int& x0) {
+        int t = tl;
+        const int tx_ = t % a.ntx; t /= a.ntx;
+        const int ty_ = t % a.nty; t /= a.nty;
+        const int tz_ = t % a.ntz;
+        b = t / a.ntz;
+        z0 = tz_ * TZ; y0 = ty_ * TY; x0 = tx_ * TX;
+    };
+    // One "body" = 4 voxel-pair steps.  Rows beyond the matrix (last partial row tile, or a whole spare tile) read valid
+    // LDS words of tap 0 and accumulate garbage into accumulator rows that the flush never writes: MFMA rows are independent,
+    // so no masking is needed.
+    auto load_body = [&](float (&A)[4][NTW], float (&Bv)[4], const float* xs_c, const float* dys_c, int sb) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int vox = 2 * (sb * 4 + q4) + kk;
+            const int hbk = (((vox >> 6) * HY + ((vox >> 3) & 7)) * HX + (vox & 7)) * STR;
+            Bv[q4] = dys_c[vox * WG_NT + i];
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) A[q4][u] = xs_c[rowoff[u] + hbk];
+        }
+    };
+    auto mma_body = [&](const float (&A)[4][NTW], const float (&Bv)[4]) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q4][u], Bv[q4], acc[u], 0, 0, 0);
+    };
+    float A0[4][NTW], A1[4][NTW], B0[4], B1[4];       // register double buffer of the fragments
+
+    if constexpr (VEC) {
+        // LDS-DMA pipeline.  The A-operand lanes index consecutive (tap, ci) rows, so the halo image needs no padding
+        // ([halo voxel][32 ci], 128 B per voxel) and is filled by global_load_lds: no staging registers.  Two image sets
+        // (X 50 KiB + dY 16 KiB each) ping-pong: the 17 DMA pieces of tile t+1 are issued one per 4 voxel-pair steps inside
+        // the MFMA loop of tile t (their address arithmetic hides behind the matrix pipe) and are drained by the
+        // s_waitcnt vmcnt(0) + barrier at the tile boundary.
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const float* zero = reinterpret_cast<const float*>(g_zero_page);
+        constexpr int XIMG = 13 * 4 * 256;            // halo image padded to 52 DMA pieces (50 used): every piece is unconditional
+        constexpr int SET = XIMG + MV * WG_NT;        // floats per image set
+        int nb = 0, nz0 = 0, ny0 = 0, nx0 = 0;        // next tile
+        bool more = false;
+        // piece pc in [0, 17): 0..12 = halo (piece 12 of waves 2,3 is padding), 13..16 = dY.  Branch-free: lanes with nothing
+        // to fetch (out of volume / channel range / no next tile / padding) source the zero page.
+        auto issue_piece = [&](int pc, float* xd) {
+            if (pc < 13) {
+                const int j = tid + pc * 256;
+                const int hv = j >> 3, q = j & 7;
+                const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+                const int gz = nz0 - 1 + hz, gy = ny0 - 1 + hy, gx = nx0 - 1 + hx;
+                const bool ok = more && hv < HV && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
+                                ci0 + 4 * q < a.Cin;
+                const float* src = ok ? a.in + (long)nb * a.in_bs + ((long)(gz * a.H + gy) * a.W + gx) * a.in_ps + ci0 + 4 * q : zero;
+                dma16(src, xd + (wave_u + 4 * pc) * 256);
+            } else {
+                const int u = pc - 13;
+                const int j = tid + u * 256;
+                const int vv = j >> 3, q = j & 7;
+                const int gz = nz0 + (vv >> 6), gy = ny0 + ((vv >> 3) & 7), gx = nx0 + (vv & 7);
+                const bool ok = more && gz < a.D && gy < a.H && gx < a.W && co0 + 4 * q < a.Cout;
+                const float* src = ok ? a.dy + (long)nb * a.dy_bs + ((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + co0 + 4 * q : zero;
+                dma16(src, xd + XIMG + (wave_u + 4 * u) * 256);
+            }
+        };
+        if (t_begin < t_end) {
+            more = true;
+            decode(t_begin, nb, nz0, ny0, nx0);
+#pragma unroll
+            for (int pc = 0; pc < 17; ++pc) issue_piece(pc, smem);
+        }
+        int cur = 0;
+        for (int tl = t_begin; tl < t_end; ++tl, cur ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile tl have landed
+            __syncthreads();      // (a) everybody's pieces have landed  (b) everybody left the other image set
+            more = tl + 1 < t_end;
+            if (more) decode(tl + 1, nb, nz0, ny0, nx0);
+            const float* xs_c = smem + cur * SET;
+            const float* dys_c = xs_c + XIMG;
+            float* xnext = smem + (cur ^ 1) * SET;
+            load_body(A0, B0, xs_c, dys_c, 0);
+#pragma unroll
+            for (int sb = 0; sb < 16; sb += 2) {            // fully unrolled: 16 bodies of 4 steps, fragments one body ahead
+                load_body(A1, B1, xs_c, dys_c, sb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                // the next tile's 17 DMA pieces go out during the first nine bodies, so they have half a tile of MFMAs to land
+                if (sb < 8) { issue_piece(2 * sb, xnext); issue_piece(2 * sb + 1, xnext); }
+                if (sb == 8) issue_piece(16, xnext);
+                mma_body(A0, B0);
+                load_body(A0, B0, xs_c, dys_c, (sb + 2) & 15);   // (wraps to body 0 on the last trip: harmless re-read)
+                __builtin_amdgcn_sched_barrier(0);
+                if (sb < 8) { issue_piece(2 * sb + 2, xnext); issue_piece(2 * sb + 3, xnext); }
+                mma_body(A1, B1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the (zero-sourced) pieces issued during the last tile
+    } else {
+        // scalar-staging path (planar / narrow inputs: the 2- and 3-channel first layers).  Only the Cc real channels of the
+        // halo are staged (rows of other channels are never flushed); dY goes through float4 when it is channels-last.
+        float* xs = smem;
+        float* dys = smem + XS;
+        const bool dyvec = (a.dy_cs == 1) && (a.dy_ps % 4 == 0) && (a.dy_bs % 4 == 0) && (a.Cout % 4 == 0) && (((uintptr_t)a.dy & 15) == 0);
+        for (int tl = t_begin; tl < t_end; ++tl) {
+            int b, z0, y0, x0;
+            decode(tl, b, z0, y0, x0);
+            __syncthreads();
+            const float* in_b = a.in + (long)b * a.in_bs;
+            for (int j = tid; j < HV * Cc; j += 256) {
+                const int c = j / HV, hv = j - c * HV;              // voxel fastest: coalesced for planar inputs
+                const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+                const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                float v = 0.f;
+                if ((unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                    v = in_b[((long)(gz * a.H + gy) * a.W + gx) * a.in_ps + (long)(ci0 + c) * a.in_cs];
+                xs[hv * WG_CP + c] = v;
+            }
+            const float* dyb = a.dy + (long)b * a.dy_bs;
+            if (dyvec) {
+                float4 val[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = tid + u * 256;
+                    const int vv = j >> 3, q = j & 7;
+                    const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
+                    val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gz < a.D && gy < a.H && gx < a.W && co0 + 4 * q < a.Cout)
+                        val[u] = *reinterpret_cast<const float4*>(dyb + ((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + co0 + 4 * q);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = tid + u * 256;
+                    *reinterpret_cast<float4*>(dys + (j >> 3) * WG_NT + 4 * (j & 7)) = val[u];
+                }
+            } else {
+                for (int j = tid; j < MV * WG_NT; j += 256) {
+                    const int vv = j >> 5, c = j & 31;
+                    const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
+                    float val = 0.f;
+                    if (gz < a.D && gy < a.H && gx < a.W && co0 + c < a.Cout)
+                        val = dyb[((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + (long)(co0 + c) * a.dy_cs];
+                    dys[vv * WG_NT + c] = val;
+                }
+            }
+            __syncthreads();
+            load_body(A0, B0, xs, dys, 0);
+#pragma unroll 1
+            for (int sb = 0; sb < 16; sb += 2) {
+                load_body(A1, B1, xs, dys, sb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_body(A0, B0);
+                load_body(A0, B0, xs, dys, (sb + 2) & 15);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_body(A1, B1);
+            }
+        }
+    }
+
+    // flush: one 128-byte run of couts per (tap, ci) row -> float atomics at full rate
+    const int co = co0 + i;
+    if (co < a.Cout) {
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) {
+            if (wave + 4 * u < nrt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rg = 32 * (wave + 4 * u) + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    if (rg < rows) {
+                        const int tap = rg / Cc, ci = rg - tap * Cc;
+                        atomicAdd(a.dwp + ((long)tap * a.Cin + ci0 + ci) * a.NPad + co, acc[u][r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient, Winograd along x
+// The transpose of the forward identity: with V = B^T d (four transformed inputs per x-pair) and E = A dy (four combinations of the
+// pair's two output gradients), M_p[(dz,dy,ci)][co] = sum over x-pairs V_p * E_p and dw[.., t] = G^T M - 36 instead of 54 matrix
+// products per x-pair.  Wave p of the workgroup owns transformed point p (all nine (dz, dy) row tiles of its 32-channel slice), so
+// both operand transforms are wave-uniform two-term combinations formed from the raw LDS-DMA images as the fragments are read
+// (A: two ds_read + one fma, B: two ds_read + two fma per nine MFMAs), and every wave adds its share of G^T M at the flush.
+// Same persistent one-workgroup-per-CU LDS-DMA pipeline as conv3d_k3_wgrad_mfma<true, NTW>.
+template <int NTW>
+__global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
+    const int npair = a.ncit * a.ncot;
+    const int pair = lid % npair, split = lid / npair;
+    const int cit = pair / a.ncot, cot = pair - cit * a.ncot;
+    const int ci0 = cit * WG_CH, co0 = cot * WG_NT;
+    const int Cc = min(WG_CH, a.Cin - ci0);
+    const int rows = 9 * Cc;
+    const int nrt = (rows + 31) >> 5;                 // host guarantees nrt <= NTW
+    const int i = lane & 31, kk = lane >> 5;
+    const int pt = __builtin_amdgcn_readfirstlane(wave);
+    // A = X[x + ta] + sa * X[x + tb];  B = c0 * dY[x] + c1 * dY[x + 1]
+    const int ta = pt == 0 ? 0 : pt == 2 ? 2 : 1;
+    const int tb = pt == 2 ? 1 : pt == 3 ? 3 : 2;
+    const float sa = pt == 1 ? 1.f : -1.f;
+    const float c0 = pt == 3 ? 0.f : 1.f;
+    const float c1 = pt == 0 ? 0.f : pt == 1 ? 1.f : -1.f;
+
+    int rowoff[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        const int r = 32 * u + i;
+        const int zy = r < rows ? r / Cc : 0, ci = r < rows ? r - zy * Cc : 0;
+        rowoff[u] = ((zy / 3) * HY + zy % 3) * HX * 32 + ci;
+    }
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+
+    const int ntile = a.B * a.ntz * a.nty * a.ntx;
+    const int per = (ntile + a.nsplit - 1) / a.nsplit;
+    const int t_begin = split * per, t_end = min(ntile, t_begin + per);
+    auto decode = [&](int tl, int& b, int& z0, int& y0, int& x0) {
+        int t = tl;
+        const int tx_ = t % a.ntx; t /= a.ntx;
+        const int ty_ = t % a.nty; t /= a.nty;
+        const int tz_ = t % a.ntz;
+        b = t / a.ntz;
+        z0 = tz_ * TZ; y0 = ty_ * TY; x0 = tx_ * TX;
+    };
+    // one body = 2 K-steps of two x-pairs each; x-pair b = (z, y, xb) with xb fastest: 64 per 2x8x8 tile = 16 bodies.
+    // The RAW operand pairs are fetched one body ahead; the two-term combinations are formed right in front of the MFMA that
+    // consumes them (a VALU op in the shadow of the previous MFMA), so no LDS latency is exposed between bodies.
+    constexpr int NQ = 2;
+    // per-lane LDS addresses are loop invariant (row offset, the lane's half of the x-pair couple, the point's two taps); the position
+    // of the K-step inside the tile is a compile-time constant of the unrolled body => every ds_read is base register + immediate
+    int offa[NTW], offb[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        offa[u] = rowoff[u] + kk * 64 + ta * 32;
+        offb[u] = rowoff[u] + kk * 64 + tb * 32;
+    }
+    const int offy = kk * 2 * WG_NT + i;
+    auto load_body = [&](float (&Ra)[NQ][NTW], float (&Rb)[NQ][NTW], float (&Y0)[NQ], float (&Y1)[NQ], const float* xs_c, const float* dys_c, int sb) {
+#pragma unroll
+        for (int q4 = 0; q4 < NQ; ++q4) {
+            const int blk = 2 * (sb * NQ + q4);                 // even x-pair of the couple; the odd one is 2 voxels further along x
+            const int z = blk >> 5, y = (blk >> 2) & 7, xb = blk & 3;
+            const int hbk = ((z * HY + y) * HX + 2 * xb) * 32;
+            const int v0 = ((z * 8 + y) * 8 + 2 * xb) * WG_NT;
+            Y0[q4] = dys_c[offy + v0];
+            Y1[q4] = dys_c[offy + v0 + WG_NT];
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+                Ra[q4][u] = xs_c[offa[u] + hbk];
+                Rb[q4][u] = xs_c[offb[u] + hbk];
+            }
+        }
+    };
+    auto mma_body = [&](const float (&Ra)[NQ][NTW], const float (&Rb)[NQ][NTW], const float (&Y0)[NQ], const float (&Y1)[NQ]) {
+#pragma unroll
+        for (int q4 = 0; q4 < NQ; ++q4) {
+            const float bv = fmaf(c1, Y1[q4], c0 * Y0[q4]);
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+                const float av = fmaf(sa, Rb[q4][u], Ra[q4][u]);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u], 0, 0, 0);
+            }
+        }
+    };
+    float Ra0[NQ][NTW], Rb0[NQ][NTW], Ra1[NQ][NTW], Rb1[NQ][NTW], Ya0[NQ], Yb0[NQ], Ya1[NQ], Yb1[NQ];
+
+    const int wave_u = pt;
+    const float* zero = reinterpret_cast<const float*>(g_zero_page);
+    constexpr int XIMG = 13 * 4 * 256;
+    constexpr int SET = XIMG + MV * WG_NT;
+    int nb = 0, nz0 = 0, ny0 = 0, nx0 = 0;
+    bool more = false;
+    auto issue_piece = [&](int pc, float* xd) {
+        if (pc < 13) {
+            const int j = tid + pc * 256;
+            const int hv = j >> 3, q = j & 7;
+            const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = nz0 - 1 + hz, gy = ny0 - 1 + hy, gx = nx0 - 1 + hx;
+            const bool ok = more && hv < HV && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W &&
+                            ci0 + 4 * q < a.Cin;
+            const float* src = ok ? a.in + (long)nb * a.in_bs + ((long)(gz * a.H + gy) * a.W + gx) * a.in_ps + ci0 + 4 * q : zero;
+            dma16(src, xd + (wave_u + 4 * pc) * 256);
+        } else {
+            const int u = pc - 13;
+            const int j = tid + u * 256;
+            const int vv = j >> 3, q = j & 7;
+            const int gz = nz0 + (vv >> 6), gy = ny0 + ((vv >> 3) & 7), gx = nx0 + (vv & 7);
+            const bool ok = more && gz < a.D && gy < a.H && gx < a.W && co0 + 4 * q < a.Cout;
+            const float* src = ok ? a.dy + (long)nb * a.dy_bs + ((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + co0 + 4 * q : zero;
+            dma16(src, xd + XIMG + (wave_u + 4 * u) * 256);
+        }
+    };
+    if (t_begin < t_end) {
+        more = true;
+        decode(t_begin, nb, nz0, ny0, nx0);
+#pragma unroll
+        for (int pc = 0; pc < 17; ++pc) issue_piece(pc, smem);
+    }
+    int cur = 0;
+    for (int tl = t_begin; tl < t_end; ++tl, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        more = tl + 1 < t_end;
+        if (more) decode(tl + 1, nb, nz0, ny0, nx0);
+        const float* xs_c = smem + cur * SET;
+        const float* dys_c = xs_c + XIMG;
+        float* xnext = smem + (cur ^ 1) * SET;
+        load_body(Ra0, Rb0, Ya0, Yb0, xs_c, dys_c, 0);
+#pragma unroll
+        for (int sb = 0; sb < 16; sb += 2) {            // 16 bodies; one DMA piece of the next tile per body (+ the 17th on the last trip)
+            // the raw reads of the next body are threaded through the MFMAs of the current one (1 MFMA : 3 LDS reads : 2 VALU), so
+            // neither their issue slots nor their latency stall the matrix pipe of this single-wave-per-SIMD kernel
+            load_body(Ra1, Rb1, Ya1, Yb1, xs_c, dys_c, sb + 1);
+            if (sb < 8) { issue_piece(2 * sb, xnext); issue_piece(2 * sb + 1, xnext); }     // all 17 pieces in the first nine bodies
+            if (sb == 8) issue_piece(16, xnext);
+            mma_body(Ra0, Rb0, Ya0, Yb0);
+#pragma unroll
+            for (int g = 0; g < NQ * NTW; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_body(Ra0, Rb0, Ya0, Yb0, xs_c, dys_c, (sb + 2) & 15);
+            if (sb < 8) { issue_piece(2 * sb + 2, xnext); issue_piece(2 * sb + 3, xnext); }
+            mma_body(Ra1, Rb1, Ya1, Yb1);
+#pragma unroll
+            for (int g = 0; g < NQ * NTW; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // flush: dw[.., t] = G^T M needs the four points of a (dz, dy, ci, co) entry, which live in the four waves.  They meet in LDS (the image
+    // sets are free now), eight row tiles at a time, and each entry leaves as three float atomics (tap 0: M0 + (M1 + M2)/2, tap 1:
+    // (M1 - M2)/2, tap 2: (M1 + M2)/2 + M3) in 128-byte runs of couts - 2.7x fewer atomics than flushing every wave's share separately.
+    __syncthreads();
+    float* X = smem;                                       // [point][tile slot 0..7][r][lane]
+    const int co = co0 + i;
+    constexpr int GRP = 8;
+    for (int g0 = 0; g0 < nrt; g0 += GRP) {
+        const int ng = min(GRP, nrt - g0);
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) {
+            if (u >= g0 && u < g0 + ng) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) X[((pt * GRP + (u - g0)) * 16 + r) * 64 + lane] = acc[u][r];
+            }
+        }
+        __syncthreads();
+        for (int j = wave; j < ng * 16; j += 4) {
+            const int tl = j >> 4, r = j & 15;
+            const float m0 = X[((0 * GRP + tl) * 16 + r) * 64 + lane], m1 = X[((1 * GRP + tl) * 16 + r) * 64 + lane];
+            const float m2 = X[((2 * GRP + tl) * 16 + r) * 64 + lane], m3 = X[((3 * GRP + tl) * 16 + r) * 64 + lane];
+            const int rg = 32 * (g0 + tl) + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (rg < rows && co < a.Cout) {
+                const int zy = rg / Cc, ci = rg - zy * Cc;
+                float* d = a.dwp + ((long)(zy * 3) * a.Cin + ci0 + ci) * a.NPad + co;
+                const float hs = 0.5f * (m1 + m2);
+                atomicAdd(d, m0 + hs);
+                atomicAdd(d + (long)a.Cin * a.NPad, 0.5f * (m1 - m2));
+                atomicAdd(d + 2L * a.Cin * a.NPad, hs + m3);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cin, int Cout, int NPad, long total, int accumulate) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(e % 27);
+        const long r = e / 27;
+        const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        const float val = dwp[((long)tap * Cin + ci) * NPad + co];
+        dw[e] = accumulate ? dw[e] + val : val;
+    }
+}
+
+}  // namespace
+
+int pulpo_conv::launch_unpack_wgrad(const float* packed, float* dw, int Cin, int Cout, int accumulate, hipStream_t st) {
+    const long total = (long)Cout * Cin * 27;
+    const int ub = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ub), dim3(256), 0, st, packed, dw, Cin, Cout, npad(Cout), total, accumulate);
+    return pulpo::check_launch("unpack_wgrad");
+}
+
+// ================================================================================================ C ABI
+PULPO_API size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout) { return (size_t)27 * Cin * npad(Cout); }
+
+// dw[Cout][Cin][27] (+)= sum_vox in[vox+tap-1][ci] * dy[vox][co]  (accumulate != 0 adds to dw, e.g. a parameter's .grad storage).
+// scratch: pulpo_conv3d_k3_wgrad_scratch_floats floats.
+PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
+                                    int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, int B, int D, int H, int W,
+                                    int Cin, int Cout, void* stream) {
+    PULPO_REQUIRE(in && dy && dw && scratch, "conv3d_k3_wgrad: null pointer");
+    PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3d_k3_wgrad: bad dims");
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a;
+    a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
+    a.dy = dy; a.dy_bs = dy_bs; a.dy_ps = dy_ps; a.dy_cs = dy_cs;
+    a.dwp = scratch;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.NPad = npad(Cout);
+    a.ntz = pulpo::cdiv(D, TZ); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
+    a.ncit = pulpo::cdiv(Cin, WG_CH); a.ncot = pulpo::cdiv(Cout, WG_NT);
+    const int ntile = B * a.ntz * a.nty * a.ntx;
+    const int npair = a.ncit * a.ncot;
+    const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)in & 15) == 0) &&
+                     (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
+    // DMA variant: one resident workgroup per CU -> one round of <= 256 persistent workgroups (fewest atomic flushes);
+    // scalar variant: two per CU
+    int nsplit = std::max(1, (vec ? 256 : 512) / npair);
+    nsplit = std::min(nsplit, ntile);
+    a.nsplit = nsplit;
+    hipError_t e = hipMemsetAsync(scratch, 0, pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout) * sizeof(float), st);
+    if (e != hipSuccess) return pulpo::fail((int)e, "wgrad memset: %s", hipGetErrorString(e));
+    const int nrt_max = (27 * std::min(Cin, WG_CH) + 31) / 32;
+    const int ntw = (nrt_max + 3) / 4;                 // 1..7
+    constexpr size_t lds = (size_t)(((HV * WG_CP + 3) & ~3) + MV * WG_NT) * sizeof(float);
+    constexpr size_t lds_dma = (size_t)2 * (13 * 4 * 256 + MV * WG_NT) * sizeof(float);
+    const int nblk = npair * nsplit;
+    int rc = 0;
+#define PULPO_WGRAD(VECV, NTWV)                                                                                                   \
+    {                                                                                                                             \
+        static bool attr = false;                                                                                                 \
+        const size_t bytes = VECV ? lds_dma : lds;                                                                                \
+        if (!attr) {                                                                                                              \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_mfma<VECV, NTWV>),                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                        \
+            if (ea != hipSuccess) return pulpo::fail((int)ea, "hipFuncSetAttribute(wgrad): %s", hipGetErrorString(ea));           \
+            attr = true;                                                                                                          \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((conv3d_k3_wgrad_mfma<VECV, NTWV>), dim3(nblk), dim3(256), bytes, st, a);                              \
+    }
+    static int wino = -1;
+    if (wino < 0) { const char* e = getenv("PULPO_WGRAD_WINOGRAD"); wino = e ? atoi(e) : 1; }
+    if (vec && wino && Cin >= 8 && (long)D * H * W >= 32L * 32 * 32) {      // (measured: no gain on the 20^3 / 10^3 pyramid levels)
+        // Winograd-x variant: wave = transformed point, nine (dz, dy) row tiles of <= 32 channels
+        const int nrt9 = (9 * std::min(Cin, WG_CH) + 31) / 32;
+#define PULPO_WGRAD_W(NTWV)                                                                                                       \
+    {                                                                                                                             \
+        static bool attr = false;                                                                                                 \
+        if (!attr) {                                                                                                              \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_wino<NTWV>),                       \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);                      \
+            if (ea != hipSuccess) return pulpo::fail((int)ea, "hipFuncSetAttribute(wgrad wino): %s", hipGetErrorString(ea));      \
+            attr = true;                                                                                                          \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((conv3d_k3_wgrad_wino<NTWV>), dim3(nblk), dim3(256), lds_dma, st, a);                                  \
+    }
+        if (nrt9 <= 3) PULPO_WGRAD_W(3) else if (nrt9 <= 5) PULPO_WGRAD_W(5) else PULPO_WGRAD_W(9)
+#undef PULPO_WGRAD_W
+    } else if (vec) {
+        if (ntw <= 1) PULPO_WGRAD(true, 1) else if (ntw <= 2) PULPO_WGRAD(true, 2) else if (ntw <= 4) PULPO_WGRAD(true, 4) else PULPO_WGRAD(true, 7)
+    } else {
+        if (ntw <= 1) PULPO_WGRAD(false, 1) else if (ntw <= 2) PULPO_WGRAD(false, 2) else if (ntw <= 4) PULPO_WGRAD(false, 4) else PULPO_WGRAD(false, 7)
+    }
+#undef PULPO_WGRAD
+    rc = pulpo::check_launch("conv3d_k3_wgrad_mfma");
+    if (rc) return rc;
+    return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
+}

@@ -21,4 +21,31 @@ int launch_splitk_reduce(const float* part, int ksplit, float* out, long obs, lo
 // dw[Cout][Cin][27] (+)= packed[27][Cin][NPad]; see unpack_wgrad_kernel in conv3d.hip
 int launch_unpack_wgrad(const float* packed, float* dw, int Cin, int Cout, int accumulate, hipStream_t st);
 
+// ---- shared by the direct (conv3d.hip), Winograd (conv3d_wino.hip) and weight-gradient (conv3d_wgrad.hip) translation units
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int TZ = 2, MV = TZ * TY * TX;          // base output voxel tile (weight gradient; the forward kernels use conv_tz())
+constexpr int HZ = TZ + 2, HV = HZ * HY * HX;     // its halo tile
+
+struct ConvArgs {
+    const float* in;
+    long in_bs, in_ps, in_cs;     // batch / pixel / channel strides in floats
+    const float* wp;              // packed [nchunk][27][CH][NPad]
+    const float* bias;            // nullable
+    float* out;
+    long out_bs, out_ps, out_cs;
+    float* stats;                 // nullable: [voxel tile][2][Cout]  (sum, sum of squares of conv+bias)
+    int B, D, H, W, Cin, Cout, NPad;
+    int ntz, nty, ntx, ncot;
+    int ksplit;                   // > 1: the Cin chunks are split over ksplit workgroups, each storing a partial slab into `part`
+    float* part;                  // [ksplit][B*V][Cout] dense partial outputs (reduced in fixed order by splitk_reduce_kernel)
+    const float* coef;            // nullable: eval-mode BatchNorm coefficients (scale at [2C], shift at [3C]) + LeakyReLU fused into the store
+    float slope;
+};
+
+
+__device__ __forceinline__ int tap_halo_offset(int tap) {
+    return ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
+}
+
 }  // namespace pulpo_conv
