@@ -264,3 +264,17 @@ def test_2d_model_state_dict_matches_reference_fixture(golden):
     for k, shp in ref.items():
         assert tuple(sd[k].shape) == shp, k
     assert model.autoencoder.encoders[0].mu_sigma._conv_mu.weight.shape[0] == 2          # zdim = ndims
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/pulpo_hip.h is the drop-in boundary: it must compile as C99 and as C++ without any HIP / torch header"""
+    import shutil
+    src = tmp_path / "h.c"
+    src.write_text('#include "pulpo_hip.h"\nint main(void) { return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
