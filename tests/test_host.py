@@ -16,6 +16,14 @@ from conftest import GOLDEN, ROOT
 FB = ["samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed"]
 
 
+
+def _free_port() -> str:
+    """a TCP port that is free right now (the rendezvous of the multi-process tests)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
 def test_library_exports_every_declared_symbol():
     from pulpo_amd._lib import HEADER, LIB_PATH, lib, parse_header
     protos = parse_header()
@@ -164,7 +172,7 @@ dist.destroy_process_group()
 def test_data_parallel_plumbing_gloo_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
@@ -242,7 +250,7 @@ dist.destroy_process_group()
 def test_bucketed_overlapped_allreduce_gloo_world2(tmp_path):
     script = tmp_path / "bucket_worker.py"
     script.write_text(BUCKET_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29643", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
