@@ -672,3 +672,31 @@ def test_bench_two_rank_rehearsal(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2
     assert d["value"] > 0 and abs(d["value"] - 2 * 1 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]       # pairs of ALL ranks / time
     assert d["roofline"] is not None and d["cpu_baseline"] is None
+
+
+def test_bench_json_contract_single_gpu():
+    """the one JSON line bench.py prints (driver contract): every required key, the roofline and cpu_baseline objects, and the
+    arithmetic value = pairs / time - on a small workload so that the CPU-baseline leg takes seconds"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--size", "32", "32", "32",
+                        "--levels", "3", "2"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["unit"] == "volume-pairs/s" and d["dtype"] == "f32" and "workload" in d["config"]
+    assert abs(d["value"] - 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert d["value"] > cb["value"]
