@@ -85,6 +85,19 @@ class FusedAdam:
         self.v = torch.zeros_like(arena.data)
         self.t = 0
 
+    def state_dict(self) -> dict:
+        """checkpointable optimizer state, keyed like torch.optim.Adam's per-parameter state ('step', 'exp_avg', 'exp_avg_sq') but flat"""
+        return {"step": self.t, "exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone(), "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
+                "numel": self.arena.numel}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if int(sd["numel"]) != self.arena.numel:
+            raise ValueError(f"FusedAdam: checkpoint holds {sd['numel']} elements, this arena {self.arena.numel} (different model or parameter order)")
+        self.t = int(sd["step"])
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+        self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
+
     def step(self, grad_scale: float = 1.0) -> None:
         from . import ops
         self.t += 1
