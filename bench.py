@@ -4,19 +4,25 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no torchrun environment (WORLD_SIZE unset): this process becomes a launcher.  Before anything touches the
+GPU it starts N fresh rank processes of this same script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, rank r
+pinned to GPU r), relays rank 0's single JSON line, and exits non-zero if any rank fails.  Under torchrun the ranks are the driver's.
+
 Workload (BASELINE.json `metric`): synthetic 160^3 fp32 volume pairs, 4-level latent pyramid (total_levels 5,
 latent_levels 4, n0 = 32), batch 1 per GPU, weak scaling over GPUs.  One "step" = one training step on one pair per
 GPU.  Inputs live in HBM before the timed region.  Rank 0 prints ONE JSON line (see the task contract) carrying
   roofline      : the dominant kernel (the MFMA 3x3x3 convolution), algorithmic FLOP / launch over its HIP-event
                   measured mean launch time inside the timed region, against the dense fp32 MFMA peak (157.3 TFLOP/s);
   cpu_baseline  : the CPU oracle (oracle/pulpo_oracle.py, the same ATen op sequence as the reference) timed on this
-                  host's cores for ONE forward+backward step of the same 160^3 workload (N = 1 only).
+                  host's cores: 1 warm-up + 2 timed forward+backward+Adam steps of the same 160^3 workload (N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +37,15 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 matrix peak
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
 FLOP_ALG_PER_PAIR_160 = 5.708e12       # conv FLOPs fwd+bwd per pair at 160^3 / T5 / L4
 BYTES_ALG_PER_PAIR_160 = 41.98e9       # fused-kernel compulsory bytes per pair
+
+
+def ISSUED_FRACTION(kernel_name: str) -> float:
+    """matrix-pipe FLOP issued per direct-convolution FLOP for a traced kernel name"""
+    if "wgrad_w2" in kernel_name or "wino2" in kernel_name:
+        return 4.0 / 9.0
+    if "wino" in kernel_name:
+        return 2.0 / 3.0
+    return 1.0
 
 
 def parse():
@@ -54,7 +69,118 @@ def parse():
                          "keeps the pair resident in HBM as the metric prescribes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="TEST HOOK, not a measurement: run only the launch / rendezvous / barrier / max-over-ranks / JSON plumbing with a trivial "
+                         "CPU all-reduce as the 'step' (no kernels, no GPU); the line it prints carries \"valid\": false")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ self-launch (--gpus N without torchrun)
+EXIT_OVERLAP_FAILED = 17        # a rank's overlapped stepper failed on its first step: the launcher starts all ranks again with the plain one
+
+
+def _free_port() -> int:
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def _spawn_ranks(n: int, extra_env: dict) -> int:
+    """start n rank processes of this script, wait for all; returns the job's exit code.  Rank 0's stdout is relayed to ours (the one JSON
+    line); the other ranks' stdout goes to our stderr.  The first rank to fail ends the job: the others are terminated by PID."""
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), **extra_env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr, text=(r == 0) or None))
+    rc = 0
+    pending = set(range(n))
+    deadline = time.time() + float(os.environ.get("PULPO_BENCH_TIMEOUT_S", "3000"))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench launcher] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+        if (rc != 0 or time.time() > deadline) and pending:
+            if rc == 0:
+                rc = 124
+                print("[bench launcher] time limit reached; stopping the ranks", file=sys.stderr)
+            for r in pending:
+                procs[r].terminate()
+            t_end = time.time() + 15
+            for r in pending:
+                try:
+                    procs[r].wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            pending.clear()
+        if pending:
+            time.sleep(0.2)
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    if rc == 0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(out0)
+    return rc
+
+
+def launch_ranks(args) -> int:
+    """parent of a self-launched multi-GPU run.  NOTHING here initialises the GPU (torch.cuda.device_count() does not, on this image)."""
+    n = args.gpus
+    backend = os.environ.get("PULPO_DIST_BACKEND", "nccl")
+    if backend == "nccl" and not args.plumbing_only:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench launcher] --gpus {n} but only {have} GPU(s) are visible (one RCCL rank per GPU)", file=sys.stderr)
+            return 2
+    rc = _spawn_ranks(n, {})
+    if rc == EXIT_OVERLAP_FAILED:
+        print("[bench launcher] starting all ranks again with the plain stepper (PULPO_DP_OVERLAP=0 PULPO_ASYNC_WGRAD=0)", file=sys.stderr)
+        rc = _spawn_ranks(n, {"PULPO_DP_OVERLAP": "0", "PULPO_ASYNC_WGRAD": "0"})
+    return rc
+
+
+def plumbing_only(args) -> None:
+    """the multi-rank plumbing of this script with a trivial CPU 'step' (test hook for boxes without a GPU; prints "valid": false)"""
+    from pulpo_amd import dp
+    dp.init_from_env("gloo")
+    world = dp.world()
+    rank = dist.get_rank() if world > 1 else 0
+    buf = torch.ones(1024)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        dp.allreduce_sum_(buf.clone())
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = dp.allreduce_sum_(buf.clone())
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert float(got[0]) == float(world)
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing only (no kernels run; not a measurement)", "valid": False, "value": None, "unit": "volume-pairs/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(1, args.steps) * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "config": {"workload": "launcher / rendezvous / barrier / max-over-ranks rehearsal", "global_batch": world,
+                                     "parallelism": f"dp{world}"}, "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def usable_cores() -> int:
@@ -79,48 +205,84 @@ def usable_cores() -> int:
     return int(os.environ.get("PULPO_CPU_CORES", min(n, 32)))
 
 
-def cpu_baseline(size, T, L, B):
-    """one un-warmed forward+backward of the CPU oracle on the same workload (bounded sample: 1 step)"""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(size, T, L, B, warm: int = 1, timed: int = 2):
+    """the CPU oracle's training step (forward + backward + torch.optim.Adam, the reference's optimizer - models.py:398-400) on the same
+    workload: `warm` untimed + `timed` timed steps (1 + 2), autograd anomaly mode off"""
     from oracle import pulpo_oracle as O
     torch.set_num_threads(usable_cores())
     cfg = O.Cfg(T, L, list(size), n0=32)
     sd = O.clone_sd(O.init_state_dict(cfg, seed=0), requires_grad=True)
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4)
     g = torch.Generator().manual_seed(1234)
     x, y = torch.rand(B, 1, *size, generator=g), torch.rand(B, 1, *size, generator=g)
+
+    def step():
+        _, grads, _ = O.train_step(sd, cfg, x, y, None)
+        for k, v in sd.items():
+            if v.requires_grad:
+                v.grad = grads.get(k)
+        opt.step()
+
+    for _ in range(warm):
+        step()
     t0 = time.perf_counter()
-    O.train_step(sd, cfg, x, y, None)
-    dt = time.perf_counter() - t0
-    return {"value": B / dt, "unit": "volume-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 un-warmed fwd+bwd step (no optimizer) of the same {size[0]}x{size[1]}x{size[2]} T{T}/L{L} B={B} fp32 workload, "
-                      f"oracle/pulpo_oracle.py on torch-CPU, {dt:.1f} s"}
+    for _ in range(timed):
+        step()
+    dt = (time.perf_counter() - t0) / timed
+    return {"value": B / dt, "unit": "volume-pairs/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"{warm} warm-up + {timed} timed fwd+bwd+Adam steps of the same {size[0]}x{size[1]}x{size[2]} T{T}/L{L} B={B} fp32 workload, "
+                      f"oracle/pulpo_oracle.py on torch-CPU ({torch.get_num_threads()} threads, {cpu_model()}), {dt:.1f} s per step"}
 
 
 def pmc_traffic(kernel: str) -> dict:
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of this same command
-    (profiles/r1_bench160_pmc_traffic.json, made by scripts/pmc_traffic.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs;
-    counters cannot be read from inside the process).  Launch-weighted over the kernel's tile variants."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_bench160_pmc_traffic.json")
-    if not os.path.exists(path):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of this same command (the newest
+    profiles/r*_bench160_pmc_traffic.json, made by scripts/pmc_traffic.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs; counters
+    cannot be read from inside the process).  Launch-weighted over the kernel's tile variants."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench160_pmc_traffic.json")))
+    if not files:
         return {"traffic": None}
+    path = files[-1]
     rows = json.load(open(path))["per_launch"]
     stem = kernel.replace(" ", "").rstrip(">")
     hit = [r for k, r in rows.items() if k.replace(" ", "").startswith(stem)]
     n = sum(r["launches"] for r in hit)
     if n == 0:
-        return {"traffic": None}
+        return {"traffic": None, "traffic_source": f"{os.path.relpath(path, ROOT)} holds no launch of {kernel} (regenerate it for this build)"}
+    factors = sorted({r["fetch_factor"] for r in hit})
     return {"traffic": sum(r["traffic_bytes"] * r["launches"] for r in hit) / n, "traffic_unit": "bytes/launch",
-            "traffic_source": "profiles/r1_bench160_pmc_traffic.json (rocprofv3 --pmc passes of this command: FETCH_SIZE raw for the conv kernels' short gathers + WRITE_SIZE)"}
+            "traffic_fetch_bytes": sum(r["fetch_raw_bytes"] * r["launches"] for r in hit) / n,
+            "traffic_write_bytes": sum(r["write_bytes"] * r["launches"] for r in hit) / n,
+            "traffic_source": f"{os.path.relpath(path, ROOT)}: rocprofv3 --pmc passes of this command, traffic = FETCH_SIZE x {'/'.join(f'{f:g}' for f in factors)} "
+                              "+ WRITE_SIZE (factor 2 = the guide's gfx950 correction for 16 B/lane streaming reads; factor 1 = raw, for the "
+                              "convolutions' 32-64 B per-voxel gathers, an uncalibrated width: a lower bound)"}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))           # (nothing has touched the GPU in this process)
+    if args.plumbing_only:
+        return plumbing_only(args)
     from pulpo_amd import dp, ops
     from pulpo_amd._lib import lib
     local = dp.init_from_env(os.environ.get("PULPO_DIST_BACKEND", "nccl"))     # (gloo: rehearsal of the multi-rank path on a one-GPU box)
     world = dp.world()
     rank = dist.get_rank() if world > 1 else 0
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE is {world}; using {world}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU (or drop the torchrun environment "
+                         "and let bench.py start the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
     if local >= torch.cuda.device_count():           # only in the gloo rehearsal with more ranks than GPUs
@@ -173,19 +335,42 @@ def main():
         def one_step():
             return stepper.step(batch)
 
-    # insurance for the multi-rank runs, which cannot be rehearsed with RCCL on a one-GPU box: if the first step fails with the overlapped
-    # gradient exchange / second-stream weight gradients, every rank (the failure would be deterministic) falls back to the plain
-    # single-all-reduce stepper and says so on stderr
-    if world > 1 and not infer and args.warmup > 0:
+    # Insurance for the multi-rank RCCL runs, which a one-GPU box cannot rehearse: the first step with the overlapped gradient exchange /
+    # second-stream weight gradients is tried, and the outcome is agreed on by ALL ranks before anybody goes on - a flag all-reduce over a
+    # separate gloo (CPU) group, issued before the GPU is synchronised, so a rank whose peer failed is not left waiting inside a collective
+    # the peer never joins.  All ranks failed (a deterministic failure is the same everywhere and leaves no half-issued collective): every
+    # rank switches to the plain single-all-reduce stepper.  Some failed: nothing in this process can be trusted any more - every rank
+    # exits with EXIT_OVERLAP_FAILED and the launcher starts the job again with PULPO_DP_OVERLAP=0 PULPO_ASYNC_WGRAD=0.
+    if world > 1 and not infer and args.warmup > 0 and (stepper.overlap or stepper.async_wgrad):
+        import datetime
+        side = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("PULPO_BENCH_AGREE_TIMEOUT_S", "300"))))
+        ok = 1.0
         try:
+            if os.environ.get("PULPO_BENCH_INJECT_FAILURE", "") in ("all", str(rank)):      # test hook
+                raise RuntimeError("injected first-step failure")
             one_step()
-            torch.cuda.synchronize()
         except Exception as exc:  # noqa: BLE001
-            print(f"[bench] rank {rank}: overlapped stepper failed ({type(exc).__name__}: {exc}); falling back to overlap=False, async_wgrad=False",
-                  file=sys.stderr)
+            ok = 0.0
+            print(f"[bench] rank {rank}: overlapped stepper failed on its first step ({type(exc).__name__}: {exc})", file=sys.stderr)
+        votes = torch.tensor([ok, 1.0])
+        try:
+            dist.all_reduce(votes, op=dist.ReduceOp.SUM, group=side)
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] rank {rank}: no agreement on the first step's outcome ({type(exc).__name__}: {exc})", file=sys.stderr)
+            os._exit(EXIT_OVERLAP_FAILED)
+        n_ok = int(votes[0].item())
+        if n_ok == world:
+            torch.cuda.synchronize()
+        elif n_ok == 0:
+            if rank == 0:
+                print("[bench] every rank failed alike: falling back to overlap=False, async_wgrad=False on all ranks", file=sys.stderr)
             ops.ASYNC_WGRAD_STREAM = None
             ops.DIRECT_PARAM_GRADS = False
             stepper = dp.DataParallelStepper(model, overlap=False, async_wgrad=False)
+        else:
+            print(f"[bench] rank {rank}: {world - n_ok} of {world} ranks failed their first step; leaving with code {EXIT_OVERLAP_FAILED}", file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(EXIT_OVERLAP_FAILED)
     for _ in range(args.warmup):
         one_step()
     barrier()
@@ -231,35 +416,41 @@ def main():
         roof = None
         per_kernel = {}
         if trace:
-            for name, flops, s, e in trace:
-                k = per_kernel.setdefault(name, [0, 0.0, 0.0])
+            for name, flops, s_, e_, nb in trace:
+                k = per_kernel.setdefault(name, [0, 0.0, 0.0, 0.0])
                 k[0] += 1
                 k[1] += flops
-                k[2] += s.elapsed_time(e) * 1e-3
+                k[2] += s_.elapsed_time(e_) * 1e-3
+                k[3] += nb
             dom = max(per_kernel.items(), key=lambda kv: kv[1][2])
-            n, fl, sec = dom[1]
+            n, fl, sec, nbytes = dom[1]
             peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom[0] else PEAK_FP32_MFMA_TFLOPS
-            roof = {"bound": "mfma", "kernel": dom[0], "achieved": fl / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
-                    "frac": fl / sec / 1e12 / peak, "traffic": None, "launches": n, "launch_sampling": f"every {ops.CONV_TRACE_STRIDE_USED}th conv launch of the timed region",
+            # FLOP the kernel ISSUES on the matrix pipe per algorithmic (direct-convolution) FLOP: the Winograd forms evaluate the
+            # same convolution with 2/3 (F(2,3) along x) or 4/9 (F(2x2,3x3) in y and x) of the direct form's multiply-adds
+            issued = ISSUED_FRACTION(dom[0])
+            eff = fl / sec / 1e12
+            roof = {"bound": "mfma", "kernel": dom[0], "achieved": eff * issued, "peak": peak, "unit": "TFLOP/s",
+                    "frac": eff * issued / peak, "traffic": None, "launches": n,
+                    "launch_sampling": f"every {ops.CONV_TRACE_STRIDE_USED}th conv launch of the timed region",
                     "avg_launch_ms": sec / n * 1e3,
-                    "flop_per_launch": fl / n}
-            if "wino" in dom[0]:
-                # algorithmic FLOP are those of the direct convolution; the Winograd kernels issue 2/3 (F(2,3) along x) or
-                # 4/9 (F(2x2,3x3) in y and x) of them
-                issued = 4.0 / 9.0 if "wino2" in dom[0] else 2.0 / 3.0
-                roof["matrix_pipe_TFLOPs"] = roof["achieved"] * issued
-                roof["matrix_pipe_frac"] = roof["matrix_pipe_TFLOPs"] / peak
-                roof["note"] = ("achieved/frac count the direct convolution's 54*K*N*V FLOP; the kernel evaluates the "
-                                + ("y and x taps with F(2x2,3x3) and issues 24*K*N*V" if "wino2" in dom[0] else "x taps with F(2,3) and issues 36*K*N*V"))
+                    "issued_flop_per_launch": fl * issued / n,
+                    "effective_TFLOPs": eff, "effective_flop_per_launch": fl / n,
+                    "alg_bytes_per_launch": nbytes / n,
+                    "flop_definition": "achieved / frac = FLOP the kernel issues on the matrix pipe (utilisation, <= 1); effective_TFLOPs = the direct "
+                                       "convolution's 54*K*N*V FLOP (SURVEY 8(d)) over the same time" + ("" if issued == 1.0 else
+                                       f"; this Winograd kernel issues {issued:.4f} of them")}
             if trace_serial:
-                ts = [(fl_, s_.elapsed_time(e_) * 1e-3) for name_, fl_, s_, e_ in trace_serial if name_ == dom[0]]
+                ts = [(fl_, s_.elapsed_time(e_) * 1e-3) for name_, fl_, s_, e_, _ in trace_serial if name_ == dom[0]]
                 if ts:
                     fls, secs = sum(a_ for a_, _ in ts), sum(b_ for _, b_ in ts)
-                    roof["serialized"] = {"achieved": fls / secs / 1e12, "frac": fls / secs / 1e12 / peak, "avg_launch_ms": secs / len(ts) * 1e3,
-                                          "launches": len(ts), "note": "same kernel, weight-gradient stream overlap switched off (2 untimed steps)"}
+                    roof["serialized"] = {"achieved": fls * issued / secs / 1e12, "frac": fls * issued / secs / 1e12 / peak,
+                                          "effective_TFLOPs": fls / secs / 1e12, "avg_launch_ms": secs / len(ts) * 1e3, "launches": len(ts),
+                                          "note": "same kernel, weight-gradient stream overlap switched off (2 untimed steps)"}
                 roof["overlap_note"] = "timed-region brackets include CU sharing with the weight-gradient kernels on the second stream"
             if is160_cfg and not bf16:
                 roof.update(pmc_traffic(dom[0]))
+                if roof.get("traffic"):
+                    roof["traffic_over_alg_bytes"] = roof["traffic"] / roof["alg_bytes_per_launch"]
         # ---- the HBM-bound family (BatchNorm / LeakyReLU passes): algorithmic bytes over the same live brackets, against 8 TB/s
         hbm_roof = None
         if hbm_trace:
@@ -285,15 +476,17 @@ def main():
             "roofline": roof,
             "hbm_rooflines": hbm_roof,
             "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
-            "conv_kernels": {k: {"launches_sampled": v[0], "TFLOP/s": v[1] / v[2] / 1e12,
+            "conv_kernels": {k: {"launches_sampled": v[0], "effective_TFLOPs": v[1] / v[2] / 1e12, "matrix_pipe_TFLOPs": v[1] * ISSUED_FRACTION(k) / v[2] / 1e12,
                                  "ms_total_per_step_est": v[2] * ops.CONV_TRACE_STRIDE_USED / args.steps * 1e3}
                              for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][2])},
         }
         if is160 and not infer:
             per_gpu = value / world
             mpeak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-            out["step_rooflines"] = {f"conv_flop_frac_of_{mpeak:g}TF": FLOP_ALG_PER_PAIR_160 * per_gpu / 1e12 / mpeak,
-                                     "alg_bytes_frac_of_8TBps": BYTES_ALG_PER_PAIR_160 * per_gpu / 8.0e12}
+            out["step_rooflines"] = {f"effective_conv_TFLOPs_over_{mpeak:g}TF": FLOP_ALG_PER_PAIR_160 * per_gpu / 1e12 / mpeak,
+                                     "alg_bytes_frac_of_8TBps": BYTES_ALG_PER_PAIR_160 * per_gpu / 8.0e12,
+                                     "note": "whole step: SURVEY 8(d)'s 5.708 TFLOP (direct-convolution count) and 41.98 GB per pair over the step time; "
+                                             "the first is an effective rate (Winograd kernels issue fewer FLOP), not a utilisation"}
         if world == 1 and not args.no_cpu_baseline and not bf16 and not infer:
             out["cpu_baseline"] = cpu_baseline(size, T, L, B)
         else:

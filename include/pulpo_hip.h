@@ -190,6 +190,19 @@ int pulpo_kl_nondiag_bwd(const float* mu, const float* sigma, const float* gscal
 int pulpo_jdetstd_bwd(const float* df, const float* jdet, const double* stat, const float* gscale, float lamb, float* gdf, int B, int D, int H, int W,
                       int normalize, void* stream);
 
+/* Evaluation scalars of the reference's harness, finished on the device:
+ *   pulpo_rmse           Evaluate.rmse, evaluate.py:315-319   sqrt(MSELoss(input, target))
+ *   pulpo_dsc            Evaluate.dsc, evaluate.py:321-327    mean over (B, C) of (2 mean(t i) + 1e-6) / (mean(t^2) + mean(i^2) + 1e-6)
+ *   pulpo_percent_leq0   evaluate.py:1441-1446 ("JDetLeq0")   100 * count(jacobian_det <= 0) / numel
+ *   pulpo_warp_landmarks Evaluate.warp_landmarks, evaluate.py:410-423 = src/components/utils.py:15-25
+ *                        out[s][k][:] = long(lm[k]) - df[s, :, lm[k][0], lm[k][1], lm[k][2]]; *flag = 1 if an index is out of range */
+int pulpo_rmse(const float* a, const float* b, int64_t n, float* partial /* pulpo_metric_blocks(n) */, float* out, void* stream);
+int pulpo_dsc(const float* inp, const float* tgt, int nplanes, int64_t V, float* partial /* nplanes*pulpo_dice_blocks(V)*3 */, float* out,
+              void* stream);
+int pulpo_percent_leq0(const float* x, int64_t n, float* partial /* pulpo_metric_blocks(n) */, float* out, void* stream);
+int pulpo_warp_landmarks(const float* lm /*(nlm,nd)*/, const float* df /*(nsamp,nd,D,H,W)*/, float* out /*(nsamp,nlm,nd)*/, int nlm, int nsamp,
+                         int nd, int D, int H, int W, int* flag, void* stream);
+
 /* ------------------------------------------------------------------------------- Monte-Carlo uncertainty statistics
  * evaluate.py:222-251 stacks N sampled volumes / fields per level and takes torch.std(axis=0) (unbiased) then torch.mean over the
  * channel axis.  Streaming form: fold sample k (1-based count) into running (mean, M2) images of the sample's shape, then

@@ -362,6 +362,57 @@ def kl_nondiagonal(mu: Tensor, sigma: Tensor, prior_lambda: float = 20.0) -> Ten
     return (sigma_term.mean() + (prior_lambda / 2) * precision) * nd * 0.5 * float(math.prod(S))
 
 
+def rmse(inp: Tensor, tgt: Tensor) -> Tensor:
+    """Evaluate.rmse   evaluate.py:315-319"""
+    return torch.sqrt(((inp - tgt) ** 2).mean())
+
+
+def dsc(inp: Tensor, tgt: Tensor) -> Tensor:
+    """Evaluate.dsc   evaluate.py:321-327 (means over the spatial dims, then over batch and channel)"""
+    dims = list(range(2, inp.dim()))
+    return (((2.0 * tgt * inp).mean(dim=dims) + 1e-6) / ((tgt ** 2).mean(dim=dims) + (inp ** 2).mean(dim=dims) + 1e-6)).mean()
+
+
+def jdet_leq0_percent(df: Tensor) -> Tensor:
+    """the 'JDetLeq0' metric   evaluate.py:1441-1446"""
+    jd = jacobian_det(df)
+    return (jd <= 0).sum() / jd.numel() * 100
+
+
+def warp_landmarks(lm: Tensor, df: Tensor) -> Tensor:
+    """Evaluate.warp_landmarks   evaluate.py:410-423 (= src/components/utils.py:15-25)"""
+    i = lm.long()
+    return i - df[:, :, i[0, :, 0], i[0, :, 1], i[0, :, 2]].transpose(-2, -1)
+
+
+def transform_segmentation(sd, cfg: "Cfg", final_dfs: Dict[int, Tensor], seg: Tensor) -> Dict[int, Tensor]:
+    """PULPo.transform_segmentation   models.py:370-388: the full-resolution map on every level for df_resolution 'full_res', else the
+    avg-pool chain (level 0 keeps the full map)"""
+    L, o = cfg.latent_levels, cfg.total_levels - cfg.latent_levels
+    if cfg.df_resolution == "full_res":
+        level_seg = {l: seg for l in range(L)}
+    else:
+        level_seg = {0: seg}
+        for _ in range(o):
+            level_seg[0] = pool2(level_seg[0])
+        for l in range(1, L):
+            level_seg[l] = pool2(level_seg[l - 1])
+        level_seg[0] = seg
+    return {k: warp(final_dfs[k], level_seg[k]) for k in final_dfs}
+
+
+def recon_ncc_dice(outs, y: Tensor, yhat_seg: Dict[int, Tensor], seg_y: Tensor, cfg: "Cfg", dice_factor: float = 1):
+    """HierarchicalReconstructionLoss with recon_loss = ['ncc', 'dice']   losses.py:301-325"""
+    window, _, rec_w, _ = weight_tables(cfg)
+    yhat = outs[7]
+    rec_l = {}
+    for l, w in rec_w.items():
+        t = w * ncc(yhat[l], resize_to(y, yhat[l].shape[2:]), window[l], cfg.gamma)
+        t = t + w * soft_dice(yhat_seg[l], resize_to(seg_y, yhat_seg[l].shape[2:]), dice_factor)
+        rec_l[l] = t / 2
+    return sum(rec_l.values()), rec_l
+
+
 # =============================================================================== network
 OUT_NAMES = ("mus", "sigmas", "samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed")
 

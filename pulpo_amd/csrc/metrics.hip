@@ -302,6 +302,120 @@ PULPO_API int pulpo_jdetstd_bwd(const float* df, const float* jdet, const double
     return pulpo::check_launch("jdetstd_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------ evaluation scalars (evaluate.py)
+// rmse (evaluate.py:315-319), dsc (:321-327), % of voxels with |J| <= 0 (:1441-1446), landmark warp (:410-423 = src/components/utils.py:15-25)
+namespace {
+
+__global__ void rmse_finalize_kernel(const float* __restrict__ partial, int nblk, double n, float* __restrict__ out) {
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 64) s += partial[k];
+    s = pulpo::wave_sum_d(s);
+    if (threadIdx.x == 0) out[0] = (float)sqrt(s / n);
+}
+
+// dsc = mean over planes of ((2 t i).mean + 1e-6) / ((t^2).mean + (i^2).mean + 1e-6), means over the plane's V voxels
+__global__ void dsc_finalize_kernel(const float* __restrict__ partial, int nplanes, int nb, double V, float* __restrict__ out) {
+    double acc = 0.0;
+    for (int p = threadIdx.x; p < nplanes; p += 64) {
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int k = 0; k < nb; ++k) {
+            const float* q = partial + ((long)p * nb + k) * 3;
+            s0 += q[0]; s1 += q[1]; s2 += q[2];
+        }
+        acc += (2.0 * s0 / V + 1e-6) / (s1 / V + s2 / V + 1e-6);
+    }
+    acc = pulpo::wave_sum_d(acc);
+    if (threadIdx.x == 0) out[0] = (float)(acc / nplanes);
+}
+
+__global__ __launch_bounds__(256) void count_leq0_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float local = 0.f;                               // <= 2^24 elements per thread: exact in fp32
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) local += x[e] <= 0.f ? 1.f : 0.f;
+    const float t = block_sum_256(local, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ void percent_finalize_kernel(const float* __restrict__ partial, int nblk, double n, float* __restrict__ out) {
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 64) s += partial[k];
+    s = pulpo::wave_sum_d(s);
+    if (threadIdx.x == 0) out[0] = (float)(s / n) * 100.f;          // (count / numel) * 100 in fp32 like the reference's tensor expression
+}
+
+// out[s][k][c] = trunc(lm[k][c]) - df[s][c][i0][i1][i2], i = trunc(lm[k]) with Python-style negative wrap; flag[0] = 1 if any index is out of range
+__global__ void warp_landmarks_kernel(const float* __restrict__ lm, const float* __restrict__ df, float* __restrict__ out, int nlm, int nsamp, int nd,
+                                      int D, int H, int W, int* __restrict__ flag) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlm * nsamp) return;
+    const int k = t % nlm, s = t / nlm;
+    const int S[3] = {D, H, W};
+    long idx[3] = {0, 0, 0};
+    float base[3];
+    bool ok = true;
+    for (int c = 0; c < nd; ++c) {
+        const long i = (long)lm[(long)k * nd + c];            // .long(): truncation toward zero
+        base[c] = (float)i;
+        const int dim = nd == 3 ? c : c + 1;                    // 2-D fields are (B,2,H,W): D == 1
+        long j = i < 0 ? i + S[dim] : i;
+        if (j < 0 || j >= S[dim]) { ok = false; j = 0; }
+        idx[dim] = j;
+    }
+    if (!ok) atomicOr(flag, 1);
+    const long V = (long)D * H * W, v = (idx[0] * H + idx[1]) * W + idx[2];
+    for (int c = 0; c < nd; ++c)
+        out[((long)s * nlm + k) * nd + c] = ok ? base[c] - df[((long)s * nd + c) * V + v] : __builtin_nanf("");
+}
+
+}  // namespace
+
+// rmse = sqrt(mean((a - b)^2)) over all n elements; partial: pulpo_metric_blocks(n) floats; out: 1 float
+PULPO_API int pulpo_rmse(const float* a, const float* b, int64_t n, float* partial, float* out, void* stream) {
+    PULPO_REQUIRE(a && b && partial && out && n > 0, "rmse: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = pulpo_metric_blocks(n);
+    hipLaunchKernelGGL(sqdiff_fwd_kernel, dim3(nblk), dim3(256), 0, st, a, b, (long)n, partial);
+    int rc = pulpo::check_launch("rmse sums");
+    if (rc) return rc;
+    hipLaunchKernelGGL(rmse_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nblk, (double)n, out);
+    return pulpo::check_launch("rmse finalize");
+}
+// dice similarity coefficient of evaluate.py:321-327; nplanes = B*C planes of V voxels; partial: nplanes*pulpo_dice_blocks(V)*3 floats
+PULPO_API int pulpo_dsc(const float* inp, const float* tgt, int nplanes, int64_t V, float* partial, float* out, void* stream) {
+    PULPO_REQUIRE(inp && tgt && partial && out && nplanes > 0 && V > 0, "dsc: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = pulpo_dice_blocks(V);
+    hipLaunchKernelGGL(dice_sums_kernel, dim3(nb, nplanes), dim3(256), 0, st, inp, tgt, (long)V, partial);
+    int rc = pulpo::check_launch("dsc sums");
+    if (rc) return rc;
+    hipLaunchKernelGGL(dsc_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nplanes, nb, (double)V, out);
+    return pulpo::check_launch("dsc finalize");
+}
+// 100 * count(x <= 0) / n (the JDetLeq0 metric on a Jacobian-determinant map); partial: pulpo_metric_blocks(n) floats
+PULPO_API int pulpo_percent_leq0(const float* x, int64_t n, float* partial, float* out, void* stream) {
+    PULPO_REQUIRE(x && partial && out && n > 0, "percent_leq0: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = pulpo_metric_blocks(n);
+    hipLaunchKernelGGL(count_leq0_kernel, dim3(nblk), dim3(256), 0, st, x, (long)n, partial);
+    int rc = pulpo::check_launch("percent_leq0 count");
+    if (rc) return rc;
+    hipLaunchKernelGGL(percent_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nblk, (double)n, out);
+    return pulpo::check_launch("percent_leq0 finalize");
+}
+// lm: (nlm, nd) landmark coordinates (floats, truncated like .long()); df: (nsamp, nd, D, H, W) planar (nd == 2: D must be 1);
+// out: (nsamp, nlm, nd); flag: one int, zeroed here, set to 1 when a landmark indexes outside the field (the reference raises IndexError)
+PULPO_API int pulpo_warp_landmarks(const float* lm, const float* df, float* out, int nlm, int nsamp, int nd, int D, int H, int W, int* flag,
+                                   void* stream) {
+    PULPO_REQUIRE(lm && df && out && flag && nlm > 0 && nsamp > 0 && (nd == 3 || (nd == 2 && D == 1)) && D > 0 && H > 0 && W > 0,
+                  "warp_landmarks: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
+    if (e != hipSuccess) return pulpo::fail((int)e, "warp_landmarks memset: %s", hipGetErrorString(e));
+    const int n = nlm * nsamp;
+    hipLaunchKernelGGL(warp_landmarks_kernel, dim3((n + 127) / 128), dim3(128), 0, st, lm, df, out, nlm, nsamp, nd, D, H, W, flag);
+    return pulpo::check_launch("warp_landmarks");
+}
+
 // ------------------------------------------------------------------------------------------------ KL_nondiagonal
 // src/losses.py:8-44.  loss = (mean(lambda*D*sigma^2 - log sigma^2) + lambda/2 * (0.5/3) * sum_axes mean(fwd diff of mu)^2) * 3 * 0.5 * V
 // D(v) = number of in-volume voxels of the 3x3x3 neighbourhood minus one.

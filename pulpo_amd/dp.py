@@ -28,8 +28,10 @@ class FlatArena:
     def __init__(self, module: nn.Module, params: Optional[List[nn.Parameter]] = None):
         """params: optional explicit order of the module's trainable parameters inside the arena (bucketed all-reduce keeps
         every bucket contiguous); default = module.parameters() order"""
+        self.module_order: List[nn.Parameter] = [p for p in module.parameters() if p.requires_grad]     # torch.optim.Adam(module.parameters()) order
+        self.module_names: List[str] = [n for n, p in module.named_parameters() if p.requires_grad]
         if params is None:
-            params = [p for p in module.parameters() if p.requires_grad]
+            params = list(self.module_order)
         elif {id(p) for p in params} != {id(p) for p in module.parameters() if p.requires_grad}:
             raise ValueError("FlatArena: `params` must be a permutation of the module's trainable parameters")
         if not params:
@@ -86,17 +88,60 @@ class FusedAdam:
         self.t = 0
 
     def state_dict(self) -> dict:
-        """checkpointable optimizer state, keyed like torch.optim.Adam's per-parameter state ('step', 'exp_avg', 'exp_avg_sq') but flat"""
-        return {"step": self.t, "exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone(), "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
-                "numel": self.arena.numel}
+        """Optimizer state in torch.optim.Adam's own layout - `state[i] = {step, exp_avg, exp_avg_sq}` and `param_groups[0]['params'] =
+        [0..n-1]` with i the parameter's index in `module.parameters()` order - so a checkpoint written here resumes under
+        `configure_optimizers()`'s torch.optim.Adam (Lightning `optimizer_states`, reference models.py:398-400) and the reverse.  The arena's
+        internal (bucket) order never reaches the file; `param_names` additionally keys every entry by parameter name."""
+        a = self.arena
+        slot = {id(p): (o, p) for p, o in zip(a.params, a.offsets)}
+        state = {}
+        for i, p in enumerate(a.module_order):
+            o, _ = slot[id(p)]
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": self.m[o:o + n].view_as(p).clone(),
+                        "exp_avg_sq": self.v[o:o + n].view_as(p).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(len(a.module_order)))}
+        return {"state": state, "param_groups": [group], "param_names": list(a.module_names)}
 
     def load_state_dict(self, sd: dict) -> None:
-        if int(sd["numel"]) != self.arena.numel:
-            raise ValueError(f"FusedAdam: checkpoint holds {sd['numel']} elements, this arena {self.arena.numel} (different model or parameter order)")
-        self.t = int(sd["step"])
-        self.m.copy_(sd["exp_avg"])
-        self.v.copy_(sd["exp_avg_sq"])
-        self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
+        """accepts state_dict() of this class or of torch.optim.Adam over the same module's parameters; entries are scattered into the
+        arena by parameter (matched by name when the checkpoint carries `param_names`, else by index) and shape-checked"""
+        if "state" not in sd or "param_groups" not in sd:
+            raise ValueError("FusedAdam.load_state_dict: expected torch.optim.Adam's layout ('state', 'param_groups')")
+        a = self.arena
+        slot = {id(p): o for p, o in zip(a.params, a.offsets)}
+        group = sd["param_groups"][0]
+        if len(sd["param_groups"]) != 1 or len(group["params"]) != len(a.module_order):
+            raise ValueError(f"FusedAdam: checkpoint holds {sum(len(g['params']) for g in sd['param_groups'])} parameters in "
+                             f"{len(sd['param_groups'])} group(s), this model {len(a.module_order)} in one")
+        if group.get("amsgrad") or group.get("weight_decay", 0) or group.get("maximize"):
+            raise ValueError("FusedAdam: amsgrad / weight_decay / maximize are not part of the reference's optimizer (models.py:399)")
+        names = sd.get("param_names")
+        if names is not None:
+            if sorted(names) != sorted(a.module_names):
+                raise ValueError("FusedAdam: checkpoint parameter names differ from this model's")
+            index_of = {n: i for i, n in enumerate(names)}
+            order = [index_of[n] for n in a.module_names]           # checkpoint index of our i-th parameter
+        else:
+            order = list(range(len(a.module_order)))
+        steps = set()
+        self.m.zero_()
+        self.v.zero_()
+        for i, p in enumerate(a.module_order):
+            st = sd["state"].get(group["params"][order[i]])
+            if st is None:                    # torch creates state lazily: a parameter that never received a gradient has none
+                continue
+            for key, dst in (("exp_avg", self.m), ("exp_avg_sq", self.v)):
+                if tuple(st[key].shape) != tuple(p.shape):
+                    raise ValueError(f"FusedAdam: {key} of '{a.module_names[i]}' has shape {tuple(st[key].shape)}, parameter {tuple(p.shape)}")
+                dst[slot[id(p)]:slot[id(p)] + p.numel()].view_as(p).copy_(st[key])
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"FusedAdam: per-parameter step counts differ ({sorted(steps)}); one shared step count is assumed")
+        self.t = steps.pop() if steps else 0
+        self.lr, self.betas, self.eps = float(group["lr"]), tuple(group["betas"]), float(group["eps"])
 
     def step(self, grad_scale: float = 1.0) -> None:
         from . import ops
@@ -156,7 +201,7 @@ class DataParallelStepper:
         self.arena = FlatArena(model, params)
         off = self.arena.offsets + [self.arena.numel]
         self.buckets = [(off[a], off[b]) for a, b in ranges]            # float ranges of the arena, in completion order
-        self.overlap = bool(overlap) and len(self.buckets) > 1
+        self.overlap = bool(overlap) and len(self.buckets) > 1 and os.environ.get("PULPO_DP_OVERLAP", "1") != "0"
         self._works: List = []
         self._launched = 0
         self._armed = False

@@ -208,7 +208,7 @@ class PULPo(ABC, LightningModule):
     def predict_output_samples(self, x: torch.Tensor, y: torch.Tensor, N: int = 1):
         """N stochastic forward passes stacked on the batch axis -> ({l: (B,N,1,...)}, {l: (B,N,3,...)})"""
         bs = x.shape[0]
-        xb, yb = x.repeat(N, 1, 1, 1, 1), y.repeat(N, 1, 1, 1, 1)
+        xb, yb = torch.cat([x] * N, dim=0), torch.cat([y] * N, dim=0)          # rank-agnostic (3-D volumes and 2-D slices), models.py:314-315
         outs = self.autoencoder(xb, self.downpath(xb, yb))
         individual_dfs, outputs = outs[4], outs[7]
         fold = lambda t: t.view([N, bs] + list(t.shape[1:])).transpose(0, 1)
@@ -246,12 +246,16 @@ class PULPo(ABC, LightningModule):
         return combined, final
 
     def transform_segmentation(self, dfs: Dict[int, torch.Tensor], seg: torch.Tensor):
-        level_seg = {0: seg}
-        for _ in range(self.lk_offset):
-            level_seg[0] = ops.avg_pool2(level_seg[0])
-        for l in range(1, self.latent_levels):
-            level_seg[l] = ops.avg_pool2(level_seg[l - 1])
-        level_seg[0] = seg
+        """warp the (pooled) segmentation maps with each level's field (reference models.py:370-388)"""
+        if self.df_resolution == "full_res":        # every level's field is full resolution: every level warps the full map (models.py:375-376)
+            level_seg = {l: seg for l in range(self.latent_levels)}
+        else:
+            level_seg = {0: seg}
+            for _ in range(self.lk_offset):
+                level_seg[0] = ops.avg_pool2(level_seg[0])
+            for l in range(1, self.latent_levels):
+                level_seg[l] = ops.avg_pool2(level_seg[l - 1])
+            level_seg[0] = seg
         return {k: self.autoencoder.decoders[k].spatial_transform(dfs[k], level_seg[k]) for k in dfs}
 
     def configure_optimizers(self):

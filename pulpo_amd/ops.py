@@ -176,12 +176,13 @@ def _hbm_end(start, name: str, nbytes: float):
     HBM_TRACE.append((name, nbytes, start, end))
 
 
-def _trace_end(start, name: str, flops: float):
+def _trace_end(start, name: str, flops: float, nbytes: float = 0.0):
+    """nbytes: algorithmic HBM bytes of the launch (operands read once + result written once)"""
     if start is None:
         return
     end = torch.cuda.Event(enable_timing=True)
     end.record()
-    CONV_TRACE.append((name, flops, start, end))
+    CONV_TRACE.append((name, flops, start, end, nbytes))
 
 
 # Operand precision of the 3x3x3 convolutions: "fp32" (the reference's arithmetic; exact-fp32 MFMA) or "bf16" (BASELINE configs
@@ -244,7 +245,7 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
         lib.call(f"pulpo_conv3d_k3_fwd_{algo}", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc, _ptr(stats),
                  B, D, H, W, K, N, _stream())
         tmpl = f"<32,{'true' if vec_ok else 'false'}>" if algo == "wino" else f"<{'true' if vec_ok else 'false'}>"
-        _trace_end(t0, f"conv3d_k3_{algo}_mfma{tmpl}", 54.0 * K * N * B * D * H * W)
+        _trace_end(t0, f"conv3d_k3_{algo}_mfma{tmpl}", 54.0 * K * N * B * D * H * W, 4.0 * (K + N) * B * D * H * W)
         return
     sfx = "_bf16" if bf16 else ""
     nscr = lib.query(f"pulpo_conv3d_k3_fwd{sfx}_scratch_floats", B, D, H, W, K, N)
@@ -262,7 +263,7 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
         else:
             cfg = lib.query("pulpo_conv3d_k3_tile_config", K, N)
             name = f"conv3d_k3_mfma<{cfg // 1000},{cfg % 1000},{'true' if vec_ok and cfg // 1000 >= 16 else 'false'}>"
-        _trace_end(t0, name, 54.0 * K * N * B * D * H * W)
+        _trace_end(t0, name, 54.0 * K * N * B * D * H * W, 4.0 * (K + N) * B * D * H * W)
 
 
 def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -276,7 +277,7 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
     sfx = "_bf16" if _use_bf16(Cin) else ""
     lib.call(f"pulpo_conv3d_k3_wgrad{sfx}", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), int(into is not None), _ptr(scratch), B, D, H, W,
              Cin, Cout, _stream())
-    _trace_end(t0, f"conv3d_k3_wgrad{sfx or '_mfma'}(+memset,unpack)", 54.0 * Cin * Cout * B * D * H * W)
+    _trace_end(t0, f"conv3d_k3_wgrad{sfx or '_mfma'}(+memset,unpack)", 54.0 * Cin * Cout * B * D * H * W, 4.0 * (Cin + Cout) * B * D * H * W)
     return None if into is not None else dw
 
 
@@ -935,3 +936,59 @@ class StreamingMoments:
 def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, gscale: float = 1.0):
     _require_gpu(p, g, m, v)
     lib.call("pulpo_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, int(step), gscale, _stream())
+
+
+# ------------------------------------------------------------------------------------------------ evaluation scalars (evaluate.py)
+def rmse(inp, target):
+    """sqrt(MSELoss(inp, target)) as a 0-d device tensor (evaluate.py:315-319)"""
+    _require_gpu(inp, target)
+    a, b = inp.detach().contiguous(), target.detach().expand_as(inp).contiguous()
+    n = a.numel()
+    part = torch.empty(lib.query("pulpo_metric_blocks", n), device=a.device, dtype=torch.float32)
+    out = torch.empty((), device=a.device, dtype=torch.float32)
+    lib.call("pulpo_rmse", _ptr(a), _ptr(b), n, _ptr(part), _ptr(out), _stream())
+    return out
+
+
+def dsc(inp, target):
+    """dice similarity coefficient of two (soft) segmentation maps (evaluate.py:321-327), 0-d device tensor"""
+    _require_gpu(inp, target)
+    a, b = inp.detach().contiguous(), target.detach().expand_as(inp).contiguous()
+    nplanes = a.shape[0] * a.shape[1]
+    V = a.numel() // nplanes
+    part = torch.empty(nplanes * lib.query("pulpo_dice_blocks", V) * 3, device=a.device, dtype=torch.float32)
+    out = torch.empty((), device=a.device, dtype=torch.float32)
+    lib.call("pulpo_dsc", _ptr(a), _ptr(b), nplanes, V, _ptr(part), _ptr(out), _stream())
+    return out
+
+
+def percent_leq0(x):
+    """100 * (x <= 0).sum() / x.numel() as a 0-d device tensor (the 'JDetLeq0' metric, evaluate.py:1441-1446)"""
+    _require_gpu(x)
+    a = x.detach().contiguous()
+    n = a.numel()
+    part = torch.empty(lib.query("pulpo_metric_blocks", n), device=a.device, dtype=torch.float32)
+    out = torch.empty((), device=a.device, dtype=torch.float32)
+    lib.call("pulpo_percent_leq0", _ptr(a), n, _ptr(part), _ptr(out), _stream())
+    return out
+
+
+def warp_landmarks(lm, df):
+    """lm.long() - df[:, :, lm[0,:,0], lm[0,:,1], lm[0,:,2]].transpose(-2, -1)   (evaluate.py:410-423, src/components/utils.py:15-25)
+    lm: (1, n_landmarks, ndims); df: (n_samples, ndims, ...) -> (n_samples, n_landmarks, ndims) float.  Out-of-range landmarks raise
+    IndexError like the reference's tensor indexing (one host read of a device flag: an evaluation-time helper)."""
+    _require_gpu(df)
+    nd = df.dim() - 2
+    if lm.dim() != 3 or lm.shape[0] != 1 or lm.shape[2] != nd or df.shape[1] != nd or nd not in (2, 3):
+        raise PulpoHipError(f"warp_landmarks: lm (1, n, ndims) and df (samples, ndims, ...) expected, got {tuple(lm.shape)} and {tuple(df.shape)}")
+    d = df.detach().contiguous()
+    l = lm.detach().to(device=d.device, dtype=torch.float32).contiguous()
+    nlm, ns = int(lm.shape[1]), int(d.shape[0])
+    D, H, W = (1, *d.shape[2:]) if nd == 2 else d.shape[2:]
+    out = torch.empty((ns, nlm, nd), device=d.device, dtype=torch.float32)
+    flag = torch.empty(1, device=d.device, dtype=torch.int32)
+    lib.call("pulpo_warp_landmarks", _ptr(l), _ptr(d), _ptr(out), nlm, ns, nd, int(D), int(H), int(W),
+             ctypes.cast(flag.data_ptr(), ctypes.POINTER(ctypes.c_int)), _stream())
+    if int(flag.item()):
+        raise IndexError("warp_landmarks: landmark index out of bounds of the displacement field")
+    return out

@@ -33,7 +33,7 @@ def collect(d: str, counter: str):
     return tot, cnt
 
 
-FETCH_FACTOR = [(re.compile(r"conv3d_k3_wgrad_mfma<true|conv3d_k3_wgrad_wino"), 2.0), (re.compile(r"conv3d_k3_(wino_)?mfma"), 1.0),
+FETCH_FACTOR = [(re.compile(r"conv3d_k3_wgrad_mfma<true|conv3d_k3_wgrad_wino|conv3d_k3_wgrad_w2"), 2.0), (re.compile(r"conv3d_k3_(wino2?_)?mfma"), 1.0),
                 (re.compile(r"conv3d_k3_wgrad_mfma<false"), 1.0)]
 
 

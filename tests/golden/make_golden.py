@@ -360,6 +360,56 @@ def gen_step(name, T, L, size, n0, B, seed, with_grads=True, smooth=False, df_re
     return float(total)
 
 
+# --------------------------------------------------------------------------- 11b. --recon_loss ncc dice with segmentations
+def gen_step_dice(name, df_resolution, T=3, L=2, size=(16, 16, 16), n0=2, B=1, seed=160):
+    """training step with recon_loss = ["ncc", "dice"] (train.py:29, --segs): the segmentation maps are warped per level exactly as
+    models.py:370-388 (transform_segmentation) does - full-resolution map on EVERY level when df_resolution == "full_res", the avg-pool
+    chain otherwise - with the reference's own SpatialTransformer instances, then fed to the reference's HierarchicalReconstructionLoss."""
+    st = Step(T, L, list(size), n0, seed, df_resolution)
+    st.rec = ls.HierarchicalReconstructionLoss(["ncc", "dice"], dict(st.rec.weight_dict), False, 3, st.rec.window_size)
+    g = torch.Generator().manual_seed(seed + 2)
+    y = smooth_volume(g, tuple(size), B)
+    x = 0.6 * smooth_volume(g, tuple(size), B) + 0.4 * y
+    # soft 3-label "segmentations" (3 channels, like one-hot label maps after interpolation)
+    seg_x = torch.softmax(4 * torch.cat([smooth_volume(g, tuple(size), B) for _ in range(3)], dim=1), dim=1)
+    seg_y = torch.softmax(4 * torch.cat([smooth_volume(g, tuple(size), B) for _ in range(3)], dim=1), dim=1)
+    o = T - L
+    eps = {l: torch.randn(B, 3, *[s // 2 ** (l + o) for s in size], generator=g) for l in range(L)}
+    st.set_eps(eps)
+    out = {"cfg": np.array([T, L, n0, B] + list(size), dtype=np.int64), "x": npy(x), "y": npy(y), "seg_x": npy(seg_x), "seg_y": npy(seg_y)}
+    out.update({f"eps.{l}": npy(e) for l, e in eps.items()})
+    out.update({"sd0." + k: npy(v) for k, v in st.state_dict().items() if not k.endswith(".grid")})
+    st.down.train(); st.ae.train()
+    outs = st.forward(x, y)
+    mus, sigmas, samples, vfs, ind, comb, fin, yhat = outs
+    # models.py:370-388
+    if df_resolution == "full_res":
+        level_seg = {l: seg_x for l in range(L)}
+    else:
+        level_seg = {0: seg_x}
+        for _ in range(o):
+            level_seg[0] = F.avg_pool3d(level_seg[0], kernel_size=2, stride=2, padding=0, ceil_mode=True)
+        for l in range(1, L):
+            level_seg[l] = F.avg_pool3d(level_seg[l - 1], kernel_size=2, stride=2, padding=0, ceil_mode=True)
+        level_seg[0] = seg_x
+    yhat_seg = {k: st.ae.decoders[k].spatial_transform(fin[k], level_seg[k]) for k in fin}
+    pm, ps = st.prior(mus, sigmas)
+    kl, _ = st.kl(pm, ps, mus, sigmas)
+    kl = kl * 0.1
+    rec, rec_l = st.rec(yhat, y, yhat_seg, seg_y, gamma=0.05, dice_factor=1)
+    reg, _ = st.reg(fin, lamb=0.025)
+    total = kl + rec + reg
+    out.update({f"train.y_hat_seg.{l}": npy(v) for l, v in yhat_seg.items()})
+    out.update({f"train.rec_l.{l}": npy(v) for l, v in rec_l.items()})
+    out.update({"train.total": npy(total), "train.kl": npy(kl), "train.rec": npy(rec), "train.reg": npy(reg)})
+    total.backward()
+    for k, p_ in st.named_parameters():
+        if p_.grad is not None:
+            out["grad." + k] = npy(p_.grad)
+    save(name, **out)
+    return float(total)
+
+
 # --------------------------------------------------------------------------- 12. alternative losses / evaluation metrics (SURVEY §8f.3-4)
 def gen_metrics():
     g = torch.Generator().manual_seed(130)
@@ -397,6 +447,37 @@ def gen_metrics():
     gm, gs = torch.autograd.grad(l, [mu, sg])
     out.update(kln_mu=npy(mu), kln_sigma=npy(sg), kln_loss=npy(l), kln_gmu=npy(gm), kln_gsigma=npy(gs), kln_D=npy(kln.D))
     save("metrics", **out)
+
+
+def gen_evalmetrics():
+    """evaluation scalars of the harness.  warp_landmarks comes from the REAL reference module
+    (src/components/utils.py:15-25, identical to Evaluate.warp_landmarks evaluate.py:410-423); rmse / dsc / JDetLeq0 are methods or inline
+    code of evaluate.py (not importable here: h5py, seaborn, torchvision are absent), so their arithmetic is restated verbatim:
+        rmse      evaluate.py:315-319   sqrt(torch.nn.MSELoss()(input, target))
+        dsc       evaluate.py:321-327   ((2*t*i).mean(spatial) + 1e-6) / ((t**2).mean(spatial) + (i**2).mean(spatial) + 1e-6), .mean()
+        JDetLeq0  evaluate.py:1441-1446 (sum(jdet <= 0) / prod(jdet.squeeze().size())) * 100 with the reference's jacobian_det"""
+    import src.components.utils as cu
+    g = torch.Generator().manual_seed(170)
+    out = {}
+    a = torch.rand(2, 1, 9, 10, 11, generator=g)
+    b = torch.rand(2, 1, 9, 10, 11, generator=g)
+    out.update(rmse_a=npy(a), rmse_b=npy(b), rmse=npy(torch.sqrt(torch.nn.MSELoss()(a, b))))
+    i = torch.softmax(3 * torch.randn(2, 4, 7, 8, 9, generator=g), dim=1)
+    t = torch.softmax(3 * torch.randn(2, 4, 7, 8, 9, generator=g), dim=1)
+    sumdims = [2, 3, 4]
+    d = (((2. * t * i).mean(dim=sumdims) + 1e-6) / ((t ** 2).mean(dim=sumdims) + (i ** 2).mean(dim=sumdims) + 1e-6)).mean()
+    out.update(dsc_in=npy(i), dsc_tgt=npy(t), dsc=npy(d))
+    df = torch.randn(1, 3, 10, 12, 14, generator=g) * 4.0            # large enough for folding voxels
+    jd = ls.jacobian_det(df)
+    pct = (torch.sum(jd <= 0) / torch.prod(torch.tensor(jd.squeeze().size()))) * 100
+    assert 1.0 < float(pct) < 99.0
+    out.update(leq_df=npy(df), leq_jdet=npy(jd), leq_pct=npy(pct))
+    # landmarks: float coordinates (the datasets store them as floats; .long() truncates), 3 samples of a field
+    dfl = torch.randn(3, 3, 10, 12, 14, generator=g) * 2.0
+    lm = torch.stack([torch.rand(1, 17, generator=g) * 9.99, torch.rand(1, 17, generator=g) * 11.99, torch.rand(1, 17, generator=g) * 13.99], dim=-1)
+    lm[0, 0] = torch.tensor([-1.0, -2.0, -3.0])                       # negative indices wrap in the reference's tensor indexing
+    out.update(lm=npy(lm), lm_df=npy(dfl), lm_out=npy(cu.warp_landmarks(lm, dfl).float()))
+    save("evalmetrics", **out)
 
 
 def gen_init_tables():
@@ -506,6 +587,13 @@ if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "2d":
         gen_2d()
+        raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "evalmetrics":
+        gen_evalmetrics()
+        raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dice":
+        for res in ("full_res", "level_res"):
+            print("   total loss", gen_step_dice(f"step_dice_{res}_T3L2_n2_16", res))
         raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "step32":
         # a step large enough (32^3) for the Winograd forward / data-gradient and weight-gradient kernels to be the ones compared

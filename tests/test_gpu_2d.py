@@ -176,3 +176,19 @@ def test_training_step_2d_matches_reference_golden(api, golden):
         det_out, det_ind = model.predict_deterministic(x, y)
         for l in det_out:
             np.testing.assert_allclose(det_out[l].cpu().numpy(), g[f"det.transformed.{l}"], atol=1e-4)
+            np.testing.assert_allclose(det_ind[l].cpu().numpy(), g[f"det.individual_dfs.{l}"], atol=1e-4)
+        # predict_output_samples / predict on slices (reference models.py:312-331 stacks with torch.vstack, rank-agnostic): N copies on
+        # the batch axis with the SAME injected noise -> every sample equals the single stochastic eval forward
+        for l in range(L):
+            e = model.autoencoder.encoders[l].sampler.fixed_eps
+            model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(e.repeat(2, 1, 1, 1))
+        o_s, d_s = model.predict_output_samples(x, y, N=2)
+        for l in o_s:
+            assert tuple(o_s[l].shape[:3]) == (B, 2, 1) and tuple(d_s[l].shape[:3]) == (B, 2, 2) and o_s[l].dim() == 5
+            np.testing.assert_allclose(o_s[l][:, 0].cpu().numpy(), g[f"eval.transformed.{l}"], atol=1e-4)
+            np.testing.assert_allclose(d_s[l][:, 1].cpu().numpy(), g[f"eval.individual_dfs.{l}"], atol=1e-4)
+        avg_out, avg_dfs = model.predict(x, y, N=2)
+        for l in avg_dfs:
+            np.testing.assert_allclose(avg_dfs[l].cpu().numpy(), g[f"eval.individual_dfs.{l}"], atol=1e-4)
+            assert tuple(avg_out[l].shape) == (B, 1) + tuple(avg_dfs[l].shape[2:]) and bool(torch.isfinite(avg_out[l]).all())
+        np.testing.assert_allclose(avg_out[0].cpu().numpy(), g["eval.transformed.0"], atol=1e-4)

@@ -264,7 +264,6 @@ def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size, algo):
     direct kernels; ragged H / W (odd sizes: half-filled blocks) included"""
     from pulpo_amd._lib import lib
     assert lib.query("pulpo_conv3d_k3_algo", B, *size, Cin, Cout) in (1, 2)
-    ops.CONV_ALGO = algo                      # "wino2" is the library's default choice; "wino" (x only) stays selectable
     gen = torch.Generator().manual_seed(B * 1000 + Cin * 10 + Cout)
     x = torch.randn(B, Cin, *size, generator=gen)
     w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (27 * Cin) ** 0.5
@@ -275,9 +274,13 @@ def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size, algo):
     gref = torch.autograd.grad((ref * up.double()).sum(), [xr, wr, br])
     xd = x.cuda().contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
     wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
-    out = ops.conv3d_k3(xd, wd, bd)
+    ops.CONV_ALGO = algo                      # "wino2" is the library's default choice; "wino" (x only) stays selectable
+    try:
+        out = ops.conv3d_k3(xd, wd, bd)
+        gx, gw, gb = torch.autograd.grad((out * up.cuda()).sum(), [xd, wd, bd])
+    finally:
+        ops.CONV_ALGO = None
     assert rel_l2(out, ref) < 2e-6
-    gx, gw, gb = torch.autograd.grad((out * up.cuda()).sum(), [xd, wd, bd])
     assert rel_l2(gx, gref[0]) < 2e-6
     assert rel_l2(gw, gref[1]) < 1e-5
     assert rel_l2(gb, gref[2]) < 1e-5
@@ -396,6 +399,31 @@ def test_alternative_losses_and_metrics_golden(ops, golden):
         s_ = ops.jdet_std(d, 0.3, bool(norm))
         close(s_, g[f"jstd_norm{norm}"], rtol=1e-4)
         close(torch.autograd.grad(s_, [d])[0], g[f"jstd_gd_norm{norm}"], atol=1e-6, rtol=1e-3)
+
+
+def test_eval_metrics_golden(ops, golden):
+    """rmse / dsc / % |J| <= 0 / landmark warp of the evaluation harness (evaluate.py:315-327, 410-423, 1441-1446) on the device against
+    goldens made with the reference's warp_landmarks / jacobian_det and the harness's expressions (make_golden.py evalmetrics)"""
+    from pulpo_amd import eval_metrics as M
+    import src.components.utils as shim_utils
+    g = golden("evalmetrics")
+    close(M.rmse(dev(g["rmse_a"]), dev(g["rmse_b"])), g["rmse"], rtol=1e-6)
+    close(M.dsc(dev(g["dsc_in"]), dev(g["dsc_tgt"])), g["dsc"], rtol=1e-6)
+    df = dev(g["leq_df"])
+    close(M.jdet(df), g["leq_jdet"], atol=1e-4, rtol=1e-5)
+    # a determinant within rounding of 0 may fall on either side: allow the count to differ by the number of such voxels
+    near = float((np.abs(g["leq_jdet"]) < 1e-4).sum()) * 100.0 / g["leq_jdet"].size
+    assert abs(float(M.jdet_leq0_percent(df)) - float(g["leq_pct"])) <= near + 1e-4
+    close(ops.percent_leq0(dev(g["leq_jdet"])), g["leq_pct"], rtol=1e-6)
+    out = shim_utils.warp_landmarks(dev(g["lm"]), dev(g["lm_df"]))
+    assert tuple(out.shape) == g["lm_out"].shape
+    close(out, g["lm_out"], atol=1e-6)
+    out_cpu_lm = M.warp_landmarks(T(g["lm"]), dev(g["lm_df"]))          # landmarks may arrive on the host (dataset tensors)
+    close(out_cpu_lm, g["lm_out"], atol=1e-6)
+    bad = T(g["lm"]).clone()
+    bad[0, 3, 1] = 12.0                                                   # H = 12: out of range -> IndexError like the reference
+    with pytest.raises(IndexError):
+        M.warp_landmarks(bad, dev(g["lm_df"]))
 
 
 def test_recon_loss_options_through_the_model_api(ops):

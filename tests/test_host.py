@@ -142,6 +142,55 @@ def test_flat_arena_views_and_zero_grad():
     assert float(arena.grad.abs().sum()) == 0 and all(float(p.grad.abs().sum()) == 0 for p in lin.parameters())
 
 
+def test_fused_adam_state_dict_is_torch_adam_layout_whatever_the_arena_order():
+    """FusedAdam.state_dict() is torch.optim.Adam's layout (per parameter, module.parameters() order), independent of the arena's internal
+    (bucket) order: round trip through torch.optim.Adam and into an arena with a different permutation"""
+    import pytest
+    from pulpo_amd.dp import FlatArena, FusedAdam
+    torch.manual_seed(0)
+
+    def net():
+        return torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.Linear(5, 2), torch.nn.Linear(2, 7))
+
+    a = net()
+    pa = list(a.parameters())
+    arena = FlatArena(a, params=pa[::-1])                     # permuted arena, like the completion-ordered buckets
+    opt = FusedAdam(arena, lr=3e-4)
+    opt.m.copy_(torch.randn(arena.numel)); opt.v.copy_(torch.rand(arena.numel)); opt.t = 5
+    sd = opt.state_dict()
+    assert sd["param_names"] == [n for n, _ in a.named_parameters()]
+    for i, p in enumerate(pa):
+        o = arena.offsets[arena.params.index(p)] if False else arena.offsets[[id(q) for q in arena.params].index(id(p))]
+        assert torch.equal(sd["state"][i]["exp_avg"], opt.m[o:o + p.numel()].view_as(p))
+        assert float(sd["state"][i]["step"]) == 5.0
+    topt = torch.optim.Adam(a.parameters(), lr=1.0)
+    topt.load_state_dict({k: v for k, v in sd.items() if k != "param_names"})
+    assert topt.param_groups[0]["lr"] == 3e-4
+    back = topt.state_dict()
+    b = net()
+    pb = list(b.parameters())
+    arena_b = FlatArena(b, params=[pb[2], pb[0], pb[1], pb[5], pb[3], pb[4]])
+    opt_b = FusedAdam(arena_b)
+    opt_b.load_state_dict(back)
+    assert opt_b.t == 5 and opt_b.lr == 3e-4
+    sd_b = opt_b.state_dict()
+    for i in range(len(pa)):
+        assert torch.equal(sd_b["state"][i]["exp_avg"], sd["state"][i]["exp_avg"]) and torch.equal(sd_b["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])
+    # by name: a checkpoint whose parameter order differs is scattered correctly; wrong shapes / counts are refused
+    perm = [3, 0, 5, 1, 4, 2]
+    shuffled = {"state": {j: sd["state"][i] for j, i in enumerate(perm)}, "param_groups": [dict(sd["param_groups"][0])],
+                "param_names": [sd["param_names"][i] for i in perm]}
+    opt_c = FusedAdam(FlatArena(net()))
+    opt_c.load_state_dict(shuffled)
+    assert all(torch.equal(opt_c.state_dict()["state"][i]["exp_avg"], sd["state"][i]["exp_avg"]) for i in range(len(pa)))
+    bad = {"state": {i: dict(st) for i, st in sd["state"].items()}, "param_groups": sd["param_groups"]}
+    bad["state"][0]["exp_avg"] = torch.zeros(4, 4)
+    with pytest.raises(ValueError):
+        FusedAdam(FlatArena(net())).load_state_dict(bad)
+    with pytest.raises(ValueError):
+        FusedAdam(FlatArena(net())).load_state_dict({"step": 1, "numel": 10})
+
+
 WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
@@ -286,3 +335,58 @@ def test_public_header_is_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_src_shim_extends_its_path_so_reference_subpackages_resolve(tmp_path):
+    """INTEGRATION.md option 1: this repository's root AHEAD of the reference on PYTHONPATH.  `src.models` etc. must come from the shim
+    while `src.data.*` (train.py:7-8, evaluate.py:19-20; not provided here) resolves from the reference's src/ further down the path.
+    A stand-in tree plays the reference (its real dataset modules need h5py, absent from the image)."""
+    ref = tmp_path / "ref"
+    (ref / "src" / "data" / "OASIS").mkdir(parents=True)
+    (ref / "src" / "__init__.py").write_text("")
+    (ref / "src" / "models.py").write_text("raise ImportError('the reference models module must be shadowed by the shim')\n")
+    (ref / "src" / "data" / "OASIS" / "oasis.py").write_text("class Oasis:\n    where = 'reference tree'\n")
+    code = ("import src.models, src.losses, src.components.pulpo, src.components.utils, src.network_blocks, src.utils\n"
+            "from src.data.OASIS import oasis\n"
+            "import os\n"
+            "assert oasis.Oasis.where == 'reference tree'\n"
+            "assert 'pulpo_amd' in src.models.PULPo.__module__, src.models.PULPo.__module__\n"
+            "assert callable(src.components.utils.warp_landmarks)\n"
+            "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, str(ref)]))
+    out = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+def _bench(args, env_extra, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_gpus_2_starts_its_own_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with NO torchrun environment must start two fresh rank processes itself (before any GPU call), rendezvous
+    them on 127.0.0.1, and relay exactly one JSON line with n_gpus 2 from rank 0.  No GPU here, so the ranks run the plumbing-only body
+    (launcher, rendezvous, barrier, max-over-ranks timing, JSON) over gloo; the same launcher code starts the real ranks on a GPU box
+    (tests/test_gpu_step.py::test_bench_two_rank_rehearsal)."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--plumbing-only"], {"PULPO_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["parallelism"] == "dp2" and d["valid"] is False
+
+
+def test_bench_launcher_fails_loudly_when_a_rank_dies():
+    """a rank that exits non-zero ends the whole job with a non-zero code (no silent single-GPU result, no hang)"""
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"PULPO_DIST_BACKEND": "gloo", "HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    assert r.returncode != 0                          # no GPU: every rank refuses to run the product path
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout
+    assert "needs a ROCm GPU" in r.stderr or "exited with code" in r.stderr, r.stderr[-2000:]
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """--gpus N under a torchrun environment of a different size is an error, not a silently different measurement"""
+    r = _bench(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

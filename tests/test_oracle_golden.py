@@ -286,3 +286,58 @@ def test_eval_and_deterministic_modes(golden, case):
     for l in comb:
         close(comb[l], g[f"eval.combined_dfs.{l}"], atol=1e-5)
         close(fin[l], g[f"eval.final_dfs.{l}"], atol=1e-5)
+
+
+def test_eval_scalars_and_landmark_warp(golden):
+    """evaluate.py's rmse / dsc / JDetLeq0 / warp_landmarks restatements against the evalmetrics fixture (landmark warp: the real
+    src/components/utils.py; the others: the harness's expressions evaluated next to the reference's jacobian_det)"""
+    g = golden("evalmetrics")
+    close(O.rmse(T(g["rmse_a"]), T(g["rmse_b"])), g["rmse"], rtol=1e-6)
+    close(O.dsc(T(g["dsc_in"]), T(g["dsc_tgt"])), g["dsc"], rtol=1e-6)
+    close(O.jacobian_det(T(g["leq_df"])), g["leq_jdet"], atol=1e-5, rtol=1e-5)
+    close(O.jdet_leq0_percent(T(g["leq_df"])), g["leq_pct"], rtol=1e-6)
+    close(O.warp_landmarks(T(g["lm"]), T(g["lm_df"])), g["lm_out"], atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("res", ["full_res", "level_res"])
+def test_dice_step_with_segmentations(golden, res):
+    """--recon_loss ncc dice --segs: segmentation warp per level (models.py:370-388; full map on every level for 'full_res') and the
+    two-term reconstruction loss, total loss and every parameter gradient against the reference-made fixture"""
+    g = golden(f"step_dice_{res}_T3L2_n2_16")
+    Tl, L, n0, B, *size = [int(v) for v in g["cfg"]]
+    cfg = O.Cfg(Tl, L, size, n0=n0, df_resolution=res)
+    sd = O.init_state_dict(cfg)
+    for k, v in g.items():
+        if k.startswith("sd0."):
+            assert k[4:] in sd, k
+            sd[k[4:]] = T(v.copy())
+    sd = O.clone_sd(sd, requires_grad=True)
+    eps = {l: T(g[f"eps.{l}"]) for l in range(L)}
+    x, y, seg_x, seg_y = (T(g[k]) for k in ("x", "y", "seg_x", "seg_y"))
+    outs = O.forward(sd, cfg, x, y, eps, training=True)
+    segs = O.transform_segmentation(sd, cfg, outs[6], seg_x)
+    for l, v in segs.items():
+        close(v, g[f"train.y_hat_seg.{l}"], atol=1e-5)
+    _, kl, _, reg, *_ = O.losses(outs, y, cfg)
+    rec, rec_l = O.recon_ncc_dice(outs, y, segs, seg_y, cfg)
+    total = kl + rec + reg
+    for l, v in rec_l.items():
+        close(v, g[f"train.rec_l.{l}"], rtol=2e-6)
+    for key, val in zip(("total", "kl", "rec", "reg"), (total, kl, rec, reg)):
+        close(val, g["train." + key], rtol=2e-6)
+    params = {k: v for k, v in sd.items() if v.requires_grad}
+    grads = torch.autograd.grad(total, list(params.values()), allow_unused=True)
+    n = 0
+    for k, gr in zip(params, grads):
+        if "grad." + k in g:
+            ref = g["grad." + k]
+            assert gr is not None, k
+            if k.endswith("_op.0.bias") and "velocity_field._op.2" not in k:
+                # conv bias in front of a BatchNorm: true gradient zero, rounding noise on both sides (SURVEY 7) - compare on the scale of
+                # the layer's weight gradient
+                wref = np.abs(g["grad." + k[:-4] + "weight"]).max()
+                assert np.abs(gr.numpy()).max() <= 1e-3 * max(wref, 1e-3) and np.abs(ref).max() <= 1e-3 * max(wref, 1e-3), k
+                continue
+            assert np.abs(gr.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
+            n += 1
+    assert n > 40
