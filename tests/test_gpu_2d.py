@@ -190,5 +190,6 @@ def test_training_step_2d_matches_reference_golden(api, golden):
         avg_out, avg_dfs = model.predict(x, y, N=2)
         for l in avg_dfs:
             np.testing.assert_allclose(avg_dfs[l].cpu().numpy(), g[f"eval.individual_dfs.{l}"], atol=1e-4)
-            assert tuple(avg_out[l].shape) == (B, 1) + tuple(avg_dfs[l].shape[2:]) and bool(torch.isfinite(avg_out[l]).all())
+            want = tuple(size) if l == 0 else tuple(avg_dfs[l].shape[2:])          # level 0's field is resized to full resolution (models.py:364-366)
+            assert tuple(avg_out[l].shape) == (B, 1) + want and bool(torch.isfinite(avg_out[l]).all())
         np.testing.assert_allclose(avg_out[0].cpu().numpy(), g["eval.transformed.0"], atol=1e-4)
