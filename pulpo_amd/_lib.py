@@ -14,7 +14,8 @@ import torch  # noqa: F401  -- must be imported before the library so that torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pulpo_hip.h")
-LIB_PATH = os.path.join(_HERE, "csrc", "libpulpo_hip.so")
+# PULPO_HIP_LIB: load a differently built copy of the library (diagnostic ablation builds of scripts/ablate.py); default = the in-tree build
+LIB_PATH = os.environ.get("PULPO_HIP_LIB") or os.path.join(_HERE, "csrc", "libpulpo_hip.so")
 
 _CTYPE = {
     "int": ctypes.c_int,

@@ -370,7 +370,7 @@ static int conv_fwd_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t 
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd: null pointer");
     PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd: batch statistics are not available from the fused eval-mode epilogue");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd: bad dims");
-    ConvArgs a;
+    ConvArgs a{};
     a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
     a.wp = wp; a.bias = bias;
     a.out = out; a.out_bs = out_bs; a.out_ps = out_ps; a.out_cs = out_cs;

@@ -4,6 +4,10 @@
 #include "conv_shared.h"
 #include <stdlib.h>
 
+#ifndef PULPO_ABL
+#define PULPO_ABL 0          // diagnostic ablation builds (scripts/ablate.py): 11 no in-loop DMA, 12 no matrix instructions, 13 no flush
+#endif
+
 namespace {
 
 using namespace pulpo_conv;
@@ -328,7 +332,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino(WgradArgs a) {
 #pragma unroll
             for (int u = 0; u < NTW; ++u) {
                 const float av = fmaf(sa, Rb[q4][u], Ra[q4][u]);
+#if PULPO_ABL == 12
+                acc[u][0] += av * bv;
+#else
                 acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u], 0, 0, 0);
+#endif
             }
         }
     };
@@ -381,8 +389,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino(WgradArgs a) {
             // the raw reads of the next body are threaded through the MFMAs of the current one (1 MFMA : 3 LDS reads : 2 VALU), so
             // neither their issue slots nor their latency stall the matrix pipe of this single-wave-per-SIMD kernel
             load_body(Ra1, Rb1, Ya1, Yb1, xs_c, dys_c, sb + 1);
+#if PULPO_ABL != 11
             if (sb < 8) { issue_piece(2 * sb, xnext); issue_piece(2 * sb + 1, xnext); }     // all 17 pieces in the first nine bodies
             if (sb == 8) issue_piece(16, xnext);
+#endif
             mma_body(Ra0, Rb0, Ya0, Yb0);
 #pragma unroll
             for (int g = 0; g < NQ * NTW; ++g) {
@@ -392,7 +402,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino(WgradArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
             load_body(Ra0, Rb0, Ya0, Yb0, xs_c, dys_c, (sb + 2) & 15);
+#if PULPO_ABL != 11
             if (sb < 8) { issue_piece(2 * sb + 2, xnext); issue_piece(2 * sb + 3, xnext); }
+#endif
             mma_body(Ra1, Rb1, Ya1, Yb1);
 #pragma unroll
             for (int g = 0; g < NQ * NTW; ++g) {
@@ -408,6 +420,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino(WgradArgs a) {
     // flush: dw[.., t] = G^T M needs the four points of a (dz, dy, ci, co) entry, which live in the four waves.  They meet in LDS (the image
     // sets are free now), eight row tiles at a time, and each entry leaves as three float atomics (tap 0: M0 + (M1 + M2)/2, tap 1:
     // (M1 - M2)/2, tap 2: (M1 + M2)/2 + M3) in 128-byte runs of couts - 2.7x fewer atomics than flushing every wave's share separately.
+#if PULPO_ABL == 13
+    if (a.Cin != -7) return;
+#endif
     __syncthreads();
     float* X = smem;                                       // [point][tile slot 0..7][r][lane]
     const int co = co0 + i;

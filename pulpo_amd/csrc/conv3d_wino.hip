@@ -4,9 +4,35 @@
 #include "conv_shared.h"
 #include <stdlib.h>
 
+#ifndef PULPO_ABL
+#define PULPO_ABL 0          // diagnostic ablation builds (scripts/ablate.py): 2 no staging stores, 3 no epilogue, 5 no matrix instructions
+#endif
+
+#if PULPO_ABL == 9
+// in-kernel phase stamps (diagnostic build only): g_stamps[block][slot] = s_memtime at phase boundaries of wave 0
+__device__ unsigned long long g_stamps[20000 * 32];
+#define STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 20000) g_stamps[blockIdx.x * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+PULPO_API int pulpo_debug_read_stamps(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 namespace {
 
 using namespace pulpo_conv;
+
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS starting at the WAVE-UNIFORM byte address lds_addr.
+// Issued through inline asm on purpose: behind the builtin, hipcc makes every following ds_read wait for vmcnt(0) (the DMA may alias it),
+// which would expose the whole global latency at every use; the kernel waits for its DMA pieces itself (s_waitcnt vmcnt(0) in front of
+// the barrier that hands a slab over).  Compiler-issued loads in flight at the same time are only ever over-waited for (in-order return).
+__device__ __forceinline__ void dma16(const float* src, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_address(const float* p) {
+    return (unsigned)(uintptr_t)((const __attribute__((address_space(3))) float*)p);
+}
 
 // ------------------------------------------------------------------------------------------------ Winograd F(2,3) along x
 // Large volumes: the 3 x-taps of the 3x3x3 stencil are evaluated with the minimal-filtering identity F(2,3) (two neighbouring
@@ -291,6 +317,53 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// ---- LDS image of the (y, x) kernel: the same (hz, px, hy, x-pair) row order as above, but rows of 12 floats (8 channels + 4 pad = 48 bytes,
+// 16-byte aligned) and hz planes of 164 rows, so that the MFMA operands of FOUR consecutive k-steps arrive with ONE ds_read_b128: lane (row i,
+// half kk) reads channels 4 kk .. 4 kk + 3 of its row and k-step s uses channel 4 kk + s (the weights are packed to match).  A row is three
+// 16-byte bank slots and 3 is a unit mod 16, the planes are 4 rows apart mod 16: the 16 lanes of every ds_read_b128 lane group hit 16 distinct slots.
+constexpr int W2_RS = 12, W2_PLROWS = 4 * WN_PL + 4, W2_PS = W2_PLROWS * W2_RS, W2_XS = WN_HZ * W2_PS;
+
+__device__ __forceinline__ void w2_store_transformed(float* xs, const float4 (&d)[WN_NIT][4], int tid) {
+#pragma unroll
+    for (int u = 0; u < WN_NIT; ++u) {
+        const int j = tid + u * 256;
+        if (j < WN_NITEM) {
+            const int q = j % WN_Q, rb = j / WN_Q;                // rb = (hz*HY + hy)*4 + xb
+            const int hz = rb / (HY * 4), yx = rb - hz * (HY * 4);
+            float* o = xs + hz * W2_PS + yx * W2_RS + 4 * q;      // row (hz, point 0, hy, xb); points are WN_PL rows apart
+            const float4 d0 = d[u][0], d1 = d[u][1], d2 = d[u][2], d3 = d[u][3];
+            *reinterpret_cast<float4*>(o) = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
+            *reinterpret_cast<float4*>(o + WN_PL * W2_RS) = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+            *reinterpret_cast<float4*>(o + 2 * WN_PL * W2_RS) = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+            *reinterpret_cast<float4*>(o + 3 * WN_PL * W2_RS) = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+        }
+    }
+}
+
+// scalar staging into the same image (planar inputs, channel counts that are not multiples of 4)
+__device__ __forceinline__ void w2_stage_scalar(float* xs, const float* __restrict__ in, long in_ps, long in_cs, int c0, int Cin, int z0, int y0, int x0,
+                                                int D, int H, int W, int tid) {
+    for (int j = tid; j < WN_HZ * HY * 4 * WN_CH; j += 256) {
+        const int c = j % WN_CH, rb = j / WN_CH;
+        const int xb = rb & 3, hrow = rb >> 2;
+        const int hz = hrow / HY, hy = hrow - hz * HY;
+        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy;
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && c0 + c < Cin) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int gx = x0 - 1 + 2 * xb + t;
+                if ((unsigned)gx < (unsigned)W) d[t] = in[((long)(gz * H + gy) * W + gx) * in_ps + (long)(c0 + c) * in_cs];
+            }
+        }
+        float* o = xs + hz * W2_PS + (hy * 4 + xb) * W2_RS + c;
+        o[0] = d[0] - d[2];
+        o[WN_PL * W2_RS] = d[1] + d[2];
+        o[2 * WN_PL * W2_RS] = d[2] - d[1];
+        o[3 * WN_PL * W2_RS] = d[1] - d[3];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Winograd F(2x2,3x3) in (y, x)
 // The y taps get the same treatment as the x taps: 16 transformed points per 2x2 output block, 3 (dz) x 16 matrix products per four
 // outputs = 2.25x fewer than the direct kernel (1.5x fewer than F(2,3) along x alone).  The halo is staged x-transformed exactly as
@@ -300,15 +373,16 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __re
 // once per tile, after which wave w finishes row tile w >> 1, x parity w & 1 (bias, BatchNorm partials, store).
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
-    constexpr int CH = WN_CH, CP = WN_CP, NT = 32;
-    constexpr int XS = WN_HZ * WN_PS;
-    constexpr int WSL = 16 * CH * NT;                // floats of one dz weight slab set: [py][px][k][NT]
+    constexpr int CH = WN_CH, NT = 32;
+    constexpr int XS = W2_XS;
+    constexpr int WSL = 16 * CH * NT;                // floats of one dz weight slab set: [py][px][n][k]
     constexpr int RED = 4 * 2 * 2 * 16 * 64;         // floats of the cross-wave exchange buffer (reuses xs / ws)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
     float* ws = smem + XS;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
     const int cot = lid % a.ncot;
     const int tile_lin = lid / a.ncot;
@@ -323,35 +397,76 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
     const int niter = nchunk * 3;
     const float* in_b = a.in + (long)b * a.in_bs;
 
-    // weight slab prefetch: 16 KB per dz = four float4 per thread (scalars, not an array: the array form ended up in scratch)
-    float4 w0, w1, w2, w3;
-    const float* wsrc = a.wp + (long)(tid >> 3) * a.NPad + co0 + (tid & 7) * 4;      // row = (py * 4 + px) * CH + k; 32 rows per 256 threads
-    auto load_w = [&](int it) {
-        const float* p = wsrc + (long)it * 16 * CH * a.NPad;
-        w0 = *reinterpret_cast<const float4*>(p);
-        w1 = *reinterpret_cast<const float4*>(p + 32L * a.NPad);
-        w2 = *reinterpret_cast<const float4*>(p + 64L * a.NPad);
-        w3 = *reinterpret_cast<const float4*>(p + 96L * a.NPad);
-    };
-    auto store_w = [&](int buf) {
-        float* d = ws + buf * WSL + tid * 4;
-        *reinterpret_cast<float4*>(d) = w0;
-        *reinterpret_cast<float4*>(d + 1024) = w1;
-        *reinterpret_cast<float4*>(d + 2048) = w2;
-        *reinterpret_cast<float4*>(d + 3072) = w3;
+    // Weight slabs travel global -> LDS by LDS-DMA (no staging registers, no ds_write): slab `it` of this cout tile = 16 pieces (points) of
+    // 1 KB ([32 n][8 k], contiguous in the packed weights); wave w copies pieces w, w + 4, w + 8, w + 12.
+    const float* wsrc = a.wp + ((long)wave * a.NPad + co0) * CH + lane * 4;
+    const unsigned ws_lds = lds_address(ws);
+    auto dma_w_piece = [&](int it, int buf, int u) {
+        dma16(wsrc + (long)it * 16 * CH * a.NPad + (long)u * 4 * CH * a.NPad, ws_lds + (unsigned)(buf * WSL + wave * 256 + u * 4 * 256) * 4u);
     };
 
+    // Halo gather of the channels-last input (VEC): what a thread fetches does not depend on the channel chunk, so the byte offsets of its
+    // items relative to the tile's halo origin and their in-volume bits are computed once; per chunk only the (uniform) base moves.
+    unsigned roff[VEC ? WN_NIT : 1];
+    unsigned rmask = 0;
+    const unsigned ps_bytes = (unsigned)a.in_ps * 4u;
+    const char* origin = reinterpret_cast<const char*>(in_b) + ((long)((z0 - 1) * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.in_ps * 4;
+    const int rq = tid % WN_Q;
+    if constexpr (VEC) {
+#pragma unroll
+        for (int u = 0; u < WN_NIT; ++u) {
+            const int j = tid + u * 256;
+            const int xb = (j / WN_Q) & 3, hrow = j / (4 * WN_Q);
+            const int hz = hrow / HY, hy = hrow - hz * HY;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy;
+            const bool rowok = j < WN_NITEM && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H;
+            roff[u] = ((unsigned)((hz * a.H + hy) * a.W + 2 * xb) * (unsigned)a.in_ps + 4u * rq) * 4u;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                if (rowok && (unsigned)(x0 - 1 + 2 * xb + tt) < (unsigned)a.W) rmask |= 1u << (u * 4 + tt);
+        }
+    }
+    float4 raw[VEC ? WN_NIT : 1][4];
+    // loads k = 2 * part, 2 * part + 1 of the eight (u, tap) loads of a chunk: the in-loop prefetch issues two per point step
+    auto load_raw_part = [&](int c0, int part) {
+        const char* base = origin + (long)c0 * 4;
+        const bool cok = c0 + 4 * rq < a.Cin;
+#pragma unroll
+        for (int k = 2 * part; k < 2 * part + 2; ++k) {
+            const int u = k >> 2, tt = k & 3;
+            raw[u][tt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cok && ((rmask >> (u * 4 + tt)) & 1u)) raw[u][tt] = *reinterpret_cast<const float4*>(base + (roff[u] + tt * ps_bytes));
+        }
+    };
+    auto load_raw = [&](int c0) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) load_raw_part(c0, part);
+    };
+
+    // (optional, off by default) start-up offset of the second workgroup of a CU; measured without effect, kept for experiments
+    if (a.stagger > 0 && blockIdx.x < 512) {            // (block-uniform condition)
+        if (tid == 0) smem[0] = (float)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15);      // HW_REG_HW_ID[3:0]: wave slot on the SIMD
+        __syncthreads();
+        const bool second = smem[0] != 0.f;
+        __syncthreads();
+        if (second)
+            for (int s_ = 0; s_ < a.stagger; ++s_) __builtin_amdgcn_s_sleep(127);
+    }
     const int i = lane & 31, kk = lane >> 5;
-    const int py = __builtin_amdgcn_readfirstlane(wave);
+    const int py = wave;
     // y combination of this wave's point row: v = X[2 yb + ta] + sa * X[2 yb + tb]   (same table as the x transform)
     const int ta = py == 0 ? 0 : py == 2 ? 2 : 1;
     const int tb = py == 2 ? 1 : py == 3 ? 3 : 2;
     const float sa = py == 1 ? 1.f : -1.f;
     // MFMA row i of row tile m = block (z = 2 m + (i >> 4), yb = (i >> 2) & 3, xb = i & 3); LDS rows are (hz, px, hy, xb)
     const int lrow = ((i >> 2) & 3) * 8 + (i & 3);
-    const float* pa = xs + (i >> 4) * WN_PS + (lrow + ta * 4) * CP + kk;
-    const float* pb = xs + (i >> 4) * WN_PS + (lrow + tb * 4) * CP + kk;
-    const float* wbase = ws + (py * 4 * CH + kk) * NT + i;
+    const float* pa = xs + (i >> 4) * W2_PS + (lrow + ta * 4) * W2_RS + 4 * kk;
+    const float* pb = xs + (i >> 4) * W2_PS + (lrow + tb * 4) * W2_RS + 4 * kk;
+    const float* wbase = ws + ((py * 4) * NT + i) * CH + 4 * kk;
+
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dma_w_piece(0, 0, u);
+    if constexpr (VEC) load_raw(0);
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -361,50 +476,83 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][p][r] = 0.f;
 
-    load_w(0);
     int buf = 0, it = 0;
-    // (VEC) the raw halo loads of chunk c+1 are issued in front of the last dz iteration of chunk c: their latency hides behind
-    // its 32 MFMAs, and the registers are only live for that third of the loop
-    float4 raw[VEC ? WN_NIT : 1][4];
-    if constexpr (VEC) wino_load_raw(raw, in_b, a.in_ps, 0, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+    float4 ra[2][2], rb[2][2], rw[2];                   // two register sets of operand rows (activations: (ta, tb) x two row tiles; weights)
+    STAMP(1);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-        __syncthreads();
-        if constexpr (VEC) wino_store_transformed(xs, raw, tid);
-        else stage_halo_wino<false>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+        __syncthreads();                                // every wave has finished reading xs (previous chunk)
+        if (chunk < 4) STAMP(2 + chunk * 5);
+        if constexpr (VEC) {
+            // every thread "uses" its raw registers here, unconditionally: the compiler's wait for those loads then sits in straight-line
+            // code, and it does not have to assume them still in flight (and drain the queue, DMA included) when they are reloaded
+#pragma unroll
+            for (int u = 0; u < WN_NIT; ++u)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+                    asm volatile("" : : "v"(raw[u][tt].x), "v"(raw[u][tt].y), "v"(raw[u][tt].z), "v"(raw[u][tt].w));
+        }
+#if PULPO_ABL != 2
+        if constexpr (VEC) w2_store_transformed(xs, raw, tid);
+        else w2_stage_scalar(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+#endif
+        if (chunk < 4) STAMP(3 + chunk * 5);
 #pragma unroll
         for (int dz = 0; dz < 3; ++dz, ++it) {
-            store_w(buf);
-            __syncthreads();
-            if (it + 1 < niter) load_w(it + 1);
-            if constexpr (VEC) {
-                if (dz == 2 && chunk + 1 < nchunk) wino_load_raw(raw, in_b, a.in_ps, (chunk + 1) * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
-            }
-            const float* xa = pa + dz * WN_PS;
-            const float* xb_ = pb + dz * WN_PS;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of slab `it` have landed
+            __syncthreads();                            // all pieces landed, staged rows visible, everybody has left ws[buf ^ 1]
+            if (chunk < 4) STAMP(4 + chunk * 5 + dz);
+            const float* xa = pa + dz * W2_PS;
+            const float* xb_ = pb + dz * W2_PS;
             const float* wb = wbase + buf * WSL;
-            // 16 steps (px, s) of two MFMAs (row tiles m = 0, 1).  The five LDS words of step n+2 are requested before the MFMAs of step
-            // n are issued (three-slot register ring, pinned by sched_barrier), so no ds_read -> s_waitcnt -> v_mfma chain is exposed.
-            float ra[3][2], rb[3][2], rw[3];
-            auto fetch = [&](int st, int slot) {
-                const int px = st >> 2, s2 = st & 3;
-                rw[slot] = wb[(px * CH + 2 * s2) * NT];
+            // 4 point steps (px) of 8 MFMAs: one ds_read_b128 per operand row delivers four k-steps (two row tiles x (ta, tb) rows + the weight
+            // row = 5 reads per 8 MFMAs).  The reads of step px + 1 are requested before the MFMAs of step px are issued (two register sets); the
+            // activation rows of the next dz iteration's first step are requested before its barrier (the weight row has to wait for it).
+            // The next slab's four DMA pieces and (dz == 2) the next chunk's eight raw loads are issued one / two per step, right behind the
+            // step's first MFMAs, so their issue time is covered by the matrix pipe instead of preceding it.
+            auto fetch_a = [&](const float* xa_, const float* xbb_, int px, int slot) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const int off = 2 * m * WN_PS + px * WN_PL * CP + 2 * s2;
-                    ra[slot][m] = xa[off];
-                    rb[slot][m] = xb_[off];
+                    const int off = 2 * m * W2_PS + px * WN_PL * W2_RS;
+                    ra[slot][m] = *reinterpret_cast<const float4*>(xa_ + off);
+                    rb[slot][m] = *reinterpret_cast<const float4*>(xbb_ + off);
                 }
             };
-            fetch(0, 0);
-            fetch(1, 1);
+            if (dz == 0) fetch_a(xa, xb_, 0, 0);
+            rw[0] = *reinterpret_cast<const float4*>(wb);
+            const bool more_w = it + 1 < niter;
+            const bool more_raw = VEC && dz == 2 && chunk + 1 < nchunk;
 #pragma unroll
-            for (int st = 0; st < 16; ++st) {
-                if (st + 2 < 16) fetch(st + 2, (st + 2) % 3);         // two steps (four MFMAs) of slack for the LDS round trip (three measured slower)
+            for (int px = 0; px < 4; ++px) {
+                if (px + 1 < 4) {
+                    rw[(px + 1) & 1] = *reinterpret_cast<const float4*>(wb + (px + 1) * NT * CH);
+                    fetch_a(xa, xb_, px + 1, (px + 1) & 1);
+                } else if (dz < 2) {
+                    fetch_a(xa + W2_PS, xb_ + W2_PS, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
+                const int sl = px & 1;
+                const float wv[4] = {rw[sl].x, rw[sl].y, rw[sl].z, rw[sl].w};
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const float av = fmaf(sa, rb[st % 3][m], ra[st % 3][m]);
-                    acc[m][st >> 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, rw[st % 3], acc[m][st >> 2], 0, 0, 0);
+                for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const float a_ = s2 == 0 ? ra[sl][m].x : s2 == 1 ? ra[sl][m].y : s2 == 2 ? ra[sl][m].z : ra[sl][m].w;
+                        const float b_ = s2 == 0 ? rb[sl][m].x : s2 == 1 ? rb[sl][m].y : s2 == 2 ? rb[sl][m].z : rb[sl][m].w;
+                        const float av = fmaf(sa, b_, a_);
+#if PULPO_ABL == 5
+                        acc[m][px][0] += av * wv[s2];
+#else
+                        acc[m][px] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv[s2], acc[m][px], 0, 0, 0);
+#endif
+                    }
+                    if (s2 == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more_w) dma_w_piece(it + 1, buf ^ 1, px);
+                        if constexpr (VEC) {
+                            if (more_raw) load_raw_part((chunk + 1) * CH, px);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -412,8 +560,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         }
     }
 
+#if PULPO_ABL == 3
+    if (a.slope != 12345.f) return;                    // (ablation: no epilogue at all)
+#endif
+    STAMP(24);
     // ---- x inverse transform in registers, y inverse transform across the four waves through LDS
     __syncthreads();                                   // every wave has left xs / ws
+    STAMP(25);
     float* R = smem;                                   // [py][m][ox][r][lane]
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -425,8 +578,81 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         }
     }
     __syncthreads();
-    const int fm = wave >> 1, fox = wave & 1;           // this wave finishes row tile fm, x parity fox
+    STAMP(26);
     float* out_b = a.out + (long)b * a.out_bs;
+    // Fast path (whole tile inside the volume, all 32 couts real, channels-last 16-byte aligned output - every tile of the BASELINE layers):
+    // lane = (channel quad q, row half, row group): the four waves' partial rows are fetched with ds_read_b128 (all 16 issued before the
+    // first use), the y inverse transform is done on float4s, and each voxel leaves as one 128-byte line written by 8 lanes x 16 bytes -
+    // 8 wide stores per lane instead of 32 scalar ones behind a ds_read -> wait -> 64-bit address chain each.
+    const bool fast = a.out_cs == 1 && (a.out_ps & 3) == 0 && (a.out_bs & 3) == 0 && (((uintptr_t)a.out) & 15) == 0 && co0 + NT <= a.Cout &&
+                      z0 + 4 <= a.D && y0 + TY <= a.H && x0 + TX <= a.W &&
+                      (a.bias == nullptr || (((uintptr_t)a.bias) & 15) == 0) && (a.coef == nullptr || ((((uintptr_t)a.coef) & 15) == 0 && (a.Cout & 3) == 0));
+    if (fast) {
+        const int q = lane & 7, kh = (lane >> 3) & 1, g = lane >> 4;
+        float4 tq[4][4];
+#pragma unroll
+        for (int it4 = 0; it4 < 4; ++it4) {
+            const int combo = it4 * 16 + wave * 4 + g;                 // (m, ox, r) = (combo >> 5, (combo >> 4) & 1, combo & 15)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                tq[it4][p] = *reinterpret_cast<const float4*>(R + ((p * 4 + (combo >> 4)) * 16 + (combo & 15)) * 64 + kh * 32 + 4 * q);
+        }
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 b4 = zero4, sc4 = zero4, sh4 = zero4;
+        if (a.bias != nullptr) b4 = *reinterpret_cast<const float4*>(a.bias + co0 + 4 * q);
+        const bool fuse = a.coef != nullptr;
+        if (fuse) {
+            sc4 = *reinterpret_cast<const float4*>(a.coef + 2 * a.Cout + co0 + 4 * q);
+            sh4 = *reinterpret_cast<const float4*>(a.coef + 3 * a.Cout + co0 + 4 * q);
+        }
+        float4 s4 = zero4, q4 = zero4;
+        float* obase = out_b + co0 + 4 * q;
+#pragma unroll
+        for (int it4 = 0; it4 < 4; ++it4) {
+            const int combo = it4 * 16 + wave * 4 + g;
+            const int m = combo >> 5, ox = (combo >> 4) & 1, r = combo & 15;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int gz = z0 + 2 * m + (row >> 4), gy = y0 + 2 * ((row >> 2) & 3), gx = x0 + 2 * (row & 3) + ox;
+            const long vox = (long)(gz * a.H + gy) * a.W + gx;
+            const float4 t0 = tq[it4][0], t1 = tq[it4][1], t2 = tq[it4][2], t3 = tq[it4][3];
+            float4 v0 = make_float4(t0.x + t1.x + t2.x + b4.x, t0.y + t1.y + t2.y + b4.y, t0.z + t1.z + t2.z + b4.z, t0.w + t1.w + t2.w + b4.w);
+            float4 v1 = make_float4(t1.x - t2.x - t3.x + b4.x, t1.y - t2.y - t3.y + b4.y, t1.z - t2.z - t3.z + b4.z, t1.w - t2.w - t3.w + b4.w);
+            s4.x += v0.x + v1.x; s4.y += v0.y + v1.y; s4.z += v0.z + v1.z; s4.w += v0.w + v1.w;
+            q4.x += v0.x * v0.x + v1.x * v1.x; q4.y += v0.y * v0.y + v1.y * v1.y; q4.z += v0.z * v0.z + v1.z * v1.z; q4.w += v0.w * v0.w + v1.w * v1.w;
+            if (fuse) {
+                auto act = [&](float v, float sc, float sh) { const float tt = v * sc + sh; return tt > 0.f ? tt : tt * a.slope; };
+                v0 = make_float4(act(v0.x, sc4.x, sh4.x), act(v0.y, sc4.y, sh4.y), act(v0.z, sc4.z, sh4.z), act(v0.w, sc4.w, sh4.w));
+                v1 = make_float4(act(v1.x, sc4.x, sh4.x), act(v1.y, sc4.y, sh4.y), act(v1.z, sc4.z, sh4.z), act(v1.w, sc4.w, sh4.w));
+            }
+            *reinterpret_cast<float4*>(obase + vox * a.out_ps) = v0;
+            *reinterpret_cast<float4*>(obase + (vox + a.W) * a.out_ps) = v1;
+        }
+        STAMP(27);
+        if (a.stats != nullptr) {
+            // per-channel sums: lanes with equal q (lane bits 3..5 differ) hold partial sums of the same four channels
+#pragma unroll
+            for (int o = 8; o <= 32; o <<= 1) {
+                s4.x += __shfl_xor(s4.x, o, 64); s4.y += __shfl_xor(s4.y, o, 64); s4.z += __shfl_xor(s4.z, o, 64); s4.w += __shfl_xor(s4.w, o, 64);
+                q4.x += __shfl_xor(q4.x, o, 64); q4.y += __shfl_xor(q4.y, o, 64); q4.z += __shfl_xor(q4.z, o, 64); q4.w += __shfl_xor(q4.w, o, 64);
+            }
+            float* red = smem + RED;                        // [4 waves][2][NT], behind the exchange buffer
+            if (lane < 8) {
+                *reinterpret_cast<float4*>(red + (wave * 2 + 0) * NT + 4 * q) = s4;
+                *reinterpret_cast<float4*>(red + (wave * 2 + 1) * NT + 4 * q) = q4;
+            }
+            __syncthreads();
+            if (tid < 2 * NT) {
+                const int which = tid / NT, c = tid - which * NT;
+                const float tot = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] + red[(2 * 2 + which) * NT + c] +
+                                  red[(3 * 2 + which) * NT + c];
+                a.stats[((long)tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
+            }
+        }
+        STAMP(28);
+        return;
+    }
+    // general path: ragged tiles (volume edge), partial cout tiles, planar / strided outputs
+    const int fm = wave >> 1, fox = wave & 1;           // this wave finishes row tile fm, x parity fox
     const int co = co0 + i;
     const bool cok = co < a.Cout;
     const float bias = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
@@ -455,6 +681,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
             }
         }
     }
+    STAMP(27);
     ssum += __shfl_xor(ssum, 32, 64);
     ssq += __shfl_xor(ssq, 32, 64);
     if (a.stats != nullptr) {
@@ -473,9 +700,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
             }
         }
     }
+    STAMP(28);
 }
 
-// packing for the (y, x) Winograd kernel: wp[k/8][dz][py][px][k%8][n] = sum_dy sum_dx G[py][dy] G[px][dx] g[dz][dy][dx]
+// packing for the (y, x) Winograd kernel: wp[k/8][dz][py][px][n][k%8] = sum_dy sum_dx G[py][dy] G[px][dx] g[dz][dy][dx]
 __global__ void pack_weight_wino2_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int NPad, int dgrad, long total) {
     // one thread per (chunk, dz, k, n): nine taps in, sixteen transformed points out
     const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
@@ -499,7 +727,7 @@ __global__ void pack_weight_wino2_kernel(const float* __restrict__ w, float* __r
             }
             ux[dy][0] = g[0]; ux[dy][1] = 0.5f * (g[0] + g[1] + g[2]); ux[dy][2] = 0.5f * (g[0] - g[1] + g[2]); ux[dy][3] = g[2];
         }
-        float* o = wp + (((long)(chunk * 3 + dz) * 16) * WN_CH + kc) * NPad + n;          // + (py * 4 + px) * WN_CH * NPad
+        float* o = wp + (((long)(chunk * 3 + dz) * 16) * NPad + n) * WN_CH + kc;          // + (py * 4 + px) * NPad * WN_CH
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             const float u0 = ux[0][px], u1 = ux[1][px], u2 = ux[2][px];
@@ -547,7 +775,7 @@ PULPO_API int pulpo_conv3d_k3_fwd_wino(const float* in, int64_t in_bs, int64_t i
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd_wino: bad dims");
     PULPO_REQUIRE(conv_tz(D, H, W) == 4, "conv3d_k3_fwd_wino: volume %dx%dx%d is not tiled 4x8x8 (see pulpo_conv3d_k3_algo)", D, H, W);
     PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd_wino: batch statistics are not available from the fused eval-mode epilogue");
-    ConvArgs a;
+    ConvArgs a{};
     a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
     a.wp = wp; a.bias = bias;
     a.out = out; a.out_bs = out_bs; a.out_ps = out_ps; a.out_cs = out_cs;
@@ -579,8 +807,9 @@ PULPO_API int pulpo_conv3d_k3_pack_weight_wino2(const float* w, float* wp, int C
 
 template <bool VEC>
 static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
-    constexpr size_t lds = (size_t)(WN_HZ * WN_PS + 2 * 16 * WN_CH * 32) * sizeof(float);
+    constexpr size_t lds = (size_t)(W2_XS + 2 * 16 * WN_CH * 32) * sizeof(float);
     static_assert(lds >= (size_t)(4 * 2 * 2 * 16 * 64 + 4 * 2 * 32) * sizeof(float), "exchange buffer must fit");
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino2_mfma<VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -598,7 +827,7 @@ PULPO_API int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t 
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd_wino2: bad dims");
     PULPO_REQUIRE(conv_tz(D, H, W) == 4, "conv3d_k3_fwd_wino2: volume %dx%dx%d is not tiled 4x8x8 (see pulpo_conv3d_k3_algo)", D, H, W);
     PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd_wino2: batch statistics are not available from the fused eval-mode epilogue");
-    ConvArgs a;
+    ConvArgs a{};
     a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
     a.wp = wp; a.bias = bias;
     a.out = out; a.out_bs = out_bs; a.out_ps = out_ps; a.out_cs = out_cs;
@@ -610,6 +839,13 @@ PULPO_API int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t 
     a.ksplit = 1; a.part = nullptr;
     const long nblk_l = (long)B * a.ntz * a.nty * a.ntx * a.ncot;
     PULPO_REQUIRE(nblk_l < (1L << 31), "conv3d_k3_fwd_wino2: grid too large");
+    {
+        // start-up offset of the second workgroup per CU, in percent of one wave's matrix time per tile (nchunk x 96 MFMAs x 64 clocks)
+        static int pct = -1;
+        if (pct < 0) { const char* e = getenv("PULPO_CONV_STAGGER"); pct = e ? atoi(e) : 0; }
+        const long clocks = ((long)((K + WN_CH - 1) / WN_CH) * 96 * 64 * 2 + 33000) * pct / 100;      // pct of a (lockstep) tile time
+        a.stagger = nblk_l > 512 ? (int)(clocks / (64 * 127)) : 0;
+    }
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
     return vec ? launch_wino2<true>(a, (int)nblk_l, st) : launch_wino2<false>(a, (int)nblk_l, st);

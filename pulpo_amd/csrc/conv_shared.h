@@ -41,6 +41,7 @@ struct ConvArgs {
     float* part;                  // [ksplit][B*V][Cout] dense partial outputs (reduced in fixed order by splitk_reduce_kernel)
     const float* coef;            // nullable: eval-mode BatchNorm coefficients (scale at [2C], shift at [3C]) + LeakyReLU fused into the store
     float slope;
+    int stagger;                  // Winograd (y, x) kernel: start-up delay (units of 64 x 127 clocks) of the second workgroup of every CU, 0 = none
 };
 
 
