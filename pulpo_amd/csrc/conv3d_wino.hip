@@ -4,19 +4,19 @@
 #include "conv_shared.h"
 #include <stdlib.h>
 
-#ifndef PULPO_ABL
-#define PULPO_ABL 0          // diagnostic ablation builds (scripts/ablate.py): 2 no staging stores, 3 no epilogue, 5 no matrix instructions
-#endif
 
+#ifndef PULPO_ABL
+#define PULPO_ABL 0          // diagnostic builds (scripts/ablate.py): 9 = in-kernel stamps of the (y, x) Winograd kernel
+#endif
 #if PULPO_ABL == 9
-// in-kernel phase stamps (diagnostic build only): g_stamps[block][slot] = s_memtime at phase boundaries of wave 0
-__device__ unsigned long long g_stamps[20000 * 32];
-#define STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 20000) g_stamps[blockIdx.x * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+// g_stamps[block][0] = HW_REG_HW_ID, [1] = HW_REG_XCC_ID, [2] = start clock, [3 + 2k] / [4 + 2k] = main-loop end / tile end of the block's k-th tile
+__device__ unsigned long long g_stamps[512 * 80];
+#define STAMP(slot, val) do { if (threadIdx.x == 0 && (slot) < 80) g_stamps[blockIdx.x * 80 + (slot)] = (val); } while (0)
 PULPO_API int pulpo_debug_read_stamps(void* dst, size_t bytes) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost);
 }
 #else
-#define STAMP(slot) do {} while (0)
+#define STAMP(slot, val) do {} while (0)
 #endif
 
 namespace {
@@ -366,95 +366,57 @@ __device__ __forceinline__ void w2_stage_scalar(float* xs, const float* __restri
 
 // ------------------------------------------------------------------------------------------------ Winograd F(2x2,3x3) in (y, x)
 // The y taps get the same treatment as the x taps: 16 transformed points per 2x2 output block, 3 (dz) x 16 matrix products per four
-// outputs = 2.25x fewer than the direct kernel (1.5x fewer than F(2,3) along x alone).  The halo is staged x-transformed exactly as
-// for the x-only kernel; WAVE py OWNS THE FOUR POINTS (py, px = 0..3) and forms the y combination of its A fragments as they are
-// read (two ds_read + one fma per MFMA, wave-uniform tap pair), for all 64 blocks of the 4x8x8 tile (two MFMA row tiles of
-// 2 z-planes x 4 x 4 blocks).  The x inverse transform is in-lane; the y inverse transform sums over the four waves through LDS
-// once per tile, after which wave w finishes row tile w >> 1, x parity w & 1 (bias, BatchNorm partials, store).
+// outputs = 2.25x fewer than the direct kernel (1.5x fewer than F(2,3) along x alone).  The halo is staged x-transformed; WAVE py OWNS THE
+// FOUR POINTS (py, px = 0..3) and forms the y combination of its A fragments as they are read (wave-uniform tap pair), for all 64 blocks
+// of the 4x8x8 tile (two MFMA row tiles of 2 z-planes x 4 x 4 blocks).  The x inverse transform is in-lane; the y inverse transform sums
+// over the four waves through LDS, one row tile at a time.
+//
+// What the phase stamps of a diagnostic build showed (scripts/ablate.py, scripts/stamps.py; 32->32 @160^3: 84k clocks per tile of which
+// 49k are the two co-resident waves' matrix time), and what this version does about it:
+//   * 2.5 ds_read_b32 per MFMA kept the LDS issue path, not the matrix pipe, busy  -> operand rows of four k-steps by ONE ds_read_b128
+//     (row / plane strides chosen for a conflict-free bank map), 0.63 reads per MFMA;
+//   * a scalar-store epilogue of 16k clocks (ds_read -> wait -> 64-bit address -> 4-byte store, 32 times per lane)  -> rows re-mapped so
+//     that a lane holds four channels: ds_read_b128 + 16-byte stores, one 128-byte line per 8 lanes;
+//   * weight slabs through registers + ds_write, and hipcc's vmcnt(0) in front of every LDS read that follows a DMA  -> LDS-DMA issued
+//     from inline asm, one piece per point step behind the step's first MFMAs, waited for by hand at the hand-over barrier;
+//   * 10k clocks of prologue per tile (argument loads, index arithmetic, first-touch latency of halo and weights)  -> PERSISTENT
+//     workgroups (two per CU) that fetch the next tile's first slab and halo chunk during the last dz iteration of the current tile.
+// A start-up offset of the second workgroup of each CU (to break the lockstep of the pair) was measured without effect and is not kept.
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
     constexpr int CH = WN_CH, NT = 32;
     constexpr int XS = W2_XS;
     constexpr int WSL = 16 * CH * NT;                // floats of one dz weight slab set: [py][px][n][k]
-    constexpr int RED = 4 * 2 * 2 * 16 * 64;         // floats of the cross-wave exchange buffer (reuses xs / ws)
+    constexpr int RH = 4 * 2 * 16 * 64;              // floats of the cross-wave exchange buffer of ONE row tile: [py][ox][r][lane] (inside xs)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
     float* ws = smem + XS;
+    static_assert(RH + 4 * 2 * NT <= XS, "exchange buffer + statistics rows must stay inside the halo image (the next tile's slab lands in ws)");
 
-    STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
-    const int cot = lid % a.ncot;
-    const int tile_lin = lid / a.ncot;
-    int t = tile_lin;
-    const int tx_ = t % a.ntx; t /= a.ntx;
-    const int ty_ = t % a.nty; t /= a.nty;
-    const int tz_ = t % a.ntz;
-    const int b = t / a.ntz;
-    const int z0 = tz_ * 4, y0 = ty_ * TY, x0 = tx_ * TX;
-    const int co0 = cot * NT;
+    const int i = lane & 31, kk = lane >> 5;
     const int nchunk = (a.Cin + CH - 1) / CH;
     const int niter = nchunk * 3;
-    const float* in_b = a.in + (long)b * a.in_bs;
-
-    // Weight slabs travel global -> LDS by LDS-DMA (no staging registers, no ds_write): slab `it` of this cout tile = 16 pieces (points) of
-    // 1 KB ([32 n][8 k], contiguous in the packed weights); wave w copies pieces w, w + 4, w + 8, w + 12.
-    const float* wsrc = a.wp + ((long)wave * a.NPad + co0) * CH + lane * 4;
+    const int nwork = a.B * a.ntz * a.nty * a.ntx * a.ncot;
+    const int nwg = gridDim.x;
     const unsigned ws_lds = lds_address(ws);
-    auto dma_w_piece = [&](int it, int buf, int u) {
-        dma16(wsrc + (long)it * 16 * CH * a.NPad + (long)u * 4 * CH * a.NPad, ws_lds + (unsigned)(buf * WSL + wave * 256 + u * 4 * 256) * 4u);
-    };
-
-    // Halo gather of the channels-last input (VEC): what a thread fetches does not depend on the channel chunk, so the byte offsets of its
-    // items relative to the tile's halo origin and their in-volume bits are computed once; per chunk only the (uniform) base moves.
-    unsigned roff[VEC ? WN_NIT : 1];
-    unsigned rmask = 0;
     const unsigned ps_bytes = (unsigned)a.in_ps * 4u;
-    const char* origin = reinterpret_cast<const char*>(in_b) + ((long)((z0 - 1) * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.in_ps * 4;
     const int rq = tid % WN_Q;
+
+    // ---- tile-invariant per-lane data
+    // halo gather (VEC): byte offsets of a thread's items relative to the tile's halo origin
+    unsigned roff[VEC ? WN_NIT : 1];
     if constexpr (VEC) {
 #pragma unroll
         for (int u = 0; u < WN_NIT; ++u) {
             const int j = tid + u * 256;
             const int xb = (j / WN_Q) & 3, hrow = j / (4 * WN_Q);
             const int hz = hrow / HY, hy = hrow - hz * HY;
-            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy;
-            const bool rowok = j < WN_NITEM && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H;
             roff[u] = ((unsigned)((hz * a.H + hy) * a.W + 2 * xb) * (unsigned)a.in_ps + 4u * rq) * 4u;
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-                if (rowok && (unsigned)(x0 - 1 + 2 * xb + tt) < (unsigned)a.W) rmask |= 1u << (u * 4 + tt);
         }
     }
-    float4 raw[VEC ? WN_NIT : 1][4];
-    // loads k = 2 * part, 2 * part + 1 of the eight (u, tap) loads of a chunk: the in-loop prefetch issues two per point step
-    auto load_raw_part = [&](int c0, int part) {
-        const char* base = origin + (long)c0 * 4;
-        const bool cok = c0 + 4 * rq < a.Cin;
-#pragma unroll
-        for (int k = 2 * part; k < 2 * part + 2; ++k) {
-            const int u = k >> 2, tt = k & 3;
-            raw[u][tt] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cok && ((rmask >> (u * 4 + tt)) & 1u)) raw[u][tt] = *reinterpret_cast<const float4*>(base + (roff[u] + tt * ps_bytes));
-        }
-    };
-    auto load_raw = [&](int c0) {
-#pragma unroll
-        for (int part = 0; part < 4; ++part) load_raw_part(c0, part);
-    };
-
-    // (optional, off by default) start-up offset of the second workgroup of a CU; measured without effect, kept for experiments
-    if (a.stagger > 0 && blockIdx.x < 512) {            // (block-uniform condition)
-        if (tid == 0) smem[0] = (float)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15);      // HW_REG_HW_ID[3:0]: wave slot on the SIMD
-        __syncthreads();
-        const bool second = smem[0] != 0.f;
-        __syncthreads();
-        if (second)
-            for (int s_ = 0; s_ < a.stagger; ++s_) __builtin_amdgcn_s_sleep(127);
-    }
-    const int i = lane & 31, kk = lane >> 5;
-    const int py = wave;
     // y combination of this wave's point row: v = X[2 yb + ta] + sa * X[2 yb + tb]   (same table as the x transform)
+    const int py = wave;
     const int ta = py == 0 ? 0 : py == 2 ? 2 : 1;
     const int tb = py == 2 ? 1 : py == 3 ? 3 : 2;
     const float sa = py == 1 ? 1.f : -1.f;
@@ -464,243 +426,316 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
     const float* pb = xs + (i >> 4) * W2_PS + (lrow + tb * 4) * W2_RS + 4 * kk;
     const float* wbase = ws + ((py * 4) * NT + i) * CH + 4 * kk;
 
-#pragma unroll
-    for (int u = 0; u < 4; ++u) dma_w_piece(0, 0, u);
-    if constexpr (VEC) load_raw(0);
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][p][r] = 0.f;
-
-    int buf = 0, it = 0;
-    float4 ra[2][2], rb[2][2], rw[2];                   // two register sets of operand rows (activations: (ta, tb) x two row tiles; weights)
-    STAMP(1);
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        __syncthreads();                                // every wave has finished reading xs (previous chunk)
-        if (chunk < 4) STAMP(2 + chunk * 5);
+    // ---- per-tile descriptor
+    struct Tile {
+        int tile_lin, b, z0, y0, x0, co0;
+        const char* origin;          // halo origin voxel (z0 - 1, y0 - 1, x0 - 1) of the input, channel 0 (may lie in front of the tensor)
+        const float* wsrc;           // this wave's source of DMA piece 0 of slab 0 (uniform)
+        unsigned rmask;              // in-volume bits of the thread's (item, tap) loads
+    };
+    auto describe = [&](int work) {
+        Tile t;
+        const int cot = work % a.ncot;
+        t.tile_lin = work / a.ncot;
+        int q = t.tile_lin;
+        const int tx_ = q % a.ntx; q /= a.ntx;
+        const int ty_ = q % a.nty; q /= a.nty;
+        const int tz_ = q % a.ntz;
+        t.b = q / a.ntz;
+        t.z0 = tz_ * 4; t.y0 = ty_ * TY; t.x0 = tx_ * TX;
+        t.co0 = cot * NT;
+        t.origin = reinterpret_cast<const char*>(a.in + (long)t.b * a.in_bs) + ((long)((t.z0 - 1) * a.H + (t.y0 - 1)) * a.W + (t.x0 - 1)) * a.in_ps * 4;
+        t.wsrc = a.wp + ((long)wave * a.NPad + t.co0) * CH;                      // (wave-uniform; the lane's 16 bytes are added at the issue)
+        t.rmask = 0;
         if constexpr (VEC) {
-            // every thread "uses" its raw registers here, unconditionally: the compiler's wait for those loads then sits in straight-line
-            // code, and it does not have to assume them still in flight (and drain the queue, DMA included) when they are reloaded
 #pragma unroll
-            for (int u = 0; u < WN_NIT; ++u)
+            for (int u = 0; u < WN_NIT; ++u) {
+                const int j = tid + u * 256;
+                const int xb = (j / WN_Q) & 3, hrow = j / (4 * WN_Q);
+                const int hz = hrow / HY, hy = hrow - hz * HY;
+                const bool rowok = j < WN_NITEM && (unsigned)(t.z0 - 1 + hz) < (unsigned)a.D && (unsigned)(t.y0 - 1 + hy) < (unsigned)a.H;
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
-                    asm volatile("" : : "v"(raw[u][tt].x), "v"(raw[u][tt].y), "v"(raw[u][tt].z), "v"(raw[u][tt].w));
-        }
-#if PULPO_ABL != 2
-        if constexpr (VEC) w2_store_transformed(xs, raw, tid);
-        else w2_stage_scalar(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
-#endif
-        if (chunk < 4) STAMP(3 + chunk * 5);
-#pragma unroll
-        for (int dz = 0; dz < 3; ++dz, ++it) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of slab `it` have landed
-            __syncthreads();                            // all pieces landed, staged rows visible, everybody has left ws[buf ^ 1]
-            if (chunk < 4) STAMP(4 + chunk * 5 + dz);
-            const float* xa = pa + dz * W2_PS;
-            const float* xb_ = pb + dz * W2_PS;
-            const float* wb = wbase + buf * WSL;
-            // 4 point steps (px) of 8 MFMAs: one ds_read_b128 per operand row delivers four k-steps (two row tiles x (ta, tb) rows + the weight
-            // row = 5 reads per 8 MFMAs).  The reads of step px + 1 are requested before the MFMAs of step px are issued (two register sets); the
-            // activation rows of the next dz iteration's first step are requested before its barrier (the weight row has to wait for it).
-            // The next slab's four DMA pieces and (dz == 2) the next chunk's eight raw loads are issued one / two per step, right behind the
-            // step's first MFMAs, so their issue time is covered by the matrix pipe instead of preceding it.
-            auto fetch_a = [&](const float* xa_, const float* xbb_, int px, int slot) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int off = 2 * m * W2_PS + px * WN_PL * W2_RS;
-                    ra[slot][m] = *reinterpret_cast<const float4*>(xa_ + off);
-                    rb[slot][m] = *reinterpret_cast<const float4*>(xbb_ + off);
-                }
-            };
-            if (dz == 0) fetch_a(xa, xb_, 0, 0);
-            rw[0] = *reinterpret_cast<const float4*>(wb);
-            const bool more_w = it + 1 < niter;
-            const bool more_raw = VEC && dz == 2 && chunk + 1 < nchunk;
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                if (px + 1 < 4) {
-                    rw[(px + 1) & 1] = *reinterpret_cast<const float4*>(wb + (px + 1) * NT * CH);
-                    fetch_a(xa, xb_, px + 1, (px + 1) & 1);
-                } else if (dz < 2) {
-                    fetch_a(xa + W2_PS, xb_ + W2_PS, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const int sl = px & 1;
-                const float wv[4] = {rw[sl].x, rw[sl].y, rw[sl].z, rw[sl].w};
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const float a_ = s2 == 0 ? ra[sl][m].x : s2 == 1 ? ra[sl][m].y : s2 == 2 ? ra[sl][m].z : ra[sl][m].w;
-                        const float b_ = s2 == 0 ? rb[sl][m].x : s2 == 1 ? rb[sl][m].y : s2 == 2 ? rb[sl][m].z : rb[sl][m].w;
-                        const float av = fmaf(sa, b_, a_);
-#if PULPO_ABL == 5
-                        acc[m][px][0] += av * wv[s2];
-#else
-                        acc[m][px] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv[s2], acc[m][px], 0, 0, 0);
-#endif
-                    }
-                    if (s2 == 0) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (more_w) dma_w_piece(it + 1, buf ^ 1, px);
-                        if constexpr (VEC) {
-                            if (more_raw) load_raw_part((chunk + 1) * CH, px);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                    if (rowok && (unsigned)(t.x0 - 1 + 2 * xb + tt) < (unsigned)a.W) t.rmask |= 1u << (u * 4 + tt);
             }
-            buf ^= 1;
         }
-    }
+        return t;
+    };
 
-#if PULPO_ABL == 3
-    if (a.slope != 12345.f) return;                    // (ablation: no epilogue at all)
-#endif
-    STAMP(24);
-    // ---- x inverse transform in registers, y inverse transform across the four waves through LDS
-    __syncthreads();                                   // every wave has left xs / ws
-    STAMP(25);
-    float* R = smem;                                   // [py][m][ox][r][lane]
+    // Weight slabs travel global -> LDS by LDS-DMA (no staging registers, no ds_write): slab `it` of a cout tile = 16 pieces (points) of
+    // 1 KB ([32 n][8 k], contiguous in the packed weights); wave w copies pieces w, w + 4, w + 8, w + 12.
+    auto dma_w_piece = [&](const float* wsrc, int it, int buf, int u) {
+        dma16(wsrc + (long)it * 16 * CH * a.NPad + (long)u * 4 * CH * a.NPad + lane * 4, ws_lds + (unsigned)(buf * WSL + wave * 256 + u * 4 * 256) * 4u);
+    };
+    float4 raw[VEC ? WN_NIT : 1][4];
+    // loads 2 * part, 2 * part + 1 of the eight (item, tap) loads of a halo chunk: the in-loop prefetch issues two per point step
+    auto load_raw_part = [&](const Tile& t, int c0, int part) {
+        const char* base = t.origin + (long)c0 * 4;
+        const bool cok = c0 + 4 * rq < a.Cin;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float m0 = acc[m][0][r], m1 = acc[m][1][r], m2 = acc[m][2][r], m3 = acc[m][3][r];
-            R[(((py * 2 + m) * 2 + 0) * 16 + r) * 64 + lane] = m0 + m1 + m2;
-            R[(((py * 2 + m) * 2 + 1) * 16 + r) * 64 + lane] = m1 - m2 - m3;
+        for (int k = 2 * part; k < 2 * part + 2; ++k) {
+            const int u = k >> 2, tt = k & 3;
+            raw[u][tt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cok && ((t.rmask >> (u * 4 + tt)) & 1u)) raw[u][tt] = *reinterpret_cast<const float4*>(base + (roff[u] + tt * ps_bytes));
         }
+    };
+
+    STAMP(0, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));        // HW_REG_HW_ID
+    STAMP(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));       // HW_REG_XCC_ID
+    STAMP(2, __builtin_amdgcn_s_memtime());
+    if (a.stagger > 0) {                                // (diagnostic: start-up offset of the CU's second workgroup, by its wave slot)
+        if (tid == 0) smem[0] = (float)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15);
+        __syncthreads();
+        const bool second = smem[0] != 0.f;
+        __syncthreads();
+        if (second)
+            for (int s_ = 0; s_ < a.stagger; ++s_) __builtin_amdgcn_s_sleep(127);
     }
-    __syncthreads();
-    STAMP(26);
-    float* out_b = a.out + (long)b * a.out_bs;
-    // Fast path (whole tile inside the volume, all 32 couts real, channels-last 16-byte aligned output - every tile of the BASELINE layers):
-    // lane = (channel quad q, row half, row group): the four waves' partial rows are fetched with ds_read_b128 (all 16 issued before the
-    // first use), the y inverse transform is done on float4s, and each voxel leaves as one 128-byte line written by 8 lanes x 16 bytes -
-    // 8 wide stores per lane instead of 32 scalar ones behind a ds_read -> wait -> 64-bit address chain each.
-    const bool fast = a.out_cs == 1 && (a.out_ps & 3) == 0 && (a.out_bs & 3) == 0 && (((uintptr_t)a.out) & 15) == 0 && co0 + NT <= a.Cout &&
-                      z0 + 4 <= a.D && y0 + TY <= a.H && x0 + TX <= a.W &&
-                      (a.bias == nullptr || (((uintptr_t)a.bias) & 15) == 0) && (a.coef == nullptr || ((((uintptr_t)a.coef) & 15) == 0 && (a.Cout & 3) == 0));
-    if (fast) {
-        const int q = lane & 7, kh = (lane >> 3) & 1, g = lane >> 4;
-        float4 tq[4][4];
+    int tile_no = 0;
+    int work = pulpo::xcd_remap(blockIdx.x, nwg);      // works of one round are dealt so that an XCD's workgroups hold neighbouring tiles
+    Tile cur = describe(work);
 #pragma unroll
-        for (int it4 = 0; it4 < 4; ++it4) {
-            const int combo = it4 * 16 + wave * 4 + g;                 // (m, ox, r) = (combo >> 5, (combo >> 4) & 1, combo & 15)
+    for (int u = 0; u < 4; ++u) dma_w_piece(cur.wsrc, 0, 0, u);
+    if constexpr (VEC) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) load_raw_part(cur, 0, part);
+    }
+    int buf = 0;
+    float4 ra[2][2], rb[2][2], rw[2];                   // two register sets of operand rows (activations: (ta, tb) x two row tiles; weights)
+
+    for (;;) {
+        const int next_work = work + nwg;
+        const bool has_next = next_work < nwork;
+        Tile nxt = cur;
+
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int p = 0; p < 4; ++p)
-                tq[it4][p] = *reinterpret_cast<const float4*>(R + ((p * 4 + (combo >> 4)) * 16 + (combo & 15)) * 64 + kh * 32 + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][p][r] = 0.f;
+
+        const float* in_b = a.in + (long)cur.b * a.in_bs;
+        int it = 0;
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            __syncthreads();                            // every wave has finished reading xs (previous chunk / previous tile's exchange)
+            if constexpr (VEC) {
+                // every thread "uses" its raw registers here, unconditionally: the compiler's wait for those loads then sits in straight-line
+                // code, and it does not have to assume them still in flight (and drain the queue, DMA included) when they are reloaded
+#pragma unroll
+                for (int u = 0; u < WN_NIT; ++u)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+                        asm volatile("" : : "v"(raw[u][tt].x), "v"(raw[u][tt].y), "v"(raw[u][tt].z), "v"(raw[u][tt].w));
+                w2_store_transformed(xs, raw, tid);
+            } else {
+                w2_stage_scalar(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, cur.z0, cur.y0, cur.x0, a.D, a.H, a.W, tid);
+            }
+            const bool last_chunk = chunk + 1 == nchunk;
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz, ++it) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of slab `it` have landed
+                __syncthreads();                        // all pieces landed, staged rows visible, everybody has left ws[buf ^ 1]
+                const float* xa = pa + dz * W2_PS;
+                const float* xb_ = pb + dz * W2_PS;
+                const float* wb = wbase + buf * WSL;
+                // what is fetched underneath this iteration's MFMAs: the next slab of this tile, or - in the tile's last iteration - slab 0 of
+                // the next tile; and (dz == 2) the next halo chunk of this tile, or chunk 0 of the next tile
+                const bool tile_end = dz == 2 && last_chunk;
+                if (tile_end && has_next) nxt = describe(next_work);
+                const bool more_w = !tile_end || has_next;
+                const float* w_src = tile_end ? nxt.wsrc : cur.wsrc;
+                const int w_it = tile_end ? 0 : it + 1;
+                const bool more_raw = VEC && dz == 2 && (!last_chunk || has_next);
+                const int raw_c0 = tile_end ? 0 : (chunk + 1) * CH;
+                // 4 point steps (px) of 8 MFMAs: one ds_read_b128 per operand row delivers four k-steps (two row tiles x (ta, tb) rows + the
+                // weight row = 5 reads per 8 MFMAs).  The reads of step px + 1 are requested before the MFMAs of step px are issued (two register
+                // sets); the activation rows of the next dz iteration's first step before its barrier (the weight row has to wait for it).
+                auto fetch_a = [&](const float* xa_, const float* xbb_, int px, int slot) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int off = 2 * m * W2_PS + px * WN_PL * W2_RS;
+                        ra[slot][m] = *reinterpret_cast<const float4*>(xa_ + off);
+                        rb[slot][m] = *reinterpret_cast<const float4*>(xbb_ + off);
+                    }
+                };
+                if (dz == 0) fetch_a(xa, xb_, 0, 0);
+                rw[0] = *reinterpret_cast<const float4*>(wb);
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    if (px + 1 < 4) {
+                        rw[(px + 1) & 1] = *reinterpret_cast<const float4*>(wb + (px + 1) * NT * CH);
+                        fetch_a(xa, xb_, px + 1, (px + 1) & 1);
+                    } else if (dz < 2) {
+                        fetch_a(xa + W2_PS, xb_ + W2_PS, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int sl = px & 1;
+                    const float wv[4] = {rw[sl].x, rw[sl].y, rw[sl].z, rw[sl].w};
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const float a_ = s2 == 0 ? ra[sl][m].x : s2 == 1 ? ra[sl][m].y : s2 == 2 ? ra[sl][m].z : ra[sl][m].w;
+                            const float b_ = s2 == 0 ? rb[sl][m].x : s2 == 1 ? rb[sl][m].y : s2 == 2 ? rb[sl][m].z : rb[sl][m].w;
+                            acc[m][px] = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaf(sa, b_, a_), wv[s2], acc[m][px], 0, 0, 0);
+                        }
+                        if (s2 == 0) {                  // behind the step's first MFMAs: their 128 pipe clocks cover the issue of these
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more_w) dma_w_piece(w_src, w_it, buf ^ 1, px);
+                            if constexpr (VEC) {
+                                if (more_raw) load_raw_part(tile_end ? nxt : cur, raw_c0, px);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                buf ^= 1;
+            }
         }
+
+        STAMP(3 + 2 * tile_no, __builtin_amdgcn_s_memtime());
+        // ---- epilogue: x inverse transform in registers, y inverse transform across the four waves through LDS, one row tile (two z-planes) at
+        // a time so that the exchange buffer stays inside the halo image (the next tile's first weight slab is landing in ws meanwhile)
+        float* R = smem;                                    // [py][ox][r][lane]
+        float* red = smem + RH;                             // [4 waves][2][NT]
+        float* out_b = a.out + (long)cur.b * a.out_bs;
+        const int z0 = cur.z0, y0 = cur.y0, x0 = cur.x0, co0 = cur.co0;
+        // Fast path (whole tile inside the volume, all 32 couts real, channels-last 16-byte aligned output - every tile of the BASELINE layers):
+        // lane = (channel quad q, row half, row group): the four waves' partial rows are fetched with ds_read_b128 (all issued before the first
+        // use), the y inverse transform is done on float4s, and each voxel leaves as one 128-byte line written by 8 lanes x 16 bytes.
+        const bool fast = a.out_cs == 1 && (a.out_ps & 3) == 0 && (a.out_bs & 3) == 0 && (((uintptr_t)a.out) & 15) == 0 && co0 + NT <= a.Cout &&
+                          z0 + 4 <= a.D && y0 + TY <= a.H && x0 + TX <= a.W &&
+                          (a.bias == nullptr || (((uintptr_t)a.bias) & 15) == 0) &&
+                          (a.coef == nullptr || ((((uintptr_t)a.coef) & 15) == 0 && (a.Cout & 3) == 0));
+        // (the lane id passes through an opaque asm here: everything the epilogue derives from it - output addresses, bias / coefficient
+        //  loads - is then computed here and not hoisted above the main loop, where it would sit in registers the loop needs)
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
+        const int q = elane & 7, kh = (elane >> 3) & 1, g = elane >> 4;
+        const int ei = elane & 31, ekk = elane >> 5;
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 b4 = zero4, sc4 = zero4, sh4 = zero4;
-        if (a.bias != nullptr) b4 = *reinterpret_cast<const float4*>(a.bias + co0 + 4 * q);
+        float4 b4 = zero4, sc4 = zero4, sh4 = zero4, s4 = zero4, q4 = zero4;        // fast path: four channels per lane
+        float bias1 = 0.f, fsc1 = 1.f, fsh1 = 0.f, ssum = 0.f, ssq = 0.f;             // general path: channel co0 + i
         const bool fuse = a.coef != nullptr;
-        if (fuse) {
-            sc4 = *reinterpret_cast<const float4*>(a.coef + 2 * a.Cout + co0 + 4 * q);
-            sh4 = *reinterpret_cast<const float4*>(a.coef + 3 * a.Cout + co0 + 4 * q);
-        }
-        float4 s4 = zero4, q4 = zero4;
-        float* obase = out_b + co0 + 4 * q;
-#pragma unroll
-        for (int it4 = 0; it4 < 4; ++it4) {
-            const int combo = it4 * 16 + wave * 4 + g;
-            const int m = combo >> 5, ox = (combo >> 4) & 1, r = combo & 15;
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int gz = z0 + 2 * m + (row >> 4), gy = y0 + 2 * ((row >> 2) & 3), gx = x0 + 2 * (row & 3) + ox;
-            const long vox = (long)(gz * a.H + gy) * a.W + gx;
-            const float4 t0 = tq[it4][0], t1 = tq[it4][1], t2 = tq[it4][2], t3 = tq[it4][3];
-            float4 v0 = make_float4(t0.x + t1.x + t2.x + b4.x, t0.y + t1.y + t2.y + b4.y, t0.z + t1.z + t2.z + b4.z, t0.w + t1.w + t2.w + b4.w);
-            float4 v1 = make_float4(t1.x - t2.x - t3.x + b4.x, t1.y - t2.y - t3.y + b4.y, t1.z - t2.z - t3.z + b4.z, t1.w - t2.w - t3.w + b4.w);
-            s4.x += v0.x + v1.x; s4.y += v0.y + v1.y; s4.z += v0.z + v1.z; s4.w += v0.w + v1.w;
-            q4.x += v0.x * v0.x + v1.x * v1.x; q4.y += v0.y * v0.y + v1.y * v1.y; q4.z += v0.z * v0.z + v1.z * v1.z; q4.w += v0.w * v0.w + v1.w * v1.w;
+        const bool cok = co0 + ei < a.Cout;
+        if (fast) {
+            if (a.bias != nullptr) b4 = *reinterpret_cast<const float4*>(a.bias + co0 + 4 * q);
             if (fuse) {
-                auto act = [&](float v, float sc, float sh) { const float tt = v * sc + sh; return tt > 0.f ? tt : tt * a.slope; };
-                v0 = make_float4(act(v0.x, sc4.x, sh4.x), act(v0.y, sc4.y, sh4.y), act(v0.z, sc4.z, sh4.z), act(v0.w, sc4.w, sh4.w));
-                v1 = make_float4(act(v1.x, sc4.x, sh4.x), act(v1.y, sc4.y, sh4.y), act(v1.z, sc4.z, sh4.z), act(v1.w, sc4.w, sh4.w));
+                sc4 = *reinterpret_cast<const float4*>(a.coef + 2 * a.Cout + co0 + 4 * q);
+                sh4 = *reinterpret_cast<const float4*>(a.coef + 3 * a.Cout + co0 + 4 * q);
             }
-            *reinterpret_cast<float4*>(obase + vox * a.out_ps) = v0;
-            *reinterpret_cast<float4*>(obase + (vox + a.W) * a.out_ps) = v1;
+        } else if (cok) {
+            if (a.bias != nullptr) bias1 = a.bias[co0 + ei];
+            if (fuse) { fsc1 = a.coef[2 * a.Cout + co0 + ei]; fsh1 = a.coef[3 * a.Cout + co0 + ei]; }
         }
-        STAMP(27);
-        if (a.stats != nullptr) {
-            // per-channel sums: lanes with equal q (lane bits 3..5 differ) hold partial sums of the same four channels
 #pragma unroll
-            for (int o = 8; o <= 32; o <<= 1) {
-                s4.x += __shfl_xor(s4.x, o, 64); s4.y += __shfl_xor(s4.y, o, 64); s4.z += __shfl_xor(s4.z, o, 64); s4.w += __shfl_xor(s4.w, o, 64);
-                q4.x += __shfl_xor(q4.x, o, 64); q4.y += __shfl_xor(q4.y, o, 64); q4.z += __shfl_xor(q4.z, o, 64); q4.w += __shfl_xor(q4.w, o, 64);
+        for (int m = 0; m < 2; ++m) {
+            __syncthreads();                                // every wave has left xs (main loop) / the exchange buffer (previous row tile)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m0 = acc[m][0][r], m1 = acc[m][1][r], m2 = acc[m][2][r], m3 = acc[m][3][r];
+                R[((py * 2 + 0) * 16 + r) * 64 + elane] = m0 + m1 + m2;
+                R[((py * 2 + 1) * 16 + r) * 64 + elane] = m1 - m2 - m3;
             }
-            float* red = smem + RED;                        // [4 waves][2][NT], behind the exchange buffer
-            if (lane < 8) {
-                *reinterpret_cast<float4*>(red + (wave * 2 + 0) * NT + 4 * q) = s4;
-                *reinterpret_cast<float4*>(red + (wave * 2 + 1) * NT + 4 * q) = q4;
+            __syncthreads();
+            if (fast) {
+                float4 tq[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int combo = h * 16 + wave * 4 + g;               // (ox, r) = (combo >> 4, combo & 15)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        tq[h][p] = *reinterpret_cast<const float4*>(R + ((p * 2 + (combo >> 4)) * 16 + (combo & 15)) * 64 + kh * 32 + 4 * q);
+                }
+                float* obase = out_b + co0 + 4 * q;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int combo = h * 16 + wave * 4 + g;
+                    const int ox = combo >> 4, r = combo & 15;
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int gz = z0 + 2 * m + (row >> 4), gy = y0 + 2 * ((row >> 2) & 3), gx = x0 + 2 * (row & 3) + ox;
+                    const long vox = (long)(gz * a.H + gy) * a.W + gx;
+                    const float4 t0 = tq[h][0], t1 = tq[h][1], t2 = tq[h][2], t3 = tq[h][3];
+                    float4 v0 = make_float4(t0.x + t1.x + t2.x + b4.x, t0.y + t1.y + t2.y + b4.y, t0.z + t1.z + t2.z + b4.z, t0.w + t1.w + t2.w + b4.w);
+                    float4 v1 = make_float4(t1.x - t2.x - t3.x + b4.x, t1.y - t2.y - t3.y + b4.y, t1.z - t2.z - t3.z + b4.z, t1.w - t2.w - t3.w + b4.w);
+                    s4.x += v0.x + v1.x; s4.y += v0.y + v1.y; s4.z += v0.z + v1.z; s4.w += v0.w + v1.w;
+                    q4.x += v0.x * v0.x + v1.x * v1.x; q4.y += v0.y * v0.y + v1.y * v1.y; q4.z += v0.z * v0.z + v1.z * v1.z; q4.w += v0.w * v0.w + v1.w * v1.w;
+                    if (fuse) {
+                        auto act = [&](float v, float sc, float sh) { const float tt = v * sc + sh; return tt > 0.f ? tt : tt * a.slope; };
+                        v0 = make_float4(act(v0.x, sc4.x, sh4.x), act(v0.y, sc4.y, sh4.y), act(v0.z, sc4.z, sh4.z), act(v0.w, sc4.w, sh4.w));
+                        v1 = make_float4(act(v1.x, sc4.x, sh4.x), act(v1.y, sc4.y, sh4.y), act(v1.z, sc4.z, sh4.z), act(v1.w, sc4.w, sh4.w));
+                    }
+                    *reinterpret_cast<float4*>(obase + vox * a.out_ps) = v0;
+                    *reinterpret_cast<float4*>(obase + (vox + a.W) * a.out_ps) = v1;
+                }
+            } else {
+                // general path: ragged tiles (volume edge), partial cout tiles, planar / strided outputs.  Wave w finishes x parity w & 1, rows
+                // 8 (w >> 1) .. 8 (w >> 1) + 7 of the row tile; lane = (row half kk, channel i)
+                const int fox = wave & 1;
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * (wave >> 1) + rr;
+                    float tq[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) tq[p] = R[((p * 2 + fox) * 16 + r) * 64 + elane];
+                    float v0 = tq[0] + tq[1] + tq[2] + bias1, v1 = tq[1] - tq[2] - tq[3] + bias1;
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * ekk;
+                    const int gz = z0 + 2 * m + (row >> 4), gy = y0 + 2 * ((row >> 2) & 3), gx = x0 + 2 * (row & 3) + fox;
+                    if (cok && gz < a.D && gx < a.W) {
+                        const long vox = (long)(gz * a.H + gy) * a.W + gx;
+                        if (gy < a.H) {
+                            ssum += v0; ssq += v0 * v0;
+                            if (fuse) { const float tt = v0 * fsc1 + fsh1; v0 = tt > 0.f ? tt : tt * a.slope; }
+                            out_b[vox * a.out_ps + (long)(co0 + ei) * a.out_cs] = v0;
+                        }
+                        if (gy + 1 < a.H) {
+                            ssum += v1; ssq += v1 * v1;
+                            if (fuse) { const float tt = v1 * fsc1 + fsh1; v1 = tt > 0.f ? tt : tt * a.slope; }
+                            out_b[(vox + a.W) * a.out_ps + (long)(co0 + ei) * a.out_cs] = v1;
+                        }
+                    }
+                }
+            }
+        }
+        if (a.stats != nullptr) {
+            // per-tile BatchNorm partial sums: reduce over the lanes that hold the same channel(s), then over the four waves
+            if (fast) {
+#pragma unroll
+                for (int o = 8; o <= 32; o <<= 1) {
+                    s4.x += __shfl_xor(s4.x, o, 64); s4.y += __shfl_xor(s4.y, o, 64); s4.z += __shfl_xor(s4.z, o, 64); s4.w += __shfl_xor(s4.w, o, 64);
+                    q4.x += __shfl_xor(q4.x, o, 64); q4.y += __shfl_xor(q4.y, o, 64); q4.z += __shfl_xor(q4.z, o, 64); q4.w += __shfl_xor(q4.w, o, 64);
+                }
+                if (elane < 8) {
+                    *reinterpret_cast<float4*>(red + (wave * 2 + 0) * NT + 4 * q) = s4;
+                    *reinterpret_cast<float4*>(red + (wave * 2 + 1) * NT + 4 * q) = q4;
+                }
+            } else {
+                ssum += __shfl_xor(ssum, 32, 64);
+                ssq += __shfl_xor(ssq, 32, 64);
+                if (elane < 32) {
+                    red[(wave * 2 + 0) * NT + ei] = ssum;
+                    red[(wave * 2 + 1) * NT + ei] = ssq;
+                }
             }
             __syncthreads();
             if (tid < 2 * NT) {
                 const int which = tid / NT, c = tid - which * NT;
-                const float tot = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] + red[(2 * 2 + which) * NT + c] +
-                                  red[(3 * 2 + which) * NT + c];
-                a.stats[((long)tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
+                if (co0 + c < a.Cout) {
+                    const float tot = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] + red[(2 * 2 + which) * NT + c] +
+                                      red[(3 * 2 + which) * NT + c];
+                    a.stats[((long)cur.tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
+                }
             }
         }
-        STAMP(28);
-        return;
+        STAMP(4 + 2 * tile_no, __builtin_amdgcn_s_memtime());
+        ++tile_no;
+        if (!has_next) break;
+        cur = nxt;
+        work = next_work;
     }
-    // general path: ragged tiles (volume edge), partial cout tiles, planar / strided outputs
-    const int fm = wave >> 1, fox = wave & 1;           // this wave finishes row tile fm, x parity fox
-    const int co = co0 + i;
-    const bool cok = co < a.Cout;
-    const float bias = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
-    const bool fuse = a.coef != nullptr && cok;
-    const float fsc = fuse ? a.coef[2 * a.Cout + co] : 1.f, fsh = fuse ? a.coef[3 * a.Cout + co] : 0.f;
-    float ssum = 0.f, ssq = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float tq[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) tq[p] = R[(((p * 2 + fm) * 2 + fox) * 16 + r) * 64 + lane];
-        float v0 = tq[0] + tq[1] + tq[2] + bias, v1 = tq[1] - tq[2] - tq[3] + bias;
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-        const int gz = z0 + 2 * fm + (row >> 4), gy = y0 + 2 * ((row >> 2) & 3), gx = x0 + 2 * (row & 3) + fox;
-        if (cok && gz < a.D && gx < a.W) {
-            const long vox = (long)(gz * a.H + gy) * a.W + gx;
-            if (gy < a.H) {
-                ssum += v0; ssq += v0 * v0;
-                if (fuse) { const float tt = v0 * fsc + fsh; v0 = tt > 0.f ? tt : tt * a.slope; }
-                out_b[vox * a.out_ps + (long)co * a.out_cs] = v0;
-            }
-            if (gy + 1 < a.H) {
-                ssum += v1; ssq += v1 * v1;
-                if (fuse) { const float tt = v1 * fsc + fsh; v1 = tt > 0.f ? tt : tt * a.slope; }
-                out_b[(vox + a.W) * a.out_ps + (long)co * a.out_cs] = v1;
-            }
-        }
-    }
-    STAMP(27);
-    ssum += __shfl_xor(ssum, 32, 64);
-    ssq += __shfl_xor(ssq, 32, 64);
-    if (a.stats != nullptr) {
-        float* red = smem + RED;                        // [4 waves][2][NT], behind the exchange buffer
-        if (lane < 32) {
-            red[(wave * 2 + 0) * NT + i] = ssum;
-            red[(wave * 2 + 1) * NT + i] = ssq;
-        }
-        __syncthreads();
-        if (tid < 2 * NT) {
-            const int which = tid / NT, c = tid - which * NT;
-            if (co0 + c < a.Cout) {
-                const float tot = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] + red[(2 * 2 + which) * NT + c] +
-                                  red[(3 * 2 + which) * NT + c];
-                a.stats[((long)tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
-            }
-        }
-    }
-    STAMP(28);
 }
 
 // packing for the (y, x) Winograd kernel: wp[k/8][dz][py][px][n][k%8] = sum_dy sum_dx G[py][dy] G[px][dx] g[dz][dy][dx]
@@ -816,7 +851,14 @@ static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
         if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(conv3d wino2): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3d_k3_wino2_mfma<VEC>), dim3(nblk), dim3(256), lds, st, a);
+    {
+        static int pct = -1;                            // diagnostic: PULPO_CONV_STAGGER = start-up offset of a CU's second workgroup, % of a tile time
+        if (pct < 0) { const char* e = getenv("PULPO_CONV_STAGGER"); pct = e ? atoi(e) : 0; }
+        const long clocks = ((long)((a.Cin + WN_CH - 1) / WN_CH) * 96 * 64 * 2 + 20000) * pct / 100;
+        const_cast<ConvArgs&>(a).stagger = (int)(clocks / (64 * 127));
+    }
+    // persistent workgroups: two per CU (LDS and registers admit exactly two), each walking the tile list with stride gridDim.x
+    hipLaunchKernelGGL((conv3d_k3_wino2_mfma<VEC>), dim3(std::min(nblk, 512)), dim3(256), lds, st, a);
     return pulpo::check_launch("conv3d_k3_wino2_mfma");
 }
 
@@ -839,13 +881,6 @@ PULPO_API int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t 
     a.ksplit = 1; a.part = nullptr;
     const long nblk_l = (long)B * a.ntz * a.nty * a.ntx * a.ncot;
     PULPO_REQUIRE(nblk_l < (1L << 31), "conv3d_k3_fwd_wino2: grid too large");
-    {
-        // start-up offset of the second workgroup per CU, in percent of one wave's matrix time per tile (nchunk x 96 MFMAs x 64 clocks)
-        static int pct = -1;
-        if (pct < 0) { const char* e = getenv("PULPO_CONV_STAGGER"); pct = e ? atoi(e) : 0; }
-        const long clocks = ((long)((K + WN_CH - 1) / WN_CH) * 96 * 64 * 2 + 33000) * pct / 100;      // pct of a (lockstep) tile time
-        a.stagger = nblk_l > 512 ? (int)(clocks / (64 * 127)) : 0;
-    }
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
     return vec ? launch_wino2<true>(a, (int)nblk_l, st) : launch_wino2<false>(a, (int)nblk_l, st);

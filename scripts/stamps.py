@@ -1,4 +1,5 @@
-"""Phase stamps of the (y, x) Winograd kernel (diagnostic build -DPULPO_ABL=9): median clock counts between phase boundaries."""
+"""Stamps of the persistent (y, x) Winograd kernel (diagnostic build -DPULPO_ABL=9): which workgroups share a CU, how their tile
+boundaries are phased against each other, clocks per tile."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,32 +17,34 @@ def main():
     for _ in range(3):
         ops._conv_raw(x, wp, None, y, ci, co, stats)
     torch.cuda.synchronize()
-    buf = np.zeros(20000 * 32, dtype=np.uint64)
+    buf = np.zeros(512 * 80, dtype=np.uint64)
     f = lib._dll.pulpo_debug_read_stamps
     f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     assert f(buf.ctypes.data, buf.nbytes) == 0
-    nblk = min(20000, (S // 4) * (S // 8) * (S // 8) * ((co + 31) // 32))
-    st = buf.reshape(20000, 32)[:nblk].astype(np.int64)
-    names = {0: "start", 1: "prologue (index math, first loads issued)", 24: "main loop end", 25: "barrier before exchange", 26: "exchange written + barrier",
-             27: "exchange read + stores issued", 28: "end"}
-    for c in range(4):
-        names[2 + c * 5] = f"chunk {c}: barrier"
-        names[3 + c * 5] = f"chunk {c}: staged (stores issued)"
-        for dz in range(3):
-            names[4 + c * 5 + dz] = f"chunk {c} dz {dz}: weights stored + barrier"
-    nch = (ci + 7) // 8
-    slots = [s for s in sorted(names) if not (2 <= s < 22 and (s - 2) // 5 >= nch)]
-    # steady-state blocks only (skip the first round, which starts cold)
-    sel = st[1024:] if nblk > 2048 else st
-    prev = slots[0]
-    print(f"{ci}->{co} @{S}^3: {nblk} workgroups; median clocks per phase (wave 0), total median {np.median(sel[:, 28] - sel[:, 0]):.0f}")
-    for s_ in slots[1:]:
-        d = sel[:, s_] - sel[:, prev]
-        print(f"  {names[s_]:48s} {np.median(d):9.0f}   (p10 {np.percentile(d, 10):7.0f}  p90 {np.percentile(d, 90):7.0f})")
-        prev = s_
-    # lockstep? start-time differences between blocks b and b+256 in the first round
-    first = st[:512, 0]
-    print("first-round start spread (clocks): ", int(first.max() - first.min()), " second-residents minus first: median", int(np.median(first[256:512] - first[:256])))
+    st = buf.reshape(512, 80).astype(np.int64)
+    hw, xcc, t0 = st[:, 0], st[:, 1] & 15, st[:, 2]
+    wave_id, simd, cu, sh, se = hw & 15, (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+    key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    ntile = int(((st[0, 3:] > 0).sum()) // 2)
+    print(f"{ci}->{co} @{S}^3: tiles per workgroup {ntile}; wave slots seen {sorted(set(wave_id.tolist()))}; distinct CU keys {len(set(key.tolist()))}")
+    ends = st[:, 4:4 + 2 * ntile:2]
+    loop_ends = st[:, 3:3 + 2 * ntile:2]
+    dur = np.diff(np.concatenate([t0[:, None], ends], axis=1), axis=1)
+    print(f"  clocks per tile: median {np.median(dur[:, 1:-1]):.0f}  (first tile {np.median(dur[:, 0]):.0f}); epilogue median {np.median(ends - loop_ends):.0f}")
+    # phase of the partner: for every CU with two workgroups, offset of the second's tile ends against the first's, as a fraction of the tile time
+    offs = []
+    for k in set(key.tolist()):
+        idx = np.where(key == k)[0]
+        if len(idx) == 2:
+            a_, b_ = idx
+            T = np.median(dur[a_, 1:-1])
+            mid = ntile // 2
+            d = (ends[b_, mid] - ends[a_, mid]) / T
+            offs.append(d - np.floor(d))
+    offs = np.array(offs)
+    print(f"  CUs with two workgroups: {len(offs)}; partner phase (fraction of a tile, 0 = lockstep): "
+          f"hist {np.histogram(offs, bins=10, range=(0, 1))[0].tolist()}  block ids of a pair e.g. {np.where(key == key[0])[0].tolist()}")
+    print(f"  start clock spread {int(t0.max() - t0.min())}")
 
 if __name__ == "__main__":
     main()
