@@ -522,7 +522,13 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
         hipLaunchKernelGGL((conv3d_k3_wgrad_mfma<VECV, NTWV>), dim3(nblk), dim3(256), bytes, st, a);                              \
     }
     static int wino = -1;
-    if (wino < 0) { const char* e = getenv("PULPO_WGRAD_WINOGRAD"); wino = e ? atoi(e) : 1; }
+    if (wino < 0) { const char* e = getenv("PULPO_WGRAD_WINOGRAD"); wino = e ? atoi(e) : 2; }      // 2: (y, x) Winograd, 1: x only, 0: direct
+    if (vec && wino >= 2 && Cin >= 8 && (long)D * H * W >= 32L * 32 * 32) {
+        // F(2x2,3x3) in (y, x), register-staged transposed operand images, z-streaming workgroups (conv3d_wgrad_w2.hip)
+        rc = pulpo_conv::launch_wgrad_w2(in, in_bs, in_ps, dy, dy_bs, dy_ps, scratch, B, D, H, W, Cin, Cout, st);
+        if (rc) return rc;
+        return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
+    }
     if (vec && wino && Cin >= 8 && (long)D * H * W >= 32L * 32 * 32) {      // (measured: no gain on the 20^3 / 10^3 pyramid levels)
         // Winograd-x variant: wave = transformed point, nine (dz, dy) row tiles of <= 32 channels
         const int nrt9 = (9 * std::min(Cin, WG_CH) + 31) / 32;

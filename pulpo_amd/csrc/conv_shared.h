@@ -21,6 +21,10 @@ int launch_splitk_reduce(const float* part, int ksplit, float* out, long obs, lo
 // dw[Cout][Cin][27] (+)= packed[27][Cin][NPad]; see unpack_wgrad_kernel in conv3d.hip
 int launch_unpack_wgrad(const float* packed, float* dw, int Cin, int Cout, int accumulate, hipStream_t st);
 
+// weight gradient, Winograd F(2x2,3x3) form (conv3d_wgrad_w2.hip): channels-last operands, accumulates into the zeroed packed scratch
+int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, long go_bs, long go_ps, float* scratch, int B, int D, int H, int W,
+                    int Cin, int Cout, hipStream_t st);
+
 // ---- shared by the direct (conv3d.hip), Winograd (conv3d_wino.hip) and weight-gradient (conv3d_wgrad.hip) translation units
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
