@@ -72,6 +72,9 @@ int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int
                               int K, int N, void* stream);
 /* weight gradient: dw[Cout][Cin][27] = sum_voxels in[v + tap - 1][ci] * dy[v][co]; scratch is overwritten */
 size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
+/* which weight-gradient kernel pulpo_conv3d_k3_wgrad runs for a shape: 2 = Winograd F(2x2,3x3) in (y, x), 1 = Winograd F(2,3) along x,
+ * 0 = direct.  vec != 0: both operands channels-last, 16-byte aligned, channel counts multiples of 4 (diagnostics / roofline accounting) */
+int pulpo_conv3d_k3_wgrad_algo(int B, int D, int H, int W, int Cin, int Cout, int vec);
 int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs, int64_t dy_ps,
                           int64_t dy_cs, float* dw, int accumulate /*dw += instead of dw =*/, float* scratch, int B, int D, int H, int W, int Cin,
                           int Cout, void* stream);

@@ -477,6 +477,15 @@ int pulpo_conv::launch_unpack_wgrad(const float* packed, float* dw, int Cin, int
 // ================================================================================================ C ABI
 PULPO_API size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout) { return (size_t)27 * Cin * npad(Cout); }
 
+// weight-gradient kernel for a shape with 16-byte-vectorisable channels-last operands (vec != 0) or not: 2 = Winograd F(2x2,3x3) in (y, x)
+// (conv3d_wgrad_w2.hip), 1 = Winograd F(2,3) along x, 0 = direct; PULPO_WGRAD_WINOGRAD = 0 / 1 caps the choice (A/B runs)
+PULPO_API int pulpo_conv3d_k3_wgrad_algo(int B, int D, int H, int W, int Cin, int Cout, int vec) {
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("PULPO_WGRAD_WINOGRAD"); cap = e ? atoi(e) : 2; }
+    const bool big = vec && Cin >= 8 && (long)D * H * W >= 32L * 32 * 32;     // (measured: no gain on the 20^3 / 10^3 pyramid levels)
+    return big ? std::min(cap, 2) : 0;
+}
+
 // dw[Cout][Cin][27] (+)= sum_vox in[vox+tap-1][ci] * dy[vox][co]  (accumulate != 0 adds to dw, e.g. a parameter's .grad storage).
 // scratch: pulpo_conv3d_k3_wgrad_scratch_floats floats.
 PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
@@ -521,15 +530,14 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
         }                                                                                                                         \
         hipLaunchKernelGGL((conv3d_k3_wgrad_mfma<VECV, NTWV>), dim3(nblk), dim3(256), bytes, st, a);                              \
     }
-    static int wino = -1;
-    if (wino < 0) { const char* e = getenv("PULPO_WGRAD_WINOGRAD"); wino = e ? atoi(e) : 2; }      // 2: (y, x) Winograd, 1: x only, 0: direct
-    if (vec && wino >= 2 && Cin >= 8 && (long)D * H * W >= 32L * 32 * 32) {
+    const int algo = pulpo_conv3d_k3_wgrad_algo(B, D, H, W, Cin, Cout, (int)vec);
+    if (algo == 2) {
         // F(2x2,3x3) in (y, x), register-staged transposed operand images, z-streaming workgroups (conv3d_wgrad_w2.hip)
         rc = pulpo_conv::launch_wgrad_w2(in, in_bs, in_ps, dy, dy_bs, dy_ps, scratch, B, D, H, W, Cin, Cout, st);
         if (rc) return rc;
         return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
     }
-    if (vec && wino && Cin >= 8 && (long)D * H * W >= 32L * 32 * 32) {      // (measured: no gain on the 20^3 / 10^3 pyramid levels)
+    if (algo == 1) {
         // Winograd-x variant: wave = transformed point, nine (dz, dy) row tiles of <= 32 channels
         const int nrt9 = (9 * std::min(Cin, WG_CH) + 31) / 32;
 #define PULPO_WGRAD_W(NTWV)                                                                                                       \

@@ -12,8 +12,10 @@
 // combination (two rows, wave-uniform coefficients) is formed in registers as in the forward kernel.  Row strides of 11 and 9 sixteen-byte
 // slots are units mod 16: the 16 lanes of every ds_read_b128 group land on 16 distinct slots.
 //
-// One workgroup of 8 waves per CU (wave = (py, half of px)): 6 accumulator tiles (2 px x 3 dz) of a 32 ci x 32 co pair per wave.  A
-// workgroup STREAMS ALONG z through 8x8 (y, x) columns: per plane step it needs the transformed input planes z - 1, z, z + 1 (a ring of four
+// One workgroup of 4 waves per CU (wave = py, ONE wave per SIMD): 12 accumulator tiles (4 px x 3 dz) of a 32 ci x 32 co pair per wave,
+// ~260 of the SIMD's 512 registers - the other half stays free, so the HBM-bound kernels of the other stream (BatchNorm passes) keep
+// running on the same CUs while this matrix-bound kernel holds them (an 8-wave variant at 2 x 236 registers ran 3 % faster alone and
+// starved everything else: the step got slower).  A workgroup STREAMS ALONG z through 8x8 (y, x) columns: per plane step it needs the transformed input planes z - 1, z, z + 1 (a ring of four
 // slots) and the output-gradient plane z (two slots); the planes of step z + 1 are fetched into registers during step z - 1, transformed and
 // written during step z (a quarter behind each group of MFMAs) - one barrier per plane step, no halo re-read along z.  Work = contiguous
 // ranges of the linearised (column, z) plane steps, so the load balance is exact to one plane.  Flush: G^T M G (in-lane over the wave's px,
@@ -42,14 +44,14 @@ struct Wgrad2Args {
 };
 
 template <int DUMMY>
-__global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
+__global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* VX = smem;
     float* EX = smem + W2G_VX;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kk = lane >> 5;
-    const int py = wave & 3, pxh = wave >> 2;             // this wave's points: (py, px = 2 pxh, 2 pxh + 1)
+    const int py = wave;                                  // this wave's points: (py, px = 0..3)
     const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
     const int npair = a.ncit * a.ncot;
     const int pair = lid % npair, split = lid / npair;
@@ -69,52 +71,52 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
     const long p_begin = nstep * split / a.nsplit, p_end = nstep * (split + 1) / a.nsplit;
 
     // ---- staging items of this thread (column-invariant geometry)
-    // X plane: items (hy 0..9, channel quad q 0..7, xb 0..3) = 320 of 512 threads; four x taps (gx = x0 - 1 + 2 xb + t) of four channels
-    const bool x_item = tid < 320;
-    const int x_q = tid & 7, x_xb = (tid >> 3) & 3, x_hy = tid >> 5;
-    // dY plane: items (y 0..7, channel quad q, xb) = 256 threads (the upper half: threads 256..511, so that the two kinds of item are spread)
-    const bool e_item = tid >= 256;
-    const int e_t = tid - 256;
-    const int e_q = e_t & 7, e_xb = (e_t >> 3) & 3, e_y = (e_t >> 5) & 7;
-    const bool x_cok = ci0 + 4 * x_q < a.Cin, e_cok = co0 + 4 * e_q < a.Cout;
-    float* const x_dst = VX + (4 * x_q) * W2G_VROW + x_hy * 4 + x_xb;          // + (px * 4 + slot) * VSLOT + c * VROW
-    float* const e_dst = EX + (4 * e_q) * W2G_EROW + e_y * 4 + e_xb;           // + (px * 2 + slot) * ESLOT + c * EROW
+    // X plane: 320 items (hy 0..9, channel quad q 0..7, xb 0..3), four x taps (gx = x0 - 1 + 2 xb + t) of four channels each: item A = tid
+    // (hy 0..7) for every thread, item B = 256 + tid (hy 8, 9) for the first 64.  dY plane: 256 items (y 0..7, q, xb), two x taps: item = tid.
+    const int it_q = tid & 7, it_xb = (tid >> 3) & 3, it_y = tid >> 5;          // shared by item A (hy = it_y) and the dY item (y = it_y)
+    const bool xb_item = tid < 64;                                                // item B: hy = 8 + (tid >> 5)
+    const bool x_cok = ci0 + 4 * it_q < a.Cin, e_cok = co0 + 4 * it_q < a.Cout;
+    float* const xa_dst = VX + (4 * it_q) * W2G_VROW + it_y * 4 + it_xb;          // + (px * 4 + slot) * VSLOT + c * VROW
+    float* const xb_dst = xa_dst + 8 * 4;                                          // hy + 8
+    float* const e_dst = EX + (4 * it_q) * W2G_EROW + it_y * 4 + it_xb;           // + (px * 2 + slot) * ESLOT + c * EROW
 
-    int cb = 0, y0 = 0, x0 = 0;                           // current column
-    unsigned x_ok = 0;                                    // in-volume bits of the four x taps (row in range), e_ok likewise (two taps)
-    unsigned e_ok = 0;
-    const float* x_src = a.in;                            // tap 0 of this thread's X item in plane 0 of the column
+    unsigned xa_ok = 0, xb_ok = 0, e_ok = 0;              // in-volume bits of the x taps of the three items (row in range)
+    const float* xa_src = a.in;                           // tap 0 of item A in plane 0 of the column; item B is 8 rows further down
     const float* e_src = a.go;
     auto set_column = [&](int col) {
         int t = col;
         const int tx_ = t % a.ntx; t /= a.ntx;
         const int ty_ = t % a.nty;
-        cb = t / a.nty;
-        y0 = ty_ * 8; x0 = tx_ * 8;
-        const int gy = y0 - 1 + x_hy;
-        x_ok = 0;
-        if (x_item && x_cok && (unsigned)gy < (unsigned)a.H)
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4)
-                if ((unsigned)(x0 - 1 + 2 * x_xb + t4) < (unsigned)a.W) x_ok |= 1u << t4;
-        x_src = a.in + (long)cb * a.in_bs + ((long)gy * a.W + (x0 - 1 + 2 * x_xb)) * a.in_ps + ci0 + 4 * x_q;
-        const int ey = y0 + e_y;
-        e_ok = 0;
-        if (e_item && e_cok && ey < a.H)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-                if (x0 + 2 * e_xb + t2 < a.W) e_ok |= 1u << t2;
-        e_src = a.go + (long)cb * a.go_bs + ((long)ey * a.W + (x0 + 2 * e_xb)) * a.go_ps + co0 + 4 * e_q;
-    };
-    const long x_plane = (long)a.H * a.W * a.in_ps, e_plane = (long)a.H * a.W * a.go_ps;
-
-    float4 xr[4], er[2];                                  // raw registers of the plane being fetched
-    auto issue_x = [&](int zp) {                          // input plane zp (zeros outside the volume)
-        const bool zok = (unsigned)zp < (unsigned)a.D;
+        const int cb = t / a.nty;
+        const int y0 = ty_ * 8, x0 = tx_ * 8;
+        const int gy = y0 - 1 + it_y;
+        xa_ok = 0; xb_ok = 0; e_ok = 0;
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
-            xr[t4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (zok && ((x_ok >> t4) & 1u)) xr[t4] = *reinterpret_cast<const float4*>(x_src + (long)zp * x_plane + (long)t4 * a.in_ps);
+            const bool xin = (unsigned)(x0 - 1 + 2 * it_xb + t4) < (unsigned)a.W;
+            if (x_cok && xin && (unsigned)gy < (unsigned)a.H) xa_ok |= 1u << t4;
+            if (xb_item && x_cok && xin && (unsigned)(gy + 8) < (unsigned)a.H) xb_ok |= 1u << t4;
+        }
+        xa_src = a.in + (long)cb * a.in_bs + ((long)gy * a.W + (x0 - 1 + 2 * it_xb)) * a.in_ps + ci0 + 4 * it_q;
+        const int ey = y0 + it_y;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+            if (e_cok && ey < a.H && x0 + 2 * it_xb + t2 < a.W) e_ok |= 1u << t2;
+        e_src = a.go + (long)cb * a.go_bs + ((long)ey * a.W + (x0 + 2 * it_xb)) * a.go_ps + co0 + 4 * it_q;
+    };
+    const long x_plane = (long)a.H * a.W * a.in_ps, e_plane = (long)a.H * a.W * a.go_ps;
+    const long x_rows8 = 8L * a.W * a.in_ps;
+
+    float4 xra[4], xrb[4], er[2];                         // raw registers of the planes being fetched
+    auto issue_x = [&](int zp) {                          // input plane zp (zeros outside the volume)
+        const bool zok = (unsigned)zp < (unsigned)a.D;
+        const float* src = xa_src + (long)zp * x_plane;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            xra[t4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (zok && ((xa_ok >> t4) & 1u)) xra[t4] = *reinterpret_cast<const float4*>(src + (long)t4 * a.in_ps);
+            xrb[t4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (zok && ((xb_ok >> t4) & 1u)) xrb[t4] = *reinterpret_cast<const float4*>(src + x_rows8 + (long)t4 * a.in_ps);
         }
     };
     auto issue_e = [&](int zp) {                          // output-gradient plane zp
@@ -125,42 +127,50 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
             if (zok && ((e_ok >> t2) & 1u)) er[t2] = *reinterpret_cast<const float4*>(e_src + (long)zp * e_plane + (long)t2 * a.go_ps);
         }
     };
-    // point px of the x-transformed item -> LDS (transposed: one ds_write_b32 per channel)
-    auto write_x = [&](int px, int slot) {
-        if (x_item) {
-            const float4 d0 = xr[0], d1 = xr[1], d2 = xr[2], d3 = xr[3];
-            float4 v;
-            if (px == 0) v = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
-            else if (px == 1) v = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
-            else if (px == 2) v = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
-            else v = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
-            float* o = x_dst + (px * 4 + slot) * W2G_VSLOT;
-            o[0] = v.x; o[W2G_VROW] = v.y; o[2 * W2G_VROW] = v.z; o[3 * W2G_VROW] = v.w;
-        }
+    // point px of an x-transformed item -> LDS (transposed: one ds_write_b32 per channel)
+    auto write_x = [&](const float4 (&d)[4], float* dst, int px, int slot) {
+        const float4 d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+        float4 v;
+        if (px == 0) v = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
+        else if (px == 1) v = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+        else if (px == 2) v = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+        else v = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+        float* o = dst + (px * 4 + slot) * W2G_VSLOT;
+        o[0] = v.x; o[W2G_VROW] = v.y; o[2 * W2G_VROW] = v.z; o[3 * W2G_VROW] = v.w;
     };
     auto write_e = [&](int px, int slot) {
-        if (e_item) {
-            const float4 d0 = er[0], d1 = er[1];
-            float4 v;
-            if (px == 0) v = d0;
-            else if (px == 1) v = make_float4(d0.x + d1.x, d0.y + d1.y, d0.z + d1.z, d0.w + d1.w);
-            else if (px == 2) v = make_float4(d0.x - d1.x, d0.y - d1.y, d0.z - d1.z, d0.w - d1.w);
-            else v = make_float4(-d1.x, -d1.y, -d1.z, -d1.w);
-            float* o = e_dst + (px * 2 + slot) * W2G_ESLOT;
-            o[0] = v.x; o[W2G_EROW] = v.y; o[2 * W2G_EROW] = v.z; o[3 * W2G_EROW] = v.w;
+        const float4 d0 = er[0], d1 = er[1];
+        float4 v;
+        if (px == 0) v = d0;
+        else if (px == 1) v = make_float4(d0.x + d1.x, d0.y + d1.y, d0.z + d1.z, d0.w + d1.w);
+        else if (px == 2) v = make_float4(d0.x - d1.x, d0.y - d1.y, d0.z - d1.z, d0.w - d1.w);
+        else v = make_float4(-d1.x, -d1.y, -d1.z, -d1.w);
+        float* o = e_dst + (px * 2 + slot) * W2G_ESLOT;
+        o[0] = v.x; o[W2G_EROW] = v.y; o[2 * W2G_EROW] = v.z; o[3 * W2G_EROW] = v.w;
+    };
+    // staging part k of 8: point k & 3 of item A and of the gradient item (k < 4), point k & 3 of item B (k >= 4)
+    auto stage_part = [&](int k, int xslot, int eslot) {
+        if (k < 4) {
+            write_x(xra, xa_dst, k, xslot);
+            write_e(k, eslot);
+        } else if (xb_item) {
+            write_x(xrb, xb_dst, k - 4, xslot);
         }
     };
     // every thread "uses" its raw registers unconditionally (see conv3d_wino.hip): the compiler's wait for the loads sits in straight-line code
     auto touch_raw = [&]() {
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) asm volatile("" : : "v"(xr[t4].x), "v"(xr[t4].y), "v"(xr[t4].z), "v"(xr[t4].w));
+        for (int t4 = 0; t4 < 4; ++t4) {
+            asm volatile("" : : "v"(xra[t4].x), "v"(xra[t4].y), "v"(xra[t4].z), "v"(xra[t4].w));
+            asm volatile("" : : "v"(xrb[t4].x), "v"(xrb[t4].y), "v"(xrb[t4].z), "v"(xrb[t4].w));
+        }
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) asm volatile("" : : "v"(er[t2].x), "v"(er[t2].y), "v"(er[t2].z), "v"(er[t2].w));
     };
 
-    f32x16 acc[2][3];                                     // [px of this wave][dz]
+    f32x16 acc[4][3];                                     // [px][dz]
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
@@ -173,9 +183,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
     const float* ea = EX + i * W2G_EROW + (2 * kk) * 4;
 
     // ---- main loop: column segments [zs, ze) of this split's plane-step range, each entered through three warm-up iterations (j = zs - 3 ..
-    // zs - 1: stage only) so that the loads have exactly one definition inside the loop (a second, conditional one costs register copies and a
-    // vmcnt(0) on the back edge).  Iteration j: barrier; [j >= zs: plane step j = E[j] x V[j - 1 .. j + 1]]; the registers (input plane j + 2,
-    // gradient plane j + 1) are transformed and written into the free slots; the loads of planes j + 3 / j + 2 are issued.
+    // zs - 1: stage only; a loop of their own - a conditional around the MFMAs costs a second copy of the accumulators).  Iteration j:
+    // barrier; plane step j = E[j] x V[j - 1 .. j + 1]; the registers (input plane j + 2, gradient plane j + 1) are transformed and written
+    // into the free slots, one part behind each group's first MFMAs; the loads of planes j + 3 / j + 2 are issued.
     long p = p_begin;
     while (p < p_end) {
         const int pc = (int)(p / a.D);
@@ -185,14 +195,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
         issue_x(zs - 1);
         er[0] = make_float4(0.f, 0.f, 0.f, 0.f); er[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
-        for (int j = zs - 3; j < zs; ++j) {               // warm-up: stage only (its own loop: the accumulators must not see a conditional)
+        for (int j = zs - 3; j < zs; ++j) {
             __syncthreads();
             touch_raw();
 #pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {
-                write_x(gi, (j + 3) & 3);
-                write_e(gi, (j & 1) ^ 1);
-            }
+            for (int k = 0; k < 8; ++k) stage_part(k, (j + 3) & 3, (j & 1) ^ 1);
             issue_x(j + 3);
             issue_e(j + 2);
         }
@@ -201,45 +208,42 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
             __syncthreads();                              // staged planes visible; everybody has finished the previous iteration's reads
             touch_raw();
             const int xs_slot = (j + 3) & 3, es = j & 1;
-            {
-                // four groups (g, pl) of 12 MFMAs; the eight ds_read_b128 of group k + 1 are requested before the MFMAs of group k are issued
-                float4 av[2][3], bv[2][3], e0[2], e1[2];
-                auto fetch = [&](int gi, int set) {
-                    const int g = gi >> 1, px = 2 * pxh + (gi & 1);
-                    const float* eb = ea + (px * 2 + es) * W2G_ESLOT + g * 16;
-                    e0[set] = *reinterpret_cast<const float4*>(eb);
-                    e1[set] = *reinterpret_cast<const float4*>(eb + 4);
+            // eight groups (g, px) of 12 MFMAs; the eight ds_read_b128 of group k + 1 are requested before the MFMAs of group k are issued
+            // (two register sets: with one wave per SIMD nothing else hides the LDS round trip)
+            float4 av[2][3], bv[2][3], e0[2], e1[2];
+            auto fetch = [&](int gi, int set) {
+                const int g = gi >> 2, px = gi & 3;
+                const float* eb = ea + (px * 2 + es) * W2G_ESLOT + g * 16;
+                e0[set] = *reinterpret_cast<const float4*>(eb);
+                e1[set] = *reinterpret_cast<const float4*>(eb + 4);
 #pragma unroll
-                    for (int dz = 0; dz < 3; ++dz) {
-                        const int off = (px * 4 + ((j + dz) & 3)) * W2G_VSLOT + g * 16;
-                        av[set][dz] = *reinterpret_cast<const float4*>(va + off);
-                        bv[set][dz] = *reinterpret_cast<const float4*>(vb + off);
-                    }
-                };
-                fetch(0, 0);
-#pragma unroll
-                for (int gi = 0; gi < 4; ++gi) {
-                    const int set = gi & 1, pl = gi & 1;
-                    if (gi + 1 < 4) fetch(gi + 1, set ^ 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const float4 f0 = e0[set], f1 = e1[set];
-                    const float ev[4] = {fmaf(c1, f1.x, c0 * f0.x), fmaf(c1, f1.y, c0 * f0.y), fmaf(c1, f1.z, c0 * f0.z), fmaf(c1, f1.w, c0 * f0.w)};
-#pragma unroll
-                    for (int dz = 0; dz < 3; ++dz) {
-                        const float4 pa_ = av[set][dz], pb_ = bv[set][dz];
-                        const float v4[4] = {fmaf(sa, pb_.x, pa_.x), fmaf(sa, pb_.y, pa_.y), fmaf(sa, pb_.z, pa_.z), fmaf(sa, pb_.w, pa_.w)};
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_) acc[pl][dz] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[s_], ev[s_], acc[pl][dz], 0, 0, 0);
-                        if (dz == 0) {
-                            // staging quarter gi: point gi of both items, behind the group's first MFMAs
-                            __builtin_amdgcn_sched_barrier(0);
-                            write_x(gi, xs_slot);
-                            write_e(gi, es ^ 1);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int dz = 0; dz < 3; ++dz) {
+                    const int off = (px * 4 + ((j + dz) & 3)) * W2G_VSLOT + g * 16;
+                    av[set][dz] = *reinterpret_cast<const float4*>(va + off);
+                    bv[set][dz] = *reinterpret_cast<const float4*>(vb + off);
                 }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int gi = 0; gi < 8; ++gi) {
+                const int set = gi & 1, px = gi & 3;
+                if (gi + 1 < 8) fetch(gi + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 f0 = e0[set], f1 = e1[set];
+                const float ev[4] = {fmaf(c1, f1.x, c0 * f0.x), fmaf(c1, f1.y, c0 * f0.y), fmaf(c1, f1.z, c0 * f0.z), fmaf(c1, f1.w, c0 * f0.w)};
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    const float4 pa_ = av[set][dz], pb_ = bv[set][dz];
+                    const float v4[4] = {fmaf(sa, pb_.x, pa_.x), fmaf(sa, pb_.y, pa_.y), fmaf(sa, pb_.z, pa_.z), fmaf(sa, pb_.w, pa_.w)};
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) acc[px][dz] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[s_], ev[s_], acc[px][dz], 0, 0, 0);
+                    if (dz == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        stage_part(gi, xs_slot, es ^ 1);  // behind the group's first MFMAs
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             issue_x(j + 3);
             issue_e(j + 2);
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
     }
 
     // ---- flush: dw[dz][ky][kx] = sum_py sum_px G[py][ky] G[px][kx] M[py][px][dz], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].  The px sum
-    // is in-lane (this wave's two px), the (py, px-half) sum meets in LDS, one dz at a time: X[wave][kx][r][lane] (8 x 3 x 1024 floats = 96 KB)
+    // is in-lane, the py sum meets in LDS, one dz at a time: X[py][kx][r][lane] (4 x 3 x 1024 floats = 48 KB)
     __syncthreads();
     float* X = smem;
     const int Cc = min(32, a.Cin - ci0);
@@ -259,29 +263,28 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
         for (int r = 0; r < 16; ++r) {
             const float m0 = dz == 0 ? acc[0][0][r] : dz == 1 ? acc[0][1][r] : acc[0][2][r];
             const float m1 = dz == 0 ? acc[1][0][r] : dz == 1 ? acc[1][1][r] : acc[1][2][r];
-            float t0, t1, t2;                             // kx = 0, 1, 2 from px = 2 pxh (m0), 2 pxh + 1 (m1)
-            if (pxh == 0) { t0 = m0 + 0.5f * m1; t1 = 0.5f * m1; t2 = 0.5f * m1; }               // px 0: G = (1,0,0); px 1: (.5,.5,.5)
-            else { t0 = 0.5f * m0; t1 = -0.5f * m0; t2 = 0.5f * m0 + m1; }                          // px 2: (.5,-.5,.5); px 3: (0,0,1)
-            X[((wave * 3 + 0) * 16 + r) * 64 + lane] = t0;
-            X[((wave * 3 + 1) * 16 + r) * 64 + lane] = t1;
-            X[((wave * 3 + 2) * 16 + r) * 64 + lane] = t2;
+            const float m2 = dz == 0 ? acc[2][0][r] : dz == 1 ? acc[2][1][r] : acc[2][2][r];
+            const float m3 = dz == 0 ? acc[3][0][r] : dz == 1 ? acc[3][1][r] : acc[3][2][r];
+            const float hs = 0.5f * (m1 + m2);
+            X[((py * 3 + 0) * 16 + r) * 64 + lane] = m0 + hs;
+            X[((py * 3 + 1) * 16 + r) * 64 + lane] = 0.5f * (m1 - m2);
+            X[((py * 3 + 2) * 16 + r) * 64 + lane] = hs + m3;
         }
         __syncthreads();
-        // 3 kx x 16 r x 64 lanes = 3072 entries, 6 per thread; each yields the three ky taps
-        for (int e = tid; e < 3 * 16 * 64; e += 512) {
+        // 3 kx x 16 r x 64 lanes = 3072 entries, 12 per thread; each yields the three ky taps
+        for (int e = tid; e < 3 * 16 * 64; e += 256) {
             const int l = e & 63, r = (e >> 6) & 15, kx = e >> 10;
-            float s[4];
+            float s4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)                   // py = q: waves q (px half 0) and q + 4 (px half 1)
-                s[q] = X[((q * 3 + kx) * 16 + r) * 64 + l] + X[(((q + 4) * 3 + kx) * 16 + r) * 64 + l];
+            for (int q = 0; q < 4; ++q) s4[q] = X[((q * 3 + kx) * 16 + r) * 64 + l];
             const int ci = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), co = co0 + (l & 31);
             if (ci < Cc && co < a.Cout) {
-                const float hs = 0.5f * (s[1] + s[2]);
+                const float hs = 0.5f * (s4[1] + s4[2]);
                 float* d = a.dwp + ((long)((dz * 3 + 0) * 3 + kx) * a.Cin + ci0 + ci) * a.NPad + co;
                 const long kystride = 3L * a.Cin * a.NPad;
-                atomicAdd(d, s[0] + hs);
-                atomicAdd(d + kystride, 0.5f * (s[1] - s[2]));
-                atomicAdd(d + 2 * kystride, hs + s[3]);
+                atomicAdd(d, s4[0] + hs);
+                atomicAdd(d + kystride, 0.5f * (s4[1] - s4[2]));
+                atomicAdd(d + 2 * kystride, hs + s4[3]);
             }
         }
         __syncthreads();
@@ -304,7 +307,7 @@ int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, lo
     a.ncit = pulpo::cdiv(Cin, 32); a.ncot = pulpo::cdiv(Cout, 32);
     const int npair = a.ncit * a.ncot;
     const long nstep = (long)B * a.nty * a.ntx * D;
-    int nsplit = std::max(1, 256 / npair);                 // one 512-thread workgroup per CU
+    int nsplit = std::max(1, 256 / npair);                 // one workgroup per CU
     nsplit = (int)std::min<long>(nsplit, nstep);
     a.nsplit = nsplit;
     static bool attr = false;
@@ -313,7 +316,7 @@ int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, lo
         if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(wgrad w2): %s", hipGetErrorString(e));
         attr = true;
     }
-    hipLaunchKernelGGL((conv3d_k3_wgrad_w2<0>), dim3(npair * nsplit), dim3(512), W2G_LDS, st, a);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_w2<0>), dim3(npair * nsplit), dim3(256), W2G_LDS, st, a);
     return pulpo::check_launch("conv3d_k3_wgrad_w2");
 }
 

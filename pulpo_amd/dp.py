@@ -212,6 +212,8 @@ class DataParallelStepper:
         self.opt = FusedAdam(self.arena, lr=lr if lr is not None else float(model.hparams.lr))
         if world() > 1:     # start from identical weights: broadcast rank 0's arena (and BN buffers)
             dist.broadcast(self.arena.data, src=0)
+            from . import ops
+            ops.invalidate_weight_packs()        # (parameters are views of the arena: their version counters did not move)
             for b in model.buffers():
                 if b.is_floating_point():
                     dist.broadcast(b, src=0)

@@ -205,7 +205,38 @@ def _use_bf16(K: int) -> bool:
     return CONV_PRECISION == "bf16" and K > 4
 
 
-def _pack_weight(w: torch.Tensor, dgrad: bool, shape=None) -> torch.Tensor:
+# Weights written behind torch's back (the fused Adam kernel, a broadcast into the parameter arena) do not move a tensor's version counter:
+# whoever does that calls invalidate_weight_packs()
+_WEIGHT_EPOCH = 0
+
+
+def invalidate_weight_packs() -> None:
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+def _pack_weight(w: torch.Tensor, dgrad: bool, shape=None, both: bool = False) -> torch.Tensor:
+    """cached front end of _pack_weight_now: a weight is packed once per (version, orientation, kernel family, precision); `both` = also
+    produce the other orientation now (training forward: the data-gradient kernel of the backward pass finds its weights ready, and a
+    repeated forward - Monte-Carlo sampling, evaluation loops - packs nothing at all)"""
+    cache = getattr(w, "_pulpo_packs", None)
+    ver = (w._version, w.data_ptr(), _WEIGHT_EPOCH)
+    if cache is None or cache[0] != ver:
+        cache = (ver, {})
+        try:
+            w._pulpo_packs = cache
+        except AttributeError:                       # (non-leaf views cannot carry attributes on some builds: pack uncached)
+            return _pack_weight_now(w, dgrad, shape)
+    def key(d):
+        return (d, CONV_PRECISION, CONV_ALGO, None if shape is None else tuple(shape))
+    if both and key(not dgrad) not in cache[1]:
+        cache[1][key(not dgrad)] = _pack_weight_now(w, not dgrad, shape)
+    if key(dgrad) not in cache[1]:
+        cache[1][key(dgrad)] = _pack_weight_now(w, dgrad, shape)
+    return cache[1][key(dgrad)]
+
+
+def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None) -> torch.Tensor:
     """GEMM-ordered copy of a (Cout, Cin, 3, 3, 3) weight for the forward (dgrad=False) or data-gradient (True) convolution.
     shape = (B, D, H, W) of the volume it will be applied to: large volumes use the Winograd-x kernel, which has its own packing
     (the returned tensor carries the choice in `_pulpo_algo`)."""
@@ -277,7 +308,13 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
     sfx = "_bf16" if _use_bf16(Cin) else ""
     lib.call(f"pulpo_conv3d_k3_wgrad{sfx}", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), int(into is not None), _ptr(scratch), B, D, H, W,
              Cin, Cout, _stream())
-    _trace_end(t0, f"conv3d_k3_wgrad{sfx or '_mfma'}(+memset,unpack)", 54.0 * Cin * Cout * B * D * H * W, 4.0 * (Cin + Cout) * B * D * H * W)
+    if t0 is not None:
+        name = "conv3d_k3_wgrad_bf16"
+        if not sfx:
+            vec = (xc == 1 and xp % 4 == 0 and xb % 4 == 0 and Cin % 4 == 0 and x.data_ptr() % 16 == 0 and dc == 1 and dp % 4 == 0 and db % 4 == 0
+                   and Cout % 4 == 0 and dy.data_ptr() % 16 == 0)
+            name = ("conv3d_k3_wgrad_mfma", "conv3d_k3_wgrad_wino", "conv3d_k3_wgrad_w2")[lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, Cin, Cout, int(vec))]
+        _trace_end(t0, name + "(+memset,unpack)", 54.0 * Cin * Cout * B * D * H * W, 4.0 * (Cin + Cout) * B * D * H * W)
     return None if into is not None else dw
 
 
@@ -289,11 +326,15 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
 ASYNC_WGRAD_STREAM = None
 
 
-def _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w):
+def _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, bias_job=None):
+    """bias_job = (partials, nrow, slot_b): the conv-bias gradient's column sum rides along (nothing on the main stream needs it)"""
     main = torch.cuda.current_stream()
     side = ASYNC_WGRAD_STREAM
     side.wait_stream(main)                       # after everything queued so far: dy, this unit's data gradient, zero_grad
     with torch.cuda.stream(side):
+        if bias_job is not None:
+            _colsum(bias_job[0], bias_job[1], Cout, into=bias_job[2])
+            bias_job[0].record_stream(side)
         _wgrad_raw(x, dy, Cin, Cout, into=slot_w)
     x.record_stream(side)                        # keep both operands' memory out of the allocator's hands until the side stream is done
     dy.record_stream(side)
@@ -315,7 +356,7 @@ class _ConvBNLReLU(torch.autograd.Function):
         B, Cin, D, H, W = x.shape
         Cout = weight.shape[0]
         dev = x.device
-        wp = _pack_weight(weight, dgrad=False, shape=(B, D, H, W))
+        wp = _pack_weight(weight, dgrad=False, shape=(B, D, H, W), both=bool(training and ctx.needs_input_grad[0]))
         y = new_cl(B, Cout, D, H, W, dev)
         coef = torch.empty(8 * Cout, device=dev, dtype=torch.float32)      # [4][C] floats + [2][C] doubles
         if training:
@@ -371,9 +412,10 @@ class _ConvBNLReLU(torch.autograd.Function):
         lib.call("pulpo_bn_lrelu_bwd_apply", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4), npix, Cout,
                  LRELU_SLOPE, _ptr(part2), _stream())
         _hbm_end(t0, "bn_lrelu_bwd_apply", 12.0 * Cout * npix)                # read dz, y; write dy
-        dbias = _colsum(part2, nblk, Cout, into=slot_b) if ctx.needs_input_grad[2] else None
-        dbeta, dgamma = (None, None) if direct_bn else (tot[:Cout], tot[Cout:])
         defer_w = ctx.needs_input_grad[1] and slot_w is not None and ASYNC_WGRAD_STREAM is not None
+        defer_b = defer_w and ctx.needs_input_grad[2] and slot_b is not None
+        dbias = _colsum(part2, nblk, Cout, into=slot_b) if (ctx.needs_input_grad[2] and not defer_b) else None
+        dbeta, dgamma = (None, None) if direct_bn else (tot[:Cout], tot[Cout:])
         dw = _wgrad_raw(x, dy, Cin, Cout, into=slot_w) if (ctx.needs_input_grad[1] and not defer_w) else None
         dx = None
         if ctx.needs_input_grad[0]:
@@ -381,7 +423,7 @@ class _ConvBNLReLU(torch.autograd.Function):
             dx = torch.empty_like(x) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, dev)
             _conv_raw(dy, wpt, None, dx, Cout, Cin, None)
         if defer_w:
-            _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w)
+            _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, (part2, nblk, slot_b) if defer_b else None)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -935,6 +977,7 @@ class StreamingMoments:
 
 def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, gscale: float = 1.0):
     _require_gpu(p, g, m, v)
+    invalidate_weight_packs()                    # the kernel rewrites parameters through raw pointers
     lib.call("pulpo_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, int(step), gscale, _stream())
 
 

@@ -286,6 +286,25 @@ def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size, algo):
     assert rel_l2(gb, gref[2]) < 1e-5
 
 
+def test_packed_weight_cache_follows_weight_updates(ops):
+    """the GEMM-ordered weight packs are cached per weight version: an in-place update through torch (optimizer) or behind its back (the
+    fused Adam kernel writes through raw pointers and calls ops.invalidate_weight_packs) must be seen by the next convolution"""
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 16, 32, 32, 32, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(16, 16, 3, 3, 3, generator=gen) / 20).cuda()
+    y0 = ops.conv3d_k3(x, w)
+    assert torch.equal(ops.conv3d_k3(x, w), y0)                      # cached pack: same result
+    w.mul_(2.0)                                                      # torch in-place: version counter moves
+    assert rel_l2(ops.conv3d_k3(x, w), 2.0 * y0) < 1e-6
+    p = w.clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    y1 = ops.conv3d_k3(x, p)
+    ops.adam_step(p.view(-1), torch.ones_like(p).view(-1), m.view(-1), v.view(-1), lr=0.1, step=1)       # raw-pointer update
+    y2 = ops.conv3d_k3(x, p)
+    ref = F.conv3d(x.cpu().double(), p.cpu().double(), padding=1)
+    assert rel_l2(y2, ref) < 2e-6 and rel_l2(y1, ref) > 1e-2
+
+
 def test_conv_linearity_at_full_channel_width(ops):
     """size-independent property at a BASELINE layer shape (32->32 @ 48^3): conv(a*x1 + x2) = a*conv(x1) + conv(x2) (no bias)"""
     gen = torch.Generator().manual_seed(3)
