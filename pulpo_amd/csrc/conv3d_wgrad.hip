@@ -482,7 +482,9 @@ PULPO_API size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout) { retur
 PULPO_API int pulpo_conv3d_k3_wgrad_algo(int B, int D, int H, int W, int Cin, int Cout, int vec) {
     static int cap = -1;
     if (cap < 0) { const char* e = getenv("PULPO_WGRAD_WINOGRAD"); cap = e ? atoi(e) : 2; }
-    const bool big = vec && Cin >= 8 && (long)D * H * W >= 32L * 32 * 32;     // (measured: no gain on the 20^3 / 10^3 pyramid levels)
+    static long minvox = -1;                                                   // PULPO_WGRAD_MIN_VOXELS: smallest volume for the Winograd forms (A/B runs)
+    if (minvox < 0) { const char* e = getenv("PULPO_WGRAD_MIN_VOXELS"); minvox = e ? atol(e) : 1000; }
+    const bool big = vec && Cin >= 8 && (long)D * H * W >= minvox;             // (measured: the (y, x) form also wins on the 20^3 and 10^3 pyramid levels)
     return big ? std::min(cap, 2) : 0;
 }
 

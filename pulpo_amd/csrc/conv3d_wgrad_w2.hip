@@ -148,14 +148,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
         float* o = e_dst + (px * 2 + slot) * W2G_ESLOT;
         o[0] = v.x; o[W2G_EROW] = v.y; o[2 * W2G_EROW] = v.z; o[3 * W2G_EROW] = v.w;
     };
-    // staging part k of 8: point k & 3 of item A and of the gradient item (k < 4), point k & 3 of item B (k >= 4)
+    // staging part k of 4: point k of the three items
     auto stage_part = [&](int k, int xslot, int eslot) {
-        if (k < 4) {
-            write_x(xra, xa_dst, k, xslot);
-            write_e(k, eslot);
-        } else if (xb_item) {
-            write_x(xrb, xb_dst, k - 4, xslot);
-        }
+        write_x(xra, xa_dst, k, xslot);
+        write_e(k, eslot);
+        if (xb_item) write_x(xrb, xb_dst, k, xslot);
     };
     // every thread "uses" its raw registers unconditionally (see conv3d_wino.hip): the compiler's wait for the loads sits in straight-line code
     auto touch_raw = [&]() {
@@ -185,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
     // ---- main loop: column segments [zs, ze) of this split's plane-step range, each entered through three warm-up iterations (j = zs - 3 ..
     // zs - 1: stage only; a loop of their own - a conditional around the MFMAs costs a second copy of the accumulators).  Iteration j:
     // barrier; plane step j = E[j] x V[j - 1 .. j + 1]; the registers (input plane j + 2, gradient plane j + 1) are transformed and written
-    // into the free slots, one part behind each group's first MFMAs; the loads of planes j + 3 / j + 2 are issued.
+    // into the free slots, one point behind each of the first four groups' first MFMAs; then the loads of planes j + 3 / j + 2 are issued.
     long p = p_begin;
     while (p < p_end) {
         const int pc = (int)(p / a.D);
@@ -199,14 +196,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
             __syncthreads();
             touch_raw();
 #pragma unroll
-            for (int k = 0; k < 8; ++k) stage_part(k, (j + 3) & 3, (j & 1) ^ 1);
+            for (int k = 0; k < 4; ++k) stage_part(k, (j + 3) & 3, (j & 1) ^ 1);
             issue_x(j + 3);
             issue_e(j + 2);
         }
 #pragma unroll 1
         for (int j = zs; j < ze; ++j) {
             __syncthreads();                              // staged planes visible; everybody has finished the previous iteration's reads
-            touch_raw();
             const int xs_slot = (j + 3) & 3, es = j & 1;
             // eight groups (g, px) of 12 MFMAs; the eight ds_read_b128 of group k + 1 are requested before the MFMAs of group k are issued
             // (two register sets: with one wave per SIMD nothing else hides the LDS round trip)
@@ -237,16 +233,22 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
                     const float v4[4] = {fmaf(sa, pb_.x, pa_.x), fmaf(sa, pb_.y, pa_.y), fmaf(sa, pb_.z, pa_.z), fmaf(sa, pb_.w, pa_.w)};
 #pragma unroll
                     for (int s_ = 0; s_ < 4; ++s_) acc[px][dz] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[s_], ev[s_], acc[px][dz], 0, 0, 0);
-                    if (dz == 0) {
+                    if (dz == 0 && gi < 4) {
+                        // behind the group's first MFMAs: the registers (planes j + 2 / j + 1, requested half an iteration ago) are transformed
+                        // and written, one point per group; after the fourth they are free and the next planes are requested, which leaves
+                        // those loads groups 4..7 and the barrier to land
                         __builtin_amdgcn_sched_barrier(0);
-                        stage_part(gi, xs_slot, es ^ 1);  // behind the group's first MFMAs
+                        if (gi == 0) touch_raw();
+                        stage_part(gi, xs_slot, es ^ 1);
+                        if (gi == 3) {
+                            issue_x(j + 3);
+                            issue_e(j + 2);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            issue_x(j + 3);
-            issue_e(j + 2);
         }
         p += ze - zs;
         __syncthreads();                                  // (the next segment's warm-up overwrites the rings)
