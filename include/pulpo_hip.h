@@ -75,9 +75,23 @@ size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
 /* which weight-gradient kernel pulpo_conv3d_k3_wgrad runs for a shape: 2 = Winograd F(2x2,3x3) in (y, x), 1 = Winograd F(2,3) along x,
  * 0 = direct.  vec != 0: both operands channels-last, 16-byte aligned, channel counts multiples of 4 (diagnostics / roofline accounting) */
 int pulpo_conv3d_k3_wgrad_algo(int B, int D, int H, int W, int Cin, int Cout, int vec);
+/* accumulate: 0 dw = result, 1 dw += result, 2 DEFERRED - `scratch` must arrive all zero, keeps the packed sums [27][Cin][NPad] and dw (may
+ * be NULL) is not touched: the caller finishes every deferred gradient of a backward pass with one pulpo_grad_finish_multi launch (which
+ * adds into dw and returns the scratch to all zero).  The same holds for the bf16-operand variant below. */
 int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs, int64_t dy_ps,
-                          int64_t dy_cs, float* dw, int accumulate /*dw += instead of dw =*/, float* scratch, int B, int D, int H, int W, int Cin,
+                          int64_t dy_cs, float* dw, int accumulate, float* scratch, int B, int D, int H, int W, int Cin,
                           int Cout, void* stream);
+/* One launch for the parameter-gradient epilogues of a whole backward pass (the reference has no counterpart: autograd's per-parameter
+ * AccumulateGrad adds, torch.optim's view of .grad).  jobs: DEVICE array of njobs entries.
+ *   kind 0  dst[co][ci][27] += src[tap][ci][co of NPad] and src := 0     a = Cin, b = Cout, c = NPad   (deferred pulpo_conv3d_k3_wgrad)
+ *   kind 1  dst[col] += sum_r src[r][col]                                a = rows, b = columns         (conv-bias gradient from the
+ *           pulpo_bn_lrelu_bwd_apply partials) */
+typedef struct PulpoGradJob {
+    const float* src;
+    float* dst;
+    int kind, a, b, c;
+} PulpoGradJob;
+int pulpo_grad_finish_multi(const PulpoGradJob* jobs, int njobs, void* stream);
 
 /* bf16-operand variant (BASELINE configs 4-5; no counterpart in the reference, whose arithmetic is fp32 throughout - SURVEY.md 8(d)):
  * the same convolution with both operands rounded to bf16 (round-to-nearest-even) as they are staged, products and sums in

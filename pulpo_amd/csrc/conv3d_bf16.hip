@@ -543,7 +543,7 @@ PULPO_API size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
 PULPO_API int pulpo_conv3d_k3_wgrad_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
                                          int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, int B, int D, int H, int W,
                                          int Cin, int Cout, void* stream) {
-    PULPO_REQUIRE(in && dy && dw && scratch, "conv3d_k3_wgrad_bf16: null pointer");
+    PULPO_REQUIRE(in && dy && scratch && (dw || accumulate == 2), "conv3d_k3_wgrad_bf16: null pointer");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3d_k3_wgrad_bf16: bad dims");
     hipStream_t st = (hipStream_t)stream;
     WgradArgsH a;
@@ -556,8 +556,11 @@ PULPO_API int pulpo_conv3d_k3_wgrad_bf16(const float* in, int64_t in_bs, int64_t
     const int ntile = B * a.ntz * a.nty * a.ntx;
     const int npair = a.ncit * a.ncot;
     a.nsplit = std::min(std::max(1, 512 / npair), ntile);        // two resident workgroups per CU: one stages while the other multiplies
-    hipError_t e = hipMemsetAsync(scratch, 0, pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout) * sizeof(float), st);
-    if (e != hipSuccess) return pulpo::fail((int)e, "wgrad_bf16 memset: %s", hipGetErrorString(e));
+    const bool deferred = accumulate == 2;                 // see pulpo_conv3d_k3_wgrad
+    if (!deferred) {
+        hipError_t e = hipMemsetAsync(scratch, 0, pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout) * sizeof(float), st);
+        if (e != hipSuccess) return pulpo::fail((int)e, "wgrad_bf16 memset: %s", hipGetErrorString(e));
+    }
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)in & 15) == 0) &&
                      (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
     const int nrt_max = (27 * std::min(Cin, CH) + 31) / 32;
@@ -572,6 +575,6 @@ PULPO_API int pulpo_conv3d_k3_wgrad_bf16(const float* in, int64_t in_bs, int64_t
     }
 #undef PULPO_WGRAD_H
     int rc = pulpo::check_launch("conv3d_k3_wgrad_bf16");
-    if (rc) return rc;
+    if (rc || deferred) return rc;
     return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
 }

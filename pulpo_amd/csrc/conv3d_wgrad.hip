@@ -2,6 +2,7 @@
 // Persistent workgroups (one per CU) fed by LDS-DMA, direct form (conv3d_k3_wgrad_mfma) and Winograd F(2,3)-along-x form
 // (conv3d_k3_wgrad_wino); atomic flush into a packed scratch, then unpack (optionally accumulating into the parameter's .grad).
 #include "conv_shared.h"
+#include "../../include/pulpo_hip.h"
 #include <stdlib.h>
 
 #ifndef PULPO_ABL
@@ -465,7 +466,50 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
     }
 }
 
+// deferred parameter-gradient jobs of a whole backward pass in ONE launch (grid = (blocks per job, jobs)):
+//   kind 0: dw[co][ci][27] += packed[tap][ci][co] and packed := 0   (a = Cin, b = Cout, c = NPad)     - weight gradients of pulpo_conv3d_k3_wgrad(accumulate = 2)
+//   kind 1: dst[col] += sum_r src[r][col]                          (a = rows, b = columns)          - conv-bias gradients from the BatchNorm backward partials
+__global__ __launch_bounds__(256) void grad_finish_multi_kernel(const PulpoGradJob* __restrict__ jobs) {
+    const PulpoGradJob j = jobs[blockIdx.y];
+    if (j.kind == 0) {
+        float* packed = const_cast<float*>(j.src);
+        const long total = (long)j.b * j.a * 27;
+        for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+            const int tap = (int)(e % 27);
+            const long r = e / 27;
+            const int ci = (int)(r % j.a), co = (int)(r / j.a);
+            const long src = ((long)tap * j.a + ci) * j.c + co;
+            j.dst[e] += packed[src];
+            packed[src] = 0.f;
+        }
+    } else {
+        __shared__ double red[8][33];
+        const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+        for (int c0 = blockIdx.x * 32; c0 < j.b; c0 += gridDim.x * 32) {
+            const int c = c0 + cx;
+            double s_ = 0.0;
+            if (c < j.b)
+                for (int r = ry; r < j.a; r += 8) s_ += (double)j.src[(long)r * j.b + c];
+            red[ry][cx] = s_;
+            __syncthreads();
+            if (ry == 0 && c < j.b) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t += red[k][cx];
+                j.dst[c] += (float)t;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
+
+PULPO_API int pulpo_grad_finish_multi(const PulpoGradJob* jobs, int njobs, void* stream) {
+    PULPO_REQUIRE(jobs && njobs > 0, "grad_finish_multi: bad arguments");
+    hipLaunchKernelGGL(grad_finish_multi_kernel, dim3(48, njobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    return pulpo::check_launch("grad_finish_multi");
+}
 
 int pulpo_conv::launch_unpack_wgrad(const float* packed, float* dw, int Cin, int Cout, int accumulate, hipStream_t st) {
     const long total = (long)Cout * Cin * 27;
@@ -493,7 +537,7 @@ PULPO_API int pulpo_conv3d_k3_wgrad_algo(int B, int D, int H, int W, int Cin, in
 PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
                                     int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, int B, int D, int H, int W,
                                     int Cin, int Cout, void* stream) {
-    PULPO_REQUIRE(in && dy && dw && scratch, "conv3d_k3_wgrad: null pointer");
+    PULPO_REQUIRE(in && dy && scratch && (dw || accumulate == 2), "conv3d_k3_wgrad: null pointer");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3d_k3_wgrad: bad dims");
     hipStream_t st = (hipStream_t)stream;
     WgradArgs a;
@@ -512,8 +556,11 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
     int nsplit = std::max(1, (vec ? 256 : 512) / npair);
     nsplit = std::min(nsplit, ntile);
     a.nsplit = nsplit;
-    hipError_t e = hipMemsetAsync(scratch, 0, pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout) * sizeof(float), st);
-    if (e != hipSuccess) return pulpo::fail((int)e, "wgrad memset: %s", hipGetErrorString(e));
+    const bool deferred = accumulate == 2;                 // scratch arrives zeroed and keeps the packed sums: the caller unpacks later
+    if (!deferred) {
+        hipError_t e = hipMemsetAsync(scratch, 0, pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout) * sizeof(float), st);
+        if (e != hipSuccess) return pulpo::fail((int)e, "wgrad memset: %s", hipGetErrorString(e));
+    }
     const int nrt_max = (27 * std::min(Cin, WG_CH) + 31) / 32;
     const int ntw = (nrt_max + 3) / 4;                 // 1..7
     constexpr size_t lds = (size_t)(((HV * WG_CP + 3) & ~3) + MV * WG_NT) * sizeof(float);
@@ -536,7 +583,7 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
     if (algo == 2) {
         // F(2x2,3x3) in (y, x), register-staged transposed operand images, z-streaming workgroups (conv3d_wgrad_w2.hip)
         rc = pulpo_conv::launch_wgrad_w2(in, in_bs, in_ps, dy, dy_bs, dy_ps, scratch, B, D, H, W, Cin, Cout, st);
-        if (rc) return rc;
+        if (rc || deferred) return rc;
         return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
     }
     if (algo == 1) {
@@ -562,6 +609,6 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
     }
 #undef PULPO_WGRAD
     rc = pulpo::check_launch("conv3d_k3_wgrad_mfma");
-    if (rc) return rc;
+    if (rc || deferred) return rc;
     return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
 }

@@ -248,9 +248,12 @@ class DataParallelStepper:
             ops.ASYNC_WGRAD_STREAM = self._side if self.async_wgrad else None
             try:
                 loss.backward()
+            except BaseException:
+                ops.reset_param_grad_buffers(self.model)        # deferred gradient sums of an interrupted backward pass are void
+                raise
             finally:
                 ops.DIRECT_PARAM_GRADS = False
-                ops.join_async_wgrad()
+                ops.join_async_wgrad()             # (also finishes the deferred weight / bias gradients in one launch)
                 ops.ASYNC_WGRAD_STREAM = None
         finally:
             self._armed = False

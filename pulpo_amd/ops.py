@@ -297,24 +297,77 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
         _trace_end(t0, name, 54.0 * K * N * B * D * H * W, 4.0 * (K + N) * B * D * H * W)
 
 
-def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-    """weight gradient; `into` -> accumulated into that (Cout,Cin,3,3,3) tensor in place, returns None"""
+# ---- deferred parameter-gradient epilogues (data-parallel stepper): inside a step the weight gradients stay in their packed scratch and
+# the conv-bias gradients in their BatchNorm-backward partials until flush_param_grads() finishes ALL of them with one launch
+# (pulpo_grad_finish_multi) - instead of a memset + an unpack + a column-sum launch per layer, each of which has to find room on CUs the
+# persistent convolution kernels hold.  The scratch buffers persist on the parameter (they are returned all zero by the finishing kernel).
+_PENDING_GRAD_JOBS: List[Tuple[int, int, int, int, int, int]] = []      # (src ptr, dst ptr, kind, a, b, c)
+_PENDING_KEEPALIVE: List[torch.Tensor] = []
+_JOB_TABLES: dict = {}
+
+
+def _persistent_buffer(owner: torch.Tensor, name: str, numel: int, zero: bool) -> torch.Tensor:
+    buf = getattr(owner, name, None)
+    if buf is None or buf.numel() != numel or buf.device != owner.device:
+        buf = (torch.zeros if zero else torch.empty)(numel, device=owner.device, dtype=torch.float32)
+        setattr(owner, name, buf)
+    return buf
+
+
+def flush_param_grads() -> None:
+    """finish every deferred weight / bias gradient on the current stream (callers have joined the weight-gradient stream first)"""
+    if not _PENDING_GRAD_JOBS:
+        return
+    key = tuple(_PENDING_GRAD_JOBS)
+    table = _JOB_TABLES.get(key)
+    if table is None:
+        import struct
+        raw = b"".join(struct.pack("<QQiiii", *job) for job in key)
+        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(_PENDING_KEEPALIVE[0].device)
+        if len(_JOB_TABLES) > 8:
+            _JOB_TABLES.clear()
+        _JOB_TABLES[key] = table
+    lib.call("pulpo_grad_finish_multi", _ptr(table), len(key), _stream())
+    _PENDING_GRAD_JOBS.clear()
+    _PENDING_KEEPALIVE.clear()
+
+
+def reset_param_grad_buffers(module: Optional[torch.nn.Module] = None) -> None:
+    """after an interrupted step: forget the pending jobs and drop the persistent scratch buffers (they may hold partial sums)"""
+    _PENDING_GRAD_JOBS.clear()
+    _PENDING_KEEPALIVE.clear()
+    if module is not None:
+        for p_ in module.parameters():
+            for name in ("_pulpo_wgrad_scratch", "_pulpo_dbias_part"):
+                if hasattr(p_, name):
+                    delattr(p_, name)
+
+
+def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Optional[torch.Tensor] = None,
+               owner: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """weight gradient; `into` -> accumulated into that (Cout,Cin,3,3,3) tensor in place, returns None.  With `owner` (the weight parameter,
+    data-parallel stepper) the accumulation is DEFERRED to flush_param_grads(): the packed sums stay in the parameter's persistent scratch."""
     B, _, D, H, W = x.shape
+    deferred = into is not None and owner is not None
     dw = into if into is not None else torch.empty((Cout, Cin, 3, 3, 3), device=x.device, dtype=torch.float32)
-    scratch = torch.empty(lib.query("pulpo_conv3d_k3_wgrad_scratch_floats", Cin, Cout), device=x.device, dtype=torch.float32)
+    nscr = lib.query("pulpo_conv3d_k3_wgrad_scratch_floats", Cin, Cout)
+    scratch = _persistent_buffer(owner, "_pulpo_wgrad_scratch", nscr, zero=True) if deferred else torch.empty(nscr, device=x.device, dtype=torch.float32)
     xb, xp, xc = grid_strides(x)
     db, dp, dc = grid_strides(dy)
     t0 = _trace_begin()
     sfx = "_bf16" if _use_bf16(Cin) else ""
-    lib.call(f"pulpo_conv3d_k3_wgrad{sfx}", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), int(into is not None), _ptr(scratch), B, D, H, W,
-             Cin, Cout, _stream())
+    lib.call(f"pulpo_conv3d_k3_wgrad{sfx}", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), 2 if deferred else int(into is not None), _ptr(scratch),
+             B, D, H, W, Cin, Cout, _stream())
+    if deferred:
+        _PENDING_GRAD_JOBS.append((scratch.data_ptr(), dw.data_ptr(), 0, Cin, Cout, (Cout + 63) // 64 * 64))
+        _PENDING_KEEPALIVE.append(scratch)
     if t0 is not None:
         name = "conv3d_k3_wgrad_bf16"
         if not sfx:
             vec = (xc == 1 and xp % 4 == 0 and xb % 4 == 0 and Cin % 4 == 0 and x.data_ptr() % 16 == 0 and dc == 1 and dp % 4 == 0 and db % 4 == 0
                    and Cout % 4 == 0 and dy.data_ptr() % 16 == 0)
             name = ("conv3d_k3_wgrad_mfma", "conv3d_k3_wgrad_wino", "conv3d_k3_wgrad_w2")[lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, Cin, Cout, int(vec))]
-        _trace_end(t0, name + "(+memset,unpack)", 54.0 * Cin * Cout * B * D * H * W, 4.0 * (Cin + Cout) * B * D * H * W)
+        _trace_end(t0, name + ("" if deferred else "(+memset,unpack)"), 54.0 * Cin * Cout * B * D * H * W, 4.0 * (Cin + Cout) * B * D * H * W)
     return None if into is not None else dw
 
 
@@ -326,24 +379,21 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
 ASYNC_WGRAD_STREAM = None
 
 
-def _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, bias_job=None):
-    """bias_job = (partials, nrow, slot_b): the conv-bias gradient's column sum rides along (nothing on the main stream needs it)"""
+def _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, owner):
     main = torch.cuda.current_stream()
     side = ASYNC_WGRAD_STREAM
     side.wait_stream(main)                       # after everything queued so far: dy, this unit's data gradient, zero_grad
     with torch.cuda.stream(side):
-        if bias_job is not None:
-            _colsum(bias_job[0], bias_job[1], Cout, into=bias_job[2])
-            bias_job[0].record_stream(side)
-        _wgrad_raw(x, dy, Cin, Cout, into=slot_w)
+        _wgrad_raw(x, dy, Cin, Cout, into=slot_w, owner=owner)
     x.record_stream(side)                        # keep both operands' memory out of the allocator's hands until the side stream is done
     dy.record_stream(side)
 
 
 def join_async_wgrad():
-    """make the current stream wait for every weight gradient queued on the side stream"""
+    """make the current stream wait for every weight gradient queued on the side stream, then finish the deferred parameter gradients"""
     if ASYNC_WGRAD_STREAM is not None:
         torch.cuda.current_stream().wait_stream(ASYNC_WGRAD_STREAM)
+    flush_param_grads()
 
 
 class _ConvBNLReLU(torch.autograd.Function):
@@ -407,23 +457,26 @@ class _ConvBNLReLU(torch.autograd.Function):
                  _ptr(slot_be if direct_bn else tot), _ptr(slot_g) if direct_bn else ctypes.c_void_p(tot.data_ptr() + 4 * Cout), int(direct_bn),
                  _ptr(totd), _stream())
         dy = new_cl(B, Cout, D, H, W, dev)
-        part2 = torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
+        defer_b = DIRECT_PARAM_GRADS and ctx.needs_input_grad[2] and slot_b is not None
+        part2 = _persistent_buffer(b_p, "_pulpo_dbias_part", nblk * Cout, zero=False) if defer_b else torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
         t0 = _hbm_begin()
         lib.call("pulpo_bn_lrelu_bwd_apply", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4), npix, Cout,
                  LRELU_SLOPE, _ptr(part2), _stream())
         _hbm_end(t0, "bn_lrelu_bwd_apply", 12.0 * Cout * npix)                # read dz, y; write dy
         defer_w = ctx.needs_input_grad[1] and slot_w is not None and ASYNC_WGRAD_STREAM is not None
-        defer_b = defer_w and ctx.needs_input_grad[2] and slot_b is not None
+        if defer_b:
+            _PENDING_GRAD_JOBS.append((part2.data_ptr(), slot_b.data_ptr(), 1, nblk, Cout, 0))
+            _PENDING_KEEPALIVE.append(part2)
         dbias = _colsum(part2, nblk, Cout, into=slot_b) if (ctx.needs_input_grad[2] and not defer_b) else None
         dbeta, dgamma = (None, None) if direct_bn else (tot[:Cout], tot[Cout:])
-        dw = _wgrad_raw(x, dy, Cin, Cout, into=slot_w) if (ctx.needs_input_grad[1] and not defer_w) else None
+        dw = _wgrad_raw(x, dy, Cin, Cout, into=slot_w, owner=w_p if slot_w is not None else None) if (ctx.needs_input_grad[1] and not defer_w) else None
         dx = None
         if ctx.needs_input_grad[0]:
             wpt = _pack_weight(weight, dgrad=True, shape=(B, D, H, W))
             dx = torch.empty_like(x) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, dev)
             _conv_raw(dy, wpt, None, dx, Cout, Cin, None)
         if defer_w:
-            _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, (part2, nblk, slot_b) if defer_b else None)
+            _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, w_p)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
