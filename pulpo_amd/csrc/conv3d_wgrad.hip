@@ -472,15 +472,30 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
 __global__ __launch_bounds__(256) void grad_finish_multi_kernel(const PulpoGradJob* __restrict__ jobs) {
     const PulpoGradJob j = jobs[blockIdx.y];
     if (j.kind == 0) {
+        // transposed through LDS: a block takes one (ci, 32 couts) strip = 27 x 32 packed values read in 128-byte runs (and zeroed), written
+        // to dw[co][ci][0..26] in 108-byte runs
+        __shared__ float tile[27][33];
         float* packed = const_cast<float*>(j.src);
-        const long total = (long)j.b * j.a * 27;
-        for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-            const int tap = (int)(e % 27);
-            const long r = e / 27;
-            const int ci = (int)(r % j.a), co = (int)(r / j.a);
-            const long src = ((long)tap * j.a + ci) * j.c + co;
-            j.dst[e] += packed[src];
-            packed[src] = 0.f;
+        const int ncog = (j.b + 31) / 32;
+        const long nstrip = (long)j.a * ncog;
+        for (long sidx = blockIdx.x; sidx < nstrip; sidx += gridDim.x) {
+            const int ci = (int)(sidx % j.a), co0 = (int)(sidx / j.a) * 32;
+            for (int e = threadIdx.x; e < 27 * 32; e += blockDim.x) {
+                const int tap = e >> 5, c = e & 31;
+                float v = 0.f;
+                if (co0 + c < j.b) {
+                    const long src = ((long)tap * j.a + ci) * j.c + co0 + c;
+                    v = packed[src];
+                    packed[src] = 0.f;
+                }
+                tile[tap][c] = v;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < 27 * 32; e += blockDim.x) {
+                const int c = e / 27, tap = e - c * 27;
+                if (co0 + c < j.b) j.dst[((long)(co0 + c) * j.a + ci) * 27 + tap] += tile[tap][c];
+            }
+            __syncthreads();
         }
     } else {
         __shared__ double red[8][33];

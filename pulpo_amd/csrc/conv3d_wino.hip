@@ -743,9 +743,9 @@ __global__ void pack_weight_wino2_kernel(const float* __restrict__ w, float* __r
     // one thread per (chunk, dz, k, n): nine taps in, sixteen transformed points out
     const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int n = (int)(e % NPad);
-        long r = e / NPad;
-        const int kc = (int)(r % WN_CH); r /= WN_CH;
+        const int kc = (int)(e % WN_CH);                 // (k fastest: consecutive threads write consecutive floats of the [n][k % 8] rows)
+        long r = e / WN_CH;
+        const int n = (int)(r % NPad); r /= NPad;
         const int dz = (int)(r % 3);
         const int chunk = (int)(r / 3);
         const int k = chunk * WN_CH + kc;
