@@ -840,6 +840,28 @@ def test_bench_two_rank_rehearsal(tmp_path):
     assert d["roofline"] is not None and d["cpu_baseline"] is None
 
 
+def test_bench_self_launch_two_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with NO torchrun environment: the script starts its two ranks itself (before touching a GPU), runs the real
+    training step on each (gloo instead of RCCL - two ranks share the one GPU of the test box), and relays exactly one JSON line; also the
+    first-step agreement: with an injected first-step failure on every rank all ranks fall back to the plain stepper together, and with one
+    on a single rank the job is restarted by the launcher with the overlapped exchange switched off."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    base.update(PULPO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "32", "32", "32", "--levels", "3", "2",
+           "--no-cpu-baseline"]
+    for inject, expect in (("", None), ("all", "falling back"), ("1", "starting all ranks again")):
+        r = subprocess.run(cmd, env=dict(base, PULPO_BENCH_INJECT_FAILURE=inject), capture_output=True, text=True, timeout=900, cwd=root)
+        assert r.returncode == 0, (inject, r.stdout[-1500:], r.stderr[-3000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, (inject, r.stdout[-1500:])
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["value"] > 0
+        if expect is not None:
+            assert expect in r.stderr, (inject, r.stderr[-3000:])
+
+
 def test_bench_json_contract_single_gpu():
     """the one JSON line bench.py prints (driver contract): every required key, the roofline and cpu_baseline objects, and the
     arithmetic value = pairs / time - on a small workload so that the CPU-baseline leg takes seconds"""
