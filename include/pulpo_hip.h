@@ -70,6 +70,16 @@ int pulpo_conv3d_k3_pack_weight_wino2(const float* w /*[Cout][Cin][3][3][3]*/, f
 int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
                               float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W,
                               int K, int N, void* stream);
+/* The data-gradient convolution of a ConvUnit (in = dy of that unit, wp packed with dgrad = 1, N = the unit's input channels) with the
+ * FIRST pass of the BatchNorm/LeakyReLU backward of the ConvUnit in front of it fused into the store (the reference runs these as
+ * separate autograd nodes: ConvolutionBackward of src/network_blocks.py:23, then LeakyReluBackward / NativeBatchNormBackward of :24-25):
+ * part[tile][2][N], tile < pulpo_conv3d_k3_stat_tiles(), receives sum(dbn) and sum(dbn * (bn_y - fp32 batch mean)) per voxel tile, where
+ * dbn = out * lrelu'(bn_y * scale + shift); pulpo_bn_bwd_finalize_tiles turns them into what pulpo_bn_bwd_finalize delivers.  bn_y / bn_coef: pre-norm tensor (channels-last,
+ * N channels) and coefficient block (pulpo_bn_fwd_finalize) of the unit in front.  _ok() = 1 when the shape is accepted. */
+int pulpo_conv3d_k3_dgrad_wino2_bnred_ok(int B, int D, int H, int W, int K, int N);
+int pulpo_conv3d_k3_dgrad_wino2_bnred(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, float* out, int64_t out_bs,
+                                      int64_t out_ps, const float* bn_y, int64_t bn_y_bs, int64_t bn_y_ps, const float* bn_coef, float slope,
+                                      float* part, int B, int D, int H, int W, int K, int N, void* stream);
 /* weight gradient: dw[Cout][Cin][27] = sum_voxels in[v + tap - 1][ci] * dy[v][co]; scratch is overwritten */
 size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
 /* which weight-gradient kernel pulpo_conv3d_k3_wgrad runs for a shape: 2 = Winograd F(2x2,3x3) in (y, x), 1 = Winograd F(2,3) along x,
@@ -128,6 +138,10 @@ int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const float* y, int
                               float* partial /*[blocks][2C]*/, void* stream);
 int pulpo_bn_bwd_finalize(const float* partial, int nrow, int C, double count, int use_means, float* dbeta, float* dgamma, int accumulate,
                           double* totd /*[2C]: mean(dbn) | mean(dbn*xhat)*/, void* stream);
+/* pulpo_bn_bwd_finalize over per-voxel-tile rows (pulpo_conv3d_k3_dgrad_wino2_bnred); scratch: pulpo_bn_fwd_finalize_scratch_doubles(ntile, C)
+ * doubles (NULL when that is 0) */
+int pulpo_bn_bwd_finalize_tiles(const float* tile_part, int ntile, int C, const float* coef, double count, int use_means, float* dbeta,
+                                float* dgamma, int accumulate, double* totd, double* scratch, void* stream);
 int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd, float* dy,
                              int64_t dyps, int64_t npix, int C, float slope, float* partial2 /*[blocks][C]*/, void* stream);
 

@@ -382,7 +382,7 @@ __device__ __forceinline__ void w2_stage_scalar(float* xs, const float* __restri
 //   * 10k clocks of prologue per tile (argument loads, index arithmetic, first-touch latency of halo and weights)  -> PERSISTENT
 //     workgroups (two per CU) that fetch the next tile's first slab and halo chunk during the last dz iteration of the current tile.
 // A start-up offset of the second workgroup of each CU (to break the lockstep of the pair) was measured without effect and is not kept.
-template <bool VEC>
+template <bool VEC, bool BNR = false>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
     constexpr int CH = WN_CH, NT = 32;
     constexpr int XS = W2_XS;
@@ -606,10 +606,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         // Fast path (whole tile inside the volume, all 32 couts real, channels-last 16-byte aligned output - every tile of the BASELINE layers):
         // lane = (channel quad q, row half, row group): the four waves' partial rows are fetched with ds_read_b128 (all issued before the first
         // use), the y inverse transform is done on float4s, and each voxel leaves as one 128-byte line written by 8 lanes x 16 bytes.
-        const bool fast = a.out_cs == 1 && (a.out_ps & 3) == 0 && (a.out_bs & 3) == 0 && (((uintptr_t)a.out) & 15) == 0 && co0 + NT <= a.Cout &&
+        // (BNR: the host launches this instantiation only when every tile qualifies, without bias and without the eval-mode store)
+        const bool fast = BNR || (a.out_cs == 1 && (a.out_ps & 3) == 0 && (a.out_bs & 3) == 0 && (((uintptr_t)a.out) & 15) == 0 && co0 + NT <= a.Cout &&
                           z0 + 4 <= a.D && y0 + TY <= a.H && x0 + TX <= a.W &&
                           (a.bias == nullptr || (((uintptr_t)a.bias) & 15) == 0) &&
-                          (a.coef == nullptr || ((((uintptr_t)a.coef) & 15) == 0 && (a.Cout & 3) == 0));
+                          (a.coef == nullptr || ((((uintptr_t)a.coef) & 15) == 0 && (a.Cout & 3) == 0)));
         // (the lane id passes through an opaque asm here: everything the epilogue derives from it - output addresses, bias / coefficient
         //  loads - is then computed here and not hoisted above the main loop, where it would sit in registers the loop needs)
         int elane = lane;
@@ -619,13 +620,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 b4 = zero4, sc4 = zero4, sh4 = zero4, s4 = zero4, q4 = zero4;        // fast path: four channels per lane
         float bias1 = 0.f, fsc1 = 1.f, fsh1 = 0.f, ssum = 0.f, ssq = 0.f;             // general path: channel co0 + i
-        const bool fuse = a.coef != nullptr;
+        const bool fuse = !BNR && a.coef != nullptr;
         const bool cok = co0 + ei < a.Cout;
+        // data-gradient launch with the BatchNorm-backward reduction of the unit in front fused in (host: every tile takes the fast path)
+        const bool bnr = BNR && fast;        // (own instantiation: its extra epilogue registers stay out of the plain kernel)
+        float4 bm4 = zero4;                  // the channel means rounded to fp32 (pulpo_bn_bwd_finalize_tiles corrects for the rounding)
+        const float* bn_b = bnr ? a.bn_y + (long)cur.b * a.bn_y_bs + co0 + 4 * q : nullptr;
         if (fast) {
-            if (a.bias != nullptr) b4 = *reinterpret_cast<const float4*>(a.bias + co0 + 4 * q);
+            if (!BNR && a.bias != nullptr) b4 = *reinterpret_cast<const float4*>(a.bias + co0 + 4 * q);
             if (fuse) {
                 sc4 = *reinterpret_cast<const float4*>(a.coef + 2 * a.Cout + co0 + 4 * q);
                 sh4 = *reinterpret_cast<const float4*>(a.coef + 3 * a.Cout + co0 + 4 * q);
+            }
+            if (bnr) {
+                sc4 = *reinterpret_cast<const float4*>(a.bn_coef + 2 * a.Cout + co0 + 4 * q);
+                sh4 = *reinterpret_cast<const float4*>(a.bn_coef + 3 * a.Cout + co0 + 4 * q);
+                bm4 = *reinterpret_cast<const float4*>(a.bn_coef + co0 + 4 * q);
             }
         } else if (cok) {
             if (a.bias != nullptr) bias1 = a.bias[co0 + ei];
@@ -639,6 +649,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
                 const float m0 = acc[m][0][r], m1 = acc[m][1][r], m2 = acc[m][2][r], m3 = acc[m][3][r];
                 R[((py * 2 + 0) * 16 + r) * 64 + elane] = m0 + m1 + m2;
                 R[((py * 2 + 1) * 16 + r) * 64 + elane] = m1 - m2 - m3;
+            }
+            float4 yv[2][2];                                // (bnr) the pre-norm activations of this lane's four voxels, requested once this row tile's accumulators are dead
+            if (bnr) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int combo = h * 16 + wave * 4 + g;
+                    const int ox = combo >> 4, r = combo & 15;
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int gz = z0 + 2 * m + (row >> 4), gy = y0 + 2 * ((row >> 2) & 3), gx = x0 + 2 * (row & 3) + ox;
+                    const long vox = (long)(gz * a.H + gy) * a.W + gx;
+                    yv[h][0] = *reinterpret_cast<const float4*>(bn_b + vox * a.bn_y_ps);
+                    yv[h][1] = *reinterpret_cast<const float4*>(bn_b + (vox + a.W) * a.bn_y_ps);
+                }
             }
             __syncthreads();
             if (fast) {
@@ -661,8 +684,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
                     const float4 t0 = tq[h][0], t1 = tq[h][1], t2 = tq[h][2], t3 = tq[h][3];
                     float4 v0 = make_float4(t0.x + t1.x + t2.x + b4.x, t0.y + t1.y + t2.y + b4.y, t0.z + t1.z + t2.z + b4.z, t0.w + t1.w + t2.w + b4.w);
                     float4 v1 = make_float4(t1.x - t2.x - t3.x + b4.x, t1.y - t2.y - t3.y + b4.y, t1.z - t2.z - t3.z + b4.z, t1.w - t2.w - t3.w + b4.w);
-                    s4.x += v0.x + v1.x; s4.y += v0.y + v1.y; s4.z += v0.z + v1.z; s4.w += v0.w + v1.w;
-                    q4.x += v0.x * v0.x + v1.x * v1.x; q4.y += v0.y * v0.y + v1.y * v1.y; q4.z += v0.z * v0.z + v1.z * v1.z; q4.w += v0.w * v0.w + v1.w * v1.w;
+                    if (bnr) {
+                        // dbn = dz * lrelu'(bn(y));  sums of dbn and of dbn * (y - fp32 mean): all fp32 (the difference of two floats carries
+                        // a relative error of 2^-24 however close they are; what the ROUNDED mean leaves out is added back, in double, by
+                        // the finalize kernel: sum dbn * xhat = rstd * (sum dbn * (y - m32) - (mean - m32) * sum dbn))
+                        auto red1 = [&](float dzv, float yy, float sc, float sh, float m32, float& s_, float& q_) {
+                            const float bn = yy * sc + sh;
+                            const float d = bn > 0.f ? dzv : dzv * a.slope;
+                            s_ += d;
+                            q_ = fmaf(d, yy - m32, q_);
+                        };
+                        red1(v0.x, yv[h][0].x, sc4.x, sh4.x, bm4.x, s4.x, q4.x);
+                        red1(v0.y, yv[h][0].y, sc4.y, sh4.y, bm4.y, s4.y, q4.y);
+                        red1(v0.z, yv[h][0].z, sc4.z, sh4.z, bm4.z, s4.z, q4.z);
+                        red1(v0.w, yv[h][0].w, sc4.w, sh4.w, bm4.w, s4.w, q4.w);
+                        red1(v1.x, yv[h][1].x, sc4.x, sh4.x, bm4.x, s4.x, q4.x);
+                        red1(v1.y, yv[h][1].y, sc4.y, sh4.y, bm4.y, s4.y, q4.y);
+                        red1(v1.z, yv[h][1].z, sc4.z, sh4.z, bm4.z, s4.z, q4.z);
+                        red1(v1.w, yv[h][1].w, sc4.w, sh4.w, bm4.w, s4.w, q4.w);
+                    } else {
+                        s4.x += v0.x + v1.x; s4.y += v0.y + v1.y; s4.z += v0.z + v1.z; s4.w += v0.w + v1.w;
+                        q4.x += v0.x * v0.x + v1.x * v1.x; q4.y += v0.y * v0.y + v1.y * v1.y; q4.z += v0.z * v0.z + v1.z * v1.z; q4.w += v0.w * v0.w + v1.w * v1.w;
+                    }
                     if (fuse) {
                         auto act = [&](float v, float sc, float sh) { const float tt = v * sc + sh; return tt > 0.f ? tt : tt * a.slope; };
                         v0 = make_float4(act(v0.x, sc4.x, sh4.x), act(v0.y, sc4.y, sh4.y), act(v0.z, sc4.z, sh4.z), act(v0.w, sc4.w, sh4.w));
@@ -840,14 +883,14 @@ PULPO_API int pulpo_conv3d_k3_pack_weight_wino2(const float* w, float* wp, int C
     return pulpo::check_launch("pack_weight_wino2");
 }
 
-template <bool VEC>
+template <bool VEC, bool BNR = false>
 static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
     constexpr size_t lds = (size_t)(W2_XS + 2 * 16 * WN_CH * 32) * sizeof(float);
     static_assert(lds >= (size_t)(4 * 2 * 2 * 16 * 64 + 4 * 2 * 32) * sizeof(float), "exchange buffer must fit");
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino2_mfma<VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino2_mfma<VEC, BNR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(conv3d wino2): %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -858,13 +901,48 @@ static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
         const_cast<ConvArgs&>(a).stagger = (int)(clocks / (64 * 127));
     }
     // persistent workgroups: two per CU (LDS and registers admit exactly two), each walking the tile list with stride gridDim.x
-    hipLaunchKernelGGL((conv3d_k3_wino2_mfma<VEC>), dim3(std::min(nblk, 512)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3d_k3_wino2_mfma<VEC, BNR>), dim3(std::min(nblk, 512)), dim3(256), lds, st, a);
     return pulpo::check_launch("conv3d_k3_wino2_mfma");
 }
+
+static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
+                          float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, const float* bn_y, int64_t bn_y_bs,
+                          int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream);
 
 PULPO_API int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
                                         const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats,
                                         int B, int D, int H, int W, int K, int N, void* stream) {
+    return fwd_wino2_impl(in, in_bs, in_ps, in_cs, wp, bias, coef, slope, out, out_bs, out_ps, out_cs, stats, nullptr, 0, 0, nullptr, B, D, H, W, K, N,
+                          stream);
+}
+
+// 1 when pulpo_conv3d_k3_dgrad_wino2_bnred accepts the shape: every voxel tile whole (4 x 8 x 8) and every channel tile full (32)
+PULPO_API int pulpo_conv3d_k3_dgrad_wino2_bnred_ok(int B, int D, int H, int W, int K, int N) {
+    return B > 0 && K > 0 && N > 0 && conv_tz(D, H, W) == 4 && D % 4 == 0 && H % TY == 0 && W % TX == 0 && N % 32 == 0;
+}
+
+// The data-gradient convolution of ConvUnit u (dz = conv^T(dy_u), in = dy_u, N = that unit's input channels) with the first pass of the
+// BatchNorm/LeakyReLU backward of ConvUnit u-1 - whose output z = lrelu(bn(y)) fed unit u - fused into its store: part[tile][2][N] receives
+// per voxel tile sum(dbn) and sum(dbn * (y - fp32 mean)), dbn = dz * lrelu'(y * scale + shift), for pulpo_bn_bwd_finalize_tiles.  bn_y: the pre-norm
+// tensor y of unit u-1 (channels-last, N channels, 16-byte aligned rows); bn_coef: its coefficient block (pulpo_bn_fwd_finalize).
+// Replaces one pulpo_bn_lrelu_bwd_reduce pass (a read of dz and y from HBM) by a read of y underneath the convolution's epilogue.
+PULPO_API int pulpo_conv3d_k3_dgrad_wino2_bnred(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, float* out,
+                                                int64_t out_bs, int64_t out_ps, const float* bn_y, int64_t bn_y_bs, int64_t bn_y_ps,
+                                                const float* bn_coef, float slope, float* part, int B, int D, int H, int W, int K, int N,
+                                                void* stream) {
+    PULPO_REQUIRE(bn_y && bn_coef && part, "conv3d_k3_dgrad_wino2_bnred: null pointer");
+    PULPO_REQUIRE(pulpo_conv3d_k3_dgrad_wino2_bnred_ok(B, D, H, W, K, N), "conv3d_k3_dgrad_wino2_bnred: shape %dx%dx%d, %d -> %d channels has ragged tiles",
+                  D, H, W, K, N);
+    PULPO_REQUIRE(out_ps % 4 == 0 && out_bs % 4 == 0 && (((uintptr_t)out) & 15) == 0 && bn_y_ps % 4 == 0 && bn_y_bs % 4 == 0 &&
+                      (((uintptr_t)bn_y) & 15) == 0 && (((uintptr_t)bn_coef) & 15) == 0,
+                  "conv3d_k3_dgrad_wino2_bnred: output, pre-norm tensor and coefficients must be channels-last and 16-byte aligned");
+    return fwd_wino2_impl(in, in_bs, in_ps, in_cs, wp, nullptr, nullptr, slope, out, out_bs, out_ps, 1, part, bn_y, bn_y_bs, bn_y_ps, bn_coef, B, D, H,
+                          W, K, N, stream);
+}
+
+static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
+                          float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, const float* bn_y, int64_t bn_y_bs,
+                          int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream) {
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_wino2: null pointer");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd_wino2: bad dims");
     PULPO_REQUIRE(conv_tz(D, H, W) == 4, "conv3d_k3_fwd_wino2: volume %dx%dx%d is not tiled 4x8x8 (see pulpo_conv3d_k3_algo)", D, H, W);
@@ -875,6 +953,7 @@ PULPO_API int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t 
     a.out = out; a.out_bs = out_bs; a.out_ps = out_ps; a.out_cs = out_cs;
     a.stats = stats;
     a.coef = coef; a.slope = slope;
+    a.bn_y = bn_y; a.bn_y_bs = bn_y_bs; a.bn_y_ps = bn_y_ps; a.bn_coef = bn_coef;
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
     a.ntz = pulpo::cdiv(D, 4); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
     a.ncot = pulpo::cdiv(N, 32);
@@ -883,5 +962,9 @@ PULPO_API int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t 
     PULPO_REQUIRE(nblk_l < (1L << 31), "conv3d_k3_fwd_wino2: grid too large");
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
+    if (bn_y != nullptr) {
+        PULPO_REQUIRE(vec, "conv3d_k3_dgrad_wino2_bnred: the gradient operand must be channels-last, 16-byte aligned, with a multiple of 4 channels");
+        return launch_wino2<true, true>(a, (int)nblk_l, st);
+    }
     return vec ? launch_wino2<true>(a, (int)nblk_l, st) : launch_wino2<false>(a, (int)nblk_l, st);
 }

@@ -45,6 +45,12 @@ struct ConvArgs {
     float* part;                  // [ksplit][B*V][Cout] dense partial outputs (reduced in fixed order by splitk_reduce_kernel)
     const float* coef;            // nullable: eval-mode BatchNorm coefficients (scale at [2C], shift at [3C]) + LeakyReLU fused into the store
     float slope;
+    // Winograd (y, x) kernel used as a data-gradient convolution whose result is the gradient dz of a ConvUnit's output z = lrelu(bn(y)):
+    // bn_y / bn_coef non-null -> `stats` receives, instead of (sum, sum of squares), that unit's BatchNorm-backward partial sums
+    // (sum dbn, sum dbn * xhat) per voxel tile - what bn_lrelu_bwd_reduce_kernel would compute in a pass of its own over dz and y
+    const float* bn_y;
+    long bn_y_bs, bn_y_ps;
+    const float* bn_coef;
     int stagger;                  // Winograd (y, x) kernel: start-up delay (units of 64 x 127 clocks) of the second workgroup of every CU, 0 = none
 };
 

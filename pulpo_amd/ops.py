@@ -9,6 +9,7 @@ wider buffer; 1- and 3-channel images / fields are plain contiguous (N,C,D,H,W) 
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -316,6 +317,7 @@ def _persistent_buffer(owner: torch.Tensor, name: str, numel: int, zero: bool) -
 
 def flush_param_grads() -> None:
     """finish every deferred weight / bias gradient on the current stream (callers have joined the weight-gradient stream first)"""
+    _BN_TILE_PARTS.clear()
     if not _PENDING_GRAD_JOBS:
         return
     key = tuple(_PENDING_GRAD_JOBS)
@@ -336,6 +338,7 @@ def reset_param_grad_buffers(module: Optional[torch.nn.Module] = None) -> None:
     """after an interrupted step: forget the pending jobs and drop the persistent scratch buffers (they may hold partial sums)"""
     _PENDING_GRAD_JOBS.clear()
     _PENDING_KEEPALIVE.clear()
+    _BN_TILE_PARTS.clear()
     if module is not None:
         for p_ in module.parameters():
             for name in ("_pulpo_wgrad_scratch", "_pulpo_dbias_part"):
@@ -396,12 +399,57 @@ def join_async_wgrad():
     flush_param_grads()
 
 
+# ---- BatchNorm-backward reduction inside the data-gradient convolution.  In a ConvSequence unit u consumes z = lrelu(bn(y)) of unit u-1,
+# and the gradient dz that unit u-1's backward receives is exactly what unit u's data-gradient kernel stores: that kernel's epilogue has
+# every dz element in registers, so with y of unit u-1 read alongside it also delivers the per-tile sums (sum dbn, sum dbn * xhat) that
+# unit u-1 would otherwise compute in a pass of its own over dz and y (pulpo_bn_lrelu_bwd_reduce).  The forward pass hands (y, coef) of
+# the producer to the consumer on the tensor z itself (`_pulpo_bn_src`); the backward pass of the consumer leaves the sums here, keyed by
+# the producer's y, and the producer takes them only if the gradient it is given IS that kernel's output, untouched (same storage, same
+# version: a gradient that autograd accumulated from several consumers is a different tensor or carries a bumped version).
+BN_REDUCE_IN_DGRAD = os.environ.get("PULPO_BN_REDUCE_IN_DGRAD", "1") != "0"      # (A/B switch)
+_BN_TILE_PARTS: dict = {}
+
+
+def _dgrad_with_bn_reduction(bn_src, x, dy, wpt, dx, K: int, N: int) -> bool:
+    if bn_src is None or not BN_REDUCE_IN_DGRAD or getattr(wpt, "_pulpo_algo", "") != "wino2":
+        return False
+    y_prev, coef_prev = bn_src
+    B, _, D, H, W = dy.shape
+    db, dp, dc = grid_strides(dy)
+    ob, op, oc = grid_strides(dx)
+    yb, yp, yc = grid_strides(y_prev)
+    if (y_prev.shape != dx.shape or oc != 1 or yc != 1 or op % 4 or ob % 4 or yp % 4 or yb % 4 or dx.data_ptr() % 16 or y_prev.data_ptr() % 16
+            or not lib.query("pulpo_conv3d_k3_dgrad_wino2_bnred_ok", B, D, H, W, K, N)):
+        return False
+    ntile = lib.query("pulpo_conv3d_k3_stat_tiles", B, D, H, W)
+    part = torch.empty(ntile * 2 * N, device=dy.device, dtype=torch.float32)
+    t0 = _trace_begin()
+    lib.call("pulpo_conv3d_k3_dgrad_wino2_bnred", _ptr(dy), db, dp, dc, _ptr(wpt), _ptr(dx), ob, op, _ptr(y_prev), yb, yp, _ptr(coef_prev), LRELU_SLOPE,
+             _ptr(part), B, D, H, W, K, N, _stream())
+    vec_ok = dc == 1 and dp % 4 == 0 and db % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0
+    _trace_end(t0, f"conv3d_k3_wino2_mfma<{'true' if vec_ok else 'false'}>", 54.0 * K * N * B * D * H * W, 4.0 * (K + 2 * N) * B * D * H * W)
+    _BN_TILE_PARTS[y_prev.data_ptr()] = (part, ntile, coef_prev.data_ptr(), dx.data_ptr(), dx._version, tuple(dx.shape), tuple(dx.stride()))
+    return True
+
+
+def _take_bn_tile_parts(y: torch.Tensor, coef: torch.Tensor, dz: torch.Tensor):
+    entry = _BN_TILE_PARTS.pop(y.data_ptr(), None)
+    if entry is None:
+        return None
+    part, ntile, coef_ptr, ptr, version, shape, stride = entry
+    if coef.data_ptr() != coef_ptr or dz.data_ptr() != ptr or dz._version != version or tuple(dz.shape) != shape or tuple(dz.stride()) != stride:
+        return None
+    return part, ntile
+
+
 class _ConvBNLReLU(torch.autograd.Function):
     """ConvUnit: Conv3d(k3,p1,bias) -> BatchNorm3d -> LeakyReLU(0.2)   (reference src/network_blocks.py:22-26)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool, momentum: float, eps: float):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool, momentum: float, eps: float,
+                bn_src=None):
         _require_gpu(x, weight, bias, gamma, beta)
+        ctx.bn_src = bn_src
         x = as_grid(x)
         B, Cin, D, H, W = x.shape
         Cout = weight.shape[0]
@@ -431,6 +479,7 @@ class _ConvBNLReLU(torch.autograd.Function):
         ctx.save_for_backward(x, weight, y, coef)
         ctx.training = training
         ctx.params = (weight, bias, gamma, beta)      # for DIRECT_PARAM_GRADS (their .grad slots)
+        ctx.produced = (y, coef)
         return z
 
     @staticmethod
@@ -442,10 +491,14 @@ class _ConvBNLReLU(torch.autograd.Function):
         npix = B * D * H * W
         dz = to_cl(dz)
         nblk = lib.query("pulpo_bn_bwd_blocks", npix, Cout)
-        part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
-        t0 = _hbm_begin()
-        lib.call("pulpo_bn_lrelu_bwd_reduce", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE, _ptr(part), _stream())
-        _hbm_end(t0, "bn_lrelu_bwd_reduce", 8.0 * Cout * npix)                # read dz, y
+        # first pass (sum dbn, sum dbn * xhat): already done by the epilogue of the data-gradient convolution that PRODUCED dz, if that was
+        # the ConvUnit behind this one (see _BN_TILE_PARTS); else a pass of its own over dz and y
+        tiles = _take_bn_tile_parts(y, coef, dz)
+        if tiles is None:
+            part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
+            t0 = _hbm_begin()
+            lib.call("pulpo_bn_lrelu_bwd_reduce", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE, _ptr(part), _stream())
+            _hbm_end(t0, "bn_lrelu_bwd_reduce", 8.0 * Cout * npix)                # read dz, y
         w_p, b_p, g_p, be_p = ctx.params
         slot_w, slot_b, slot_g, slot_be = (_grad_slot(t) if need else None
                                            for t, need in zip((w_p, b_p, g_p, be_p), ctx.needs_input_grad[1:5]))
@@ -453,9 +506,15 @@ class _ConvBNLReLU(torch.autograd.Function):
         tot = None if direct_bn else torch.empty(2 * Cout, device=dev, dtype=torch.float32)           # dbeta | dgamma
         totd = torch.empty(2 * Cout, device=dev, dtype=torch.float64)          # mean(dbn) | mean(dbn * xhat), kept in double
         # eval-mode BatchNorm is a fixed affine map (dy = scale * dbn): the batch means do not enter
-        lib.call("pulpo_bn_bwd_finalize", _ptr(part), nblk, Cout, float(npix), int(ctx.training),
-                 _ptr(slot_be if direct_bn else tot), _ptr(slot_g) if direct_bn else ctypes.c_void_p(tot.data_ptr() + 4 * Cout), int(direct_bn),
-                 _ptr(totd), _stream())
+        fin_out = (_ptr(slot_be if direct_bn else tot), _ptr(slot_g) if direct_bn else ctypes.c_void_p(tot.data_ptr() + 4 * Cout), int(direct_bn), _ptr(totd))
+        if tiles is None:
+            lib.call("pulpo_bn_bwd_finalize", _ptr(part), nblk, Cout, float(npix), int(ctx.training), *fin_out, _stream())
+        else:
+            tile_part, ntile = tiles
+            nsd = lib.query("pulpo_bn_fwd_finalize_scratch_doubles", ntile, Cout)
+            scratch = torch.empty(nsd, device=dev, dtype=torch.float64) if nsd else None
+            lib.call("pulpo_bn_bwd_finalize_tiles", _ptr(tile_part), ntile, Cout, _ptr(coef), float(npix), int(ctx.training), *fin_out, _ptr(scratch),
+                     _stream())
         dy = new_cl(B, Cout, D, H, W, dev)
         defer_b = DIRECT_PARAM_GRADS and ctx.needs_input_grad[2] and slot_b is not None
         part2 = _persistent_buffer(b_p, "_pulpo_dbias_part", nblk * Cout, zero=False) if defer_b else torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
@@ -474,10 +533,11 @@ class _ConvBNLReLU(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpt = _pack_weight(weight, dgrad=True, shape=(B, D, H, W))
             dx = torch.empty_like(x) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, dev)
-            _conv_raw(dy, wpt, None, dx, Cout, Cin, None)
+            if not _dgrad_with_bn_reduction(ctx.bn_src, x, dy, wpt, dx, Cout, Cin):
+                _conv_raw(dy, wpt, None, dx, Cout, Cin, None)
         if defer_w:
             _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, w_p)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None):
@@ -485,8 +545,14 @@ def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, train
     if _is2d(x):
         return conv_bn_lrelu(_lift(x), _lift_w3(weight), bias, gamma, beta, running_mean, running_var, training, momentum, eps,
                              num_batches_tracked).squeeze(2)
-    return _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
-                              float(eps))
+    src = getattr(x, "_pulpo_bn_src", None)          # x is the untouched output of another ConvUnit: (y, coef, version at production)
+    bn_src = src[:2] if (src is not None and src[2] == x._version and training and torch.is_grad_enabled()) else None
+    z = _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
+                           float(eps), bn_src)
+    produced = getattr(z.grad_fn, "produced", None) if training else None
+    if produced is not None:
+        z._pulpo_bn_src = (produced[0], produced[1], z._version)
+    return z
 
 
 class _Conv3dK3(torch.autograd.Function):

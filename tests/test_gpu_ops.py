@@ -305,6 +305,79 @@ def test_packed_weight_cache_follows_weight_updates(ops):
     assert rel_l2(y2, ref) < 2e-6 and rel_l2(y1, ref) > 1e-2
 
 
+@pytest.mark.parametrize("chans,size", [((16, 32, 64, 32), (24, 32, 40)), ((32, 32, 32), (32, 32, 32)), ((8, 96, 96), (20, 24, 24))])
+def test_bn_backward_reduction_inside_the_data_gradient_kernel(ops, chans, size):
+    """In a ConvSequence the data-gradient convolution of unit u also delivers the BatchNorm-backward sums of unit u-1 (one HBM pass over
+    dz and y less per unit).  Checked: the fused path IS taken on every inner link of these shapes, its gradients equal those of the
+    separate-pass path to fp32 rounding, both match the float64 oracle, and a unit whose output has a second consumer (autograd sums two
+    gradients) falls back to the separate pass with the right result."""
+    gen = torch.Generator().manual_seed(sum(chans))
+    x = torch.randn(1, chans[0], *size, generator=gen)
+    sd = {}
+    for u in range(len(chans) - 1):
+        ci, co = chans[u], chans[u + 1]
+        sd.update({f"u{u}._op.0.weight": torch.randn(co, ci, 3, 3, 3, generator=gen) / (27 * ci) ** 0.5, f"u{u}._op.0.bias": torch.randn(co, generator=gen),
+                   f"u{u}._op.1.weight": torch.rand(co, generator=gen) + 0.5, f"u{u}._op.1.bias": torch.randn(co, generator=gen)})
+    up = torch.randn(1, chans[-1], *size, generator=gen)
+    side = torch.randn(1, chans[1], *size, generator=gen)
+
+    def run(fused, second_consumer):
+        ops.BN_REDUCE_IN_DGRAD = fused
+        d = {k: v.cuda().requires_grad_(True) for k, v in sd.items()}
+        xg = x.cuda().requires_grad_(True)
+        h = xg
+        taken = []
+        orig = ops._take_bn_tile_parts
+        def spy(*a):
+            r = orig(*a)
+            taken.append(r is not None)
+            return r
+        ops._take_bn_tile_parts = spy
+        try:
+            extra = 0.0
+            for u in range(len(chans) - 1):
+                co = chans[u + 1]
+                h = ops.conv_bn_lrelu(h, d[f"u{u}._op.0.weight"], d[f"u{u}._op.0.bias"], d[f"u{u}._op.1.weight"], d[f"u{u}._op.1.bias"],
+                                      torch.zeros(co, device="cuda"), torch.ones(co, device="cuda"), training=True)
+                if second_consumer and u == 0:
+                    extra = (h * side.cuda()).sum()
+            loss = (h * up.cuda()).sum() + extra
+            grads = torch.autograd.grad(loss, [xg] + [d[k] for k in sorted(sd)])
+        finally:
+            ops._take_bn_tile_parts = orig
+            ops.BN_REDUCE_IN_DGRAD = True
+        return [g.cpu() for g in grads], taken
+
+    def oracle(second_consumer):
+        d = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+        xr = x.double().requires_grad_(True)
+        h, extra = xr, 0.0
+        for u in range(len(chans) - 1):
+            d[f"u{u}._op.1.running_mean"] = torch.zeros(chans[u + 1], dtype=torch.float64)
+            d[f"u{u}._op.1.running_var"] = torch.ones(chans[u + 1], dtype=torch.float64)
+            h = O.conv_unit(h, d, f"u{u}", training=True)
+            if second_consumer and u == 0:
+                extra = (h * side.double()).sum()
+        return torch.autograd.grad((h * up.double()).sum() + extra, [xr] + [d[k] for k in sorted(sd)])
+
+    nlink = len(chans) - 2
+    for second in (False, True):
+        gf, taken_f = run(True, second)
+        gs, taken_s = run(False, second)
+        gr = oracle(second)
+        assert not any(taken_s)
+        # units are walked last to first; unit u < last is offered the sums of its consumer, unit 0 with a second consumer must refuse them
+        want = [False] + [True] * nlink
+        if second:
+            want[-1] = False
+        assert taken_f == want, (taken_f, want)
+        for a, b, r in zip(gf, gs, gr):
+            if r.dim() == 1 and r.numel() in chans[1:] and float(r.abs().max()) < 1e-6 * float(gr[0].abs().max()):
+                continue                     # conv bias in front of a training-mode BatchNorm: exact gradient 0, computed value is rounding noise
+            assert rel_l2(a, b) < 2e-5
+            assert rel_l2(a, r) < 2e-3 and rel_l2(b, r) < 2e-3      # (fp32 vs float64 through three units: LeakyReLU branch flips near 0)
+
+
 def test_conv_linearity_at_full_channel_width(ops):
     """size-independent property at a BASELINE layer shape (32->32 @ 48^3): conv(a*x1 + x2) = a*conv(x1) + conv(x2) (no bias)"""
     gen = torch.Generator().manual_seed(3)
