@@ -80,6 +80,15 @@ int pulpo_conv3d_k3_dgrad_wino2_bnred_ok(int B, int D, int H, int W, int K, int 
 int pulpo_conv3d_k3_dgrad_wino2_bnred(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, float* out, int64_t out_bs,
                                       int64_t out_ps, const float* bn_y, int64_t bn_y_bs, int64_t bn_y_ps, const float* bn_coef, float slope,
                                       float* part, int B, int D, int H, int W, int K, int N, void* stream);
+/* Re-packing of many weights in one launch (after an optimizer step wrote the parameters through raw pointers): jobs is a DEVICE array,
+ * wp buffers as sized by pulpo_conv3d_k3_packed_floats (kind 0, the layout of pulpo_conv3d_k3_pack_weight) or
+ * pulpo_conv3d_k3_packed_wino2_floats (kind 2, the layout of pulpo_conv3d_k3_pack_weight_wino2). */
+typedef struct PulpoPackJob {
+    const float* w;   /* [Cout][Cin][3][3][3] */
+    float* wp;
+    int Cin, Cout, dgrad, kind;
+} PulpoPackJob;
+int pulpo_conv3d_k3_pack_weights_multi(const PulpoPackJob* jobs, int njobs, void* stream);
 /* weight gradient: dw[Cout][Cin][27] = sum_voxels in[v + tap - 1][ci] * dy[v][co]; scratch is overwritten */
 size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
 /* which weight-gradient kernel pulpo_conv3d_k3_wgrad runs for a shape: 2 = Winograd F(2x2,3x3) in (y, x), 1 = Winograd F(2,3) along x,

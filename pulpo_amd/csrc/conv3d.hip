@@ -284,7 +284,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 // Cin chunk staged per pass: 16 channels (27 KB halo tile + 8 KB weight double buffer => 4 workgroups per CU; measured
 // faster than 32- and 8-channel chunks on MI355X), 4 for the 2-/3-channel input layers
-int pick_ch(int K) { return K <= 4 ? 4 : 16; }
+int pick_ch(int K) { return direct_ch(K); }
 
 template <int CH, int NT, bool VEC, int TZv>
 int launch_conv_tz(const ConvArgs& a, int nblk, hipStream_t st) {

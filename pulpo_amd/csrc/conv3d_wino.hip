@@ -2,6 +2,7 @@
 // F(2x2,3x3) in (y, x) (conv3d_k3_wino2_mfma, the default), both direct over the z taps, all arithmetic fp32 on v_mfma_f32_32x32x2_f32.
 // Same argument block, tile order, BatchNorm partial statistics and fused eval-mode epilogue as the direct kernel in conv3d.hip.
 #include "conv_shared.h"
+#include "../../include/pulpo_hip.h"
 #include <stdlib.h>
 
 
@@ -782,37 +783,66 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
 }
 
 // packing for the (y, x) Winograd kernel: wp[k/8][dz][py][px][n][k%8] = sum_dy sum_dx G[py][dy] G[px][dx] g[dz][dy][dx]
-__global__ void pack_weight_wino2_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int NPad, int dgrad, long total) {
-    // one thread per (chunk, dz, k, n): nine taps in, sixteen transformed points out
+// element e = one (chunk, dz, n, k % 8): nine taps in, sixteen transformed points out
+__device__ __forceinline__ void pack_wino2_one(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int NPad, int dgrad, long e) {
     const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int kc = (int)(e % WN_CH);                 // (k fastest: consecutive threads write consecutive floats of the [n][k % 8] rows)
-        long r = e / WN_CH;
-        const int n = (int)(r % NPad); r /= NPad;
-        const int dz = (int)(r % 3);
-        const int chunk = (int)(r / 3);
-        const int k = chunk * WN_CH + kc;
-        float ux[3][4];
+    const int kc = (int)(e % WN_CH);                 // (k fastest: consecutive threads write consecutive floats of the [n][k % 8] rows)
+    long r = e / WN_CH;
+    const int n = (int)(r % NPad); r /= NPad;
+    const int dz = (int)(r % 3);
+    const int chunk = (int)(r / 3);
+    const int k = chunk * WN_CH + kc;
+    float ux[3][4];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            float g[3] = {0.f, 0.f, 0.f};
-            if (k < K && n < N) {
+    for (int dy = 0; dy < 3; ++dy) {
+        float g[3] = {0.f, 0.f, 0.f};
+        if (k < K && n < N) {
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int tap = (dz * 3 + dy) * 3 + dx;
-                    g[dx] = dgrad ? w[((long)k * Cin + n) * 27 + (26 - tap)] : w[((long)n * Cin + k) * 27 + tap];
-                }
+            for (int dx = 0; dx < 3; ++dx) {
+                const int tap = (dz * 3 + dy) * 3 + dx;
+                g[dx] = dgrad ? w[((long)k * Cin + n) * 27 + (26 - tap)] : w[((long)n * Cin + k) * 27 + tap];
             }
-            ux[dy][0] = g[0]; ux[dy][1] = 0.5f * (g[0] + g[1] + g[2]); ux[dy][2] = 0.5f * (g[0] - g[1] + g[2]); ux[dy][3] = g[2];
         }
-        float* o = wp + (((long)(chunk * 3 + dz) * 16) * NPad + n) * WN_CH + kc;          // + (py * 4 + px) * NPad * WN_CH
+        ux[dy][0] = g[0]; ux[dy][1] = 0.5f * (g[0] + g[1] + g[2]); ux[dy][2] = 0.5f * (g[0] - g[1] + g[2]); ux[dy][3] = g[2];
+    }
+    float* o = wp + (((long)(chunk * 3 + dz) * 16) * NPad + n) * WN_CH + kc;          // + (py * 4 + px) * NPad * WN_CH
 #pragma unroll
-        for (int px = 0; px < 4; ++px) {
-            const float u0 = ux[0][px], u1 = ux[1][px], u2 = ux[2][px];
-            o[(long)(0 * 4 + px) * WN_CH * NPad] = u0;
-            o[(long)(1 * 4 + px) * WN_CH * NPad] = 0.5f * (u0 + u1 + u2);
-            o[(long)(2 * 4 + px) * WN_CH * NPad] = 0.5f * (u0 - u1 + u2);
-            o[(long)(3 * 4 + px) * WN_CH * NPad] = u2;
+    for (int px = 0; px < 4; ++px) {
+        const float u0 = ux[0][px], u1 = ux[1][px], u2 = ux[2][px];
+        o[(long)(0 * 4 + px) * WN_CH * NPad] = u0;
+        o[(long)(1 * 4 + px) * WN_CH * NPad] = 0.5f * (u0 + u1 + u2);
+        o[(long)(2 * 4 + px) * WN_CH * NPad] = 0.5f * (u0 - u1 + u2);
+        o[(long)(3 * 4 + px) * WN_CH * NPad] = u2;
+    }
+}
+
+__global__ void pack_weight_wino2_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int NPad, int dgrad, long total) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+        pack_wino2_one(w, wp, Cin, Cout, NPad, dgrad, e);
+}
+
+// every packed weight of a model in ONE launch (after an optimizer step that wrote the parameters): grid = (blocks per job, jobs)
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PulpoPackJob* __restrict__ jobs) {
+    const PulpoPackJob j = jobs[blockIdx.y];
+    const int K = j.dgrad ? j.Cout : j.Cin, N = j.dgrad ? j.Cin : j.Cout;
+    const int NPad = npad(N);
+    const long step = (long)gridDim.x * blockDim.x;
+    if (j.kind == 2) {
+        const long total = (long)((K + WN_CH - 1) / WN_CH) * 3 * WN_CH * NPad;
+        for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += step) pack_wino2_one(j.w, j.wp, j.Cin, j.Cout, NPad, j.dgrad, e);
+    } else {
+        // the direct kernel's layout (conv3d.hip pack_weight_kernel): wp[k / CH][tap][k % CH][n]
+        const int CH = direct_ch(K);
+        const long total = (long)((K + CH - 1) / CH) * 27 * CH * NPad;
+        for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += step) {
+            const int n = (int)(e % NPad);
+            long r = e / NPad;
+            const int kc = (int)(r % CH); r /= CH;
+            const int tap = (int)(r % 27);
+            const int k = (int)(r / 27) * CH + kc;
+            float val = 0.f;
+            if (k < K && n < N) val = j.dgrad ? j.w[((long)k * j.Cin + n) * 27 + (26 - tap)] : j.w[((long)n * j.Cin + k) * 27 + tap];
+            j.wp[e] = val;
         }
     }
 }
@@ -881,6 +911,13 @@ PULPO_API int pulpo_conv3d_k3_pack_weight_wino2(const float* w, float* wp, int C
     const int nb = (int)std::min<long>((total + 255) / 256, 8192);
     hipLaunchKernelGGL(pack_weight_wino2_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wp, Cin, Cout, npad(N), dgrad, total);
     return pulpo::check_launch("pack_weight_wino2");
+}
+
+// jobs: DEVICE array; kind 0 = the layout of pulpo_conv3d_k3_pack_weight, 2 = of pulpo_conv3d_k3_pack_weight_wino2
+PULPO_API int pulpo_conv3d_k3_pack_weights_multi(const PulpoPackJob* jobs, int njobs, void* stream) {
+    PULPO_REQUIRE(jobs && njobs > 0, "conv3d_k3_pack_weights_multi: bad arguments");
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(32, njobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    return pulpo::check_launch("pack_weights_multi");
 }
 
 template <bool VEC, bool BNR = false>

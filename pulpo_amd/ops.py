@@ -214,6 +214,45 @@ _WEIGHT_EPOCH = 0
 def invalidate_weight_packs() -> None:
     global _WEIGHT_EPOCH
     _WEIGHT_EPOCH += 1
+    _PACK_REGISTRY.clear()
+
+
+# (weight, orientation, kernel family, ...) -> (weight, packed buffer, Cin, Cout, dgrad, kind) of every live fp32 pack that
+# pulpo_conv3d_k3_pack_weights_multi can rewrite in place; a pack of another family (bf16, Winograd-x) makes the set unrefreshable
+_PACK_REGISTRY: dict = {}
+_PACK_TABLES: dict = {}
+_UNREFRESHABLE_PACKS = False
+
+
+def refresh_weight_packs() -> None:
+    """after an update of the parameters behind torch's back (the fused Adam kernel): rewrite every cached weight pack in place with ONE
+    launch on the current stream, instead of forgetting them and packing layer by layer (55 small launches on the critical path of the
+    next forward and backward pass).  Falls back to invalidate_weight_packs() when a cached pack is of a kind the kernel does not write."""
+    global _UNREFRESHABLE_PACKS
+    if _UNREFRESHABLE_PACKS or not _PACK_REGISTRY:
+        _UNREFRESHABLE_PACKS = False
+        invalidate_weight_packs()
+        return
+    jobs = []
+    for key, (w, wp, Cin, Cout, dgrad, kind) in list(_PACK_REGISTRY.items()):
+        cache = getattr(w, "_pulpo_packs", None)
+        if cache is None or cache[0] != (w._version, w.data_ptr(), _WEIGHT_EPOCH) or not any(v is wp for v in cache[1].values()):
+            del _PACK_REGISTRY[key]                  # superseded (weight replaced or modified through torch): the next use packs afresh
+            continue
+        jobs.append((w.data_ptr(), wp.data_ptr(), Cin, Cout, int(dgrad), kind))
+    if not jobs:
+        invalidate_weight_packs()
+        return
+    tkey = tuple(jobs)
+    table = _PACK_TABLES.get(tkey)
+    if table is None:
+        import struct
+        raw = b"".join(struct.pack("<QQiiii", *job) for job in tkey)
+        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(next(iter(_PACK_REGISTRY.values()))[0].device)
+        if len(_PACK_TABLES) > 4:
+            _PACK_TABLES.clear()
+        _PACK_TABLES[tkey] = table
+    lib.call("pulpo_conv3d_k3_pack_weights_multi", _ptr(table), len(tkey), _stream())
 
 
 def _pack_weight(w: torch.Tensor, dgrad: bool, shape=None, both: bool = False) -> torch.Tensor:
@@ -243,12 +282,15 @@ def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None) -> torch.Tensor:
     (the returned tensor carries the choice in `_pulpo_algo`)."""
     Cout, Cin = w.shape[0], w.shape[1]
     K, N = (Cout, Cin) if dgrad else (Cin, Cout)
+    global _UNREFRESHABLE_PACKS
     if _use_bf16(K):
         wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_bf16_elems", K, N), device=w.device, dtype=torch.int16)
         lib.call("pulpo_conv3d_k3_pack_weight_bf16", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
         wp._pulpo_algo = "bf16"
+        _UNREFRESHABLE_PACKS = True
         return wp
     algo = lib.query("pulpo_conv3d_k3_algo", *shape, K, N) if shape is not None else 0
+    shape_key = (None if shape is None else tuple(shape), CONV_ALGO)
     if CONV_ALGO is not None and algo != 0:            # diagnostic override; only among the kernels valid for this shape
         algo = {"direct": 0, "wino": 1, "wino2": 2}[CONV_ALGO]
     if algo in (1, 2):
@@ -256,10 +298,18 @@ def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None) -> torch.Tensor:
         wp = torch.empty(lib.query(f"pulpo_conv3d_k3_packed_{name}_floats", K, N), device=w.device, dtype=torch.float32)
         lib.call(f"pulpo_conv3d_k3_pack_weight_{name}", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
         wp._pulpo_algo = name
+        if algo == 2 and w.is_contiguous():
+            _PACK_REGISTRY[(id(w), dgrad, 2, shape_key)] = (w, wp, Cin, Cout, dgrad, 2)
+        else:
+            _UNREFRESHABLE_PACKS = True
         return wp
     wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_floats", K, N), device=w.device, dtype=torch.float32)
     lib.call("pulpo_conv3d_k3_pack_weight", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
     wp._pulpo_algo = "direct"
+    if w.is_contiguous():
+        _PACK_REGISTRY[(id(w), dgrad, 0, shape_key)] = (w, wp, Cin, Cout, dgrad, 0)
+    else:
+        _UNREFRESHABLE_PACKS = True
     return wp
 
 
@@ -1096,8 +1146,8 @@ class StreamingMoments:
 
 def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, gscale: float = 1.0):
     _require_gpu(p, g, m, v)
-    invalidate_weight_packs()                    # the kernel rewrites parameters through raw pointers
     lib.call("pulpo_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, int(step), gscale, _stream())
+    refresh_weight_packs()                       # the kernel rewrote parameters through raw pointers: the cached packs follow, in one launch
 
 
 # ------------------------------------------------------------------------------------------------ evaluation scalars (evaluate.py)
