@@ -147,8 +147,9 @@ int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const float* y, int
                               float* partial /*[blocks][2C]*/, void* stream);
 int pulpo_bn_bwd_finalize(const float* partial, int nrow, int C, double count, int use_means, float* dbeta, float* dgamma, int accumulate,
                           double* totd /*[2C]: mean(dbn) | mean(dbn*xhat)*/, void* stream);
-/* pulpo_bn_bwd_finalize over per-voxel-tile rows (pulpo_conv3d_k3_dgrad_wino2_bnred); scratch: pulpo_bn_fwd_finalize_scratch_doubles(ntile, C)
- * doubles (NULL when that is 0) */
+/* pulpo_bn_bwd_finalize over per-voxel-tile rows (pulpo_conv3d_k3_dgrad_wino2_bnred); scratch:
+ * pulpo_bn_bwd_finalize_tiles_scratch_doubles(ntile, C) doubles (NULL when that is 0) */
+size_t pulpo_bn_bwd_finalize_tiles_scratch_doubles(int ntile, int C);
 int pulpo_bn_bwd_finalize_tiles(const float* tile_part, int ntile, int C, const float* coef, double count, int use_means, float* dbeta,
                                 float* dgamma, int accumulate, double* totd, double* scratch, void* stream);
 int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd, float* dy,

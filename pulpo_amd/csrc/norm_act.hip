@@ -275,16 +275,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 
 // The same from per-voxel-tile rows [ntile][2][C] = (sum dbn, sum dbn * (y - m32)) written by a convolution epilogue, m32 = coef[c] the
 // fp32-rounded batch mean (or, part != nullptr, from their double slice sums):  sum dbn * xhat = rstd * (q - (mean - m32) * s).
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_tiles_kernel(const float* __restrict__ rows, const double* __restrict__ part, int nrow, int C,
+__global__ __launch_bounds__(512) void bn_bwd_finalize_tiles_kernel(const float* __restrict__ rows, const double* __restrict__ part, int nrow, int C,
                                                                        const float* __restrict__ coef, double count, int use_means,
                                                                        float* __restrict__ dbeta, float* __restrict__ dgamma, int accumulate,
                                                                        double* __restrict__ totd) {
-    __shared__ double red[2][32][33];
+    __shared__ double red[2][16][33];      // block = (32 channels, 16 row lanes): 8 waves of <= 32 registers, see below
     const int cx = threadIdx.x, ry = threadIdx.y;
     const int c = blockIdx.x * 32 + cx;
+    // (no unrolling: this kernel runs beside the weight-gradient kernel, which leaves about 100 registers per SIMD - the 8 waves of a
+    //  workgroup have to fit into them or the launch waits for a CU the weight gradient has left)
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int r = ry; r < nrow; r += 32) {
+    if (c < C) {
+#pragma unroll 1
+        for (int r = ry; r < nrow; r += 16) {
             if (part != nullptr) {
                 s += part[((long)r * 2 + 0) * C + c];
                 q += part[((long)r * 2 + 1) * C + c];
@@ -293,13 +296,14 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_tiles_kernel(const float
                 q += (double)rows[((long)r * 2 + 1) * C + c];
             }
         }
+    }
     red[0][ry][cx] = s;
     red[1][ry][cx] = q;
     __syncthreads();
     if (ry == 0 && c < C) {
         double ts = 0.0, tq = 0.0;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) { ts += red[0][k][cx]; tq += red[1][k][cx]; }
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) { ts += red[0][k][cx]; tq += red[1][k][cx]; }
         const double* cd = reinterpret_cast<const double*>(coef + 4 * C);
         const double tx = cd[C + c] * (tq - (cd[c] - (double)coef[c]) * ts);
         dbeta[c] = accumulate ? dbeta[c] + (float)ts : (float)ts;
@@ -398,15 +402,18 @@ PULPO_API int pulpo_bn_bwd_finalize(const float* partial, int nrow, int C, doubl
 }
 
 // The same from the per-voxel-tile partial rows a convolution epilogue wrote (pulpo_conv3d_k3_dgrad_wino2_bnred; coef = the unit's
-// coefficient block): with more than 2048 tiles the rows are first summed slice-wise in double (scratch:
-// pulpo_bn_fwd_finalize_scratch_doubles(ntile, C) doubles, else NULL).
+// coefficient block): with more than 64 tiles the rows are first summed slice-wise in double (scratch:
+// pulpo_bn_bwd_finalize_tiles_scratch_doubles(ntile, C) doubles, else NULL).
+// (two-stage from 64 tiles up: the second stage alone would walk the rows with 32 threads per channel)
+PULPO_API size_t pulpo_bn_bwd_finalize_tiles_scratch_doubles(int ntile, int C) { return ntile > 64 ? (size_t)32 * 2 * C : 0; }
+
 PULPO_API int pulpo_bn_bwd_finalize_tiles(const float* tile_part, int ntile, int C, const float* coef, double count, int use_means, float* dbeta,
                                           float* dgamma, int accumulate, double* totd, double* scratch, void* stream) {
     PULPO_REQUIRE(tile_part && coef && dbeta && dgamma && totd && ntile > 0 && C > 0 && count > 0, "bn_bwd_finalize_tiles: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const double* partd = nullptr;
     int nrow = ntile;
-    if (ntile > 2048) {
+    if (pulpo_bn_bwd_finalize_tiles_scratch_doubles(ntile, C) != 0) {
         PULPO_REQUIRE(scratch != nullptr, "bn_bwd_finalize_tiles: scratch required for %d tiles", ntile);
         hipLaunchKernelGGL(colsum_slices_kernel, dim3(pulpo::cdiv(2 * C, 32), 32), dim3(32, 32), 0, st, tile_part, ntile, 2 * C, scratch);
         int rc = pulpo::check_launch("bn backward tile slices");
@@ -414,7 +421,7 @@ PULPO_API int pulpo_bn_bwd_finalize_tiles(const float* tile_part, int ntile, int
         partd = scratch;
         nrow = 32;
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel, dim3(pulpo::cdiv(C, 32)), dim3(32, 32), 0, st, tile_part, partd, nrow, C, coef, count, use_means,
+    hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel, dim3(pulpo::cdiv(C, 32)), dim3(32, 16), 0, st, tile_part, partd, nrow, C, coef, count, use_means,
                        dbeta, dgamma, accumulate, totd);
     return pulpo::check_launch("bn_bwd_finalize_tiles");
 }

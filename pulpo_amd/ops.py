@@ -561,7 +561,7 @@ class _ConvBNLReLU(torch.autograd.Function):
             lib.call("pulpo_bn_bwd_finalize", _ptr(part), nblk, Cout, float(npix), int(ctx.training), *fin_out, _stream())
         else:
             tile_part, ntile = tiles
-            nsd = lib.query("pulpo_bn_fwd_finalize_scratch_doubles", ntile, Cout)
+            nsd = lib.query("pulpo_bn_bwd_finalize_tiles_scratch_doubles", ntile, Cout)
             scratch = torch.empty(nsd, device=dev, dtype=torch.float64) if nsd else None
             lib.call("pulpo_bn_bwd_finalize_tiles", _ptr(tile_part), ntile, Cout, _ptr(coef), float(npix), int(ctx.training), *fin_out, _ptr(scratch),
                      _stream())
