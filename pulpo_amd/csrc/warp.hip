@@ -122,6 +122,91 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     }
 }
 
+// One backward squaring step of VecInt (v' = v + warp(v, v): the field is image and displacement at once) with the scatter collected in
+// LDS: a workgroup owns a 4 x 8 x 8 voxel tile and keeps a (4+2R) x (8+2R) x (8+2R) x 3 accumulation box around it; a step's displacement
+// is a fraction of the final field (v / 2^(nsteps-k)), so almost every corner a voxel scatters to lies inside the box of its own tile -
+// those adds are LDS atomics, the rest go to memory as before.  The box then leaves with one memory atomic per touched cell: 4-7 memory
+// atomics per voxel instead of 27 (24 corner adds + 3 displacement-gradient adds), which is what bounded warp_bwd_kernel here.
+// gp must hold the identity path (g) on entry, as for warp_bwd_kernel<true>.
+template <int R>
+__global__ __launch_bounds__(256) void vecint_bwd_tile_kernel(const float* __restrict__ cur, const float* __restrict__ gout, float* __restrict__ gp,
+                                                                int B, int D, int H, int W, int ntz, int nty, int ntx) {
+    constexpr int TZ_ = 4, TY_ = 8, TX_ = 8;
+    constexpr int BZ = TZ_ + 2 * R, BY = TY_ + 2 * R, BX = TX_ + 2 * R, BV = BZ * BY * BX;
+    __shared__ float box[3 * BV];
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx_ = t % ntx; t /= ntx;
+    const int ty_ = t % nty; t /= nty;
+    const int tz_ = t % ntz;
+    const int b = t / ntz;
+    const int z0 = tz_ * TZ_, y0 = ty_ * TY_, x0 = tx_ * TX_;
+    const long V = (long)D * H * W;
+    for (int j = tid; j < 3 * BV; j += 256) box[j] = 0.f;
+    __syncthreads();
+    const int z = z0 + (tid >> 6), y = y0 + ((tid >> 3) & 7), x = x0 + (tid & 7);
+    if (z < D && y < H && x < W) {
+        const long v = ((long)z * H + y) * W + x;
+        const float* d = cur + (long)b * 3 * V + v;
+        const Corner cz = sample_coord((float)z, d[0], D, D);
+        const Corner cy = sample_coord((float)y, d[V], H, H);
+        const Corner cx = sample_coord((float)x, d[2 * V], W, W);
+        const float wz0 = 1.f - cz.f, wy0 = 1.f - cy.f, wx0 = 1.f - cx.f;
+        const long o00 = ((long)cz.i0 * H + cy.i0) * W, o01 = ((long)cz.i0 * H + cy.i1) * W;
+        const long o10 = ((long)cz.i1 * H + cy.i0) * W, o11 = ((long)cz.i1 * H + cy.i1) * W;
+        // box coordinates of the corners (negative / too large = outside the box)
+        const int lz0 = cz.i0 - z0 + R, lz1 = cz.i1 - z0 + R, ly0 = cy.i0 - y0 + R, ly1 = cy.i1 - y0 + R, lx0 = cx.i0 - x0 + R, lx1 = cx.i1 - x0 + R;
+        const bool inbox = lz0 >= 0 && lz1 < BZ && ly0 >= 0 && ly1 < BY && lx0 >= 0 && lx1 < BX;
+        float gz = 0.f, gy = 0.f, gx = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = gout[((long)b * 3 + c) * V + v];
+            const float* s = cur + ((long)b * 3 + c) * V;
+            const float s000 = s[o00 + cx.i0], s001 = s[o00 + cx.i1], s010 = s[o01 + cx.i0], s011 = s[o01 + cx.i1];
+            const float s100 = s[o10 + cx.i0], s101 = s[o10 + cx.i1], s110 = s[o11 + cx.i0], s111 = s[o11 + cx.i1];
+            gz += g * (wy0 * wx0 * (s100 - s000) + wy0 * cx.f * (s101 - s001) + cy.f * wx0 * (s110 - s010) + cy.f * cx.f * (s111 - s011));
+            gy += g * (wz0 * wx0 * (s010 - s000) + wz0 * cx.f * (s011 - s001) + cz.f * wx0 * (s110 - s100) + cz.f * cx.f * (s111 - s101));
+            gx += g * (wz0 * wy0 * (s001 - s000) + wz0 * cy.f * (s011 - s010) + cz.f * wy0 * (s101 - s100) + cz.f * cy.f * (s111 - s110));
+            if (inbox) {
+                float* q = box + c * BV;
+                const int p00 = (lz0 * BY + ly0) * BX, p01 = (lz0 * BY + ly1) * BX, p10 = (lz1 * BY + ly0) * BX, p11 = (lz1 * BY + ly1) * BX;
+                atomicAdd(q + p00 + lx0, g * wz0 * wy0 * wx0);
+                atomicAdd(q + p00 + lx1, g * wz0 * wy0 * cx.f);
+                atomicAdd(q + p01 + lx0, g * wz0 * cy.f * wx0);
+                atomicAdd(q + p01 + lx1, g * wz0 * cy.f * cx.f);
+                atomicAdd(q + p10 + lx0, g * cz.f * wy0 * wx0);
+                atomicAdd(q + p10 + lx1, g * cz.f * wy0 * cx.f);
+                atomicAdd(q + p11 + lx0, g * cz.f * cy.f * wx0);
+                atomicAdd(q + p11 + lx1, g * cz.f * cy.f * cx.f);
+            } else {
+                float* q = gp + ((long)b * 3 + c) * V;
+                atomicAdd(q + o00 + cx.i0, g * wz0 * wy0 * wx0);
+                atomicAdd(q + o00 + cx.i1, g * wz0 * wy0 * cx.f);
+                atomicAdd(q + o01 + cx.i0, g * wz0 * cy.f * wx0);
+                atomicAdd(q + o01 + cx.i1, g * wz0 * cy.f * cx.f);
+                atomicAdd(q + o10 + cx.i0, g * cz.f * wy0 * wx0);
+                atomicAdd(q + o10 + cx.i1, g * cz.f * wy0 * cx.f);
+                atomicAdd(q + o11 + cx.i0, g * cz.f * cy.f * wx0);
+                atomicAdd(q + o11 + cx.i1, g * cz.f * cy.f * cx.f);
+            }
+        }
+        // the displacement-gradient term lands on the voxel itself: into its (always in-box) cell
+        const int own = ((z - z0 + R) * BY + (y - y0 + R)) * BX + (x - x0 + R);
+        atomicAdd(box + own, gz * cz.dscale);
+        atomicAdd(box + BV + own, gy * cy.dscale);
+        atomicAdd(box + 2 * BV + own, gx * cx.dscale);
+    }
+    __syncthreads();
+    for (int j = tid; j < 3 * BV; j += 256) {
+        const float val = box[j];
+        if (val == 0.f) continue;
+        const int c = j / BV, r = j - c * BV;
+        const int gz_ = z0 - R + r / (BY * BX), gy_ = y0 - R + (r / BX) % BY, gx_ = x0 - R + r % BX;
+        if (gz_ >= 0 && gz_ < D && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W)
+            atomicAdd(gp + ((long)b * 3 + c) * V + ((long)gz_ * H + gy_) * W + gx_, val);
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ in, float* __restrict__ out, float s, long n) {
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) out[e] = in[e] * s;
 }
@@ -187,7 +272,12 @@ PULPO_API int pulpo_vecint_bwd(const float* work, const float* gout, float* gin,
         hipError_t e = hipMemcpyAsync(gp, g, sizeof(float) * n, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return pulpo::fail((int)e, "vecint_bwd copy: %s", hipGetErrorString(e));
         const float* cur = work + (long)k * n;
-        hipLaunchKernelGGL(warp_bwd_kernel<true>, dim3(eblocks(total)), dim3(256), 0, st, cur, cur, g, gp, gp, B, D, H, W, D, H, W, 3);
+        if (D >= 16 && H >= 16 && W >= 16) {           // (smaller fields: a handful of tiles, the plain scatter is as fast)
+            const int ntz = pulpo::cdiv(D, 4), nty = pulpo::cdiv(H, 8), ntx = pulpo::cdiv(W, 8);
+            hipLaunchKernelGGL(vecint_bwd_tile_kernel<1>, dim3((unsigned)((long)B * ntz * nty * ntx)), dim3(256), 0, st, cur, g, gp, B, D, H, W, ntz, nty, ntx);
+        } else {
+            hipLaunchKernelGGL(warp_bwd_kernel<true>, dim3(eblocks(total)), dim3(256), 0, st, cur, cur, g, gp, gp, B, D, H, W, D, H, W, 3);
+        }
         int rc = pulpo::check_launch("vecint_bwd step");
         if (rc) return rc;
         g = gp;

@@ -80,6 +80,28 @@ def test_vecint_golden(ops, golden):
         assert rel_l2(gv, g["gv" + s]) < 1e-4
 
 
+@pytest.mark.parametrize("size,amp", [((24, 20, 28), 1.0), ((16, 32, 18), 12.0), ((40, 40, 40), 3.0)])
+def test_vecint_backward_lds_tiled_scatter_vs_oracle(ops, size, amp):
+    """fields of 16^3 and up run the backward squaring steps with the scatter collected in LDS boxes (vecint_bwd_tile_kernel): small
+    displacements stay inside a tile's box, large ones (amp 12: several voxels per step at the end) take the memory-atomic fallback;
+    both against autograd through the oracle's VecInt in float64"""
+    gen = torch.Generator().manual_seed(int(amp * 10) + size[0])
+    v = torch.randn(2, 3, *size, generator=gen) * amp
+    up = torch.randn(2, 3, *size, generator=gen)
+    vg = v.cuda().requires_grad_(True)
+    out = ops.vecint(vg, 7)
+    gv, = torch.autograd.grad((out * up.cuda()).sum(), [vg])
+    vr = v.double().requires_grad_(True)
+    ref = O.vecint(vr, 7)
+    gr, = torch.autograd.grad((ref * up.double()).sum(), [vr])
+    assert rel_l2(out, ref) < 1e-5
+    # a rough field puts some sample coordinates within rounding of a cell boundary, where floor() - and with it the gradient - jumps: the
+    # fp32 CPU evaluation of the same operator sets the scale of that effect
+    v32 = v.clone().requires_grad_(True)
+    g32, = torch.autograd.grad((O.vecint(v32, 7) * up).sum(), [v32])
+    assert rel_l2(gv, gr) < max(1e-4, 3.0 * rel_l2(g32, gr))
+
+
 # ================================================================================================ resampling
 def test_resample_golden(ops, golden):
     g = golden("resample")
