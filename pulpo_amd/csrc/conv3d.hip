@@ -51,6 +51,26 @@ __device__ __forceinline__ void stage_halo(float* xs, const float* __restrict__ 
                 d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
             }
         }
+    } else if constexpr (CH <= 4) {
+        // the 2-/3-channel input layers (planar operands): as above, every load of the tile in flight before the first LDS write;
+        // thread -> (channel, halo voxel) with the voxel fastest: a wave reads runs of 10 consecutive x of ONE channel plane
+        constexpr int NIT = (HV * CH + 255) / 256;
+        float v[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int j = tid + u * 256;
+            const int c = j / HV, hv = j - c * HV;
+            const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            v[u] = 0.f;
+            if (j < HV * CH && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c0 + c < Cin)
+                v[u] = in[((long)(gz * H + gy) * W + gx) * in_ps + (long)(c0 + c) * in_cs];
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int j = tid + u * 256;
+            if (j < HV * CH) xs[(j % HV) * CP + (j / HV)] = v[u];
+        }
     } else {
         for (int j = tid; j < HV * CH; j += 256) {
             const int hv = j / CH, c = j - hv * CH;
@@ -71,8 +91,12 @@ __global__ __launch_bounds__(256, TZv == 4 ? 3 : 2) void conv3d_k3_mfma(ConvArgs
     constexpr int MT = TZv / 2;                      // 32-voxel row tiles per wave: the workgroup tile is TZv x 8 x 8 voxels
     constexpr int HV = (TZv + 2) * HY * HX;
     constexpr int XS = (HV * CP + 3) & ~3;
-    constexpr int WF4 = CH * NT / 4;               // float4 per weight slab
-    constexpr int NW = (WF4 + 255) / 256;          // float4 per thread per slab
+    // taps per weight stage: the 2-/3-channel input layers (one chunk, 2-4 MFMAs per tap and wave) keep ALL 27 tap slabs in LDS - one
+    // barrier per tile instead of one per tap, which was what bounded them (400 us for 2->32 at 160^3, 205 us of matrix time)
+    constexpr int TPS = CH <= 4 ? 27 : 1;
+    constexpr int SPC = 27 / TPS;                  // stages per chunk
+    constexpr int WF4 = TPS * CH * NT / 4;         // float4 per weight stage
+    constexpr int NW = (WF4 + 255) / 256;          // float4 per thread per stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
     float* ws = smem + XS;
@@ -93,7 +117,7 @@ __global__ __launch_bounds__(256, TZv == 4 ? 3 : 2) void conv3d_k3_mfma(ConvArgs
     const int nchunk_all = (a.Cin + CH - 1) / CH;
     const int cper = (nchunk_all + a.ksplit - 1) / a.ksplit;
     const int chunk0 = split * cper, chunk1 = min(nchunk_all, chunk0 + cper);
-    const int it0 = chunk0 * 27, niter = chunk1 * 27;
+    const int it0 = chunk0 * SPC, niter = chunk1 * SPC;
     const float* in_b = a.in + (long)b * a.in_bs;
 
     // weight slab prefetch registers
@@ -104,7 +128,7 @@ __global__ __launch_bounds__(256, TZv == 4 ? 3 : 2) void conv3d_k3_mfma(ConvArgs
             const int j = tid + u * 256;
             if (WF4 % 256 == 0 || j < WF4) {
                 const int row = j / (NT / 4), c4 = j - row * (NT / 4);
-                wreg[u] = *reinterpret_cast<const float4*>(a.wp + ((long)it * CH + row) * a.NPad + co0 + c4 * 4);
+                wreg[u] = *reinterpret_cast<const float4*>(a.wp + ((long)it * TPS * CH + row) * a.NPad + co0 + c4 * 4);
             }
         }
     };
@@ -112,7 +136,7 @@ __global__ __launch_bounds__(256, TZv == 4 ? 3 : 2) void conv3d_k3_mfma(ConvArgs
 #pragma unroll
         for (int u = 0; u < NW; ++u) {
             const int j = tid + u * 256;
-            if (WF4 % 256 == 0 || j < WF4) *reinterpret_cast<float4*>(ws + buf * CH * NT + j * 4) = wreg[u];
+            if (WF4 % 256 == 0 || j < WF4) *reinterpret_cast<float4*>(ws + buf * TPS * CH * NT + j * 4) = wreg[u];
         }
     };
 
@@ -137,26 +161,30 @@ __global__ __launch_bounds__(256, TZv == 4 ? 3 : 2) void conv3d_k3_mfma(ConvArgs
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
         __syncthreads();   // every wave is done reading xs (previous chunk)
         stage_halo<CH, VEC, TZv>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
-        for (int tap = 0; tap < 27; ++tap, ++it) {
+        for (int stg = 0; stg < SPC; ++stg, ++it) {
             store_w(buf);
             __syncthreads();
             if (it + 1 < niter) load_w(it + 1);
-            const float* xa[MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) xa[m] = xs + (hb[m] + tap_halo_offset(tap)) * CP + kk;
-            const float* wb = ws + buf * CH * NT + kk * NT + i;
-            // (fragment reads are left to hipcc's placement here: with several waves per SIMD the other waves cover each read's
-            //  latency, and forcing all reads of the tap ahead of its MFMAs measured ~8 % slower)
+            for (int tt = 0; tt < TPS; ++tt) {
+                const int tap = stg * TPS + tt;
+                const float* xa[MT];
 #pragma unroll
-            for (int s = 0; s < CH / 2; ++s) {
-                float av[MT];
+                for (int m = 0; m < MT; ++m) xa[m] = xs + (hb[m] + tap_halo_offset(tap)) * CP + kk;
+                const float* wb = ws + (buf * TPS + tt) * CH * NT + kk * NT + i;
+                // (fragment reads are left to hipcc's placement here: with several waves per SIMD the other waves cover each read's
+                //  latency, and forcing all reads of the tap ahead of its MFMAs measured ~8 % slower)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) av[m] = xa[m][2 * s];
+                for (int s = 0; s < CH / 2; ++s) {
+                    float av[MT];
 #pragma unroll
-                for (int n = 0; n < NN; ++n) {
-                    const float bv = wb[2 * s * NT + n * 32];
+                    for (int m = 0; m < MT; ++m) av[m] = xa[m][2 * s];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv, acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NN; ++n) {
+                        const float bv = wb[2 * s * NT + n * 32];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv, acc[m][n], 0, 0, 0);
+                    }
                 }
             }
             buf ^= 1;
@@ -283,12 +311,12 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 }
 
 // Cin chunk staged per pass: 16 channels (27 KB halo tile + 8 KB weight double buffer => 4 workgroups per CU; measured
-// faster than 32- and 8-channel chunks on MI355X), 4 for the 2-/3-channel input layers
+// faster than 32- and 8-channel chunks on MI355X), 2 / 4 for the 2- / 3-channel input layers
 int pick_ch(int K) { return direct_ch(K); }
 
 template <int CH, int NT, bool VEC, int TZv>
 int launch_conv_tz(const ConvArgs& a, int nblk, hipStream_t st) {
-    constexpr size_t lds = (size_t)((((TZv + 2) * HY * HX * (CH + 1) + 3) & ~3) + 2 * CH * NT) * sizeof(float);
+    constexpr size_t lds = (size_t)((((TZv + 2) * HY * HX * (CH + 1) + 3) & ~3) + 2 * (CH <= 4 ? 27 : 1) * CH * NT) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma<CH, NT, VEC, TZv>),
@@ -391,7 +419,8 @@ static int conv_fwd_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t 
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0) && CH >= 16;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (CH == 4) rc = NT == 64 ? launch_conv<4, 64, false>(a, nblk, st, tz) : launch_conv<4, 32, false>(a, nblk, st, tz);
+    if (CH == 2) rc = NT == 64 ? launch_conv<2, 64, false>(a, nblk, st, tz) : launch_conv<2, 32, false>(a, nblk, st, tz);
+    else if (CH == 4) rc = NT == 64 ? launch_conv<4, 64, false>(a, nblk, st, tz) : launch_conv<4, 32, false>(a, nblk, st, tz);
     else if (vec) rc = NT == 64 ? launch_conv<16, 64, true>(a, nblk, st, tz) : launch_conv<16, 32, true>(a, nblk, st, tz);
     else rc = NT == 64 ? launch_conv<16, 64, false>(a, nblk, st, tz) : launch_conv<16, 32, false>(a, nblk, st, tz);
     if (rc == 0 && a.ksplit > 1) {

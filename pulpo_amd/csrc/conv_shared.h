@@ -13,7 +13,7 @@ int conv_tz(int D, int H, int W);
 
 __host__ __device__ inline int npad(int N) { return (N + 63) & ~63; }
 // Cin chunk of the direct kernel's weight packing (conv3d.hip pick_ch)
-__host__ __device__ inline int direct_ch(int K) { return K <= 4 ? 4 : 16; }
+__host__ __device__ inline int direct_ch(int K) { return K <= 2 ? 2 : K <= 4 ? 4 : 16; }
 
 // out = sum over the ksplit partial slabs (fixed order) + per-row BatchNorm partials; see splitk_reduce_kernel in conv3d.hip
 // (coef != nullptr: eval-mode BatchNorm + LeakyReLU applied to the reduced value, see ConvArgs::coef)
