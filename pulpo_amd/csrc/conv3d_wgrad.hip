@@ -245,6 +245,131 @@ __global__ __launch_bounds__(256, VEC ? 1 : 2) void conv3d_k3_wgrad_mfma(WgradAr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient, 2-/3-channel inputs
+// The input layers (image pair: 2 channels, latent sample: 3): the GEMM has only 27 * Cin <= 108 rows, i.e. NRT <= 4 row tiles, too few
+// to give each wave row tiles of its own (conv3d_k3_wgrad_mfma<false, 1> left two of four waves multiplying padding).  Here every wave
+// owns ALL row tiles and one z-plane (64 voxels = 32 k-steps) of a 4 x 8 x 8 voxel tile - the waves split the GEMM's K -, the next tile's
+// operands are fetched into registers underneath the current tile's MFMAs, and the four partial sums meet in LDS before one atomic flush
+// per workgroup.  x: planar or strided (scalar loads, one channel plane per run of lanes); dy: channels-last, 16-byte aligned.
+template <int NRT>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_smallc(WgradArgs a) {
+    constexpr int HV4 = 6 * HY * HX, XP = HV4 + 4;          // halo voxels of a 4 x 8 x 8 tile; plane stride of the planar halo image
+    constexpr int NIX = (4 * HV4 + 255) / 256;              // scalar halo loads per thread (<= 4 channels)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                                        // [Cin][XP]
+    float* dys = smem + 4 * XP;                              // [256 voxels][32 couts]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
+    const int cot = lid % a.ncot, split = lid / a.ncot;
+    const int co0 = cot * WG_NT;
+    const int rows = 27 * a.Cin;
+
+    int rowoff[NRT];
+#pragma unroll
+    for (int u = 0; u < NRT; ++u) {
+        const int r = 32 * u + i;
+        const int tap = r < rows ? r / a.Cin : 0, ci = r < rows ? r - tap * a.Cin : 0;
+        rowoff[u] = ci * XP + tap_halo_offset(tap);
+    }
+    f32x16 acc[NRT];
+#pragma unroll
+    for (int u = 0; u < NRT; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+
+    const int ntile = a.B * a.ntz * a.nty * a.ntx;            // (ntz counts 4-plane tiles here)
+    const int per = (ntile + a.nsplit - 1) / a.nsplit;
+    const int t_begin = split * per, t_end = min(ntile, t_begin + per);
+
+    float xr[NIX];
+    float4 dr[8];
+    auto fetch = [&](int tl) {
+        int t = tl;
+        const int tx_ = t % a.ntx; t /= a.ntx;
+        const int ty_ = t % a.nty; t /= a.nty;
+        const int tz_ = t % a.ntz;
+        const int b = t / a.ntz;
+        const int z0 = tz_ * 4, y0 = ty_ * TY, x0 = tx_ * TX;
+        const float* in_b = a.in + (long)b * a.in_bs;
+#pragma unroll
+        for (int u = 0; u < NIX; ++u) {
+            const int j = tid + u * 256;
+            const int c = j / HV4, hv = j - c * HV4;
+            const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            xr[u] = 0.f;
+            if (c < a.Cin && (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                xr[u] = in_b[((long)(gz * a.H + gy) * a.W + gx) * a.in_ps + (long)c * a.in_cs];
+        }
+        const float* dyb = a.dy + (long)b * a.dy_bs;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = tid + u * 256;
+            const int vv = j >> 3, q = j & 7;
+            const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
+            dr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gz < a.D && gy < a.H && gx < a.W && co0 + 4 * q < a.Cout)
+                dr[u] = *reinterpret_cast<const float4*>(dyb + ((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + co0 + 4 * q);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < NIX; ++u) {
+            const int j = tid + u * 256;
+            const int c = j / HV4, hv = j - c * HV4;
+            if (c < 4) xs[c * XP + hv] = xr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = tid + u * 256;
+            *reinterpret_cast<float4*>(dys + (j >> 3) * WG_NT + 4 * (j & 7)) = dr[u];
+        }
+    };
+
+    if (t_begin < t_end) fetch(t_begin);
+    for (int tl = t_begin; tl < t_end; ++tl) {
+        __syncthreads();                                  // every wave has left the images of the previous tile
+        stash();
+        __syncthreads();
+        if (tl + 1 < t_end) fetch(tl + 1);                // in flight underneath this tile's MFMAs
+        const float* xw = xs + wave * (HY * HX);          // this wave's z-plane of the tile
+        const float* dw_ = dys + wave * 64 * WG_NT + i;
+#pragma unroll 4
+        for (int s2 = 0; s2 < 32; ++s2) {
+            const int vox = 2 * s2 + kk;                  // voxel of the plane: (y, x) = (vox >> 3, vox & 7)
+            const int hb = (vox >> 3) * HX + (vox & 7);
+            const float bv = dw_[vox * WG_NT];
+#pragma unroll
+            for (int u = 0; u < NRT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(xw[rowoff[u] + hb], bv, acc[u], 0, 0, 0);
+        }
+    }
+
+    // the four waves' partial sums meet in LDS (one wave after the other), then one atomic per (row, cout) and workgroup
+    float* red = dys;                                     // [NRT * 32 rows][32 couts]
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int u = 0; u < NRT; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    float* q = red + row * WG_NT + i;
+                    *q = (w == 0 ? 0.f : *q) + acc[u][r];
+                }
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < rows * WG_NT; j += 256) {
+        const int row = j >> 5, co = co0 + (j & 31);
+        if (co < a.Cout) {
+            const int tap = row / a.Cin, ci = row - tap * a.Cin;
+            atomicAdd(a.dwp + ((long)tap * a.Cin + ci) * a.NPad + co, red[j]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient, Winograd along x
 // The transpose of the forward identity: with V = B^T d (four transformed inputs per x-pair) and E = A dy (four combinations of the
 // pair's two output gradients), M_p[(dz,dy,ci)][co] = sum over x-pairs V_p * E_p and dw[.., t] = G^T M - 36 instead of 54 matrix
@@ -617,6 +742,29 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
     }
         if (nrt9 <= 3) PULPO_WGRAD_W(3) else if (nrt9 <= 5) PULPO_WGRAD_W(5) else PULPO_WGRAD_W(9)
 #undef PULPO_WGRAD_W
+    } else if (Cin <= 4 && (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0)) {
+        // the 2-/3-channel input layers: waves split K, every wave all row tiles (conv3d_k3_wgrad_smallc)
+        WgradArgs b = a;
+        b.ntz = pulpo::cdiv(D, 4);
+        const int ntile4 = B * b.ntz * b.nty * b.ntx;
+        b.ncit = 1;
+        b.nsplit = std::min(std::max(1, 512 / b.ncot), ntile4);
+        const int nrt = (27 * Cin + 31) / 32;
+        constexpr size_t lds_s = (size_t)(4 * (6 * HY * HX + 4) + 256 * WG_NT) * sizeof(float);
+        static_assert(4 * 32 * WG_NT <= 256 * WG_NT, "the partial sums of four row tiles fit the gradient image");
+#define PULPO_WGRAD_S(NRTV)                                                                                                       \
+    {                                                                                                                             \
+        static bool attr = false;                                                                                                 \
+        if (!attr) {                                                                                                              \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_smallc<NRTV>),                     \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);                        \
+            if (ea != hipSuccess) return pulpo::fail((int)ea, "hipFuncSetAttribute(wgrad smallc): %s", hipGetErrorString(ea));    \
+            attr = true;                                                                                                          \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((conv3d_k3_wgrad_smallc<NRTV>), dim3(b.ncot * b.nsplit), dim3(256), lds_s, st, b);                     \
+    }
+        if (nrt <= 2) PULPO_WGRAD_S(2) else if (nrt <= 3) PULPO_WGRAD_S(3) else PULPO_WGRAD_S(4)
+#undef PULPO_WGRAD_S
     } else if (vec) {
         if (ntw <= 1) PULPO_WGRAD(true, 1) else if (ntw <= 2) PULPO_WGRAD(true, 2) else if (ntw <= 4) PULPO_WGRAD(true, 4) else PULPO_WGRAD(true, 7)
     } else {

@@ -213,6 +213,20 @@ def test_conv3d_vs_oracle(ops, B, Cin, Cout, size, cl):
     assert rel_l2(gb, gref[2]) < 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,size", [(1, 2, 32, (9, 11, 13)), (2, 3, 32, (20, 17, 33)), (1, 4, 48, (8, 24, 16)), (1, 1, 36, (13, 8, 9))])
+def test_weight_gradient_of_the_narrow_input_layers(ops, B, Cin, Cout, size):
+    """<= 4 input channels with a channels-last output gradient (what a ConvUnit's backward hands over) take their own kernel
+    (conv3d_k3_wgrad_smallc: waves split the voxels, every wave all row tiles); ragged volumes, two cout tiles, planar x"""
+    gen = torch.Generator().manual_seed(B * 100 + Cin * 10 + Cout)
+    x = torch.randn(B, Cin, *size, generator=gen)
+    dy = torch.randn(B, Cout, *size, generator=gen)
+    w = torch.zeros(Cout, Cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad((F.conv3d(x.double(), w, padding=1) * dy.double()).sum(), [w])
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last_3d)
+    got = ops._wgrad_raw(x.cuda(), dyd, Cin, Cout)
+    assert rel_l2(got, ref) < 1e-5
+
+
 @pytest.mark.parametrize("B,Cin,Cout,size,cl", [c for c in CONV_CASES if c[1] > 4] + [(1, 32, 64, (16, 64, 64), True), (1, 96, 96, (64, 64, 64), True)])
 def test_conv3d_bf16_operands_vs_oracle(ops, B, Cin, Cout, size, cl):
     """bf16-operand mode (BASELINE configs 4-5): the kernel against the oracle's definition (operands rounded to bf16, exact
