@@ -70,6 +70,14 @@ int pulpo_conv3d_k3_pack_weight_wino2(const float* w /*[Cout][Cin][3][3][3]*/, f
 int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
                               float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W,
                               int K, int N, void* stream);
+/* Forward convolution of a ConvUnit fed by the ConvUnit in front of it (src/network_blocks.py:32-46, ConvSequence), reading that unit's
+ * PRE-NORM tensor y_in (channels-last, 16-byte aligned) instead of its output z: BatchNorm + LeakyReLU (in_coef = the producing unit's
+ * coefficient block of pulpo_bn_fwd_finalize) are applied to the operand as it is staged and z is written to zout (same strides as y_in)
+ * for the backward pass - the producing unit's pulpo_bn_lrelu_apply pass is not run.  Otherwise the contract of pulpo_conv3d_k3_fwd_wino2. */
+int pulpo_conv3d_k3_fwd_wino2_prenorm_ok(int B, int D, int H, int W, int K, int N);
+int pulpo_conv3d_k3_fwd_wino2_prenorm(const float* y_in, int64_t in_bs, int64_t in_ps, const float* in_coef, float slope, float* zout,
+                                      const float* wp, const float* bias, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs,
+                                      float* stats, int B, int D, int H, int W, int K, int N, void* stream);
 /* The data-gradient convolution of a ConvUnit (in = dy of that unit, wp packed with dgrad = 1, N = the unit's input channels) with the
  * FIRST pass of the BatchNorm/LeakyReLU backward of the ConvUnit in front of it fused into the store (the reference runs these as
  * separate autograd nodes: ConvolutionBackward of src/network_blocks.py:23, then LeakyReluBackward / NativeBatchNormBackward of :24-25):

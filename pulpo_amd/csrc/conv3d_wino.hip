@@ -383,7 +383,11 @@ __device__ __forceinline__ void w2_stage_scalar(float* xs, const float* __restri
 //   * 10k clocks of prologue per tile (argument loads, index arithmetic, first-touch latency of halo and weights)  -> PERSISTENT
 //     workgroups (two per CU) that fetch the next tile's first slab and halo chunk during the last dz iteration of the current tile.
 // A start-up offset of the second workgroup of each CU (to break the lockstep of the pair) was measured without effect and is not kept.
-template <bool VEC, bool BNR = false>
+// rows of the halo image whose 4 pad floats hold the staged operand's BatchNorm coefficients (INAFF): beyond the exchange buffer, below the image's end
+constexpr int W2_COEF_ROW = 704, W2_COEF_QUADS = 72;
+static_assert(W2_COEF_ROW * W2_RS >= 4 * 2 * 16 * 64 + 4 * 2 * 32 && W2_COEF_ROW + 2 * W2_COEF_QUADS <= WN_HZ * W2_PLROWS, "coefficient rows");
+
+template <bool VEC, bool BNR = false, bool INAFF = false>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
     constexpr int CH = WN_CH, NT = 32;
     constexpr int XS = W2_XS;
@@ -414,6 +418,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
             const int xb = (j / WN_Q) & 3, hrow = j / (4 * WN_Q);
             const int hz = hrow / HY, hy = hrow - hz * HY;
             roff[u] = ((unsigned)((hz * a.H + hy) * a.W + 2 * xb) * (unsigned)a.in_ps + 4u * rq) * 4u;
+        }
+    }
+    if constexpr (INAFF) {
+        static_assert(VEC, "operand-side BatchNorm needs the vector staging");
+        // coefficient table: scale quads in the pad floats of rows W2_COEF_ROW + q, shift quads W2_COEF_QUADS rows further (never overwritten:
+        // the staging writes floats 0..7 of a row, the exchange buffer ends below W2_COEF_ROW)
+        for (int qd = tid; qd < (a.Cin >> 2); qd += 256) {
+            *reinterpret_cast<float4*>(xs + (W2_COEF_ROW + qd) * W2_RS + 8) = *reinterpret_cast<const float4*>(a.in_coef + 2 * a.Cin + 4 * qd);
+            *reinterpret_cast<float4*>(xs + (W2_COEF_ROW + W2_COEF_QUADS + qd) * W2_RS + 8) = *reinterpret_cast<const float4*>(a.in_coef + 3 * a.Cin + 4 * qd);
         }
     }
     // y combination of this wave's point row: v = X[2 yb + ta] + sa * X[2 yb + tb]   (same table as the x transform)
@@ -529,6 +542,39 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt)
                         asm volatile("" : : "v"(raw[u][tt].x), "v"(raw[u][tt].y), "v"(raw[u][tt].z), "v"(raw[u][tt].w));
+                if constexpr (INAFF) {
+                    // BatchNorm + LeakyReLU of the producing unit, applied to the raw operand (zero padding stays zero); the voxels of the tile
+                    // itself (window taps 1, 2 of every x-pair) leave for zout from the workgroup of cout tile 0.
+                    // (everything this block needs is derived here, from an opaque copy of the thread id: nothing of it may sit in registers
+                    //  across the matrix loop, which has none to spare)
+                    int stid = tid;
+                    asm volatile("" : "+v"(stid));
+                    const int c0 = chunk * CH;
+                    const int srq = stid % WN_Q;
+                    const float4 sc = *reinterpret_cast<const float4*>(xs + (W2_COEF_ROW + (c0 >> 2) + srq) * W2_RS + 8);
+                    const float4 sh = *reinterpret_cast<const float4*>(xs + (W2_COEF_ROW + W2_COEF_QUADS + (c0 >> 2) + srq) * W2_RS + 8);
+                    const bool cok = c0 + 4 * srq < a.Cin;
+                    const bool wr = cur.co0 == 0;
+                    const long zdelta = reinterpret_cast<const char*>(a.zout) - reinterpret_cast<const char*>(a.in);
+                    char* zbase = const_cast<char*>(cur.origin) + zdelta + (long)c0 * 4;
+#pragma unroll
+                    for (int u = 0; u < WN_NIT; ++u) {
+                        const int j = stid + u * 256;
+                        const int hrow = j / (4 * WN_Q);
+                        const int hz = hrow / HY, hy = hrow - hz * HY;
+                        const bool inner = wr && j < WN_NITEM && hz >= 1 && hz <= 4 && hy >= 1 && hy <= TY;      // a voxel row of the tile itself
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) {
+                            const bool ok = cok && ((cur.rmask >> (u * 4 + tt)) & 1u);
+                            auto act = [&](float v, float s_, float h_) { const float t_ = v * s_ + h_; return t_ > 0.f ? t_ : t_ * a.slope; };
+                            float4 v = raw[u][tt];
+                            v = ok ? make_float4(act(v.x, sc.x, sh.x), act(v.y, sc.y, sh.y), act(v.z, sc.z, sh.z), act(v.w, sc.w, sh.w))
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                            raw[u][tt] = v;
+                            if ((tt == 1 || tt == 2) && inner && ok) *reinterpret_cast<float4*>(zbase + (roff[u] + tt * ps_bytes)) = v;
+                        }
+                    }
+                }
                 w2_store_transformed(xs, raw, tid);
             } else {
                 w2_stage_scalar(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, cur.z0, cur.y0, cur.x0, a.D, a.H, a.W, tid);
@@ -607,8 +653,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         // Fast path (whole tile inside the volume, all 32 couts real, channels-last 16-byte aligned output - every tile of the BASELINE layers):
         // lane = (channel quad q, row half, row group): the four waves' partial rows are fetched with ds_read_b128 (all issued before the first
         // use), the y inverse transform is done on float4s, and each voxel leaves as one 128-byte line written by 8 lanes x 16 bytes.
-        // (BNR: the host launches this instantiation only when every tile qualifies, without bias and without the eval-mode store)
-        const bool fast = BNR || (a.out_cs == 1 && (a.out_ps & 3) == 0 && (a.out_bs & 3) == 0 && (((uintptr_t)a.out) & 15) == 0 && co0 + NT <= a.Cout &&
+        // (BNR / INAFF: the host launches these instantiations only when every tile qualifies; BNR without bias, both without the eval-mode store)
+        const bool fast = BNR || INAFF || (a.out_cs == 1 && (a.out_ps & 3) == 0 && (a.out_bs & 3) == 0 && (((uintptr_t)a.out) & 15) == 0 && co0 + NT <= a.Cout &&
                           z0 + 4 <= a.D && y0 + TY <= a.H && x0 + TX <= a.W &&
                           (a.bias == nullptr || (((uintptr_t)a.bias) & 15) == 0) &&
                           (a.coef == nullptr || ((((uintptr_t)a.coef) & 15) == 0 && (a.Cout & 3) == 0)));
@@ -621,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 b4 = zero4, sc4 = zero4, sh4 = zero4, s4 = zero4, q4 = zero4;        // fast path: four channels per lane
         float bias1 = 0.f, fsc1 = 1.f, fsh1 = 0.f, ssum = 0.f, ssq = 0.f;             // general path: channel co0 + i
-        const bool fuse = !BNR && a.coef != nullptr;
+        const bool fuse = !BNR && !INAFF && a.coef != nullptr;
         const bool cok = co0 + ei < a.Cout;
         // data-gradient launch with the BatchNorm-backward reduction of the unit in front fused in (host: every tile takes the fast path)
         const bool bnr = BNR && fast;        // (own instantiation: its extra epilogue registers stay out of the plain kernel)
@@ -920,14 +966,14 @@ PULPO_API int pulpo_conv3d_k3_pack_weights_multi(const PulpoPackJob* jobs, int n
     return pulpo::check_launch("pack_weights_multi");
 }
 
-template <bool VEC, bool BNR = false>
+template <bool VEC, bool BNR = false, bool INAFF = false>
 static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
     constexpr size_t lds = (size_t)(W2_XS + 2 * 16 * WN_CH * 32) * sizeof(float);
     static_assert(lds >= (size_t)(4 * 2 * 2 * 16 * 64 + 4 * 2 * 32) * sizeof(float), "exchange buffer must fit");
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino2_mfma<VEC, BNR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino2_mfma<VEC, BNR, INAFF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(conv3d wino2): %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -938,13 +984,14 @@ static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
         const_cast<ConvArgs&>(a).stagger = (int)(clocks / (64 * 127));
     }
     // persistent workgroups: two per CU (LDS and registers admit exactly two), each walking the tile list with stride gridDim.x
-    hipLaunchKernelGGL((conv3d_k3_wino2_mfma<VEC, BNR>), dim3(std::min(nblk, 512)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3d_k3_wino2_mfma<VEC, BNR, INAFF>), dim3(std::min(nblk, 512)), dim3(256), lds, st, a);
     return pulpo::check_launch("conv3d_k3_wino2_mfma");
 }
 
 static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
                           float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, const float* bn_y, int64_t bn_y_bs,
-                          int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream);
+                          int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream,
+                          const float* in_coef = nullptr, float* zout = nullptr);
 
 PULPO_API int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
                                         const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats,
@@ -977,9 +1024,35 @@ PULPO_API int pulpo_conv3d_k3_dgrad_wino2_bnred(const float* in, int64_t in_bs, 
                           W, K, N, stream);
 }
 
+// 1 when pulpo_conv3d_k3_fwd_wino2_prenorm accepts the shape
+PULPO_API int pulpo_conv3d_k3_fwd_wino2_prenorm_ok(int B, int D, int H, int W, int K, int N) {
+    // N == 32: with several cout tiles every one of them would repeat the operand's BatchNorm arithmetic while staging - measured slower
+    // than the separate pass from two cout tiles up (scripts/prenorm_probe.py); with one it saves the pass's read of y
+    return B > 0 && conv_tz(D, H, W) == 4 && D % 4 == 0 && H % TY == 0 && W % TX == 0 && N == 32 && K > 4 && K % 4 == 0 &&
+           K <= 4 * W2_COEF_QUADS;
+}
+
+// Forward convolution of a ConvUnit whose input is the output z = lrelu(bn(y)) of the ConvUnit in front, reading that unit's PRE-NORM
+// tensor y instead (in = y, channels-last, 16-byte aligned): BatchNorm + LeakyReLU (in_coef = the producing unit's coefficient block from
+// pulpo_bn_fwd_finalize) are applied to the operand while it is staged, and z is written to zout (same strides as y) on the way, for the
+// backward pass.  Replaces the producing unit's pulpo_bn_lrelu_apply pass (a read of y and a write of z) by the write alone.
+PULPO_API int pulpo_conv3d_k3_fwd_wino2_prenorm(const float* y_in, int64_t in_bs, int64_t in_ps, const float* in_coef, float slope, float* zout,
+                                                const float* wp, const float* bias, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs,
+                                                float* stats, int B, int D, int H, int W, int K, int N, void* stream) {
+    PULPO_REQUIRE(y_in && in_coef && zout, "conv3d_k3_fwd_wino2_prenorm: null pointer");
+    PULPO_REQUIRE(pulpo_conv3d_k3_fwd_wino2_prenorm_ok(B, D, H, W, K, N), "conv3d_k3_fwd_wino2_prenorm: shape %dx%dx%d, %d -> %d channels not accepted",
+                  D, H, W, K, N);
+    PULPO_REQUIRE(in_ps % 4 == 0 && in_bs % 4 == 0 && (((uintptr_t)y_in | (uintptr_t)zout | (uintptr_t)in_coef) & 15) == 0 && out_cs == 1 &&
+                      out_ps % 4 == 0 && out_bs % 4 == 0 && (((uintptr_t)out) & 15) == 0 && (bias == nullptr || (((uintptr_t)bias) & 15) == 0),
+                  "conv3d_k3_fwd_wino2_prenorm: operands and output must be channels-last and 16-byte aligned");
+    return fwd_wino2_impl(y_in, in_bs, in_ps, 1, wp, bias, nullptr, slope, out, out_bs, out_ps, out_cs, stats, nullptr, 0, 0, nullptr, B, D, H, W, K, N,
+                          stream, in_coef, zout);
+}
+
 static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
                           float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, const float* bn_y, int64_t bn_y_bs,
-                          int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream) {
+                          int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream, const float* in_coef,
+                          float* zout) {
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_wino2: null pointer");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd_wino2: bad dims");
     PULPO_REQUIRE(conv_tz(D, H, W) == 4, "conv3d_k3_fwd_wino2: volume %dx%dx%d is not tiled 4x8x8 (see pulpo_conv3d_k3_algo)", D, H, W);
@@ -991,6 +1064,7 @@ static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t
     a.stats = stats;
     a.coef = coef; a.slope = slope;
     a.bn_y = bn_y; a.bn_y_bs = bn_y_bs; a.bn_y_ps = bn_y_ps; a.bn_coef = bn_coef;
+    a.in_coef = in_coef; a.zout = zout;
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
     a.ntz = pulpo::cdiv(D, 4); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
     a.ncot = pulpo::cdiv(N, 32);
@@ -1002,6 +1076,10 @@ static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t
     if (bn_y != nullptr) {
         PULPO_REQUIRE(vec, "conv3d_k3_dgrad_wino2_bnred: the gradient operand must be channels-last, 16-byte aligned, with a multiple of 4 channels");
         return launch_wino2<true, true>(a, (int)nblk_l, st);
+    }
+    if (in_coef != nullptr) {
+        PULPO_REQUIRE(vec, "conv3d_k3_fwd_wino2_prenorm: the operand must be channels-last, 16-byte aligned, with a multiple of 4 channels");
+        return launch_wino2<true, false, true>(a, (int)nblk_l, st);
     }
     return vec ? launch_wino2<true>(a, (int)nblk_l, st) : launch_wino2<false>(a, (int)nblk_l, st);
 }

@@ -53,6 +53,11 @@ struct ConvArgs {
     const float* bn_y;
     long bn_y_bs, bn_y_ps;
     const float* bn_coef;
+    // Winograd (y, x) kernel reading the PRE-NORM output y of the ConvUnit in front (in = y): BatchNorm + LeakyReLU of that unit are applied
+    // to the operand while it is staged (coefficients in_coef: scale at [2 Cin], shift at [3 Cin]), and the activated tensor z - which the
+    // backward pass needs as the weight gradient's operand - is written to zout (same strides as `in`) by the workgroups of cout tile 0
+    const float* in_coef;
+    float* zout;
     int stagger;                  // Winograd (y, x) kernel: start-up delay (units of 64 x 127 clocks) of the second workgroup of every CU, 0 = none
 };
 

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -313,6 +314,29 @@ def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None) -> torch.Tensor:
     return wp
 
 
+def _prenorm_conv_ok(x: torch.Tensor, y_prev: torch.Tensor, wp: torch.Tensor, out: torch.Tensor, K: int, N: int) -> bool:
+    """can the forward convolution read the producing unit's pre-norm tensor (pulpo_conv3d_k3_fwd_wino2_prenorm)?"""
+    if not APPLY_ON_LOAD or getattr(wp, "_pulpo_algo", "") != "wino2" or y_prev.shape != x.shape or y_prev.stride() != x.stride():
+        return False
+    B, _, D, H, W = x.shape
+    xb, xp, xc = grid_strides(x)
+    ob, op, oc = grid_strides(out)
+    return (xc == 1 and xp % 4 == 0 and xb % 4 == 0 and x.data_ptr() % 16 == 0 and y_prev.data_ptr() % 16 == 0 and oc == 1 and op % 4 == 0
+            and ob % 4 == 0 and out.data_ptr() % 16 == 0 and bool(lib.query("pulpo_conv3d_k3_fwd_wino2_prenorm_ok", B, D, H, W, K, N)))
+
+
+def _conv_raw_prenorm(y_prev: torch.Tensor, coef_prev: torch.Tensor, z: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
+                      out: torch.Tensor, K: int, N: int, stats: torch.Tensor) -> None:
+    """out = conv(lrelu(bn(y_prev))) with z = lrelu(bn(y_prev)) written on the way (see include/pulpo_hip.h)"""
+    B, _, D, H, W = z.shape
+    yb, yp, _ = grid_strides(y_prev)
+    ob, op, oc = grid_strides(out)
+    t0 = _trace_begin()
+    lib.call("pulpo_conv3d_k3_fwd_wino2_prenorm", _ptr(y_prev), yb, yp, _ptr(coef_prev), LRELU_SLOPE, _ptr(z), _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc,
+             _ptr(stats), B, D, H, W, K, N, _stream())
+    _trace_end(t0, "conv3d_k3_wino2_mfma<true>", 54.0 * K * N * B * D * H * W, 4.0 * (2 * K + N) * B * D * H * W)
+
+
 def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, K: int, N: int,
               stats: Optional[torch.Tensor], coef: Optional[torch.Tensor] = None):
     """coef: eval-mode BatchNorm coefficients -> BatchNorm + LeakyReLU are applied by the convolution's store (one kernel per ConvUnit)"""
@@ -457,6 +481,14 @@ def join_async_wgrad():
 # the producer's y, and the producer takes them only if the gradient it is given IS that kernel's output, untouched (same storage, same
 # version: a gradient that autograd accumulated from several consumers is a different tensor or carries a bumped version).
 BN_REDUCE_IN_DGRAD = os.environ.get("PULPO_BN_REDUCE_IN_DGRAD", "1") != "0"      # (A/B switch)
+# The forward counterpart: inside a ConvSequence the BatchNorm + LeakyReLU of unit u is applied by unit u+1's convolution while it stages
+# its operand (pulpo_conv3d_k3_fwd_wino2_prenorm), which also writes z_u for the backward pass; unit u then runs no apply pass of its own
+# (`defer_apply`: the tensor it returns is filled by its consumer - network_blocks.ConvSequence is the only caller that may ask for that).
+# OFF by default: measured slower in the step (37.5 -> 37.8 ms at 160^3).  Every cout tile of the consumer repeats the operand's arithmetic
+# (so only 32-cout consumers are accepted at all), and the z stores issued while staging sit in front of the `s_waitcnt vmcnt(0)` with
+# which the kernel waits for its weight DMA - on gfx950 stores count in vmcnt - so every chunk waits for their write acknowledgements
+# (scripts/prenorm_probe.py: 1.32 ms against 1.18 + 0.21 ms for 32->32 at 160^3 stand-alone, a gain that the step does not keep).
+APPLY_ON_LOAD = os.environ.get("PULPO_APPLY_ON_LOAD", "0") != "0"
 _BN_TILE_PARTS: dict = {}
 
 
@@ -492,12 +524,15 @@ def _take_bn_tile_parts(y: torch.Tensor, coef: torch.Tensor, dz: torch.Tensor):
     return part, ntile
 
 
+_TLS = threading.local()
+
+
 class _ConvBNLReLU(torch.autograd.Function):
     """ConvUnit: Conv3d(k3,p1,bias) -> BatchNorm3d -> LeakyReLU(0.2)   (reference src/network_blocks.py:22-26)"""
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool, momentum: float, eps: float,
-                bn_src=None):
+                bn_src=None, lazy_in=None, defer_apply: bool = False):
         _require_gpu(x, weight, bias, gamma, beta)
         ctx.bn_src = bn_src
         x = as_grid(x)
@@ -507,10 +542,18 @@ class _ConvBNLReLU(torch.autograd.Function):
         wp = _pack_weight(weight, dgrad=False, shape=(B, D, H, W), both=bool(training and ctx.needs_input_grad[0]))
         y = new_cl(B, Cout, D, H, W, dev)
         coef = torch.empty(8 * Cout, device=dev, dtype=torch.float32)      # [4][C] floats + [2][C] doubles
+        if lazy_in is not None and not (training and _prenorm_conv_ok(x, lazy_in[0], wp, y, Cin, Cout)):
+            # the producer left its output unfilled for a consumer that could apply its BatchNorm on load; this one cannot: fill it now
+            lib.call("pulpo_bn_lrelu_apply", _ptr(lazy_in[0]), lazy_in[0].stride(4), _ptr(x), x.stride(4), _ptr(lazy_in[1]), B * D * H * W, Cin,
+                     LRELU_SLOPE, _stream())
+            lazy_in = None
         if training:
             ntile = lib.query("pulpo_conv3d_k3_fwd_bf16_stat_tiles" if wp._pulpo_algo == "bf16" else "pulpo_conv3d_k3_stat_tiles", B, D, H, W)
             stats = torch.empty(ntile * 2 * Cout, device=dev, dtype=torch.float32)
-            _conv_raw(x, wp, bias, y, Cin, Cout, stats)
+            if lazy_in is not None:
+                _conv_raw_prenorm(lazy_in[0], lazy_in[1], x, wp, bias, y, Cin, Cout, stats)
+            else:
+                _conv_raw(x, wp, bias, y, Cin, Cout, stats)
             nsd = lib.query("pulpo_bn_fwd_finalize_scratch_doubles", ntile, Cout)
             scratch = torch.empty(nsd, device=dev, dtype=torch.float64) if nsd else None
             lib.call("pulpo_bn_fwd_finalize", _ptr(stats), ntile, Cout, float(B * D * H * W), _ptr(gamma), _ptr(beta), _ptr(running_mean),
@@ -523,13 +566,15 @@ class _ConvBNLReLU(torch.autograd.Function):
                 return y
             _conv_raw(x, wp, bias, y, Cin, Cout, None)
         z = new_cl(B, Cout, D, H, W, dev)
-        t0 = _hbm_begin()
-        lib.call("pulpo_bn_lrelu_apply", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
-        _hbm_end(t0, "bn_lrelu_apply", 8.0 * Cout * B * D * H * W)            # read y, write z
+        ctx.deferred = bool(defer_apply and training and APPLY_ON_LOAD)
+        if not ctx.deferred:
+            t0 = _hbm_begin()
+            lib.call("pulpo_bn_lrelu_apply", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
+            _hbm_end(t0, "bn_lrelu_apply", 8.0 * Cout * B * D * H * W)            # read y, write z
         ctx.save_for_backward(x, weight, y, coef)
         ctx.training = training
         ctx.params = (weight, bias, gamma, beta)      # for DIRECT_PARAM_GRADS (their .grad slots)
-        ctx.produced = (y, coef)
+        _TLS.produced = (y, coef, ctx.deferred)      # read back by conv_bn_lrelu (the Function returns tensors only)
         return z
 
     @staticmethod
@@ -587,21 +632,30 @@ class _ConvBNLReLU(torch.autograd.Function):
                 _conv_raw(dy, wpt, None, dx, Cout, Cin, None)
         if defer_w:
             _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, w_p)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None):
-    """ConvUnit forward.  In training mode running_mean / running_var / num_batches_tracked are updated in place by the kernel."""
+def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None,
+                  defer_apply: bool = False):
+    """ConvUnit forward.  In training mode running_mean / running_var / num_batches_tracked are updated in place by the kernel.
+    defer_apply (ConvSequence only, see APPLY_ON_LOAD): the returned tensor may be left unfilled; the next conv_bn_lrelu call that receives it
+    - and nobody else may - fills it."""
     if _is2d(x):
         return conv_bn_lrelu(_lift(x), _lift_w3(weight), bias, gamma, beta, running_mean, running_var, training, momentum, eps,
                              num_batches_tracked).squeeze(2)
     src = getattr(x, "_pulpo_bn_src", None)          # x is the untouched output of another ConvUnit: (y, coef, version at production)
     bn_src = src[:2] if (src is not None and src[2] == x._version and training and torch.is_grad_enabled()) else None
+    lazy = getattr(x, "_pulpo_lazy", None)           # x was left unfilled by its producer: (y, coef) to make it from
+    if lazy is not None:
+        del x._pulpo_lazy
     z = _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
-                           float(eps), bn_src)
-    produced = getattr(z.grad_fn, "produced", None) if training else None
+                           float(eps), bn_src, lazy, bool(defer_apply))
+    produced = getattr(_TLS, "produced", None)
+    _TLS.produced = None
     if produced is not None:
         z._pulpo_bn_src = (produced[0], produced[1], z._version)
+        if produced[2]:
+            z._pulpo_lazy = (produced[0], produced[1])
     return z
 
 

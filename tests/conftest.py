@@ -38,9 +38,11 @@ def _clean_kernel_switches():
     """Every test starts from the library's default kernel selection (ops.CONV_ALGO None = per-shape choice, fp32 operands) and must
     leave it that way: a switch leaking out of one test would silently change which kernel the later golden comparisons exercise."""
     mod = sys.modules.get("pulpo_amd.ops")
+    fusion = None
     if mod is not None:
         assert mod.CONV_ALGO is None, f"ops.CONV_ALGO leaked from an earlier test: {mod.CONV_ALGO!r}"
         assert mod.CONV_PRECISION == "fp32", f"ops.CONV_PRECISION leaked from an earlier test: {mod.CONV_PRECISION!r}"
+        fusion = (mod.BN_REDUCE_IN_DGRAD, mod.APPLY_ON_LOAD)
     yield
     mod = sys.modules.get("pulpo_amd.ops")
     if mod is not None:
@@ -48,3 +50,7 @@ def _clean_kernel_switches():
         mod.CONV_ALGO = None
         mod.set_conv_precision("fp32")
         assert leaked == (None, "fp32"), f"test left ops.CONV_ALGO / CONV_PRECISION = {leaked!r}"
+        if fusion is not None:
+            now = (mod.BN_REDUCE_IN_DGRAD, mod.APPLY_ON_LOAD)
+            mod.BN_REDUCE_IN_DGRAD, mod.APPLY_ON_LOAD = fusion
+            assert now == fusion, f"test left ops.BN_REDUCE_IN_DGRAD / APPLY_ON_LOAD = {now!r}"

@@ -357,6 +357,8 @@ def test_bn_backward_reduction_inside_the_data_gradient_kernel(ops, chans, size)
     up = torch.randn(1, chans[-1], *size, generator=gen)
     side = torch.randn(1, chans[1], *size, generator=gen)
 
+    default_switch = ops.BN_REDUCE_IN_DGRAD
+
     def run(fused, second_consumer):
         ops.BN_REDUCE_IN_DGRAD = fused
         d = {k: v.cuda().requires_grad_(True) for k, v in sd.items()}
@@ -381,7 +383,7 @@ def test_bn_backward_reduction_inside_the_data_gradient_kernel(ops, chans, size)
             grads = torch.autograd.grad(loss, [xg] + [d[k] for k in sorted(sd)])
         finally:
             ops._take_bn_tile_parts = orig
-            ops.BN_REDUCE_IN_DGRAD = True
+            ops.BN_REDUCE_IN_DGRAD = default_switch
         return [g.cpu() for g in grads], taken
 
     def oracle(second_consumer):
@@ -412,6 +414,58 @@ def test_bn_backward_reduction_inside_the_data_gradient_kernel(ops, chans, size)
                 continue                     # conv bias in front of a training-mode BatchNorm: exact gradient 0, computed value is rounding noise
             assert rel_l2(a, b) < 2e-5
             assert rel_l2(a, r) < 2e-3 and rel_l2(b, r) < 2e-3      # (fp32 vs float64 through three units: LeakyReLU branch flips near 0)
+
+
+@pytest.mark.parametrize("chans,size,fused_links", [((16, 32, 64, 32), (24, 32, 40), 1), ((32, 32, 32), (32, 32, 32), 1), ((8, 96, 96), (20, 24, 24), 0),
+                                                   ((32, 32, 32), (18, 20, 22), 0), ((32, 48, 32, 32), (24, 24, 24), 2)])
+def test_batchnorm_applied_while_the_next_convolution_stages_its_operand(ops, chans, size, fused_links):
+    """(opt-in path, ops.APPLY_ON_LOAD / PULPO_APPLY_ON_LOAD=1; off by default because it measured slower in the step)
+    Inside a ConvSequence the BatchNorm + LeakyReLU of a unit is applied by the next unit's convolution as it reads the operand, which
+    also writes the activated tensor for the backward pass (pulpo_conv3d_k3_fwd_wino2_prenorm).  Checked: the fused kernel runs on exactly
+    the links whose shapes allow it (whole tiles, one 32-wide cout tile; the others fall back to a separate pass that fills the tensor), and the
+    module's output, every saved activation's effect - all gradients - and the BatchNorm buffers equal the separate-pass path bit for bit."""
+    from pulpo_amd.network_blocks import ConvSequence
+    gen = torch.Generator().manual_seed(sum(chans) + size[0])
+    x = torch.randn(1, chans[0], *size, generator=gen).cuda()
+    up = torch.randn(1, chans[-1], *size, generator=gen).cuda()
+
+    class Chain(torch.nn.Module):                      # a ConvSequence whose units change the channel count freely
+        def __init__(self):
+            super().__init__()
+            from pulpo_amd.network_blocks import ConvUnit
+            self._op = torch.nn.Sequential(*[ConvUnit(size, chans[u], chans[u + 1]) for u in range(len(chans) - 1)])
+        forward = ConvSequence.forward
+
+    torch.manual_seed(3)
+    ref_mod = Chain().cuda().train()
+    state = {k: v.clone() for k, v in ref_mod.state_dict().items()}
+
+    default = ops.APPLY_ON_LOAD
+
+    def run(on):
+        ops.APPLY_ON_LOAD = on
+        mod = Chain().cuda().train()
+        mod.load_state_dict(state)
+        calls = []
+        orig = ops._conv_raw_prenorm
+        ops._conv_raw_prenorm = lambda *a: (calls.append(1), orig(*a))[1]
+        try:
+            xg = x.clone().requires_grad_(True)
+            out = mod(xg)
+            grads = torch.autograd.grad((out * up).sum(), [xg] + list(mod.parameters()))
+        finally:
+            ops._conv_raw_prenorm = orig
+            ops.APPLY_ON_LOAD = default
+        return out.detach(), grads, {k: v.clone() for k, v in mod.state_dict().items()}, len(calls)
+
+    out1, g1, st1, n1 = run(True)
+    out0, g0, st0, n0 = run(False)
+    assert n0 == 0 and n1 == fused_links, (n0, n1)
+    assert torch.equal(out1, out0)
+    for a, b in zip(g1, g0):
+        assert rel_l2(a, b) < 2e-6                     # (weight gradients are atomic sums: equal up to the order of the adds)
+    for k in st0:
+        assert torch.equal(st1[k], st0[k]), k
 
 
 def test_conv_linearity_at_full_channel_width(ops):
