@@ -38,7 +38,8 @@ def test_library_exports_every_declared_symbol():
     assert lib.query("pulpo_abi_version") == 1
     # pure host-side size queries (no device work)
     assert lib.query("pulpo_conv3d_k3_packed_floats", 32, 32) == 27 * 32 * 64
-    assert lib.query("pulpo_conv3d_k3_packed_floats", 2, 32) == 27 * 4 * 64
+    assert lib.query("pulpo_conv3d_k3_packed_floats", 2, 32) == 27 * 2 * 64               # 2-channel chunks for the image-pair layer
+    assert lib.query("pulpo_conv3d_k3_packed_floats", 3, 32) == 27 * 4 * 64
     assert lib.query("pulpo_conv3d_k3_stat_tiles", 1, 160, 160, 160) == 40 * 20 * 20      # 4x8x8 voxel tiles from 20^3 up (depth % 4 == 0)
     assert lib.query("pulpo_conv3d_k3_stat_tiles", 2, 32, 32, 32) == 2 * 8 * 4 * 4
     assert lib.query("pulpo_conv3d_k3_stat_tiles", 1, 10, 10, 10) == 5 * 2 * 2             # 2x8x8 otherwise
