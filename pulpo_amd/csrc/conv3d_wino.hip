@@ -4,6 +4,7 @@
 #include "conv_shared.h"
 #include "../../include/pulpo_hip.h"
 #include <stdlib.h>
+#include <atomic>
 
 
 #ifndef PULPO_ABL
@@ -383,6 +384,12 @@ __device__ __forceinline__ void w2_stage_scalar(float* xs, const float* __restri
 //   * 10k clocks of prologue per tile (argument loads, index arithmetic, first-touch latency of halo and weights)  -> PERSISTENT
 //     workgroups (two per CU) that fetch the next tile's first slab and halo chunk during the last dz iteration of the current tile.
 // A start-up offset of the second workgroup of each CU (to break the lockstep of the pair) was measured without effect and is not kept.
+// Tile scheduler of the persistent (y, x) kernel: a ring of word sets, one per launch in flight (launches of one stream run one after the
+// other; a set is returned to zero by the last workgroup of its launch).  [0] = tiles handed out beyond the statically dealt first round,
+// [1] = workgroups that have finished.
+constexpr int W2_SCHED_SLOTS = 32, W2_SCHED_WORDS = 16;
+__device__ int g_wino2_sched[W2_SCHED_SLOTS * W2_SCHED_WORDS];
+
 // rows of the halo image whose 4 pad floats hold the staged operand's BatchNorm coefficients (INAFF): beyond the exchange buffer, below the image's end
 constexpr int W2_COEF_ROW = 704, W2_COEF_QUADS = 72;
 static_assert(W2_COEF_ROW * W2_RS >= 4 * 2 * 16 * 64 + 4 * 2 * 32 && W2_COEF_ROW + 2 * W2_COEF_QUADS <= WN_HZ * W2_PLROWS, "coefficient rows");
@@ -506,7 +513,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
             for (int s_ = 0; s_ < a.stagger; ++s_) __builtin_amdgcn_s_sleep(127);
     }
     int tile_no = 0;
-    int work = pulpo::xcd_remap(blockIdx.x, nwg);      // works of one round are dealt so that an XCD's workgroups hold neighbouring tiles
+    // ---- which tile next.  The FIRST tile of a workgroup is dealt statically (tile = block id, remapped so that an XCD's workgroups hold
+    // neighbouring tiles): the dispatcher has spread the workgroups evenly over the CUs, so a launch with fewer tiles than workgroup
+    // slots keeps one tile per CU.  Further tiles: static stride (a.sched == nullptr) or - default - the next unclaimed index of a queue
+    // shared by all workgroups, so that a workgroup that starts late (its CU was still held by a kernel of the other stream) or runs
+    // slowly takes fewer tiles instead of finishing a fixed share after everybody else has left.  The queue head is advanced by ONE lane
+    // per tile with an asynchronous returning atomic, issued at the tile's start and picked up behind the wait of the first dz iteration.
+    int* const sched = a.sched;
+    int* const next_slot = reinterpret_cast<int*>(xs + (W2_COEF_ROW + 2 * W2_COEF_QUADS) * W2_RS + 8);      // a pad word of the image nobody writes
+    auto finish = [&]() {                               // the last workgroup to leave returns the scheduler words to zero
+        if (sched != nullptr && tid == 0) {
+            if (atomicAdd(sched + 1, 1) == nwg - 1) {
+                sched[0] = 0;
+                sched[1] = 0;
+            }
+        }
+    };
+    int work = pulpo::xcd_remap(blockIdx.x, nwg);
+    int grabbed = 0;                                    // (thread 0) return register of the in-flight queue atomic
     Tile cur = describe(work);
 #pragma unroll
     for (int u = 0; u < 4; ++u) dma_w_piece(cur.wsrc, 0, 0, u);
@@ -518,8 +542,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
     float4 ra[2][2], rb[2][2], rw[2];                   // two register sets of operand rows (activations: (ta, tb) x two row tiles; weights)
 
     for (;;) {
-        const int next_work = work + nwg;
-        const bool has_next = next_work < nwork;
+        int next_work = nwork;
+        bool has_next = false;
         Tile nxt = cur;
 
         f32x16 acc[2][4];
@@ -534,6 +558,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         int it = 0;
         for (int chunk = 0; chunk < nchunk; ++chunk) {
             __syncthreads();                            // every wave has finished reading xs (previous chunk / previous tile's exchange)
+            if (chunk == 0 && sched != nullptr && tid == 0) {
+                int* qh = sched;
+                const int one = 1;
+                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(grabbed) : "v"(qh), "v"(one) : "memory");
+            }
             if constexpr (VEC) {
                 // every thread "uses" its raw registers here, unconditionally: the compiler's wait for those loads then sits in straight-line
                 // code, and it does not have to assume them still in flight (and drain the queue, DMA included) when they are reloaded
@@ -583,6 +612,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
 #pragma unroll
             for (int dz = 0; dz < 3; ++dz, ++it) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of slab `it` have landed
+                if (chunk == 0 && dz == 0 && sched != nullptr && tid == 0) {
+                    asm volatile("" : "+v"(grabbed));                // (the queue atomic issued at the tile's start has returned with the wait above)
+                    *next_slot = nwg + grabbed;
+                }
                 __syncthreads();                        // all pieces landed, staged rows visible, everybody has left ws[buf ^ 1]
                 const float* xa = pa + dz * W2_PS;
                 const float* xb_ = pb + dz * W2_PS;
@@ -590,6 +623,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
                 // what is fetched underneath this iteration's MFMAs: the next slab of this tile, or - in the tile's last iteration - slab 0 of
                 // the next tile; and (dz == 2) the next halo chunk of this tile, or chunk 0 of the next tile
                 const bool tile_end = dz == 2 && last_chunk;
+                if (tile_end) {
+                    if (sched != nullptr) {
+                        next_work = __builtin_amdgcn_readfirstlane(*next_slot);
+                    } else {
+                        next_work = work + nwg;
+                    }
+                    has_next = next_work < nwork;
+                }
                 if (tile_end && has_next) nxt = describe(next_work);
                 const bool more_w = !tile_end || has_next;
                 const float* w_src = tile_end ? nxt.wsrc : cur.wsrc;
@@ -826,6 +867,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         cur = nxt;
         work = next_work;
     }
+    finish();
 }
 
 // packing for the (y, x) Winograd kernel: wp[k/8][dz][py][px][n][k%8] = sum_dy sum_dx G[py][dy] G[px][dx] g[dz][dy][dx]
@@ -966,6 +1008,11 @@ PULPO_API int pulpo_conv3d_k3_pack_weights_multi(const PulpoPackJob* jobs, int n
     return pulpo::check_launch("pack_weights_multi");
 }
 
+static unsigned next_sched_slot() {                    // one launch counter for all instantiations (the main and the autograd thread both launch)
+    static std::atomic<unsigned> n{0};
+    return n.fetch_add(1);
+}
+
 template <bool VEC, bool BNR = false, bool INAFF = false>
 static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
     constexpr size_t lds = (size_t)(W2_XS + 2 * 16 * WN_CH * 32) * sizeof(float);
@@ -983,7 +1030,17 @@ static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
         const long clocks = ((long)((a.Cin + WN_CH - 1) / WN_CH) * 96 * 64 * 2 + 20000) * pct / 100;
         const_cast<ConvArgs&>(a).stagger = (int)(clocks / (64 * 127));
     }
-    // persistent workgroups: two per CU (LDS and registers admit exactly two), each walking the tile list with stride gridDim.x
+    {
+        static int dynamic = -1;                        // PULPO_CONV_DYNAMIC=0: static deal of the tiles (A/B switch)
+        if (dynamic < 0) { const char* e = getenv("PULPO_CONV_DYNAMIC"); dynamic = e ? atoi(e) : 1; }
+        static int* sched_base = nullptr;
+        if (dynamic && sched_base == nullptr) {
+            hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&sched_base), HIP_SYMBOL(g_wino2_sched));
+            if (e != hipSuccess) return pulpo::fail((int)e, "hipGetSymbolAddress(wino2 scheduler): %s", hipGetErrorString(e));
+        }
+        const_cast<ConvArgs&>(a).sched = dynamic ? sched_base + (next_sched_slot() % W2_SCHED_SLOTS) * W2_SCHED_WORDS : nullptr;
+    }
+    // persistent workgroups: two per CU (LDS and registers admit exactly two)
     hipLaunchKernelGGL((conv3d_k3_wino2_mfma<VEC, BNR, INAFF>), dim3(std::min(nblk, 512)), dim3(256), lds, st, a);
     return pulpo::check_launch("conv3d_k3_wino2_mfma");
 }

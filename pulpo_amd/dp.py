@@ -242,6 +242,7 @@ class DataParallelStepper:
         self.arena.zero_grad()
         self._works, self._launched = [], 0
         self._armed = self.overlap and world() > 1
+        ops._BN_TILE_PARTS.clear()                 # (BatchNorm-backward sums a data-gradient kernel left for a unit whose backward never ran)
         try:
             loss = self.model.training_step(batch, 0)
             ops.DIRECT_PARAM_GRADS = True          # conv / BN backward kernels add straight into the arena's .grad views

@@ -391,7 +391,6 @@ def _persistent_buffer(owner: torch.Tensor, name: str, numel: int, zero: bool) -
 
 def flush_param_grads() -> None:
     """finish every deferred weight / bias gradient on the current stream (callers have joined the weight-gradient stream first)"""
-    _BN_TILE_PARTS.clear()
     if not _PENDING_GRAD_JOBS:
         return
     key = tuple(_PENDING_GRAD_JOBS)
