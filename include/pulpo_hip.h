@@ -82,7 +82,7 @@ int pulpo_conv3d_k3_fwd_wino2_prenorm(const float* y_in, int64_t in_bs, int64_t 
  * FIRST pass of the BatchNorm/LeakyReLU backward of the ConvUnit in front of it fused into the store (the reference runs these as
  * separate autograd nodes: ConvolutionBackward of src/network_blocks.py:23, then LeakyReluBackward / NativeBatchNormBackward of :24-25):
  * part[tile][2][N], tile < pulpo_conv3d_k3_stat_tiles(), receives sum(dbn) and sum(dbn * (bn_y - fp32 batch mean)) per voxel tile, where
- * dbn = out * lrelu'(bn_y * scale + shift); pulpo_bn_bwd_finalize_tiles turns them into what pulpo_bn_bwd_finalize delivers.  bn_y / bn_coef: pre-norm tensor (channels-last,
+ * dbn = out * lrelu'(bn_y * scale + shift); the layout pulpo_bn_bwd_finalize takes.  bn_y / bn_coef: pre-norm tensor (channels-last,
  * N channels) and coefficient block (pulpo_bn_fwd_finalize) of the unit in front.  _ok() = 1 when the shape is accepted. */
 int pulpo_conv3d_k3_dgrad_wino2_bnred_ok(int B, int D, int H, int W, int K, int N);
 int pulpo_conv3d_k3_dgrad_wino2_bnred(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, float* out, int64_t out_bs,
@@ -153,13 +153,12 @@ int pulpo_bn_lrelu_apply(const float* y, int64_t yps, float* z, int64_t zps, con
 int pulpo_bn_bwd_blocks(int64_t npix, int C);
 int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, int64_t npix, int C, float slope,
                               float* partial /*[blocks][2C]*/, void* stream);
-int pulpo_bn_bwd_finalize(const float* partial, int nrow, int C, double count, int use_means, float* dbeta, float* dgamma, int accumulate,
-                          double* totd /*[2C]: mean(dbn) | mean(dbn*xhat)*/, void* stream);
-/* pulpo_bn_bwd_finalize over per-voxel-tile rows (pulpo_conv3d_k3_dgrad_wino2_bnred); scratch:
- * pulpo_bn_bwd_finalize_tiles_scratch_doubles(ntile, C) doubles (NULL when that is 0) */
-size_t pulpo_bn_bwd_finalize_tiles_scratch_doubles(int ntile, int C);
-int pulpo_bn_bwd_finalize_tiles(const float* tile_part, int ntile, int C, const float* coef, double count, int use_means, float* dbeta,
-                                float* dgamma, int accumulate, double* totd, double* scratch, void* stream);
+/* rows [nrow][2][C] = (sum dbn, sum dbn * (y - fp32 batch mean)): the block partials of pulpo_bn_lrelu_bwd_reduce (nrow = pulpo_bn_bwd_blocks)
+ * or the per-voxel-tile rows of pulpo_conv3d_k3_dgrad_wino2_bnred (nrow = pulpo_conv3d_k3_stat_tiles).  coef: the unit's coefficient block.
+ * scratch: pulpo_bn_bwd_finalize_scratch_doubles(nrow, C) doubles (NULL when that is 0). */
+size_t pulpo_bn_bwd_finalize_scratch_doubles(int nrow, int C);
+int pulpo_bn_bwd_finalize(const float* rows, int nrow, int C, const float* coef, double count, int use_means, float* dbeta, float* dgamma,
+                          int accumulate, double* totd /*[2C]: mean(dbn) | mean(dbn*xhat)*/, double* scratch, void* stream);
 int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd, float* dy,
                              int64_t dyps, int64_t npix, int C, float slope, float* partial2 /*[blocks][C]*/, void* stream);
 

@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         const bool cok = co0 + ei < a.Cout;
         // data-gradient launch with the BatchNorm-backward reduction of the unit in front fused in (host: every tile takes the fast path)
         const bool bnr = BNR && fast;        // (own instantiation: its extra epilogue registers stay out of the plain kernel)
-        float4 bm4 = zero4;                  // the channel means rounded to fp32 (pulpo_bn_bwd_finalize_tiles corrects for the rounding)
+        float4 bm4 = zero4;                  // the channel means rounded to fp32 (pulpo_bn_bwd_finalize corrects for the rounding)
         const float* bn_b = bnr ? a.bn_y + (long)cur.b * a.bn_y_bs + co0 + 4 * q : nullptr;
         if (fast) {
             if (!BNR && a.bias != nullptr) b4 = *reinterpret_cast<const float4*>(a.bias + co0 + 4 * q);
@@ -1064,7 +1064,7 @@ PULPO_API int pulpo_conv3d_k3_dgrad_wino2_bnred_ok(int B, int D, int H, int W, i
 
 // The data-gradient convolution of ConvUnit u (dz = conv^T(dy_u), in = dy_u, N = that unit's input channels) with the first pass of the
 // BatchNorm/LeakyReLU backward of ConvUnit u-1 - whose output z = lrelu(bn(y)) fed unit u - fused into its store: part[tile][2][N] receives
-// per voxel tile sum(dbn) and sum(dbn * (y - fp32 mean)), dbn = dz * lrelu'(y * scale + shift), for pulpo_bn_bwd_finalize_tiles.  bn_y: the pre-norm
+// per voxel tile sum(dbn) and sum(dbn * (y - fp32 mean)), dbn = dz * lrelu'(y * scale + shift), for pulpo_bn_bwd_finalize.  bn_y: the pre-norm
 // tensor y of unit u-1 (channels-last, N channels, 16-byte aligned rows); bn_coef: its coefficient block (pulpo_bn_fwd_finalize).
 // Replaces one pulpo_bn_lrelu_bwd_reduce pass (a read of dz and y from HBM) by a read of y underneath the convolution's epilogue.
 PULPO_API int pulpo_conv3d_k3_dgrad_wino2_bnred(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, float* out,

@@ -154,8 +154,11 @@ __global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(const float* __rest
     }
 }
 
-// pass 1 of the backward: partial[blk][0][c] = sum dbn, partial[blk][1][c] = sum dbn * xhat
-//   dbn = dz * (bn_out > 0 ? 1 : slope),  bn_out = y*scale + shift,  xhat = (y - mean) * rstd
+// pass 1 of the backward: partial[blk][0][c] = sum dbn, partial[blk][1][c] = sum dbn * (y - m32)
+//   dbn = dz * (bn_out > 0 ? 1 : slope),  bn_out = y*scale + shift,  m32 = the batch mean rounded to fp32 (coef[c])
+// All fp32: the difference of two floats carries a relative error of 2^-24 however close they are, and what the ROUNDED mean leaves out is
+// added back in double by bn_bwd_finalize_kernel (sum dbn * xhat = rstd * (sum dbn * (y - m32) - (mean - m32) * sum dbn)).  No doubles per
+// element: a wave needs 40 instead of 64 registers, so that two instead of one fit on a SIMD beside the weight-gradient kernel.
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* __restrict__ dz, long dzps, const float* __restrict__ y,
                                                                     long yps, const float* __restrict__ coef, long npix, int C,
@@ -168,13 +171,10 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < VEC; ++k) s0[k] = s1[k] = 0.f;
     if (row < RB) {
-        float sc[VEC], sh[VEC];
-        double mean[VEC], rstd[VEC];
-        const double* cd = reinterpret_cast<const double*>(coef + 4 * C);
+        float sc[VEC], sh[VEC], m32[VEC];
         Vec<VEC>::ld(coef + 2 * C + c, sc);
         Vec<VEC>::ld(coef + 3 * C + c, sh);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) { mean[k] = cd[c + k]; rstd[k] = cd[C + c + k]; }
+        Vec<VEC>::ld(coef + c, m32);
         for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
             float g[VEC], v[VEC];
             Vec<VEC>::ld(dz + p * dzps + c, g);
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* _
                 const float bn = v[k] * sc[k] + sh[k];
                 const float d = bn > 0.f ? g[k] : g[k] * slope;
                 s0[k] += d;
-                s1[k] += (float)((double)d * (((double)v[k] - mean[k]) * rstd[k]));
+                s1[k] = fmaf(d, v[k] - m32[k], s1[k]);
             }
         }
 #pragma unroll
@@ -202,40 +202,77 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* _
 }
 
 // pass 2: dy = scale * (dbn - mean(dbn) - xhat * mean(dbn*xhat));  partial2[blk][c] = sum dy  (conv-bias gradient)
+// Per element in fp32 as  dy = A*dbn + B*(y - m32) + C  with per-channel constants formed in double from the exact means:
+//   A = scale,  B = -scale * c2 * rstd,  C = -scale * (c1 + c2 * rstd * (m32 - mean)),  C carried as a (hi, lo) pair of floats.
+// A mean rounded to fp32 would shift every dy of the channel by the same amount, an error that the following weight-gradient sum
+// amplifies by the voxel count (ATen's CPU BatchNorm accumulates in double for the same reason): here the only systematic term, C, keeps 48
+// bits, the (y - m32) factor is centred (a rounding of B does not shift the channel) and everything else rounds without bias.
+// The six per-channel constants live in LDS and are read per element group (6 ds_read_b128 against 48 bytes of HBM traffic): the kernel
+// then needs ~40 instead of 71 registers, i.e. two waves instead of one fit on a SIMD beside the weight-gradient kernel.
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __restrict__ dz, long dzps, const float* __restrict__ y,
                                                                    long yps, const float* __restrict__ coef, const double* __restrict__ totd,
                                                                    float* __restrict__ dy, long dyps, long npix, int C,
                                                                    float slope, float* __restrict__ partial2) {
-    extern __shared__ float red[];                 // [RB][C]
+    extern __shared__ float red[];                 // [RB][C] partial sums, then [6][C] constants: scale, shift, m32, B, C hi, C lo
     const int CV = C / VEC, RB = blockDim.x / CV;
     const int col = threadIdx.x % CV, row = threadIdx.x / CV;
     const int c = col * VEC;
+    float* kst = red + RB * C;
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+        const double* cd = reinterpret_cast<const double*>(coef + 4 * C);
+        const float sc_ = coef[2 * C + ch], m32_ = coef[ch];
+        const double mean = cd[ch], rstd = cd[C + ch], c1 = totd[ch], c2 = totd[C + ch];
+        const double b = -(double)sc_ * c2 * rstd;
+        const double cc = -(double)sc_ * (c1 + c2 * rstd * ((double)m32_ - mean));
+        const float chi_ = (float)cc;
+        kst[0 * C + ch] = sc_;
+        kst[1 * C + ch] = coef[3 * C + ch];
+        kst[2 * C + ch] = m32_;
+        kst[3 * C + ch] = (float)b;
+        kst[4 * C + ch] = chi_;
+        kst[5 * C + ch] = (float)(cc - (double)chi_);
+    }
+    __syncthreads();
     float s0[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) s0[k] = 0.f;
     if (row < RB) {
-        // The per-channel means are carried in double and subtracted in double: a mean rounded to fp32 would shift every
-        // dy of the channel by the same amount, an error that the following weight-gradient sum amplifies by the voxel
-        // count (ATen's CPU BatchNorm accumulates in double for the same reason).
-        float sc[VEC], sh[VEC];
-        double mean[VEC], rstd[VEC], c1[VEC], c2[VEC];
-        const double* cd = reinterpret_cast<const double*>(coef + 4 * C);
-        Vec<VEC>::ld(coef + 2 * C + c, sc);
-        Vec<VEC>::ld(coef + 3 * C + c, sh);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) { mean[k] = cd[c + k]; rstd[k] = cd[C + c + k]; c1[k] = totd[c + k]; c2[k] = totd[C + c + k]; }
         for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
             float g[VEC], v[VEC], o[VEC];
             Vec<VEC>::ld(dz + p * dzps + c, g);
             Vec<VEC>::ld(y + p * yps + c, v);
+            int cl = c;                                 // (opaque: the constants are to be READ here every time, not kept in registers)
+            asm volatile("" : "+v"(cl));
+            // three stages, each with its own constants, so that no more than three constant vectors are live at a time
+            {
+                float sh[VEC], sc[VEC];
+                Vec<VEC>::ld(kst + 0 * C + cl, sc);
+                Vec<VEC>::ld(kst + 1 * C + cl, sh);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const float bn = v[k] * sc[k] + sh[k];
-                const float d = bn > 0.f ? g[k] : g[k] * slope;
-                const double xh = ((double)v[k] - mean[k]) * rstd[k];
-                o[k] = (float)((double)sc[k] * ((double)d - c1[k] - xh * c2[k]));
-                s0[k] += o[k];
+                for (int k = 0; k < VEC; ++k) {
+                    const float bn = v[k] * sc[k] + sh[k];
+                    g[k] = sc[k] * (bn > 0.f ? g[k] : g[k] * slope);          // scale * dbn
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                float m32[VEC], cb[VEC], chi[VEC];
+                Vec<VEC>::ld(kst + 2 * C + cl, m32);
+                Vec<VEC>::ld(kst + 3 * C + cl, cb);
+                Vec<VEC>::ld(kst + 4 * C + cl, chi);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v[k] = fmaf(cb[k], v[k] - m32[k], chi[k]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                float clo[VEC];
+                Vec<VEC>::ld(kst + 5 * C + cl, clo);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    o[k] = (g[k] + v[k]) + clo[k];
+                    s0[k] += o[k];
+                }
             }
             Vec<VEC>::st(dy + p * dyps + c, o);
         }
@@ -250,32 +287,11 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __
     }
 }
 
-// partial[nblk][2C] -> grads[2C] = (dbeta | dgamma) as floats, totd[2C] = (mean dbn | mean dbn*xhat) as doubles.
+// rows [nrow][2][C] = (sum dbn, sum dbn * (y - m32)) - the block partials of bn_lrelu_bwd_reduce_kernel or the per-voxel-tile rows a
+// convolution epilogue wrote (or, part != nullptr, their double slice sums); m32 = coef[c], the fp32-rounded batch mean
+//   -> (dbeta | dgamma) as floats, totd[2C] = (mean dbn | mean dbn * xhat) as doubles;  sum dbn * xhat = rstd * (q - (mean - m32) * s).
 // use_means == 0 (eval-mode BatchNorm is a fixed affine map): totd = 0.
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nrow, int C, double count, int use_means,
-                                                                 float* __restrict__ dbeta, float* __restrict__ dgamma, int accumulate,
-                                                                 double* __restrict__ totd) {
-    __shared__ double red[32][33];
-    const int cx = threadIdx.x, ry = threadIdx.y;
-    const int c = blockIdx.x * 32 + cx;          // column in [0, 2C)
-    double s = 0.0;
-    if (c < 2 * C)
-        for (int r = ry; r < nrow; r += 32) s += (double)partial[(long)r * 2 * C + c];
-    red[ry][cx] = s;
-    __syncthreads();
-    if (ry == 0 && c < 2 * C) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) t += red[k][cx];
-        float* dst = c < C ? dbeta + c : dgamma + (c - C);
-        *dst = accumulate ? *dst + (float)t : (float)t;
-        totd[c] = use_means ? t / count : 0.0;
-    }
-}
-
-// The same from per-voxel-tile rows [ntile][2][C] = (sum dbn, sum dbn * (y - m32)) written by a convolution epilogue, m32 = coef[c] the
-// fp32-rounded batch mean (or, part != nullptr, from their double slice sums):  sum dbn * xhat = rstd * (q - (mean - m32) * s).
-__global__ __launch_bounds__(512) void bn_bwd_finalize_tiles_kernel(const float* __restrict__ rows, const double* __restrict__ part, int nrow, int C,
+__global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const float* __restrict__ rows, const double* __restrict__ part, int nrow, int C,
                                                                        const float* __restrict__ coef, double count, int use_means,
                                                                        float* __restrict__ dbeta, float* __restrict__ dgamma, int accumulate,
                                                                        double* __restrict__ totd) {
@@ -392,38 +408,30 @@ PULPO_API int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const flo
     return pulpo::check_launch("bn_lrelu_bwd_reduce");
 }
 
-// dbeta / dgamma: [C] each, written (accumulate = 0) or added to (accumulate = 1, e.g. the parameters' .grad storage)
-PULPO_API int pulpo_bn_bwd_finalize(const float* partial, int nrow, int C, double count, int use_means, float* dbeta, float* dgamma, int accumulate,
-                                    double* totd, void* stream) {
-    PULPO_REQUIRE(partial && dbeta && dgamma && totd && nrow > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pulpo::cdiv(2 * C, 32)), dim3(32, 32), 0, (hipStream_t)stream, partial, nrow, C,
-                       count, use_means, dbeta, dgamma, accumulate, totd);
-    return pulpo::check_launch("bn_bwd_finalize");
-}
-
-// The same from the per-voxel-tile partial rows a convolution epilogue wrote (pulpo_conv3d_k3_dgrad_wino2_bnred; coef = the unit's
-// coefficient block): with more than 64 tiles the rows are first summed slice-wise in double (scratch:
-// pulpo_bn_bwd_finalize_tiles_scratch_doubles(ntile, C) doubles, else NULL).
+// dbeta / dgamma: [C] each, written (accumulate = 0) or added to (accumulate = 1, e.g. the parameters' .grad storage).
+// rows: the block partials of pulpo_bn_lrelu_bwd_reduce (nrow = pulpo_bn_bwd_blocks) or the per-voxel-tile rows of
+// pulpo_conv3d_k3_dgrad_wino2_bnred (nrow = pulpo_conv3d_k3_stat_tiles); coef = the unit's coefficient block.  With more than 64 rows they
+// are first summed slice-wise in double (scratch: pulpo_bn_bwd_finalize_scratch_doubles(nrow, C) doubles, else NULL).
 // (two-stage from 64 tiles up: the second stage alone would walk the rows with 32 threads per channel)
-PULPO_API size_t pulpo_bn_bwd_finalize_tiles_scratch_doubles(int ntile, int C) { return ntile > 64 ? (size_t)32 * 2 * C : 0; }
+PULPO_API size_t pulpo_bn_bwd_finalize_scratch_doubles(int ntile, int C) { return ntile > 64 ? (size_t)32 * 2 * C : 0; }
 
-PULPO_API int pulpo_bn_bwd_finalize_tiles(const float* tile_part, int ntile, int C, const float* coef, double count, int use_means, float* dbeta,
+PULPO_API int pulpo_bn_bwd_finalize(const float* tile_part, int ntile, int C, const float* coef, double count, int use_means, float* dbeta,
                                           float* dgamma, int accumulate, double* totd, double* scratch, void* stream) {
-    PULPO_REQUIRE(tile_part && coef && dbeta && dgamma && totd && ntile > 0 && C > 0 && count > 0, "bn_bwd_finalize_tiles: bad arguments");
+    PULPO_REQUIRE(tile_part && coef && dbeta && dgamma && totd && ntile > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const double* partd = nullptr;
     int nrow = ntile;
-    if (pulpo_bn_bwd_finalize_tiles_scratch_doubles(ntile, C) != 0) {
-        PULPO_REQUIRE(scratch != nullptr, "bn_bwd_finalize_tiles: scratch required for %d tiles", ntile);
+    if (pulpo_bn_bwd_finalize_scratch_doubles(ntile, C) != 0) {
+        PULPO_REQUIRE(scratch != nullptr, "bn_bwd_finalize: scratch required for %d tiles", ntile);
         hipLaunchKernelGGL(colsum_slices_kernel, dim3(pulpo::cdiv(2 * C, 32), 32), dim3(32, 32), 0, st, tile_part, ntile, 2 * C, scratch);
         int rc = pulpo::check_launch("bn backward tile slices");
         if (rc) return rc;
         partd = scratch;
         nrow = 32;
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_tiles_kernel, dim3(pulpo::cdiv(C, 32)), dim3(32, 16), 0, st, tile_part, partd, nrow, C, coef, count, use_means,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pulpo::cdiv(C, 32)), dim3(32, 16), 0, st, tile_part, partd, nrow, C, coef, count, use_means,
                        dbeta, dgamma, accumulate, totd);
-    return pulpo::check_launch("bn_bwd_finalize_tiles");
+    return pulpo::check_launch("bn_bwd_finalize");
 }
 
 PULPO_API int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd, float* dy,
@@ -434,7 +442,7 @@ PULPO_API int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const floa
     if (C % 4 == 0 && !v4) return pulpo::fail(-1, "bn_lrelu_bwd_apply: operands must be 16-byte aligned when C %% 4 == 0");
     const int nblk = pulpo_bn_bwd_blocks(npix, C);
     const int RB = std::max(1, 256 / (C / (v4 ? 4 : 1)));
-    const size_t lds = (size_t)RB * C * sizeof(float);
+    const size_t lds = (size_t)(RB + 6) * C * sizeof(float);
     if (v4)
         hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel<4>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2);
     else

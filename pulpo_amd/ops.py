@@ -601,14 +601,10 @@ class _ConvBNLReLU(torch.autograd.Function):
         totd = torch.empty(2 * Cout, device=dev, dtype=torch.float64)          # mean(dbn) | mean(dbn * xhat), kept in double
         # eval-mode BatchNorm is a fixed affine map (dy = scale * dbn): the batch means do not enter
         fin_out = (_ptr(slot_be if direct_bn else tot), _ptr(slot_g) if direct_bn else ctypes.c_void_p(tot.data_ptr() + 4 * Cout), int(direct_bn), _ptr(totd))
-        if tiles is None:
-            lib.call("pulpo_bn_bwd_finalize", _ptr(part), nblk, Cout, float(npix), int(ctx.training), *fin_out, _stream())
-        else:
-            tile_part, ntile = tiles
-            nsd = lib.query("pulpo_bn_bwd_finalize_tiles_scratch_doubles", ntile, Cout)
-            scratch = torch.empty(nsd, device=dev, dtype=torch.float64) if nsd else None
-            lib.call("pulpo_bn_bwd_finalize_tiles", _ptr(tile_part), ntile, Cout, _ptr(coef), float(npix), int(ctx.training), *fin_out, _ptr(scratch),
-                     _stream())
+        rows, nrow = (part, nblk) if tiles is None else tiles
+        nsd = lib.query("pulpo_bn_bwd_finalize_scratch_doubles", nrow, Cout)
+        scratch = torch.empty(nsd, device=dev, dtype=torch.float64) if nsd else None
+        lib.call("pulpo_bn_bwd_finalize", _ptr(rows), nrow, Cout, _ptr(coef), float(npix), int(ctx.training), *fin_out, _ptr(scratch), _stream())
         dy = new_cl(B, Cout, D, H, W, dev)
         defer_b = DIRECT_PARAM_GRADS and ctx.needs_input_grad[2] and slot_b is not None
         part2 = _persistent_buffer(b_p, "_pulpo_dbias_part", nblk * Cout, zero=False) if defer_b else torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
