@@ -21,6 +21,10 @@
 // ranges of the linearised (column, z) plane steps, so the load balance is exact to one plane.  Flush: G^T M G (in-lane over the wave's px,
 // across the waves through LDS), three float atomics per (dz, ci, co) triple into the packed scratch shared with the other wgrad kernels.
 #include "conv_shared.h"
+
+#ifndef PULPO_ABL
+#define PULPO_ABL 0          // diagnostic builds (scripts/ablate.py): 21 no matrix instructions, 22 no staging writes, 23 no global loads, 24 no barrier per plane step
+#endif
 #include <stdlib.h>
 
 namespace {
@@ -202,10 +206,18 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
         }
 #pragma unroll 1
         for (int j = zs; j < ze; ++j) {
+#if PULPO_ABL != 24
             __syncthreads();                              // staged planes visible; everybody has finished the previous iteration's reads
+#endif
             const int xs_slot = (j + 3) & 3, es = j & 1;
             // eight groups (g, px) of 12 MFMAs; the eight ds_read_b128 of group k + 1 are requested before the MFMAs of group k are issued
-            // (two register sets: with one wave per SIMD nothing else hides the LDS round trip)
+            // (two register sets: with one wave per SIMD nothing else hides the LDS round trip).
+            // Measured (round 2, scripts/ablate.py w2_*): with ONE wave per SIMD a wave's own MFMAs and its other instructions do not overlap -
+            // the kernel takes matrix time + everything-else time (0.73 + 0.50 ms for 32->32 at 160^3; 12 bare MFMAs 724 clocks, the same 12
+            // with 8 LDS reads and 20 VALU operations slotted one by one between them 896).  A version with every piece of side work pinned
+            // between two MFMAs (volatile-asm arithmetic, branch-free loads and staging so that the loop stays one basic block) gained 3 % for
+            // 36 more registers and nothing in the training step; not kept.  The lever left is a second wave per SIMD (an 8-wave workgroup
+            // with half the accumulators per wave), see DESIGN.md.
             float4 av[2][3], bv[2][3], e0[2], e1[2];
             auto fetch = [&](int gi, int set) {
                 const int g = gi >> 2, px = gi & 3;
@@ -232,18 +244,26 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
                     const float4 pa_ = av[set][dz], pb_ = bv[set][dz];
                     const float v4[4] = {fmaf(sa, pb_.x, pa_.x), fmaf(sa, pb_.y, pa_.y), fmaf(sa, pb_.z, pa_.z), fmaf(sa, pb_.w, pa_.w)};
 #pragma unroll
+#if PULPO_ABL == 21
+                    for (int s_ = 0; s_ < 4; ++s_) acc[px][dz][s_] = fmaf(v4[s_], ev[s_], acc[px][dz][s_]);
+#else
                     for (int s_ = 0; s_ < 4; ++s_) acc[px][dz] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[s_], ev[s_], acc[px][dz], 0, 0, 0);
+#endif
                     if (dz == 0 && gi < 4) {
                         // behind the group's first MFMAs: the registers (planes j + 2 / j + 1, requested half an iteration ago) are transformed
                         // and written, one point per group; after the fourth they are free and the next planes are requested, which leaves
                         // those loads groups 4..7 and the barrier to land
                         __builtin_amdgcn_sched_barrier(0);
                         if (gi == 0) touch_raw();
+#if PULPO_ABL != 22
                         stage_part(gi, xs_slot, es ^ 1);
+#endif
+#if PULPO_ABL != 23
                         if (gi == 3) {
                             issue_x(j + 3);
                             issue_e(j + 2);
                         }
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }

@@ -23,6 +23,12 @@ VARIANTS = {
     "wgrad_nodma": ("conv3d_wgrad", 11, {}, ["--only", "wgrad"]),
     "wgrad_nomfma": ("conv3d_wgrad", 12, {}, ["--only", "wgrad"]),
     "wgrad_noflush": ("conv3d_wgrad", 13, {}, ["--only", "wgrad"]),
+    "w2_base": ("conv3d_wgrad_w2", 0, {}, ["--only", "wgrad", "--shapes", "0", "3", "8"]),
+    "w2_nomfma": ("conv3d_wgrad_w2", 21, {}, ["--only", "wgrad", "--shapes", "0", "3", "8"]),
+    "w2_nostage": ("conv3d_wgrad_w2", 22, {}, ["--only", "wgrad", "--shapes", "0", "3", "8"]),
+    "w2_noloads": ("conv3d_wgrad_w2", 23, {}, ["--only", "wgrad", "--shapes", "0", "3", "8"]),
+    "w2_nobarrier": ("conv3d_wgrad_w2", 24, {}, ["--only", "wgrad", "--shapes", "0", "3", "8"]),
+
 }
 
 
