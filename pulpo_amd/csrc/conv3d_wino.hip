@@ -385,8 +385,8 @@ __device__ __forceinline__ void w2_stage_scalar(float* xs, const float* __restri
 //     workgroups (two per CU) that fetch the next tile's first slab and halo chunk during the last dz iteration of the current tile.
 // A start-up offset of the second workgroup of each CU (to break the lockstep of the pair) was measured without effect and is not kept.
 // Tile scheduler of the persistent (y, x) kernel: a ring of word sets, one per launch in flight (launches of one stream run one after the
-// other; a set is returned to zero by the last workgroup of its launch).  [0] = tiles handed out beyond the statically dealt first round,
-// [1] = workgroups that have finished.
+// other; a set is returned to zero by the last workgroup of its launch).  [0..7] = tiles handed out from XCD q's eighth of the work list
+// beyond the statically dealt first round, [8] = workgroups that have finished.
 constexpr int W2_SCHED_SLOTS = 32, W2_SCHED_WORDS = 16;
 __device__ int g_wino2_sched[W2_SCHED_SLOTS * W2_SCHED_WORDS];
 
@@ -515,17 +515,32 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
     int tile_no = 0;
     // ---- which tile next.  The FIRST tile of a workgroup is dealt statically (tile = block id, remapped so that an XCD's workgroups hold
     // neighbouring tiles): the dispatcher has spread the workgroups evenly over the CUs, so a launch with fewer tiles than workgroup
-    // slots keeps one tile per CU.  Further tiles: static stride (a.sched == nullptr) or - default - the next unclaimed index of a queue
-    // shared by all workgroups, so that a workgroup that starts late (its CU was still held by a kernel of the other stream) or runs
-    // slowly takes fewer tiles instead of finishing a fixed share after everybody else has left.  The queue head is advanced by ONE lane
-    // per tile with an asynchronous returning atomic, issued at the tile's start and picked up behind the wait of the first dz iteration.
+    // slots keeps one tile per CU.  Further tiles: static stride (a.sched == nullptr, the default) or from queues, so that a workgroup that
+    // starts late (its CU was still held by a kernel of the other stream) or runs slowly takes fewer tiles instead of finishing a fixed
+    // share after everybody else has left.  One queue per XCD over a contiguous eighth of the remaining work list (neighbouring tiles share
+    // halos and weight panels in that XCD's L2: one queue for the whole chip measured 1.7x the HBM fetches); an XCD that runs dry helps the
+    // others.  The head is advanced by ONE lane per tile with an asynchronous returning atomic, issued at the tile's start and picked up
+    // behind the wait of the first dz iteration.
     int* const sched = a.sched;
     int* const next_slot = reinterpret_cast<int*>(xs + (W2_COEF_ROW + 2 * W2_COEF_QUADS) * W2_RS + 8);      // a pad word of the image nobody writes
+    const int xcc = a.sched_single ? 0 : __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7));   // HW_REG_XCC_ID
+    auto queue_lo = [&](int q) { return a.sched_single ? (q == 0 ? nwg : nwork) : nwg + (int)(((long)(nwork - nwg) * q) >> 3); };
+    auto steal = [&]() {                                // (blocking; thread 0 only) a tile of any queue, the neighbours' first; nwork = none left
+        for (int k = 1; k < 8; ++k) {
+            const int q = (xcc + k) & 7;
+            const int lo = queue_lo(q), hi = queue_lo(q + 1);
+            if (lo < hi) {
+                const int t = atomicAdd(sched + q, 1);
+                if (lo + t < hi) return lo + t;
+            }
+        }
+        return nwork;
+    };
     auto finish = [&]() {                               // the last workgroup to leave returns the scheduler words to zero
         if (sched != nullptr && tid == 0) {
-            if (atomicAdd(sched + 1, 1) == nwg - 1) {
-                sched[0] = 0;
-                sched[1] = 0;
+            if (atomicAdd(sched + 8, 1) == nwg - 1) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) sched[k] = 0;
             }
         }
     };
@@ -559,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         for (int chunk = 0; chunk < nchunk; ++chunk) {
             __syncthreads();                            // every wave has finished reading xs (previous chunk / previous tile's exchange)
             if (chunk == 0 && sched != nullptr && tid == 0) {
-                int* qh = sched;
+                int* qh = sched + xcc;
                 const int one = 1;
                 asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(grabbed) : "v"(qh), "v"(one) : "memory");
             }
@@ -614,7 +629,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of slab `it` have landed
                 if (chunk == 0 && dz == 0 && sched != nullptr && tid == 0) {
                     asm volatile("" : "+v"(grabbed));                // (the queue atomic issued at the tile's start has returned with the wait above)
-                    *next_slot = nwg + grabbed;
+                    const int t_ = queue_lo(xcc) + grabbed;
+                    *next_slot = t_ < queue_lo(xcc + 1) ? t_ : -1;     // -1: this XCD's queue is dry - look at the others when the tile ends
                 }
                 __syncthreads();                        // all pieces landed, staged rows visible, everybody has left ws[buf ^ 1]
                 const float* xa = pa + dz * W2_PS;
@@ -626,6 +642,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
                 if (tile_end) {
                     if (sched != nullptr) {
                         next_work = __builtin_amdgcn_readfirstlane(*next_slot);
+                        if (next_work < 0) {            // (only once an XCD's own queue has run dry)
+                            __syncthreads();
+                            if (tid == 0) *next_slot = steal();
+                            __syncthreads();
+                            next_work = __builtin_amdgcn_readfirstlane(*next_slot);
+                        }
                     } else {
                         next_work = work + nwg;
                     }
@@ -1031,14 +1053,19 @@ static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
         const_cast<ConvArgs&>(a).stagger = (int)(clocks / (64 * 127));
     }
     {
-        static int dynamic = -1;                        // PULPO_CONV_DYNAMIC=0: static deal of the tiles (A/B switch)
-        if (dynamic < 0) { const char* e = getenv("PULPO_CONV_DYNAMIC"); dynamic = e ? atoi(e) : 1; }
+        // PULPO_CONV_DYNAMIC: 0 (default) static deal of the tiles; 1 queues per XCD; 2 one queue.  Measured on the 160^3 step (three runs
+        // each on one box): 38.08 / 38.30 / 38.07 ms - no gain over the static deal, the single queue at 1.7x the HBM fetches of the kernel
+        // (neighbouring tiles no longer share an XCD's L2), the per-XCD queues at the static deal's traffic but with the helping phase
+        // at the end.  Kept as switches: with a collective's kernels holding CUs (multi-GPU runs) a queue lets late workgroups take less.
+        static int dynamic = -1;
+        if (dynamic < 0) { const char* e = getenv("PULPO_CONV_DYNAMIC"); dynamic = e ? atoi(e) : 0; }
         static int* sched_base = nullptr;
         if (dynamic && sched_base == nullptr) {
             hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&sched_base), HIP_SYMBOL(g_wino2_sched));
             if (e != hipSuccess) return pulpo::fail((int)e, "hipGetSymbolAddress(wino2 scheduler): %s", hipGetErrorString(e));
         }
         const_cast<ConvArgs&>(a).sched = dynamic ? sched_base + (next_sched_slot() % W2_SCHED_SLOTS) * W2_SCHED_WORDS : nullptr;
+        const_cast<ConvArgs&>(a).sched_single = dynamic == 2;
     }
     // persistent workgroups: two per CU (LDS and registers admit exactly two)
     hipLaunchKernelGGL((conv3d_k3_wino2_mfma<VEC, BNR, INAFF>), dim3(std::min(nblk, 512)), dim3(256), lds, st, a);

@@ -58,7 +58,8 @@ struct ConvArgs {
     // backward pass needs as the weight gradient's operand - is written to zout (same strides as `in`) by the workgroups of cout tile 0
     const float* in_coef;
     float* zout;
-    int* sched;                   // Winograd (y, x) kernel: device words of its tile scheduler ([0] queue head, [1] finished workgroups); null = static deal
+    int* sched;                   // Winograd (y, x) kernel: device words of its tile scheduler ([0..7] per-XCD queue heads, [8] finished workgroups); null = static deal
+    int sched_single;             // 1: one queue for the whole chip instead of one per XCD (A/B switch PULPO_CONV_DYNAMIC=2)
     int stagger;                  // Winograd (y, x) kernel: start-up delay (units of 64 x 127 clocks) of the second workgroup of every CU, 0 = none
 };
 
