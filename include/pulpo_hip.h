@@ -90,7 +90,8 @@ int pulpo_conv3d_k3_dgrad_wino2_bnred(const float* in, int64_t in_bs, int64_t in
                                       float* part, int B, int D, int H, int W, int K, int N, void* stream);
 /* Re-packing of many weights in one launch (after an optimizer step wrote the parameters through raw pointers): jobs is a DEVICE array,
  * wp buffers as sized by pulpo_conv3d_k3_packed_floats (kind 0, the layout of pulpo_conv3d_k3_pack_weight) or
- * pulpo_conv3d_k3_packed_wino2_floats (kind 2, the layout of pulpo_conv3d_k3_pack_weight_wino2). */
+ * pulpo_conv3d_k3_packed_wino2_floats (kind 2, the layout of pulpo_conv3d_k3_pack_weight_wino2) or pulpo_conv3d_k3_packed_bf16_elems
+ * bf16 elements (kind 3, the layout of pulpo_conv3d_k3_pack_weight_bf16; wp then points to uint16_t). */
 typedef struct PulpoPackJob {
     const float* w;   /* [Cout][Cin][3][3][3] */
     float* wp;

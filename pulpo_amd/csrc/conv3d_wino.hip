@@ -940,6 +940,20 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PulpoPack
     if (j.kind == 2) {
         const long total = (long)((K + WN_CH - 1) / WN_CH) * 3 * WN_CH * NPad;
         for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += step) pack_wino2_one(j.w, j.wp, j.Cin, j.Cout, NPad, j.dgrad, e);
+    } else if (j.kind == 3) {
+        // the bf16-operand kernels' layout (conv3d_bf16.hip pack_weight_bf16_kernel): bf16 wp[k / 32][tap][n][k % 32]
+        uint16_t* wp16 = reinterpret_cast<uint16_t*>(j.wp);
+        const long total = (long)((K + 31) / 32) * 27 * NPad * 32;
+        for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += step) {
+            const int kc = (int)(e % 32);
+            long r = e / 32;
+            const int n = (int)(r % NPad); r /= NPad;
+            const int tap = (int)(r % 27);
+            const int k = (int)(r / 27) * 32 + kc;
+            float val = 0.f;
+            if (k < K && n < N) val = j.dgrad ? j.w[((long)k * j.Cin + n) * 27 + (26 - tap)] : j.w[((long)n * j.Cin + k) * 27 + tap];
+            wp16[e] = __builtin_bit_cast(uint16_t, (__bf16)val);
+        }
     } else {
         // the direct kernel's layout (conv3d.hip pack_weight_kernel): wp[k / CH][tap][k % CH][n]
         const int CH = direct_ch(K);
@@ -1023,7 +1037,7 @@ PULPO_API int pulpo_conv3d_k3_pack_weight_wino2(const float* w, float* wp, int C
     return pulpo::check_launch("pack_weight_wino2");
 }
 
-// jobs: DEVICE array; kind 0 = the layout of pulpo_conv3d_k3_pack_weight, 2 = of pulpo_conv3d_k3_pack_weight_wino2
+// jobs: DEVICE array; kind 0 = the layout of pulpo_conv3d_k3_pack_weight, 2 = of pulpo_conv3d_k3_pack_weight_wino2, 3 = of pulpo_conv3d_k3_pack_weight_bf16
 PULPO_API int pulpo_conv3d_k3_pack_weights_multi(const PulpoPackJob* jobs, int njobs, void* stream) {
     PULPO_REQUIRE(jobs && njobs > 0, "conv3d_k3_pack_weights_multi: bad arguments");
     hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(32, njobs), dim3(256), 0, (hipStream_t)stream, jobs);

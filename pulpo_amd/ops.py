@@ -288,7 +288,10 @@ def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None) -> torch.Tensor:
         wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_bf16_elems", K, N), device=w.device, dtype=torch.int16)
         lib.call("pulpo_conv3d_k3_pack_weight_bf16", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
         wp._pulpo_algo = "bf16"
-        _UNREFRESHABLE_PACKS = True
+        if w.is_contiguous():
+            _PACK_REGISTRY[(id(w), dgrad, 3, None)] = (w, wp, Cin, Cout, dgrad, 3)
+        else:
+            _UNREFRESHABLE_PACKS = True
         return wp
     algo = lib.query("pulpo_conv3d_k3_algo", *shape, K, N) if shape is not None else 0
     shape_key = (None if shape is None else tuple(shape), CONV_ALGO)

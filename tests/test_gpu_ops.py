@@ -339,6 +339,17 @@ def test_packed_weight_cache_follows_weight_updates(ops):
     y2 = ops.conv3d_k3(x, p)
     ref = F.conv3d(x.cpu().double(), p.cpu().double(), padding=1)
     assert rel_l2(y2, ref) < 2e-6 and rel_l2(y1, ref) > 1e-2
+    # the same through the bf16-operand packs (rewritten in place by the same launch)
+    ops.set_conv_precision("bf16")
+    try:
+        q = w.clone()
+        z1 = ops.conv3d_k3(x, q)
+        ops.adam_step(q.view(-1), torch.ones_like(q).view(-1), torch.zeros_like(q).view(-1), torch.zeros_like(q).view(-1), lr=0.1, step=1)
+        z2 = ops.conv3d_k3(x, q)
+        refq = F.conv3d(x.cpu().double(), q.cpu().double(), padding=1)
+        assert rel_l2(z2, refq) < 1e-2 and rel_l2(z1, refq) > 1e-1
+    finally:
+        ops.set_conv_precision("fp32")
 
 
 @pytest.mark.parametrize("chans,size", [((16, 32, 64, 32), (24, 32, 40)), ((32, 32, 32), (32, 32, 32)), ((8, 96, 96), (20, 24, 24))])
