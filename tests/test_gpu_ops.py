@@ -479,6 +479,31 @@ def test_batchnorm_applied_while_the_next_convolution_stages_its_operand(ops, ch
         assert torch.equal(st1[k], st0[k]), k
 
 
+def test_alternative_kernel_builds_behind_environment_switches():
+    """kernel variants that are chosen once per process from the environment (the four-wave weight-gradient kernel, the tile queues of the
+    persistent Winograd kernel) stay parity-checked: a child process per setting runs one forward / data-gradient / weight-gradient
+    comparison against float64"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, torch.nn.functional as F\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from pulpo_amd import ops\n"
+        "g = torch.Generator().manual_seed(7)\n"
+        "x = torch.randn(1, 32, 24, 32, 40, generator=g); w = torch.randn(64, 32, 3, 3, 3, generator=g) / 30; up = torch.randn(1, 64, 24, 32, 40, generator=g)\n"
+        "xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)\n"
+        "ref = F.conv3d(xr, wr, padding=1); gr = torch.autograd.grad((ref * up.double()).sum(), [xr, wr])\n"
+        "xd = x.cuda().contiguous(memory_format=torch.channels_last_3d).requires_grad_(True); wd = w.cuda().requires_grad_(True)\n"
+        "out = ops.conv3d_k3(xd, wd); gx, gw = torch.autograd.grad((out * up.cuda().contiguous(memory_format=torch.channels_last_3d)).sum(), [xd, wd])\n"
+        "rel = lambda a, b: float((a.detach().cpu().double() - b).norm() / b.norm())\n"
+        "print('REL', rel(out, ref.detach()), rel(gx, gr[0]), rel(gw, gr[1]))\n")
+    for env in ({"PULPO_WGRAD_WAVES8": "0"}, {"PULPO_CONV_DYNAMIC": "1"}, {"PULPO_CONV_DYNAMIC": "2"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (env, r.stderr[-2000:])
+        vals = [float(v) for v in r.stdout.split("REL")[1].split()]
+        assert vals[0] < 2e-6 and vals[1] < 2e-6 and vals[2] < 1e-5, (env, vals)
+
+
 def test_conv_linearity_at_full_channel_width(ops):
     """size-independent property at a BASELINE layer shape (32->32 @ 48^3): conv(a*x1 + x2) = a*conv(x1) + conv(x2) (no bias)"""
     gen = torch.Generator().manual_seed(3)
