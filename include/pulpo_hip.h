@@ -70,6 +70,10 @@ int pulpo_conv3d_k3_pack_weight_wino2(const float* w /*[Cout][Cin][3][3][3]*/, f
 int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
                               float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W,
                               int K, int N, void* stream);
+/* 1 when the _wino2 entry points run the pipelined kernel (conv3d_wino2p.hip: double-buffered halo images, weights global -> registers) for a
+ * channels-last 16-byte-aligned operand: K % 8 == 0 and D*H*W*in_ps*4 < 2^31.  Otherwise (and with PULPO_W2_PIPE=0) the round-2 kernel runs.
+ * Same results either way (network_blocks.py:23). */
+int pulpo_conv3d_k3_wino2_pipelined(int D, int H, int W, int K, int64_t in_ps);
 /* Forward convolution of a ConvUnit fed by the ConvUnit in front of it (src/network_blocks.py:32-46, ConvSequence), reading that unit's
  * PRE-NORM tensor y_in (channels-last, 16-byte aligned) instead of its output z: BatchNorm + LeakyReLU (in_coef = the producing unit's
  * coefficient block of pulpo_bn_fwd_finalize) are applied to the operand as it is staged and z is written to zout (same strides as y_in)

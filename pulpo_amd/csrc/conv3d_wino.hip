@@ -1091,6 +1091,20 @@ static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t
                           int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream,
                           const float* in_coef = nullptr, float* zout = nullptr);
 
+static int wino2_pipe_enabled() {                      // PULPO_W2_PIPE=0 keeps the round-2 kernel for every operand (A/B switch)
+    static int pipe = -1;
+    if (pipe < 0) { const char* e = getenv("PULPO_W2_PIPE"); pipe = e ? atoi(e) : 1; }
+    return pipe;
+}
+
+// 1 when pulpo_conv3d_k3_fwd_wino2 / _dgrad_wino2_bnred run the pipelined kernel (conv3d_k3_wino2p_mfma) for a channels-last, 16-byte
+// aligned operand of K channels with voxel stride in_ps: K a multiple of 8 and the volume below 2^31 bytes.  (Names the kernel in traces.)
+PULPO_API int pulpo_conv3d_k3_wino2_pipelined(int D, int H, int W, int K, int64_t in_ps) {
+    ConvArgs a{};
+    a.D = D; a.H = H; a.W = W; a.Cin = K; a.in_ps = in_ps;
+    return wino2_pipe_enabled() && wino2p_ok(a);
+}
+
 PULPO_API int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
                                         const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats,
                                         int B, int D, int H, int W, int K, int N, void* stream) {
@@ -1171,13 +1185,17 @@ static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t
     PULPO_REQUIRE(nblk_l < (1L << 31), "conv3d_k3_fwd_wino2: grid too large");
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
+    // channels-last operands without the operand-side BatchNorm: the pipelined kernel (conv3d_wino2p.hip); PULPO_W2_PIPE=0 keeps the round-2 kernel
+    const int pipe = wino2_pipe_enabled();
     if (bn_y != nullptr) {
         PULPO_REQUIRE(vec, "conv3d_k3_dgrad_wino2_bnred: the gradient operand must be channels-last, 16-byte aligned, with a multiple of 4 channels");
+        if (pipe && wino2p_ok(a)) return launch_wino2p(a, (int)nblk_l, true, st);
         return launch_wino2<true, true>(a, (int)nblk_l, st);
     }
     if (in_coef != nullptr) {
         PULPO_REQUIRE(vec, "conv3d_k3_fwd_wino2_prenorm: the operand must be channels-last, 16-byte aligned, with a multiple of 4 channels");
         return launch_wino2<true, false, true>(a, (int)nblk_l, st);
     }
+    if (vec && pipe && wino2p_ok(a)) return launch_wino2p(a, (int)nblk_l, false, st);
     return vec ? launch_wino2<true>(a, (int)nblk_l, st) : launch_wino2<false>(a, (int)nblk_l, st);
 }

@@ -27,6 +27,12 @@ int launch_unpack_wgrad(const float* packed, float* dw, int Cin, int Cout, int a
 int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, long go_bs, long go_ps, float* scratch, int B, int D, int H, int W,
                     int Cin, int Cout, hipStream_t st);
 
+// forward / data gradient, pipelined F(2x2,3x3) kernel (conv3d_wino2p.hip): channels-last 16-byte-aligned operands, K % 4 == 0; bnr = with the
+// BatchNorm-backward sums of the unit in front in the epilogue (ConvArgs::bn_y)
+struct ConvArgs;
+int launch_wino2p(const ConvArgs& a, int nblk, bool bnr, hipStream_t st);
+bool wino2p_ok(const ConvArgs& a);                 // Cin % 8 == 0 and 32-bit halo offsets
+
 // ---- shared by the direct (conv3d.hip), Winograd (conv3d_wino.hip) and weight-gradient (conv3d_wgrad.hip) translation units
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 

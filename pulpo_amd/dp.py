@@ -126,20 +126,26 @@ class FusedAdam:
             order = [index_of[n] for n in a.module_names]           # checkpoint index of our i-th parameter
         else:
             order = list(range(len(a.module_order)))
+        # first pass: validate every entry (shapes, one shared step count) - a checkpoint that fails leaves the optimizer untouched
         steps = set()
-        self.m.zero_()
-        self.v.zero_()
+        todo = []
         for i, p in enumerate(a.module_order):
             st = sd["state"].get(group["params"][order[i]])
             if st is None:                    # torch creates state lazily: a parameter that never received a gradient has none
                 continue
-            for key, dst in (("exp_avg", self.m), ("exp_avg_sq", self.v)):
+            for key in ("exp_avg", "exp_avg_sq"):
                 if tuple(st[key].shape) != tuple(p.shape):
                     raise ValueError(f"FusedAdam: {key} of '{a.module_names[i]}' has shape {tuple(st[key].shape)}, parameter {tuple(p.shape)}")
-                dst[slot[id(p)]:slot[id(p)] + p.numel()].view_as(p).copy_(st[key])
             steps.add(int(float(st["step"])))
+            todo.append((p, st))
         if len(steps) > 1:
             raise ValueError(f"FusedAdam: per-parameter step counts differ ({sorted(steps)}); one shared step count is assumed")
+        # second pass: commit
+        self.m.zero_()
+        self.v.zero_()
+        for p, st in todo:
+            for key, dst in (("exp_avg", self.m), ("exp_avg_sq", self.v)):
+                dst[slot[id(p)]:slot[id(p)] + p.numel()].view_as(p).copy_(st[key])
         self.t = steps.pop() if steps else 0
         self.lr, self.betas, self.eps = float(group["lr"]), tuple(group["betas"]), float(group["eps"])
 

@@ -218,11 +218,24 @@ def invalidate_weight_packs() -> None:
     _PACK_REGISTRY.clear()
 
 
-# (weight, orientation, kernel family, ...) -> (weight, packed buffer, Cin, Cout, dgrad, kind) of every live fp32 pack that
-# pulpo_conv3d_k3_pack_weights_multi can rewrite in place; a pack of another family (bf16, Winograd-x) makes the set unrefreshable
+# id(packed buffer) -> (weakref to the weight, packed buffer, Cin, Cout, dgrad, kind) of every live pack of a LEAF weight that
+# pulpo_conv3d_k3_pack_weights_multi can rewrite in place (kinds 0, 2, 3); a pack of another family (Winograd-x) makes the set
+# unrefreshable.  Keyed by the pack itself, so every pack of a weight (both orientations, several volume shapes, both precisions) has its
+# own entry; the weight is held weakly, so a discarded model's packs go with it (dead entries are pruned as new ones arrive).
 _PACK_REGISTRY: dict = {}
 _PACK_TABLES: dict = {}
 _UNREFRESHABLE_PACKS = False
+_registrations = 0
+
+
+def _register_pack(w: torch.Tensor, wp: torch.Tensor, Cin: int, Cout: int, dgrad: bool, kind: int) -> None:
+    global _registrations
+    import weakref
+    _PACK_REGISTRY[id(wp)] = (weakref.ref(w), wp, Cin, Cout, dgrad, kind)
+    _registrations += 1
+    if _registrations % 64 == 0:
+        for k in [k for k, e in _PACK_REGISTRY.items() if e[0]() is None]:
+            del _PACK_REGISTRY[k]
 
 
 def refresh_weight_packs() -> None:
@@ -235,12 +248,15 @@ def refresh_weight_packs() -> None:
         invalidate_weight_packs()
         return
     jobs = []
-    for key, (w, wp, Cin, Cout, dgrad, kind) in list(_PACK_REGISTRY.items()):
-        cache = getattr(w, "_pulpo_packs", None)
+    device = None
+    for key, (wref, wp, Cin, Cout, dgrad, kind) in list(_PACK_REGISTRY.items()):
+        w = wref()
+        cache = getattr(w, "_pulpo_packs", None) if w is not None else None
         if cache is None or cache[0] != (w._version, w.data_ptr(), _WEIGHT_EPOCH) or not any(v is wp for v in cache[1].values()):
-            del _PACK_REGISTRY[key]                  # superseded (weight replaced or modified through torch): the next use packs afresh
+            del _PACK_REGISTRY[key]                  # superseded (weight gone, replaced or modified through torch): the next use packs afresh
             continue
         jobs.append((w.data_ptr(), wp.data_ptr(), Cin, Cout, int(dgrad), kind))
+        device = w.device
     if not jobs:
         invalidate_weight_packs()
         return
@@ -249,7 +265,7 @@ def refresh_weight_packs() -> None:
     if table is None:
         import struct
         raw = b"".join(struct.pack("<QQiiii", *job) for job in tkey)
-        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(next(iter(_PACK_REGISTRY.values()))[0].device)
+        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         if len(_PACK_TABLES) > 4:
             _PACK_TABLES.clear()
         _PACK_TABLES[tkey] = table
@@ -260,6 +276,10 @@ def _pack_weight(w: torch.Tensor, dgrad: bool, shape=None, both: bool = False) -
     """cached front end of _pack_weight_now: a weight is packed once per (version, orientation, kernel family, precision); `both` = also
     produce the other orientation now (training forward: the data-gradient kernel of the backward pass finds its weights ready, and a
     repeated forward - Monte-Carlo sampling, evaluation loops - packs nothing at all)"""
+    if not w.is_leaf:
+        # a temporary (the 2-D mode's lifted 3x3 weight, a view, a re-parametrisation): packed per call - a cache on it would die with it,
+        # and one that outlived it (the refresh registry) would pin it and every pack made from it
+        return _pack_weight_now(w, dgrad, shape, register=False)
     cache = getattr(w, "_pulpo_packs", None)
     ver = (w._version, w.data_ptr(), _WEIGHT_EPOCH)
     if cache is None or cache[0] != ver:
@@ -267,7 +287,7 @@ def _pack_weight(w: torch.Tensor, dgrad: bool, shape=None, both: bool = False) -
         try:
             w._pulpo_packs = cache
         except AttributeError:                       # (non-leaf views cannot carry attributes on some builds: pack uncached)
-            return _pack_weight_now(w, dgrad, shape)
+            return _pack_weight_now(w, dgrad, shape, register=False)
     def key(d):
         return (d, CONV_PRECISION, CONV_ALGO, None if shape is None else tuple(shape))
     if both and key(not dgrad) not in cache[1]:
@@ -277,7 +297,7 @@ def _pack_weight(w: torch.Tensor, dgrad: bool, shape=None, both: bool = False) -
     return cache[1][key(dgrad)]
 
 
-def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None) -> torch.Tensor:
+def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None, register: bool = True) -> torch.Tensor:
     """GEMM-ordered copy of a (Cout, Cin, 3, 3, 3) weight for the forward (dgrad=False) or data-gradient (True) convolution.
     shape = (B, D, H, W) of the volume it will be applied to: large volumes use the Winograd-x kernel, which has its own packing
     (the returned tensor carries the choice in `_pulpo_algo`)."""
@@ -288,13 +308,13 @@ def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None) -> torch.Tensor:
         wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_bf16_elems", K, N), device=w.device, dtype=torch.int16)
         lib.call("pulpo_conv3d_k3_pack_weight_bf16", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
         wp._pulpo_algo = "bf16"
-        if w.is_contiguous():
-            _PACK_REGISTRY[(id(w), dgrad, 3, None)] = (w, wp, Cin, Cout, dgrad, 3)
-        else:
-            _UNREFRESHABLE_PACKS = True
+        if register:
+            if w.is_contiguous():
+                _register_pack(w, wp, Cin, Cout, dgrad, 3)
+            else:
+                _UNREFRESHABLE_PACKS = True
         return wp
     algo = lib.query("pulpo_conv3d_k3_algo", *shape, K, N) if shape is not None else 0
-    shape_key = (None if shape is None else tuple(shape), CONV_ALGO)
     if CONV_ALGO is not None and algo != 0:            # diagnostic override; only among the kernels valid for this shape
         algo = {"direct": 0, "wino": 1, "wino2": 2}[CONV_ALGO]
     if algo in (1, 2):
@@ -302,18 +322,20 @@ def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None) -> torch.Tensor:
         wp = torch.empty(lib.query(f"pulpo_conv3d_k3_packed_{name}_floats", K, N), device=w.device, dtype=torch.float32)
         lib.call(f"pulpo_conv3d_k3_pack_weight_{name}", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
         wp._pulpo_algo = name
-        if algo == 2 and w.is_contiguous():
-            _PACK_REGISTRY[(id(w), dgrad, 2, shape_key)] = (w, wp, Cin, Cout, dgrad, 2)
-        else:
-            _UNREFRESHABLE_PACKS = True
+        if register:
+            if algo == 2 and w.is_contiguous():
+                _register_pack(w, wp, Cin, Cout, dgrad, 2)
+            else:
+                _UNREFRESHABLE_PACKS = True
         return wp
     wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_floats", K, N), device=w.device, dtype=torch.float32)
     lib.call("pulpo_conv3d_k3_pack_weight", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
     wp._pulpo_algo = "direct"
-    if w.is_contiguous():
-        _PACK_REGISTRY[(id(w), dgrad, 0, shape_key)] = (w, wp, Cin, Cout, dgrad, 0)
-    else:
-        _UNREFRESHABLE_PACKS = True
+    if register:
+        if w.is_contiguous():
+            _register_pack(w, wp, Cin, Cout, dgrad, 0)
+        else:
+            _UNREFRESHABLE_PACKS = True
     return wp
 
 
@@ -354,7 +376,10 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
         lib.call(f"pulpo_conv3d_k3_fwd_{algo}", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc, _ptr(stats),
                  B, D, H, W, K, N, _stream())
         tmpl = f"<32,{'true' if vec_ok else 'false'}>" if algo == "wino" else f"<{'true' if vec_ok else 'false'}>"
-        _trace_end(t0, f"conv3d_k3_{algo}_mfma{tmpl}", 54.0 * K * N * B * D * H * W, 4.0 * (K + N) * B * D * H * W)
+        kname = f"conv3d_k3_{algo}_mfma{tmpl}"
+        if algo == "wino2" and vec_ok and t0 is not None and lib.query("pulpo_conv3d_k3_wino2_pipelined", D, H, W, K, xp):
+            kname = "conv3d_k3_wino2p_mfma<false>"
+        _trace_end(t0, kname, 54.0 * K * N * B * D * H * W, 4.0 * (K + N) * B * D * H * W)
         return
     sfx = "_bf16" if bf16 else ""
     nscr = lib.query(f"pulpo_conv3d_k3_fwd{sfx}_scratch_floats", B, D, H, W, K, N)
@@ -390,6 +415,12 @@ def _persistent_buffer(owner: torch.Tensor, name: str, numel: int, zero: bool) -
         buf = (torch.zeros if zero else torch.empty)(numel, device=owner.device, dtype=torch.float32)
         setattr(owner, name, buf)
     return buf
+
+
+def _pending_src(buf: torch.Tensor) -> bool:
+    """is this persistent buffer already the source of a deferred job of the current step?"""
+    p_ = buf.data_ptr()
+    return any(job[0] == p_ for job in _PENDING_GRAD_JOBS)
 
 
 def flush_param_grads() -> None:
@@ -437,7 +468,9 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
     sfx = "_bf16" if _use_bf16(Cin) else ""
     lib.call(f"pulpo_conv3d_k3_wgrad{sfx}", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), 2 if deferred else int(into is not None), _ptr(scratch),
              B, D, H, W, Cin, Cout, _stream())
-    if deferred:
+    if deferred and not _pending_src(scratch):
+        # (ONE finishing job per scratch: a unit applied twice in a step - shared weights, two forward passes - has accumulated both weight
+        #  gradients into the same packed sums by the time the job runs)
         _PENDING_GRAD_JOBS.append((scratch.data_ptr(), dw.data_ptr(), 0, Cin, Cout, (Cout + 63) // 64 * 64))
         _PENDING_KEEPALIVE.append(scratch)
     if t0 is not None:
@@ -502,16 +535,21 @@ def _dgrad_with_bn_reduction(bn_src, x, dy, wpt, dx, K: int, N: int) -> bool:
     db, dp, dc = grid_strides(dy)
     ob, op, oc = grid_strides(dx)
     yb, yp, yc = grid_strides(y_prev)
-    if (y_prev.shape != dx.shape or oc != 1 or yc != 1 or op % 4 or ob % 4 or yp % 4 or yb % 4 or dx.data_ptr() % 16 or y_prev.data_ptr() % 16
-            or not lib.query("pulpo_conv3d_k3_dgrad_wino2_bnred_ok", B, D, H, W, K, N)):
+    # (the C entry point also needs the gradient operand vectorisable: channels-last, 16-byte aligned, K % 4 == 0 - checked here so that a
+    #  consumer unit with an odd channel count falls back to the separate reduction pass instead of raising in the middle of backward)
+    vec_ok = dc == 1 and dp % 4 == 0 and db % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0
+    if (not vec_ok or y_prev.shape != dx.shape or oc != 1 or yc != 1 or op % 4 or ob % 4 or yp % 4 or yb % 4 or dx.data_ptr() % 16
+            or y_prev.data_ptr() % 16 or not lib.query("pulpo_conv3d_k3_dgrad_wino2_bnred_ok", B, D, H, W, K, N)):
         return False
     ntile = lib.query("pulpo_conv3d_k3_stat_tiles", B, D, H, W)
     part = torch.empty(ntile * 2 * N, device=dy.device, dtype=torch.float32)
     t0 = _trace_begin()
     lib.call("pulpo_conv3d_k3_dgrad_wino2_bnred", _ptr(dy), db, dp, dc, _ptr(wpt), _ptr(dx), ob, op, _ptr(y_prev), yb, yp, _ptr(coef_prev), LRELU_SLOPE,
              _ptr(part), B, D, H, W, K, N, _stream())
-    vec_ok = dc == 1 and dp % 4 == 0 and db % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0
-    _trace_end(t0, f"conv3d_k3_wino2_mfma<{'true' if vec_ok else 'false'}>", 54.0 * K * N * B * D * H * W, 4.0 * (K + 2 * N) * B * D * H * W)
+    kname = "conv3d_k3_wino2_mfma<true>"
+    if t0 is not None and lib.query("pulpo_conv3d_k3_wino2_pipelined", D, H, W, K, dp):
+        kname = "conv3d_k3_wino2p_mfma<true>"
+    _trace_end(t0, kname, 54.0 * K * N * B * D * H * W, 4.0 * (K + 2 * N) * B * D * H * W)
     _BN_TILE_PARTS[y_prev.data_ptr()] = (part, ntile, coef_prev.data_ptr(), dx.data_ptr(), dx._version, tuple(dx.shape), tuple(dx.stride()))
     return True
 
@@ -610,7 +648,11 @@ class _ConvBNLReLU(torch.autograd.Function):
         lib.call("pulpo_bn_bwd_finalize", _ptr(rows), nrow, Cout, _ptr(coef), float(npix), int(ctx.training), *fin_out, _ptr(scratch), _stream())
         dy = new_cl(B, Cout, D, H, W, dev)
         defer_b = DIRECT_PARAM_GRADS and ctx.needs_input_grad[2] and slot_b is not None
-        part2 = _persistent_buffer(b_p, "_pulpo_dbias_part", nblk * Cout, zero=False) if defer_b else torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
+        part2 = _persistent_buffer(b_p, "_pulpo_dbias_part", nblk * Cout, zero=False) if defer_b else None
+        if defer_b and _pending_src(part2):          # this unit has already run a backward pass in this step: its partials are still waiting
+            defer_b = False                          # for flush_param_grads() - this pass takes the immediate path into the same slot
+        if not defer_b:
+            part2 = torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
         t0 = _hbm_begin()
         lib.call("pulpo_bn_lrelu_bwd_apply", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4), npix, Cout,
                  LRELU_SLOPE, _ptr(part2), _stream())

@@ -28,15 +28,32 @@ VARIANTS = {
     "w2_nostage": ("conv3d_wgrad_w2", 22, {}, ["--only", "wgrad", "--shapes", "0", "3", "8"]),
     "w2_noloads": ("conv3d_wgrad_w2", 23, {}, ["--only", "wgrad", "--shapes", "0", "3", "8"]),
     "w2_nobarrier": ("conv3d_wgrad_w2", 24, {}, ["--only", "wgrad", "--shapes", "0", "3", "8"]),
+    # pipelined (y, x) forward / data-gradient kernel (conv3d_wino2p.hip): PULPO_ABL is a bit mask there
+    "p_base": ("conv3d_wino2p", 0, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "p_noepi": ("conv3d_wino2p", 1, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "p_nostage": ("conv3d_wino2p", 2, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "p_noweights": ("conv3d_wino2p", 4, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "p_nobarrier": ("conv3d_wino2p", 8, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "p_nomfma": ("conv3d_wino2p", 16, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "p_bare": ("conv3d_wino2p", 1 + 2 + 4 + 8, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "p_bare_noreads": ("conv3d_wino2p", 1 + 2 + 4 + 8 + 32, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "p_stamps": ("conv3d_wino2p", 64, {}, None),
+    "p_stamps_nostore": ("conv3d_wino2p", 64 + 128, {}, None),
+    "p_nostore": ("conv3d_wino2p", 128, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "q_stag25": ("conv3d_wino2p", 0, {"PULPO_W2P_STAGGER": "25"}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "q_stag50": ("conv3d_wino2p", 0, {"PULPO_W2P_STAGGER": "50"}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "q_stag75": ("conv3d_wino2p", 0, {"PULPO_W2P_STAGGER": "75"}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
 
 }
 
 
-def build():
+def build(only=()):
     build_library()
     os.makedirs(ABL, exist_ok=True)
     done = {}
     for name, (unit, val, _, _) in VARIANTS.items():
+        if only and not any(name.startswith(o) for o in only):
+            continue
         key = (unit, val)
         if key not in done:
             obj = os.path.join(ABL, f"{unit}_abl{val}.o")
@@ -50,17 +67,18 @@ def build():
 
 
 def run(extra):
-    only = [a for a in extra if a in VARIANTS]
-    extra = [a for a in extra if a not in VARIANTS]
+    only = [a for a in extra if a in VARIANTS or a.endswith("*")]
+    extra = [a for a in extra if a not in only]
     for name, (unit, val, env, args) in VARIANTS.items():
-        if only and name not in only:
+        if only and not any(name == o or (o.endswith("*") and name.startswith(o[:-1])) for o in only):
             continue
         lib = os.path.join(ABL, f"lib_{unit}_abl{val}.so")
         e = dict(os.environ, PULPO_HIP_LIB=lib, **env)
         print(f"==== {name}  ({os.path.basename(lib)} {env})", flush=True)
-        if args is None:          # stamp build: scripts/stamps.py on three layer shapes
-            for shape in (["32", "32", "160"], ["96", "96", "80"], ["128", "128", "40"]):
-                subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "stamps.py")] + shape, env=e, check=False)
+        if args is None:          # stamp build: scripts/stamps.py (stamps2.py for the pipelined kernel) on three layer shapes
+            script = "stamps2.py" if unit == "conv3d_wino2p" else "stamps.py"
+            for shape in (["32", "32", "160"], ["96", "96", "80"], ["64", "64", "80"]):
+                subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)] + shape, env=e, check=False)
             continue
         subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "conv_bench.py")] + args + extra, env=e, check=False)
         sys.stdout.flush()
@@ -68,6 +86,6 @@ def run(extra):
 
 if __name__ == "__main__":
     if sys.argv[1] == "build":
-        build()
+        build(sys.argv[2:])
     else:
         run(sys.argv[2:])

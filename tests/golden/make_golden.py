@@ -6,11 +6,15 @@ travels to the GPU box, these .npz fixtures do.  Everything is seeded, fp32, CPU
 
 The reference modules that import cleanly here are used unmodified:
   src.network_blocks, src.components.pulpo, src.losses   
-src.models needs pytorch_lightning/torchvision, which the image lacks; we do NOT
-write stand-ins for them.  The training step is assembled from the component
-modules exactly as models.py:134-164 does (DownPath -> Autoencoder -> Prior ->
-three Hierarchical* losses -> beta*KL + recon + reg), with the loss-weight
-dictionaries of models.py:104-123 evaluated in this script.
+src.models needs pytorch_lightning/torchvision, which the image lacks.  The step
+fixtures assemble the training step from the component modules exactly as
+models.py:134-164 does (DownPath -> Autoencoder -> Prior -> three Hierarchical*
+losses -> beta*KL + recon + reg), with the loss-weight dictionaries of
+models.py:104-123 evaluated in this script.  The `models` mode (round 3) imports
+src/models.py ITSELF behind two plumbing-only stand-in modules (a LightningModule
+that is an nn.Module with save_hyperparameters / log_dict, no-op make_grid /
+flow_to_image - SURVEY Appendix B) and stores what the class's own methods return:
+models_api_{level,full}_res_*.npz.
 
 usage:  python tests/golden/make_golden.py   (writes next to itself)
 """
@@ -583,6 +587,124 @@ def gen_2d():
     t = gen_step("step2d_T3L2_n4_32x24", T=3, L=2, size=[32, 24], n0=4, B=2, seed=210)
     print("   total loss", t)
 
+# --------------------------------------------------------------------------- 15. the reference's own PULPo class (models.py), API level
+def _import_reference_models():
+    """import /root/reference/src/models.py itself.  It needs pytorch_lightning and torchvision, which this image lacks: two stand-in
+    modules are registered for the duration of the import - PLUMBING ONLY: a LightningModule that is an nn.Module
+    with save_hyperparameters / log_dict / log / a trainer handle, and no-op make_grid / flow_to_image.  No arithmetic of the path lives in
+    them; everything computed below is computed by the reference's own class."""
+    import inspect
+    import types
+
+    class _HParams(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    class LightningModule(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            self.logged = {}
+            self.trainer = types.SimpleNamespace(should_stop=False, num_val_batches=[1], global_step=0)
+
+        def save_hyperparameters(self):
+            frame = inspect.currentframe().f_back
+            info = inspect.getargvalues(frame)
+            self.hparams = _HParams({k: info.locals[k] for k in info.args if k != "self"})
+
+        def log_dict(self, d, **kw):
+            self.logged.update({k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in d.items()})
+
+        def log(self, k, v, **kw):
+            self.logged[k] = v
+
+    pl = types.ModuleType("pytorch_lightning")
+    pl.LightningModule = LightningModule
+    tv = types.ModuleType("torchvision")
+    tvu = types.ModuleType("torchvision.utils")
+    tvu.make_grid = lambda imgs, **kw: imgs
+    tvu.flow_to_image = lambda flow: flow
+    tv.utils = tvu
+    sys.modules.setdefault("pytorch_lightning", pl)
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.utils", tvu)
+    import src.models as rm
+    assert os.path.abspath(rm.__file__).startswith(REF), rm.__file__
+    return rm
+
+
+def gen_models_api(df_resolution, T=3, L=2, size=(16, 16, 16), n0=2, seed=170):
+    """The class the callers use (train.py:82-87, evaluate.py:190-273) driven through its own methods: training_step (recon_loss ncc + dice, so
+    that transform_segmentation runs inside it), predict_output_samples(N=2), predict(N=2), predict_deterministic, forward, combine_dfs,
+    transform_segmentation - models.py:134-196, 312-388.  Noise: every encoder's sampler replaced by mu + sigma * eps_l (the seam of
+    pulpo.py:231,261)."""
+    rm = _import_reference_models()
+    import contextlib
+    import io
+    torch.manual_seed(seed)
+    fb = ["samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = rm.PULPo(T, L, 0.1, list(size), feedback=fb, n0=n0, df_resolution=df_resolution, recon_loss=["ncc", "dice"], segs=True)
+    torch.autograd.set_detect_anomaly(False)
+    g = torch.Generator().manual_seed(seed + 1)
+    B = 2
+    y = smooth_volume(g, tuple(size), B)
+    x = 0.6 * smooth_volume(g, tuple(size), B) + 0.4 * y
+    seg_x = torch.softmax(4 * torch.cat([smooth_volume(g, tuple(size), B) for _ in range(3)], dim=1), dim=1)
+    seg_y = torch.softmax(4 * torch.cat([smooth_volume(g, tuple(size), B) for _ in range(3)], dim=1), dim=1)
+    o = T - L
+    eps = {l: torch.randn(B, 3, *[s // 2 ** (l + o) for s in size], generator=g) for l in range(L)}
+    def set_eps(nb_):              # the first nb_ batch rows of the noise (N = 2 samples of one pair use both rows, a single pair the first)
+        for l in range(L):
+            model.autoencoder.encoders[l].sampler = (lambda mu, sigma, e=eps[l][:nb_]: mu + sigma * e)
+    set_eps(2)
+    out = {"cfg": np.array([T, L, n0, B] + list(size), dtype=np.int64), "x": npy(x), "y": npy(y), "seg_x": npy(seg_x), "seg_y": npy(seg_y)}
+    out.update({f"eps.{l}": npy(e) for l, e in eps.items()})
+    out.update({"sd0." + k: npy(v) for k, v in model.state_dict().items() if not k.endswith(".grid")})
+    out["hparams.window_size"] = np.array([model.hierarchical_recon_loss.window_size[l] for l in range(L)], dtype=np.int64)
+    out["hparams.kl_w"] = np.array([model.hierarchical_kl_loss.weight_dict[l] for l in range(L)])
+    out["hparams.rec_w"] = np.array([model.hierarchical_recon_loss.weight_dict[l] for l in range(L)])
+    out["hparams.reg_w"] = np.array([model.hierarchical_regularization.weight_dict[l] for l in range(L)])
+
+    # ---- inference API, eval mode (evaluate.py:100 puts the model in eval mode): one pair, N = 2 samples -> the batch of 2 noise tensors
+    model.eval()
+    x1, y1, s1 = x[:1], y[:1], seg_x[:1]
+    with torch.no_grad():
+        outs_s, dfs_s = model.predict_output_samples(x1, y1, N=2)
+        avg_out, avg_dfs = model.predict(x1, y1, N=2)
+        comb, fin = model.combine_dfs(avg_dfs)
+        tseg = model.transform_segmentation(fin, s1)
+        set_eps(1)
+        det_out, det_dfs = model.predict_deterministic(x1, y1)
+        set_eps(2)
+        fwd = model.forward(x, y)
+    for l in range(L):
+        out[f"samples.outputs.{l}"] = npy(outs_s[l]); out[f"samples.individual_dfs.{l}"] = npy(dfs_s[l])
+        out[f"predict.outputs.{l}"] = npy(avg_out[l]); out[f"predict.avg_dfs.{l}"] = npy(avg_dfs[l])
+        out[f"combine.combined.{l}"] = npy(comb[l]); out[f"combine.final.{l}"] = npy(fin[l])
+        out[f"transform_segmentation.{l}"] = npy(tseg[l])
+        out[f"deterministic.outputs.{l}"] = npy(det_out[l]); out[f"deterministic.individual_dfs.{l}"] = npy(det_dfs[l])
+    out["forward"] = npy(fwd)
+
+    # ---- training_step (train mode; the batch is the 8-tuple of the reference's datasets)
+    model.train()
+    total = model.training_step((x, y, seg_x, seg_y, None, None, None, None), 0)
+    out["train.total"] = npy(total)
+    for k in ("kl_loss", "reconstruction_loss", "regularization_loss", "total_loss"):
+        out["train.logged." + k] = npy(model.logged["train/" + k])
+    for l in range(L):
+        for k in ("kl loss level", "recon loss level", "regularization loss level"):
+            out[f"train.logged.{k.replace(' ', '_')}.{l}"] = npy(model.logged[f"train_levels/{k} {l}"])
+    total.backward()
+    for k, p_ in model.named_parameters():
+        if p_.grad is not None:
+            out["grad." + k] = npy(p_.grad)
+    opt = model.configure_optimizers()
+    out["optimizer.lr"] = np.array(opt.param_groups[0]["lr"])
+    out["optimizer.betas"] = np.array(opt.param_groups[0]["betas"])
+    save(f"models_api_{df_resolution}_T{T}L{L}_n{n0}_16", **out)
+    return float(total)
+
+
 if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "2d":
@@ -590,6 +712,10 @@ if __name__ == "__main__":
         raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "evalmetrics":
         gen_evalmetrics()
+        raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "models":
+        for res in ("level_res", "full_res"):
+            print("   training_step loss", gen_models_api(res))
         raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dice":
         for res in ("full_res", "level_res"):

@@ -223,6 +223,84 @@ def test_dice_recon_with_segmentations_matches_reference_golden(api, golden, res
     assert n > 40
 
 
+@pytest.mark.parametrize("res", ["level_res", "full_res"])
+def test_pulpo_class_api_matches_the_reference_class(api, golden, res):
+    """The drop-in class against what the reference's OWN `src.models.PULPo` returns (tests/golden/models_api_*.npz: generated by
+    `make_golden.py models` from /root/reference/src/models.py itself): PULPo.__init__ tables, training_step incl. what it logs,
+    predict_output_samples(N=2), predict(N=2), predict_deterministic, forward, combine_dfs, transform_segmentation
+    (models.py:104-123, 134-196, 312-388), every parameter gradient of the step, configure_optimizers."""
+    models, nb = api
+    g = golden(f"models_api_{res}_T3L2_n2_16")
+    Tl, L, n0, B, *size = [int(v) for v in g["cfg"]]
+    model = models.PULPo(Tl, L, 0.1, size, feedback=FB, n0=n0, df_resolution=res, recon_loss=["ncc", "dice"], segs=True)
+    for l in range(L):
+        assert model.hierarchical_recon_loss.window_size[l] == int(g["hparams.window_size"][l])
+        assert model.hierarchical_kl_loss.weight_dict[l] == float(g["hparams.kl_w"][l])
+        assert model.hierarchical_recon_loss.weight_dict[l] == float(g["hparams.rec_w"][l])
+        assert model.hierarchical_regularization.weight_dict[l] == float(g["hparams.reg_w"][l])
+    opt = model.configure_optimizers()
+    assert isinstance(opt, torch.optim.Adam) and opt.param_groups[0]["lr"] == float(g["optimizer.lr"]) and tuple(opt.param_groups[0]["betas"]) == tuple(g["optimizer.betas"])
+    sd = model.state_dict()
+    for k, v in g.items():
+        if k.startswith("sd0."):
+            assert k[4:] in sd, k
+            sd[k[4:]] = T(v.copy())
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda()
+    eps = {l: T(g[f"eps.{l}"]).cuda() for l in range(L)}
+
+    def set_eps(nb_):
+        for l in range(L):
+            model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(eps[l][:nb_].contiguous())
+
+    x, y, seg_x, seg_y = (T(g[k]).cuda() for k in ("x", "y", "seg_x", "seg_y"))
+    x1, y1 = x[:1].contiguous(), y[:1].contiguous()
+    dev = lambda t: t.detach().cpu().numpy()
+    model.eval()
+    with torch.no_grad():
+        set_eps(2)
+        o_s, d_s = model.predict_output_samples(x1, y1, N=2)
+        avg_out, avg_dfs = model.predict(x1, y1, N=2)
+        comb, fin = model.combine_dfs(avg_dfs)
+        tseg = model.transform_segmentation(fin, seg_x[:1].contiguous())
+        for l in range(L):
+            for got, key in ((o_s[l], "samples.outputs"), (d_s[l], "samples.individual_dfs"), (avg_out[l], "predict.outputs"),
+                             (avg_dfs[l], "predict.avg_dfs"), (comb[l], "combine.combined"), (fin[l], "combine.final"),
+                             (tseg[l], "transform_segmentation")):
+                ref = g[f"{key}.{l}"]
+                assert tuple(got.shape) == ref.shape, (key, l, got.shape, ref.shape)
+                assert np.abs(dev(got) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (key, l)
+        set_eps(1)
+        det_out, det_dfs = model.predict_deterministic(x1, y1)
+        for l in range(L):
+            np.testing.assert_allclose(dev(det_out[l]), g[f"deterministic.outputs.{l}"], atol=1e-4)
+            np.testing.assert_allclose(dev(det_dfs[l]), g[f"deterministic.individual_dfs.{l}"], atol=1e-4)
+        set_eps(2)
+        np.testing.assert_allclose(dev(model(x, y)), g["forward"], atol=1e-4)
+    model.train()
+    model.logger = object()                    # somebody reads the per-level log entries: _log_levels computes them
+    total = model.training_step((x, y, seg_x, seg_y, None, None, None, None), 0)
+    np.testing.assert_allclose(float(total), float(g["train.total"]), rtol=1e-4)
+    for k in ("kl_loss", "reconstruction_loss", "regularization_loss", "total_loss"):
+        np.testing.assert_allclose(float(model.logged["train/" + k]), float(g["train.logged." + k]), rtol=1e-4)
+    for l in range(L):
+        for k in ("kl loss level", "recon loss level", "regularization loss level"):
+            np.testing.assert_allclose(float(model.logged[f"train_levels/{k} {l}"]), float(g[f"train.logged.{k.replace(' ', '_')}.{l}"]), rtol=1e-4, atol=1e-6)
+    total.backward()
+    n = 0
+    for k, p in model.named_parameters():
+        if "grad." + k not in g:
+            continue
+        ref = g["grad." + k]
+        if k.endswith("_op.0.bias") and "velocity_field._op.2" not in k:
+            wref = np.abs(g["grad." + k[:-4] + "weight"]).max()
+            assert np.abs(p.grad.cpu().numpy()).max() <= 1e-3 * max(wref, 1e-3), k
+            continue
+        assert rel_l2(p.grad, ref) < 2e-2, (k, rel_l2(p.grad, ref))      # (flip-aware bound of the golden step test)
+        n += 1
+    assert n > 40
+
+
 @pytest.mark.parametrize("case", STEP_CASES)
 def test_eval_deterministic_and_inference_api(api, golden, case):
     models, nb = api
@@ -569,9 +647,36 @@ def test_config4_160_bf16_oasis_step(api):
         ops.set_conv_precision("fp32")
 
 
+# per-parameter bound (relative L2) of the 160^3 step's gradients against the fp32 CPU oracle; see profiles/r3_parity_160.md for the measured
+# distribution it rests on
+GRAD_BOUND_160 = 2e-2
+
+
+def _write_parity_report(vs32, e_gpu, e_ref):
+    """the measured gradient distances of the 160^3 step, kept as a file (gpurun_out/parity_160.md; a builder run's copy is committed as
+    profiles/r3_parity_160.md): the evidence the bound above is set from"""
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        d = np.array([v for v, _ in vs32])
+        worst = sorted(vs32, reverse=True)[:8]
+        with open(os.path.join(out, "parity_160.md"), "w") as f:
+            f.write("# 160^3 / T5 / L4 / n0 32 training step: parameter gradients, GPU vs CPU oracle (test_headline_160_step_vs_cpu_oracle)\n\n")
+            f.write(f"{len(d)} parameters compared (conv biases in front of a BatchNorm excluded: true gradient zero).\n\n")
+            f.write("| relative L2 distance | median | p90 | p99 | max |\n|---|---|---|---|---|\n")
+            f.write(f"| GPU vs fp32 CPU oracle | {np.median(d):.2e} | {np.percentile(d, 90):.2e} | {np.percentile(d, 99):.2e} | {d.max():.2e} |\n")
+            f.write(f"| GPU vs fp64 oracle | {np.median(e_gpu):.2e} | {np.percentile(e_gpu, 90):.2e} | {np.percentile(e_gpu, 99):.2e} | {e_gpu.max():.2e} |\n")
+            f.write(f"| fp32 CPU oracle vs fp64 oracle | {np.median(e_ref):.2e} | {np.percentile(e_ref, 90):.2e} | {np.percentile(e_ref, 99):.2e} | {e_ref.max():.2e} |\n\n")
+            f.write("Largest GPU-vs-fp32 distances:\n\n" + "".join(f"* `{k}` {v:.2e}\n" for v, k in worst))
+            f.write(f"\nBound applied by the test: every parameter < {GRAD_BOUND_160:g} of the fp32 oracle; distance from fp64 distributed like the fp32 oracle's own.\n")
+    except OSError:
+        pass
+
+
 def test_headline_160_step_vs_cpu_oracle(api):
     """The metric's workload at FULL size (160^3, T5/L4, n0 = 32, B = 1), default kernel selection (F(2x2,3x3) Winograd forward / data
-    gradient, Winograd-x weight gradient), against ONE step of the CPU oracle in fp32 (the reference's arithmetic; ~11 s) and in fp64
+    gradient, F(2x2,3x3) weight gradient), against ONE step of the CPU oracle in fp32 (the reference's arithmetic; ~11 s) and in fp64
     (the ground truth for gradients; ~30 s): every output dictionary atol 1e-4 (scaled by the tensor's magnitude), loss terms rtol 1e-4.
     Gradients: at this size every fp32 evaluation flips LeakyReLU slopes against any other (~6e8 activations) and carries the
     summation noise of 4e6-voxel reductions (the reference's own fp32-vs-fp64 envelope grows with the volume), so the
@@ -608,7 +713,7 @@ def test_headline_160_step_vs_cpu_oracle(api):
     del outs_o, gpu_out
     sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     _, grads64, _ = O.train_step(O.clone_sd(sd64, requires_grad=True), cfg, x.double(), y.double(), {l: e.double() for l, e in eps.items()})
-    vs64 = []
+    vs64, vs32 = [], []
     for k, g in gpu_grad.items():
         gr = grads.get(k)
         if gr is None:
@@ -618,13 +723,83 @@ def test_headline_160_step_vs_cpu_oracle(api):
             wref = float(grads[k[:-4] + "weight"].abs().max())          # true gradient zero (a BatchNorm follows): noise on both sides
             assert float(g.abs().max()) <= 1e-2 * max(wref, 1e-3), k
             continue
-        assert rel_l2(g, gr) < 2e-2, (k, rel_l2(g, gr))
+        d32 = rel_l2(g, gr)
+        assert d32 < GRAD_BOUND_160, (k, d32)
+        vs32.append((d32, k))
         vs64.append((rel_l2(g, grads64[k]), rel_l2(gr, grads64[k])))
     assert len(vs64) > 100
     e_gpu, e_ref = np.array(vs64).T
     print(f"160^3 gradients vs fp64: gpu median {np.median(e_gpu):.2e} max {e_gpu.max():.2e}; cpu fp32 oracle median {np.median(e_ref):.2e} max {e_ref.max():.2e}")
+    _write_parity_report(vs32, e_gpu, e_ref)
     assert np.median(e_gpu) <= 4.0 * np.median(e_ref) + 2e-4, (np.median(e_gpu), np.median(e_ref))
     assert e_gpu.max() <= 6.0 * e_ref.max() + 1e-3, (e_gpu.max(), e_ref.max())
+
+
+def test_headline_160_stepper_equals_autograd(api):
+    """The path bench.py TIMES, at the metric's size (160^3, T5/L4, n0 = 32, B = 1): one `DataParallelStepper.step` with its default
+    switches - parameter gradients written straight into the arena (DIRECT_PARAM_GRADS), weight gradients on the side stream, BatchNorm
+    sums from the data-gradient epilogue, one grad_finish_multi launch, fused Adam, in-place re-pack of the cached weight packs - against the
+    plain autograd path that test_headline_160_step_vs_cpu_oracle holds to the oracle (loss.backward(), torch.optim.Adam, packs rebuilt
+    from the updated weights).  Same weights, inputs and noise on both sides: the step's loss is bit-equal (same forward kernels), every
+    parameter gradient agrees to 1e-5 relative L2 (float-atomic order is the only difference), and the loss of a SECOND step agrees to 1e-5
+    (covers fused Adam and the in-place pack refresh at the size where the stream hazards would show)."""
+    models, nb = api
+    from pulpo_amd import dp, ops
+    size = [160, 160, 160]
+    gen = torch.Generator().manual_seed(33)
+    x, y = torch.rand(1, 1, *size, generator=gen).cuda(), torch.rand(1, 1, *size, generator=gen).cuda()
+    eps = [torch.randn(1, 3, *[160 // 2 ** (l + 1)] * 3, generator=gen).cuda() for l in range(4)]
+    batch = (x, y, None, None, None, None, None, None)
+
+    def make():
+        torch.manual_seed(5)
+        m = models.PULPo(5, 4, 0.1, size, feedback=FB, n0=32).cuda().train()
+        for l in range(4):
+            m.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(eps[l])
+        return m
+
+    # ---- reference side: plain autograd + torch.optim.Adam
+    model = make()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    loss_a = model.training_step(batch, 0)
+    loss_a.backward()
+    grads_a = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    loss_a2 = model.training_step(batch, 0).detach()
+    bn_a = {k: v.detach().clone() for k, v in model.named_buffers() if "running" in k}
+    torch.cuda.synchronize()
+    l_a, l_a2 = float(loss_a), float(loss_a2)
+    del model, opt, loss_a, loss_a2
+    torch.cuda.empty_cache()
+
+    # ---- the timed path
+    model = make()
+    stepper = dp.DataParallelStepper(model, lr=1e-4)
+    assert stepper.async_wgrad and ops.BN_REDUCE_IN_DGRAD, "default switches"
+    l_b = float(stepper.step(batch))
+    grads_b = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    l_b2 = float(stepper.step(batch))
+    torch.cuda.synchronize()
+    assert l_b == l_a, (l_b, l_a)
+    worst = 0.0
+    for k, ga in grads_a.items():
+        if float(ga.abs().max()) == 0.0:
+            assert k not in grads_b or float(grads_b[k].abs().max()) == 0.0, k
+            continue
+        if k.endswith("_op.0.bias") and "velocity_field._op.2" not in k:
+            # conv bias in front of a BatchNorm: true gradient zero, both sides hold rounding noise of differently ordered sums
+            wmax = float(grads_a[k[:-4] + "weight"].abs().max())
+            assert float((grads_b[k] - ga).abs().max()) <= 1e-4 * max(wmax, 1e-6), k
+            continue
+        d = rel_l2(grads_b[k], ga)
+        worst = max(worst, d)
+        assert d < 1e-5, (k, d)
+    np.testing.assert_allclose(l_b2, l_a2, rtol=1e-5)
+    for k, v in model.named_buffers():
+        if "running" in k:
+            np.testing.assert_allclose(v.detach().cpu().numpy(), bn_a[k].cpu().numpy(), rtol=1e-5, atol=1e-7)
+    print(f"160^3 stepper vs autograd: worst gradient distance {worst:.2e}; losses {l_b} / {l_b2} vs {l_a} / {l_a2}")
 
 
 def test_headline_config_160_direct_and_winograd_kernels_agree(api):

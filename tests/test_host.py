@@ -190,6 +190,17 @@ def test_fused_adam_state_dict_is_torch_adam_layout_whatever_the_arena_order():
         FusedAdam(FlatArena(net())).load_state_dict(bad)
     with pytest.raises(ValueError):
         FusedAdam(FlatArena(net())).load_state_dict({"step": 1, "numel": 10})
+    # a checkpoint that fails validation part-way (a wrong shape in the LAST entry, differing step counts) leaves the optimizer as it was
+    opt_d = FusedAdam(FlatArena(net()), lr=7e-4)
+    opt_d.m.fill_(0.25); opt_d.v.fill_(0.5); opt_d.t = 9
+    bad_last = {"state": {i: dict(st) for i, st in sd["state"].items()}, "param_groups": sd["param_groups"]}
+    bad_last["state"][len(pa) - 1]["exp_avg_sq"] = torch.zeros(3)
+    bad_steps = {"state": {i: dict(st) for i, st in sd["state"].items()}, "param_groups": sd["param_groups"]}
+    bad_steps["state"][2]["step"] = torch.tensor(6.0)
+    for broken in (bad_last, bad_steps):
+        with pytest.raises(ValueError):
+            opt_d.load_state_dict(broken)
+        assert bool((opt_d.m == 0.25).all()) and bool((opt_d.v == 0.5).all()) and opt_d.t == 9 and opt_d.lr == 7e-4
 
 
 WORKER = r'''

@@ -341,3 +341,63 @@ def test_dice_step_with_segmentations(golden, res):
             assert np.abs(gr.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
             n += 1
     assert n > 40
+
+
+@pytest.mark.parametrize("res", ["level_res", "full_res"])
+def test_models_py_class_api_fixture(golden, res):
+    """tests/golden/models_api_*: what the reference's OWN `src.models.PULPo` returns from training_step, predict_output_samples(N=2),
+    predict(N=2), predict_deterministic, forward, combine_dfs and transform_segmentation (models.py:134-196, 312-388; generated by
+    `make_golden.py models`, which imports models.py behind plumbing-only Lightning / torchvision stand-ins).  The oracle's restatement of
+    that layer - weight tables, loss assembly, inference helpers - is held to it here."""
+    g = golden(f"models_api_{res}_T3L2_n2_16")
+    Tl, L, n0, B, *size = [int(v) for v in g["cfg"]]
+    cfg = O.Cfg(Tl, L, size, n0=n0, df_resolution=res)
+    win, kl_w, rec_w, reg_w = O.weight_tables(cfg)
+    for l in range(L):                                   # PULPo.__init__'s tables, read off the real instance (models.py:104-123)
+        assert win[l] == int(g["hparams.window_size"][l])
+        assert kl_w[l] == float(g["hparams.kl_w"][l]) and rec_w[l] == float(g["hparams.rec_w"][l]) and reg_w[l] == float(g["hparams.reg_w"][l])
+    assert float(g["optimizer.lr"]) == 1e-4 and tuple(g["optimizer.betas"]) == (0.9, 0.999)
+    sd = O.init_state_dict(cfg)
+    for k, v in g.items():
+        if k.startswith("sd0."):
+            assert k[4:] in sd, k
+            sd[k[4:]] = T(v.copy())
+    eps = {l: T(g[f"eps.{l}"]) for l in range(L)}
+    x, y, seg_x, seg_y = (T(g[k]) for k in ("x", "y", "seg_x", "seg_y"))
+    x1, y1 = x[:1], y[:1]
+    with torch.no_grad():
+        # predict_output_samples(x1, y1, N=2): the pair stacked twice on the batch axis, one noise row per copy (models.py:312-322)
+        outs = O.forward(sd, cfg, torch.cat([x1, x1]), torch.cat([y1, y1]), eps, training=False)
+        for l in range(L):
+            close(outs[7][l].view(2, 1, *outs[7][l].shape[1:]).transpose(0, 1), g[f"samples.outputs.{l}"], atol=1e-5)
+            close(outs[4][l].view(2, 1, *outs[4][l].shape[1:]).transpose(0, 1), g[f"samples.individual_dfs.{l}"], atol=1e-5)
+        # predict: average over N, combine, integrate, warp the FULL-resolution moving image on every level (models.py:324-332)
+        avg = {l: outs[4][l].view(2, 1, *outs[4][l].shape[1:]).transpose(0, 1).mean(dim=1) for l in range(L)}
+        comb, fin = O.combine_dfs(avg, cfg)
+        for l in range(L):
+            close(avg[l], g[f"predict.avg_dfs.{l}"], atol=1e-5)
+            close(comb[l], g[f"combine.combined.{l}"], atol=1e-5)
+            close(fin[l], g[f"combine.final.{l}"], atol=1e-5)
+            close(O.warp(fin[l], x1), g[f"predict.outputs.{l}"], atol=1e-5)
+        tseg = O.transform_segmentation(sd, cfg, fin, seg_x[:1])
+        for l in range(L):
+            close(tseg[l], g[f"transform_segmentation.{l}"], atol=1e-5)
+        det = O.forward(sd, cfg, x1, y1, {l: e[:1] for l, e in eps.items()}, training=False, deterministic=True)
+        for l in range(L):
+            close(det[7][l], g[f"deterministic.outputs.{l}"], atol=1e-5)
+            close(det[4][l], g[f"deterministic.individual_dfs.{l}"], atol=1e-5)
+        close(O.forward(sd, cfg, x, y, eps, training=False)[7][0], g["forward"], atol=1e-5)
+    # training_step (train mode, recon_loss ncc + dice)
+    sdg = O.clone_sd(sd, requires_grad=True)
+    outs = O.forward(sdg, cfg, x, y, eps, training=True)
+    segs = O.transform_segmentation(sdg, cfg, outs[6], seg_x)
+    _, kl, _, reg, kl_l, _, reg_l = O.losses(outs, y, cfg)
+    rec, rec_l = O.recon_ncc_dice(outs, y, segs, seg_y, cfg)
+    total = kl + rec + reg
+    close(total, g["train.total"], rtol=2e-6)
+    for key, val in (("kl_loss", kl), ("reconstruction_loss", rec), ("regularization_loss", reg), ("total_loss", total)):
+        close(val, g["train.logged." + key], rtol=2e-6)
+    for l in range(L):
+        close(rec_l[l], g[f"train.logged.recon_loss_level.{l}"], rtol=2e-6, atol=1e-7)
+        close(kl_l[l], g[f"train.logged.kl_loss_level.{l}"], rtol=2e-6, atol=1e-7)
+        close(reg_l[l], g[f"train.logged.regularization_loss_level.{l}"], rtol=2e-6, atol=1e-7)
