@@ -1101,7 +1101,7 @@ static int wino2_pipe_enabled() {                      // PULPO_W2_PIPE=0 keeps 
 // aligned operand of K channels with voxel stride in_ps: K a multiple of 8 and the volume below 2^31 bytes.  (Names the kernel in traces.)
 PULPO_API int pulpo_conv3d_k3_wino2_pipelined(int D, int H, int W, int K, int64_t in_ps) {
     ConvArgs a{};
-    a.D = D; a.H = H; a.W = W; a.Cin = K; a.in_ps = in_ps;
+    a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = 32; a.in_ps = in_ps;      // (output channel counts up to 1024 qualify)
     return wino2_pipe_enabled() && wino2p_ok(a);
 }
 

@@ -48,7 +48,8 @@ constexpr int P_RH = 4 * 2 * 16 * 64;            // floats of the cross-wave exc
 constexpr int P_IMG = P_RH + 4 * 2 * P_NT;       // floats of one image region (halo image, or exchange buffer + statistics rows)
 static_assert(P_IMGF <= P_IMG, "halo image must fit its region");
 constexpr int P_NITEM = 6 * HY * 4 * 2;          // staging items of a chunk: (hz, hy, x-pair, channel quad), two per thread
-constexpr size_t P_LDS = (size_t)2 * P_IMG * sizeof(float);
+constexpr int P_TAB_MAX = 3 * 1024;               // floats of the per-channel table [3][ncot * 32]: up to 1024 output channels
+constexpr size_t P_LDS = (size_t)(2 * P_IMG + P_TAB_MAX) * sizeof(float);
 static_assert(2 * P_LDS <= 160 * 1024, "two workgroups per CU");
 
 // side-work schedule of a chunk's 12 point steps (s = dz * 4 + px): raw loads of staging item u at steps P_LD[u], P_LD[u] + 1 (two taps
@@ -158,6 +159,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
 
     if (a.stagger > 0 && (int)blockIdx.x >= (nwg >> 1)) {       // start-up offset of the second half of the grid (blocks b and b + nwg / 2 share a CU)
         for (int s_ = 0; s_ < a.stagger; ++s_) __builtin_amdgcn_s_sleep(127);
+    }
+    // ---- per-channel constants of the epilogue (bias | BatchNorm mean, scale, shift), once per workgroup into LDS: the epilogue reads them
+    // with ds_read_b128 instead of waiting for global loads at the head of every tile
+    float* const tab = smem + 2 * P_IMG;                // [3][ctab]
+    const int ctab = a.ncot * NT;
+    for (int c = tid; c < ctab; c += 256) {
+        const bool in = c < a.Cout;
+        float t0 = 0.f, t1 = 1.f, t2 = 0.f;
+        if (BNR) {
+            if (in) { t0 = a.bn_coef[c]; t1 = a.bn_coef[2 * a.Cout + c]; t2 = a.bn_coef[3 * a.Cout + c]; }
+        } else {
+            if (in && a.bias != nullptr) t0 = a.bias[c];
+            if (in && a.coef != nullptr) { t1 = a.coef[2 * a.Cout + c]; t2 = a.coef[3 * a.Cout + c]; }
+        }
+        tab[c] = t0; tab[ctab + c] = t1; tab[2 * ctab + c] = t2;
     }
     STAMP(0, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));        // HW_REG_HW_ID
     STAMP(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));       // HW_REG_XCC_ID
@@ -301,10 +317,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
         }
 
         STAMP(3 + 6 * tile_no, __builtin_amdgcn_s_memtime());
-        // The next tile's first weight rows are "used" here: the compiler's wait for them then sits in front of the epilogue, where only
-        // the last of the four has still to arrive, and not - as vmcnt(0), behind the epilogue's stores - in front of the next tile's first MFMA.
-#pragma unroll
-        for (int px = 0; px < 4; ++px) asm volatile("" : : "v"(wr[px].x), "v"(wr[px].y), "v"(wr[px].z), "v"(wr[px].w));
         // ---- epilogue: x inverse transform in registers, y inverse transform across the four waves through LDS, one row tile (two z-planes) at
         // a time; the exchange buffer is the image the last chunk was read from (the next tile's chunk 0 already sits in the other one)
         float* R = smem + (cb ^ 1) * P_IMG;                 // [py][ox][r][lane]
@@ -316,42 +328,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
         // done on float4s, and each voxel leaves as one 128-byte line written by 8 lanes x 16 bytes.
         // (BNR: the host launches this instantiation only when every tile qualifies; without bias and without the eval-mode store)
         const bool fast = BNR || (a.out_cs == 1 && (a.out_ps & 3) == 0 && (a.out_bs & 3) == 0 && (((uintptr_t)a.out) & 15) == 0 && co0 + NT <= a.Cout &&
-                                  z0 + 4 <= a.D && y0 + TY <= a.H && x0 + TX <= a.W &&
-                                  (a.bias == nullptr || (((uintptr_t)a.bias) & 15) == 0) &&
-                                  (a.coef == nullptr || ((((uintptr_t)a.coef) & 15) == 0 && (a.Cout & 3) == 0)));
+                                  z0 + 4 <= a.D && y0 + TY <= a.H && x0 + TX <= a.W);
         // (the lane id passes through an opaque asm: what the epilogue derives from it is computed here and not hoisted above the main loop)
         int elane = lane;
         asm volatile("" : "+v"(elane));
         const int q = elane & 7, kh = (elane >> 3) & 1, g = elane >> 4;
         const int ei = elane & 31, ekk = elane >> 5;
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 b4 = zero4, sc4 = zero4, sh4 = zero4, s4 = zero4, q4 = zero4;        // fast path: four channels per lane
-        float bias1 = 0.f, fsc1 = 1.f, fsh1 = 0.f, ssum = 0.f, ssq = 0.f;             // general path: channel co0 + i
+        float4 s4 = zero4, q4 = zero4;
+        float ssum = 0.f, ssq = 0.f;
         const bool fuse = !BNR && a.coef != nullptr;
         const bool cok = co0 + ei < a.Cout;
         const bool bnr = BNR && fast;
-        float4 bm4 = zero4;                  // the channel means rounded to fp32 (pulpo_bn_bwd_finalize corrects for the rounding)
+        // fast path: four channels per lane; general path: channel co0 + i.  From the workgroup's table in LDS: [0] the bias (BNR: the channel
+        // means rounded to fp32 - pulpo_bn_bwd_finalize corrects for the rounding), [1] / [2] scale and shift of the eval-mode store (BNR: of
+        // the unit whose BatchNorm-backward sums this launch delivers)
+        const float4 b4 = BNR ? zero4 : *reinterpret_cast<const float4*>(tab + co0 + 4 * q);
+        const float4 bm4 = *reinterpret_cast<const float4*>(tab + co0 + 4 * q);
+        const float4 sc4 = *reinterpret_cast<const float4*>(tab + ctab + co0 + 4 * q);
+        const float4 sh4 = *reinterpret_cast<const float4*>(tab + 2 * ctab + co0 + 4 * q);
+        const float bias1 = tab[co0 + ei], fsc1 = tab[ctab + co0 + ei], fsh1 = tab[2 * ctab + co0 + ei];
         const float* bn_b = bnr ? a.bn_y + (long)cur.b * a.bn_y_bs + co0 + 4 * q : nullptr;
-        if (fast) {
-            if (!BNR && a.bias != nullptr) b4 = *reinterpret_cast<const float4*>(a.bias + co0 + 4 * q);
-            if (fuse) {
-                sc4 = *reinterpret_cast<const float4*>(a.coef + 2 * a.Cout + co0 + 4 * q);
-                sh4 = *reinterpret_cast<const float4*>(a.coef + 3 * a.Cout + co0 + 4 * q);
-            }
-            if (bnr) {
-                sc4 = *reinterpret_cast<const float4*>(a.bn_coef + 2 * a.Cout + co0 + 4 * q);
-                sh4 = *reinterpret_cast<const float4*>(a.bn_coef + 3 * a.Cout + co0 + 4 * q);
-                bm4 = *reinterpret_cast<const float4*>(a.bn_coef + co0 + 4 * q);
-            }
-        } else if (cok) {
-            if (a.bias != nullptr) bias1 = a.bias[co0 + ei];
-            if (fuse) { fsc1 = a.coef[2 * a.Cout + co0 + ei]; fsh1 = a.coef[3 * a.Cout + co0 + ei]; }
-        }
-        // every load of the epilogue's head is "used" here, on every path: one that is still pending on SOME path at the loop's back edge makes
-        // the compiler drain the whole queue (vmcnt(0), this tile's output stores included) in front of the next tile's first operand reads
-        asm volatile("" : : "v"(bias1), "v"(fsc1), "v"(fsh1));
-        asm volatile("" : : "v"(b4.x), "v"(b4.y), "v"(b4.z), "v"(b4.w), "v"(sc4.x), "v"(sc4.y), "v"(sc4.z), "v"(sc4.w), "v"(sh4.x), "v"(sh4.y), "v"(sh4.z), "v"(sh4.w));
-        asm volatile("" : : "v"(bm4.x), "v"(bm4.y), "v"(bm4.z), "v"(bm4.w));
         STAMP(4 + 6 * tile_no, __builtin_amdgcn_s_memtime());
 #pragma unroll
         for (int m = 0; m < ((PULPO_ABL & 1) ? 0 : 2); ++m) {
@@ -507,7 +504,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
 
 namespace pulpo_conv {
 
-bool wino2p_ok(const ConvArgs& a) { return a.Cin % P_CH == 0 && (long)a.D * a.H * a.W * a.in_ps * 4 < (1L << 31); }
+bool wino2p_ok(const ConvArgs& a) {
+    return a.Cin % P_CH == 0 && (long)a.D * a.H * a.W * a.in_ps * 4 < (1L << 31) && 3 * ((a.Cout + P_NT - 1) / P_NT) * P_NT <= P_TAB_MAX;
+}
 
 // launch of the pipelined (y, x) Winograd kernel; operands channels-last, 16-byte aligned, K % 8 == 0, volume bytes < 2^31 (wino2p_ok)
 int launch_wino2p(const ConvArgs& a, int nblk, bool bnr, hipStream_t st) {

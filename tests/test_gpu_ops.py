@@ -352,6 +352,45 @@ def test_packed_weight_cache_follows_weight_updates(ops):
         ops.set_conv_precision("fp32")
 
 
+def test_every_live_weight_pack_follows_a_raw_pointer_update(ops):
+    """One weight used at TWO volume shapes (a training batch and a validation batch, predict_output_samples with N > 1) has two live packs
+    per orientation and precision; all of them must be rewritten by the in-place refresh behind the fused Adam kernel.  (Round 2 keyed
+    the bf16 packs of a weight without the shape: the second shape's pack replaced the first's registry entry, and the first shape kept
+    convolving with pre-update weights.)  Also: packs of temporaries (non-leaf weights, e.g. the 2-D mode's lifted 3x3 kernels) are not
+    cached or registered, so the registry does not grow with repeated forwards."""
+    gen = torch.Generator().manual_seed(6)
+    xa = torch.randn(1, 16, 24, 24, 24, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    xb = torch.randn(2, 16, 16, 16, 16, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w0 = (torch.randn(16, 16, 3, 3, 3, generator=gen) / 20).cuda()
+    for precision, tol_new, tol_old in (("fp32", 2e-6, 1e-2), ("bf16", 1e-2, 1e-1)):
+        ops.set_conv_precision(precision)
+        try:
+            p = w0.clone()
+            ya0, yb0 = ops.conv3d_k3(xa, p), ops.conv3d_k3(xb, p)              # two shapes -> two packs of the same weight
+            ops.adam_step(p.view(-1), torch.ones_like(p).view(-1), torch.zeros_like(p).view(-1), torch.zeros_like(p).view(-1), lr=0.1, step=1)
+            ya1, yb1 = ops.conv3d_k3(xa, p), ops.conv3d_k3(xb, p)
+            for x_, y_old, y_new in ((xa, ya0, ya1), (xb, yb0, yb1)):
+                ref = F.conv3d(x_.cpu().double(), p.cpu().double(), padding=1)
+                assert rel_l2(y_new, ref) < tol_new, (precision, tuple(x_.shape), rel_l2(y_new, ref))
+                assert rel_l2(y_old, ref) > tol_old
+        finally:
+            ops.set_conv_precision("fp32")
+    # temporaries: a derived (non-leaf) weight is packed per call and never enters the registry
+    base = torch.nn.Parameter(w0.clone())
+    n0 = len(ops._PACK_REGISTRY)
+    for _ in range(5):
+        derived = base * 1.0
+        assert not derived.is_leaf
+        ops.conv3d_k3(xa, derived)
+    assert len(ops._PACK_REGISTRY) == n0
+    x2 = torch.randn(2, 4, 24, 20, generator=gen).cuda()                        # 2-D mode: the 3x3 weight is lifted into a temporary per call
+    w2 = torch.nn.Parameter((torch.randn(8, 4, 3, 3, generator=gen) / 6).cuda())
+    bn = torch.nn.BatchNorm2d(8).cuda()
+    for _ in range(5):
+        ops.conv_bn_lrelu(x2, w2, torch.zeros(8, device="cuda"), bn.weight, bn.bias, bn.running_mean, bn.running_var, training=True).sum().backward()
+    assert len(ops._PACK_REGISTRY) == n0
+
+
 @pytest.mark.parametrize("chans,size", [((16, 32, 64, 32), (24, 32, 40)), ((32, 32, 32), (32, 32, 32)), ((8, 96, 96), (20, 24, 24))])
 def test_bn_backward_reduction_inside_the_data_gradient_kernel(ops, chans, size):
     """In a ConvSequence the data-gradient convolution of unit u also delivers the BatchNorm-backward sums of unit u-1 (one HBM pass over

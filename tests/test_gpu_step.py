@@ -647,9 +647,10 @@ def test_config4_160_bf16_oasis_step(api):
         ops.set_conv_precision("fp32")
 
 
-# per-parameter bound (relative L2) of the 160^3 step's gradients against the fp32 CPU oracle; see profiles/r3_parity_160.md for the measured
-# distribution it rests on
-GRAD_BOUND_160 = 2e-2
+# per-parameter bound (relative L2) of the 160^3 step's gradients against the fp32 CPU oracle.  profiles/r3_parity_160.md holds the measured
+# distribution it rests on: maximum 3.5e-3 over 129 parameters (the fp32 oracle itself sits 3.9e-3 from fp64) - SURVEY 8(c) suggested
+# 5e-3 at >= 64^3; 6e-3 leaves the run-to-run spread of the float-atomic sums (~1.7x the measured maximum) inside the bound
+GRAD_BOUND_160 = 6e-3
 
 
 def _write_parity_report(vs32, e_gpu, e_ref):
@@ -680,7 +681,7 @@ def test_headline_160_step_vs_cpu_oracle(api):
     (the ground truth for gradients; ~30 s): every output dictionary atol 1e-4 (scaled by the tensor's magnitude), loss terms rtol 1e-4.
     Gradients: at this size every fp32 evaluation flips LeakyReLU slopes against any other (~6e8 activations) and carries the
     summation noise of 4e6-voxel reductions (the reference's own fp32-vs-fp64 envelope grows with the volume), so the
-    criterion is the flip-aware one of the 32^3 golden test: every parameter within 2e-2 (relative L2) of the fp32 oracle, and the
+    criterion is the flip-aware one of the 32^3 golden test: every parameter within GRAD_BOUND_160 (relative L2) of the fp32 oracle, and the
     distance from fp64 distributed like the fp32 oracle's own (median <= 4x + 2e-4, maximum <= 6x + 1e-3)."""
     models, nb = api
     size = [160, 160, 160]
@@ -796,9 +797,13 @@ def test_headline_160_stepper_equals_autograd(api):
         worst = max(worst, d)
         assert d < 1e-5, (k, d)
     np.testing.assert_allclose(l_b2, l_a2, rtol=1e-5)
+    # BatchNorm running statistics after two steps.  The means carry the conv biases, whose gradient in front of a BatchNorm is rounding
+    # noise: Adam moves each by +-lr per step in a direction the noise decides, so the two sides' means may differ by 2 * lr * momentum.
     for k, v in model.named_buffers():
-        if "running" in k:
-            np.testing.assert_allclose(v.detach().cpu().numpy(), bn_a[k].cpu().numpy(), rtol=1e-5, atol=1e-7)
+        if k.endswith("running_var"):
+            np.testing.assert_allclose(v.detach().cpu().numpy(), bn_a[k].cpu().numpy(), rtol=1e-4, atol=1e-7)
+        elif k.endswith("running_mean"):
+            np.testing.assert_allclose(v.detach().cpu().numpy(), bn_a[k].cpu().numpy(), rtol=1e-4, atol=2.5e-5)
     print(f"160^3 stepper vs autograd: worst gradient distance {worst:.2e}; losses {l_b} / {l_b2} vs {l_a} / {l_a2}")
 
 
