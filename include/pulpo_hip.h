@@ -54,17 +54,11 @@ int pulpo_conv3d_k3_fwd(const float* in, int64_t in_bs, int64_t in_ps, int64_t i
 int pulpo_conv3d_k3_fwd_bn_lrelu(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
                                  const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* scratch, int B,
                                  int D, int H, int W, int K, int N, void* stream);
-/* Winograd F(2,3)-along-x variant of the same convolution for large volumes (1.5x fewer matrix instructions, all fp32; results
- * differ from the direct kernel by fp32 rounding only).  pulpo_conv3d_k3_algo() says which kernel family to use for a shape (0 direct,
- * 1 this one, 2 the (y, x) variant below); each has its own weight packing;
- * coef (nullable) selects the fused eval-mode BatchNorm + LeakyReLU store, stats (nullable) the BatchNorm partials (same tiles). */
+/* Winograd F(2x2,3x3) in (y, x) of the same convolution for volumes tiled 4x8x8 (2.25x fewer matrix instructions, all fp32; results differ
+ * from the direct kernel by fp32 rounding only).  pulpo_conv3d_k3_algo() says which kernel family to use for a shape (0 direct, 2 this one);
+ * each has its own weight packing; coef (nullable) selects the fused eval-mode BatchNorm + LeakyReLU store, stats (nullable) the BatchNorm
+ * partials (same tiles).  (Family 1, F(2,3) along x only, was retired in round 3: measured slower on every shape.) */
 int pulpo_conv3d_k3_algo(int B, int D, int H, int W, int K, int N);
-size_t pulpo_conv3d_k3_packed_wino_floats(int K, int N);
-int pulpo_conv3d_k3_pack_weight_wino(const float* w /*[Cout][Cin][3][3][3]*/, float* wp, int Cin, int Cout, int dgrad, void* stream);
-int pulpo_conv3d_k3_fwd_wino(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
-                             float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W,
-                             int K, int N, void* stream);
-/* F(2x2,3x3) in (y, x): pulpo_conv3d_k3_algo() = 2; same contract as the _wino entry points, own packing */
 size_t pulpo_conv3d_k3_packed_wino2_floats(int K, int N);
 int pulpo_conv3d_k3_pack_weight_wino2(const float* w /*[Cout][Cin][3][3][3]*/, float* wp, int Cin, int Cout, int dgrad, void* stream);
 int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
@@ -74,14 +68,6 @@ int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int
  * channels-last 16-byte-aligned operand: K % 8 == 0 and D*H*W*in_ps*4 < 2^31.  Otherwise (and with PULPO_W2_PIPE=0) the round-2 kernel runs.
  * Same results either way (network_blocks.py:23). */
 int pulpo_conv3d_k3_wino2_pipelined(int D, int H, int W, int K, int64_t in_ps);
-/* Forward convolution of a ConvUnit fed by the ConvUnit in front of it (src/network_blocks.py:32-46, ConvSequence), reading that unit's
- * PRE-NORM tensor y_in (channels-last, 16-byte aligned) instead of its output z: BatchNorm + LeakyReLU (in_coef = the producing unit's
- * coefficient block of pulpo_bn_fwd_finalize) are applied to the operand as it is staged and z is written to zout (same strides as y_in)
- * for the backward pass - the producing unit's pulpo_bn_lrelu_apply pass is not run.  Otherwise the contract of pulpo_conv3d_k3_fwd_wino2. */
-int pulpo_conv3d_k3_fwd_wino2_prenorm_ok(int B, int D, int H, int W, int K, int N);
-int pulpo_conv3d_k3_fwd_wino2_prenorm(const float* y_in, int64_t in_bs, int64_t in_ps, const float* in_coef, float slope, float* zout,
-                                      const float* wp, const float* bias, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs,
-                                      float* stats, int B, int D, int H, int W, int K, int N, void* stream);
 /* The data-gradient convolution of a ConvUnit (in = dy of that unit, wp packed with dgrad = 1, N = the unit's input channels) with the
  * FIRST pass of the BatchNorm/LeakyReLU backward of the ConvUnit in front of it fused into the store (the reference runs these as
  * separate autograd nodes: ConvolutionBackward of src/network_blocks.py:23, then LeakyReluBackward / NativeBatchNormBackward of :24-25):

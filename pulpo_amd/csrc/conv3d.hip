@@ -11,7 +11,7 @@
 // tile issued back to back) and re-used by all 27 taps; the 27 weight slabs stream through a double-buffered LDS tile, prefetched
 // global->registers one tap ahead.
 // Volumes of >= 20^3 voxels (depth % 4 == 0) run the Winograd forms further down instead: F(2x2,3x3) in (y, x) for forward / data
-// gradient (conv3d_k3_wino2_mfma; conv3d_k3_wino_mfma is the x-only predecessor) and F(2,3) along x for the weight gradient
+// gradient (conv3d_k3_wino2p_mfma / conv3d_k3_wino2_mfma) and F(2x2,3x3) / F(2,3) along x for the weight gradient
 // (conv3d_k3_wgrad_wino) - fewer matrix instructions, all arithmetic still fp32.
 #include "conv_shared.h"
 #include <stdlib.h>
@@ -448,14 +448,11 @@ PULPO_API int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W) {
     return B * pulpo::cdiv(D, conv_tz(D, H, W)) * pulpo::cdiv(H, TY) * pulpo::cdiv(W, TX);
 }
 
-// forward / data-gradient kernel for a shape: 2 = Winograd F(2x2,3x3) in (y, x) (default where a Winograd kernel applies: 4x8x8-tiled
-// volumes, > 4 reduction channels), 1 = Winograd F(2,3) along x only, 0 = direct implicit GEMM
+// forward / data-gradient kernel for a shape: 2 = Winograd F(2x2,3x3) in (y, x) (where it applies: 4x8x8-tiled volumes, > 4 reduction
+// channels), 0 = direct implicit GEMM.  (1, F(2,3) along x only, was retired in round 3.)
 PULPO_API int pulpo_conv3d_k3_algo(int B, int D, int H, int W, int K, int N) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("PULPO_CONV_WINOGRAD"); force = e ? atoi(e) + 1 : 0; }     // unset: policy; 0 / 1: force off / on
     if (force == 1) return 0;
-    const bool shape_ok = K > 4 && conv_tz(D, H, W) == 4;
-    static int two = -1;
-    if (two < 0) { const char* e = getenv("PULPO_CONV_WINOGRAD_2D"); two = e ? atoi(e) : 1; }      // default: the (y, x) kernel
-    return shape_ok ? (two ? 2 : 1) : 0;
+    return (K > 4 && conv_tz(D, H, W) == 4) ? 2 : 0;
 }

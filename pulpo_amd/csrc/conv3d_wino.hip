@@ -1,10 +1,11 @@
-// Winograd forms of the 3x3x3 convolution (forward and data gradient) for volumes tiled 4x8x8: F(2,3) along x (conv3d_k3_wino_mfma) and
-// F(2x2,3x3) in (y, x) (conv3d_k3_wino2_mfma, the default), both direct over the z taps, all arithmetic fp32 on v_mfma_f32_32x32x2_f32.
+// Winograd F(2x2,3x3) in (y, x) of the 3x3x3 convolution (forward and data gradient) for volumes tiled 4x8x8, direct over the z taps, all
+// arithmetic fp32 on v_mfma_f32_32x32x2_f32.  This file: the C entry points, the weight packing, and conv3d_k3_wino2_mfma - the round-2
+// kernel (LDS-DMA weight slabs, one halo image, four barriers per chunk), which serves the operands the pipelined kernel of
+// conv3d_wino2p.hip does not take: planar inputs, channel counts that are not multiples of 8, volumes of 2 GiB and more.
 // Same argument block, tile order, BatchNorm partial statistics and fused eval-mode epilogue as the direct kernel in conv3d.hip.
 #include "conv_shared.h"
 #include "../../include/pulpo_hip.h"
 #include <stdlib.h>
-#include <atomic>
 
 
 #ifndef PULPO_ABL
@@ -36,288 +37,15 @@ __device__ __forceinline__ unsigned lds_address(const float* p) {
     return (unsigned)(uintptr_t)((const __attribute__((address_space(3))) float*)p);
 }
 
-// ------------------------------------------------------------------------------------------------ Winograd F(2,3) along x
-// Large volumes: the 3 x-taps of the 3x3x3 stencil are evaluated with the minimal-filtering identity F(2,3) (two neighbouring
-// outputs from four transformed inputs and four transformed weights instead of 2 x 3 products): 36 instead of 54 MFMA row
-// products per output pair = 1.5x fewer matrix instructions, all arithmetic still fp32.
-//   input  (staging)  : v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3        per (z, y, x-pair, channel)
-//   weights (packing) : u0 = g0, u1 = (g0 + g1 + g2)/2, u2 = (g0 - g1 + g2)/2, u3 = g2  per (dz, dy, cin, cout)
-//   output (registers): y_even = m0 + m1 + m2, y_odd = m1 - m2 - m3                     the four m live in the same lane
-// Workgroup = 4 x 8 x 8 output voxels = 4 z-planes (one per wave) x 32 (y, x-pair) blocks; the MFMA rows are the blocks, one
-// accumulator set per transformed point.  8-channel chunks: 960 transformed halo rows x 9 floats (34.5 KB) + the double-buffered
-// (dz, dy) weight slabs [4 points][8][NT] (16 KB at NT = 64) => 3 workgroups per CU.
-// LDS rows are ordered (hz, point, hy, x-pair): the 32 (y, x-pair) blocks an A fragment reads are 32 consecutive rows of 9 floats
-// (odd stride => one bank per lane), a (dz, dy) tap moves the window by dz * 4 * WN_PL + dy * 4 rows
-constexpr int WN_CH = 8, WN_CP = WN_CH + 1, WN_HZ = 6, WN_PL = HY * 4;
-// floats per hz plane: 160 rows + 4 floats, so that blocks of neighbouring z-planes (the (y, x) kernel's row tiles span two) fall on
-// disjoint LDS banks
-constexpr int WN_PS = 4 * WN_PL * WN_CP + 4;
+// F(2,3) along one axis: two neighbouring outputs from four transformed inputs and four transformed weights
+//   input  (staging)  : v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3
+//   weights (packing) : u0 = g0, u1 = (g0 + g1 + g2)/2, u2 = (g0 - g1 + g2)/2, u3 = g2
+//   output            : y_even = m0 + m1 + m2, y_odd = m1 - m2 - m3
+// applied along x while the halo is staged (LDS rows ordered (hz, px, hy, x-pair)) and along y by the waves (wave py owns the points (py, 0..3))
+constexpr int WN_CH = 8, WN_HZ = 6, WN_PL = HY * 4;
 
-template <bool VEC>
-__device__ __forceinline__ void stage_halo_wino(float* xs, const float* __restrict__ in, long in_ps, long in_cs, int c0, int Cin, int z0, int y0,
-                                                int x0, int D, int H, int W, int tid) {
-    if constexpr (VEC) {
-        constexpr int Q = WN_CH / 4;
-        constexpr int NITEM = WN_HZ * HY * 4 * Q;              // (hz, hy, x-pair, channel quad)
-        constexpr int NIT = (NITEM + 255) / 256;
-        float4 d[NIT][4];
-#pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int j = tid + u * 256;
-            const int q = j % Q, xb = (j / Q) & 3, hrow = j / (4 * Q);
-            const int hz = hrow / HY, hy = hrow - hz * HY;
-            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy;
-            const bool rowok = j < NITEM && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && c0 + 4 * q < Cin;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int gx = x0 - 1 + 2 * xb + t;
-                d[u][t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rowok && (unsigned)gx < (unsigned)W) d[u][t] = *reinterpret_cast<const float4*>(in + ((long)(gz * H + gy) * W + gx) * in_ps + c0 + 4 * q);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int j = tid + u * 256;
-            if (j < NITEM) {
-                const int q = j % Q, rb = j / Q;                // rb = (hz*HY + hy)*4 + xb
-                const int hz = rb / (HY * 4), yx = rb - hz * (HY * 4);
-                float* o = xs + hz * WN_PS + yx * WN_CP + 4 * q;      // row (hz, point 0, hy, xb); points are WN_PL rows apart
-                const float4 d0 = d[u][0], d1 = d[u][1], d2 = d[u][2], d3 = d[u][3];
-                o[0] = d0.x - d2.x; o[1] = d0.y - d2.y; o[2] = d0.z - d2.z; o[3] = d0.w - d2.w;
-                o += WN_PL * WN_CP;
-                o[0] = d1.x + d2.x; o[1] = d1.y + d2.y; o[2] = d1.z + d2.z; o[3] = d1.w + d2.w;
-                o += WN_PL * WN_CP;
-                o[0] = d2.x - d1.x; o[1] = d2.y - d1.y; o[2] = d2.z - d1.z; o[3] = d2.w - d1.w;
-                o += WN_PL * WN_CP;
-                o[0] = d1.x - d3.x; o[1] = d1.y - d3.y; o[2] = d1.z - d3.z; o[3] = d1.w - d3.w;
-            }
-        }
-    } else {
-        for (int j = tid; j < WN_HZ * HY * 4 * WN_CH; j += 256) {
-            const int c = j % WN_CH, rb = j / WN_CH;
-            const int xb = rb & 3, hrow = rb >> 2;
-            const int hz = hrow / HY, hy = hrow - hz * HY;
-            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy;
-            float d[4] = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && c0 + c < Cin) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int gx = x0 - 1 + 2 * xb + t;
-                    if ((unsigned)gx < (unsigned)W) d[t] = in[((long)(gz * H + gy) * W + gx) * in_ps + (long)(c0 + c) * in_cs];
-                }
-            }
-            float* o = xs + hz * WN_PS + (hrow * 4 - hz * (HY * 4) + xb) * WN_CP + c;
-            o[0] = d[0] - d[2];
-            o[WN_PL * WN_CP] = d[1] + d[2];
-            o[2 * WN_PL * WN_CP] = d[2] - d[1];
-            o[3 * WN_PL * WN_CP] = d[1] - d[3];
-        }
-    }
-}
-
-// the VEC staging of stage_halo_wino split into its two halves, so that a kernel can issue the raw loads of the next chunk early
+// staging items of a halo chunk (vector path): (hz, hy, x-pair, channel quad), WN_NIT per thread
 constexpr int WN_Q = WN_CH / 4, WN_NITEM = WN_HZ * HY * 4 * WN_Q, WN_NIT = (WN_NITEM + 255) / 256;
-
-__device__ __forceinline__ void wino_load_raw(float4 (&d)[WN_NIT][4], const float* __restrict__ in, long in_ps, int c0, int Cin, int z0, int y0, int x0,
-                                              int D, int H, int W, int tid) {
-#pragma unroll
-    for (int u = 0; u < WN_NIT; ++u) {
-        const int j = tid + u * 256;
-        const int q = j % WN_Q, xb = (j / WN_Q) & 3, hrow = j / (4 * WN_Q);
-        const int hz = hrow / HY, hy = hrow - hz * HY;
-        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy;
-        const bool rowok = j < WN_NITEM && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && c0 + 4 * q < Cin;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int gx = x0 - 1 + 2 * xb + t;
-            d[u][t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rowok && (unsigned)gx < (unsigned)W) d[u][t] = *reinterpret_cast<const float4*>(in + ((long)(gz * H + gy) * W + gx) * in_ps + c0 + 4 * q);
-        }
-    }
-}
-
-__device__ __forceinline__ void wino_store_transformed(float* xs, const float4 (&d)[WN_NIT][4], int tid) {
-#pragma unroll
-    for (int u = 0; u < WN_NIT; ++u) {
-        const int j = tid + u * 256;
-        if (j < WN_NITEM) {
-            const int q = j % WN_Q, rb = j / WN_Q;                // rb = (hz*HY + hy)*4 + xb
-            const int hz = rb / (HY * 4), yx = rb - hz * (HY * 4);
-            float* o = xs + hz * WN_PS + yx * WN_CP + 4 * q;
-            const float4 d0 = d[u][0], d1 = d[u][1], d2 = d[u][2], d3 = d[u][3];
-            o[0] = d0.x - d2.x; o[1] = d0.y - d2.y; o[2] = d0.z - d2.z; o[3] = d0.w - d2.w;
-            o += WN_PL * WN_CP;
-            o[0] = d1.x + d2.x; o[1] = d1.y + d2.y; o[2] = d1.z + d2.z; o[3] = d1.w + d2.w;
-            o += WN_PL * WN_CP;
-            o[0] = d2.x - d1.x; o[1] = d2.y - d1.y; o[2] = d2.z - d1.z; o[3] = d2.w - d1.w;
-            o += WN_PL * WN_CP;
-            o[0] = d1.x - d3.x; o[1] = d1.y - d3.y; o[2] = d1.z - d3.z; o[3] = d1.w - d3.w;
-        }
-    }
-}
-
-template <int NT, bool VEC>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_wino_mfma(ConvArgs a) {
-    constexpr int CH = WN_CH, CP = WN_CP;
-    constexpr int NN = NT / 32;
-    constexpr int XS = WN_HZ * WN_PS;
-    constexpr int WSL = 4 * CH * NT;                 // floats of one (dz, dy) weight slab set: [point][k][NT]
-    constexpr int WF4 = WSL / 4;
-    constexpr int NW = WF4 / 256;                    // float4 per thread per slab set (1 at NT = 32, 2 at NT = 64)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;
-    float* ws = smem + XS;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
-    const int cot = lid % a.ncot;
-    const int tile_lin = lid / a.ncot;
-    int t = tile_lin;
-    const int tx_ = t % a.ntx; t /= a.ntx;
-    const int ty_ = t % a.nty; t /= a.nty;
-    const int tz_ = t % a.ntz;
-    const int b = t / a.ntz;
-    const int z0 = tz_ * 4, y0 = ty_ * TY, x0 = tx_ * TX;
-    const int co0 = cot * NT;
-    const int nchunk = (a.Cin + CH - 1) / CH;
-    const int niter = nchunk * 9;
-    const float* in_b = a.in + (long)b * a.in_bs;
-
-    float4 wreg[NW];
-    auto load_w = [&](int it) {
-#pragma unroll
-        for (int u = 0; u < NW; ++u) {
-            const int j = tid + u * 256;
-            const int row = j / (NT / 4), c4 = j - row * (NT / 4);              // row = point * CH + k
-            wreg[u] = *reinterpret_cast<const float4*>(a.wp + ((long)it * 4 * CH + row) * a.NPad + co0 + c4 * 4);
-        }
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < NW; ++u) *reinterpret_cast<float4*>(ws + buf * WSL + (tid + u * 256) * 4) = wreg[u];
-    };
-
-    const int i = lane & 31, kk = lane >> 5;
-    // MFMA row i of wave w = block (z = w, y = i >> 2, x-pair = i & 3); its transformed rows start at rowbase (+ point)
-    const int rowbase = wave * WN_PS + i * WN_CP;       // float offset of (hz = wave, point 0, block i); + point * WN_PL * CP
-
-    f32x16 acc[4][NN];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int n = 0; n < NN; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[p][n][r] = 0.f;
-
-    load_w(0);
-    int buf = 0, it = 0;
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        __syncthreads();
-        stage_halo_wino<VEC>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
-        for (int zy = 0; zy < 9; ++zy, ++it) {
-            store_w(buf);
-            __syncthreads();
-            if (it + 1 < niter) load_w(it + 1);
-            const float* xa = xs + rowbase + (zy / 3) * WN_PS + (zy % 3) * 4 * CP + kk;
-            const float* wb = ws + buf * WSL + kk * NT + i;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-#pragma unroll
-                for (int s = 0; s < CH / 2; ++s) {
-                    const float av = xa[p * WN_PL * CP + 2 * s];
-#pragma unroll
-                    for (int n = 0; n < NN; ++n) {
-                        const float bv = wb[(p * CH + 2 * s) * NT + n * 32];
-                        acc[p][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p][n], 0, 0, 0);
-                    }
-                }
-            }
-            buf ^= 1;
-        }
-    }
-
-    // ---- epilogue: inverse transform in registers, bias, [BatchNorm + LeakyReLU], store, per-tile BatchNorm partial statistics
-    float* out_b = a.out + (long)b * a.out_bs;
-    float ssum[NN], ssq[NN];
-    const int gz = z0 + wave;
-#pragma unroll
-    for (int n = 0; n < NN; ++n) {
-        const int co = co0 + n * 32 + i;
-        const bool cok = co < a.Cout;
-        const float bv = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
-        const bool fuse = a.coef != nullptr && cok;
-        const float fsc = fuse ? a.coef[2 * a.Cout + co] : 1.f, fsh = fuse ? a.coef[3 * a.Cout + co] : 0.f;
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-            const int gy = y0 + (row >> 2), gx = x0 + 2 * (row & 3);
-            const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[3][n][r];
-            float ve = m0 + m1 + m2 + bv, vo = m1 - m2 - m3 + bv;
-            if (cok && gz < a.D && gy < a.H) {
-                const long vox = (long)(gz * a.H + gy) * a.W + gx;
-                if (gx < a.W) {
-                    s += ve; q += ve * ve;
-                    if (fuse) { const float tt = ve * fsc + fsh; ve = tt > 0.f ? tt : tt * a.slope; }
-                    out_b[vox * a.out_ps + (long)co * a.out_cs] = ve;
-                }
-                if (gx + 1 < a.W) {
-                    s += vo; q += vo * vo;
-                    if (fuse) { const float tt = vo * fsc + fsh; vo = tt > 0.f ? tt : tt * a.slope; }
-                    out_b[(vox + 1) * a.out_ps + (long)co * a.out_cs] = vo;
-                }
-            }
-        }
-        ssum[n] = s + __shfl_xor(s, 32, 64);
-        ssq[n] = q + __shfl_xor(q, 32, 64);
-    }
-    if (a.stats != nullptr) {
-        __syncthreads();
-        float* red = ws;               // [4 waves][2][NT]
-        if (lane < 32) {
-#pragma unroll
-            for (int n = 0; n < NN; ++n) {
-                red[(wave * 2 + 0) * NT + n * 32 + i] = ssum[n];
-                red[(wave * 2 + 1) * NT + n * 32 + i] = ssq[n];
-            }
-        }
-        __syncthreads();
-        if (tid < 2 * NT) {
-            const int which = tid / NT, c = tid - which * NT;
-            if (co0 + c < a.Cout) {
-                const float tot = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] + red[(2 * 2 + which) * NT + c] +
-                                  red[(3 * 2 + which) * NT + c];
-                a.stats[((long)tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
-            }
-        }
-    }
-}
-
-// Winograd weight packing: wp[k/8][dz*3+dy][point][k%8][n]  (forward: K = Cin, N = Cout, g_t = w[n][k][dz][dy][t];
-// dgrad: K = Cout, N = Cin, g_t = w[k][n][2-dz][2-dy][2-t])
-__global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int NPad, int dgrad, long total) {
-    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int n = (int)(e % NPad);
-        long r = e / NPad;
-        const int kc = (int)(r % WN_CH); r /= WN_CH;
-        const int pt = (int)(r % 4); r /= 4;
-        const int zy = (int)(r % 9);
-        const int chunk = (int)(r / 9);
-        const int k = chunk * WN_CH + kc;
-        float val = 0.f;
-        if (k < K && n < N) {
-            float g[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int tap = zy * 3 + t;
-                g[t] = dgrad ? w[((long)k * Cin + n) * 27 + (26 - tap)] : w[((long)n * Cin + k) * 27 + tap];
-            }
-            val = pt == 0 ? g[0] : pt == 1 ? 0.5f * (g[0] + g[1] + g[2]) : pt == 2 ? 0.5f * (g[0] - g[1] + g[2]) : g[2];
-        }
-        wp[e] = val;
-    }
-}
 
 // ---- LDS image of the (y, x) kernel: the same (hz, px, hy, x-pair) row order as above, but rows of 12 floats (8 channels + 4 pad = 48 bytes,
 // 16-byte aligned) and hz planes of 164 rows, so that the MFMA operands of FOUR consecutive k-steps arrive with ONE ds_read_b128: lane (row i,
@@ -384,17 +112,7 @@ __device__ __forceinline__ void w2_stage_scalar(float* xs, const float* __restri
 //   * 10k clocks of prologue per tile (argument loads, index arithmetic, first-touch latency of halo and weights)  -> PERSISTENT
 //     workgroups (two per CU) that fetch the next tile's first slab and halo chunk during the last dz iteration of the current tile.
 // A start-up offset of the second workgroup of each CU (to break the lockstep of the pair) was measured without effect and is not kept.
-// Tile scheduler of the persistent (y, x) kernel: a ring of word sets, one per launch in flight (launches of one stream run one after the
-// other; a set is returned to zero by the last workgroup of its launch).  [0..7] = tiles handed out from XCD q's eighth of the work list
-// beyond the statically dealt first round, [8] = workgroups that have finished.
-constexpr int W2_SCHED_SLOTS = 32, W2_SCHED_WORDS = 16;
-__device__ int g_wino2_sched[W2_SCHED_SLOTS * W2_SCHED_WORDS];
-
-// rows of the halo image whose 4 pad floats hold the staged operand's BatchNorm coefficients (INAFF): beyond the exchange buffer, below the image's end
-constexpr int W2_COEF_ROW = 704, W2_COEF_QUADS = 72;
-static_assert(W2_COEF_ROW * W2_RS >= 4 * 2 * 16 * 64 + 4 * 2 * 32 && W2_COEF_ROW + 2 * W2_COEF_QUADS <= WN_HZ * W2_PLROWS, "coefficient rows");
-
-template <bool VEC, bool BNR = false, bool INAFF = false>
+template <bool VEC, bool BNR = false>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
     constexpr int CH = WN_CH, NT = 32;
     constexpr int XS = W2_XS;
@@ -425,15 +143,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
             const int xb = (j / WN_Q) & 3, hrow = j / (4 * WN_Q);
             const int hz = hrow / HY, hy = hrow - hz * HY;
             roff[u] = ((unsigned)((hz * a.H + hy) * a.W + 2 * xb) * (unsigned)a.in_ps + 4u * rq) * 4u;
-        }
-    }
-    if constexpr (INAFF) {
-        static_assert(VEC, "operand-side BatchNorm needs the vector staging");
-        // coefficient table: scale quads in the pad floats of rows W2_COEF_ROW + q, shift quads W2_COEF_QUADS rows further (never overwritten:
-        // the staging writes floats 0..7 of a row, the exchange buffer ends below W2_COEF_ROW)
-        for (int qd = tid; qd < (a.Cin >> 2); qd += 256) {
-            *reinterpret_cast<float4*>(xs + (W2_COEF_ROW + qd) * W2_RS + 8) = *reinterpret_cast<const float4*>(a.in_coef + 2 * a.Cin + 4 * qd);
-            *reinterpret_cast<float4*>(xs + (W2_COEF_ROW + W2_COEF_QUADS + qd) * W2_RS + 8) = *reinterpret_cast<const float4*>(a.in_coef + 3 * a.Cin + 4 * qd);
         }
     }
     // y combination of this wave's point row: v = X[2 yb + ta] + sa * X[2 yb + tb]   (same table as the x transform)
@@ -504,48 +213,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
     STAMP(0, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));        // HW_REG_HW_ID
     STAMP(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));       // HW_REG_XCC_ID
     STAMP(2, __builtin_amdgcn_s_memtime());
-    if (a.stagger > 0) {                                // (diagnostic: start-up offset of the CU's second workgroup, by its wave slot)
-        if (tid == 0) smem[0] = (float)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15);
-        __syncthreads();
-        const bool second = smem[0] != 0.f;
-        __syncthreads();
-        if (second)
-            for (int s_ = 0; s_ < a.stagger; ++s_) __builtin_amdgcn_s_sleep(127);
-    }
-    int tile_no = 0;
-    // ---- which tile next.  The FIRST tile of a workgroup is dealt statically (tile = block id, remapped so that an XCD's workgroups hold
-    // neighbouring tiles): the dispatcher has spread the workgroups evenly over the CUs, so a launch with fewer tiles than workgroup
-    // slots keeps one tile per CU.  Further tiles: static stride (a.sched == nullptr, the default) or from queues, so that a workgroup that
-    // starts late (its CU was still held by a kernel of the other stream) or runs slowly takes fewer tiles instead of finishing a fixed
-    // share after everybody else has left.  One queue per XCD over a contiguous eighth of the remaining work list (neighbouring tiles share
-    // halos and weight panels in that XCD's L2: one queue for the whole chip measured 1.7x the HBM fetches); an XCD that runs dry helps the
-    // others.  The head is advanced by ONE lane per tile with an asynchronous returning atomic, issued at the tile's start and picked up
-    // behind the wait of the first dz iteration.
-    int* const sched = a.sched;
-    int* const next_slot = reinterpret_cast<int*>(xs + (W2_COEF_ROW + 2 * W2_COEF_QUADS) * W2_RS + 8);      // a pad word of the image nobody writes
-    const int xcc = a.sched_single ? 0 : __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7));   // HW_REG_XCC_ID
-    auto queue_lo = [&](int q) { return a.sched_single ? (q == 0 ? nwg : nwork) : nwg + (int)(((long)(nwork - nwg) * q) >> 3); };
-    auto steal = [&]() {                                // (blocking; thread 0 only) a tile of any queue, the neighbours' first; nwork = none left
-        for (int k = 1; k < 8; ++k) {
-            const int q = (xcc + k) & 7;
-            const int lo = queue_lo(q), hi = queue_lo(q + 1);
-            if (lo < hi) {
-                const int t = atomicAdd(sched + q, 1);
-                if (lo + t < hi) return lo + t;
-            }
-        }
-        return nwork;
-    };
-    auto finish = [&]() {                               // the last workgroup to leave returns the scheduler words to zero
-        if (sched != nullptr && tid == 0) {
-            if (atomicAdd(sched + 8, 1) == nwg - 1) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) sched[k] = 0;
-            }
-        }
-    };
-    int work = pulpo::xcd_remap(blockIdx.x, nwg);
-    int grabbed = 0;                                    // (thread 0) return register of the in-flight queue atomic
+    [[maybe_unused]] int tile_no = 0;
+    int work = pulpo::xcd_remap(blockIdx.x, nwg);           // static deal of the tiles: tile = block id + k * grid (remapped: an XCD's workgroups hold neighbouring tiles)
     Tile cur = describe(work);
 #pragma unroll
     for (int u = 0; u < 4; ++u) dma_w_piece(cur.wsrc, 0, 0, u);
@@ -573,11 +242,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         int it = 0;
         for (int chunk = 0; chunk < nchunk; ++chunk) {
             __syncthreads();                            // every wave has finished reading xs (previous chunk / previous tile's exchange)
-            if (chunk == 0 && sched != nullptr && tid == 0) {
-                int* qh = sched + xcc;
-                const int one = 1;
-                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(grabbed) : "v"(qh), "v"(one) : "memory");
-            }
             if constexpr (VEC) {
                 // every thread "uses" its raw registers here, unconditionally: the compiler's wait for those loads then sits in straight-line
                 // code, and it does not have to assume them still in flight (and drain the queue, DMA included) when they are reloaded
@@ -586,39 +250,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt)
                         asm volatile("" : : "v"(raw[u][tt].x), "v"(raw[u][tt].y), "v"(raw[u][tt].z), "v"(raw[u][tt].w));
-                if constexpr (INAFF) {
-                    // BatchNorm + LeakyReLU of the producing unit, applied to the raw operand (zero padding stays zero); the voxels of the tile
-                    // itself (window taps 1, 2 of every x-pair) leave for zout from the workgroup of cout tile 0.
-                    // (everything this block needs is derived here, from an opaque copy of the thread id: nothing of it may sit in registers
-                    //  across the matrix loop, which has none to spare)
-                    int stid = tid;
-                    asm volatile("" : "+v"(stid));
-                    const int c0 = chunk * CH;
-                    const int srq = stid % WN_Q;
-                    const float4 sc = *reinterpret_cast<const float4*>(xs + (W2_COEF_ROW + (c0 >> 2) + srq) * W2_RS + 8);
-                    const float4 sh = *reinterpret_cast<const float4*>(xs + (W2_COEF_ROW + W2_COEF_QUADS + (c0 >> 2) + srq) * W2_RS + 8);
-                    const bool cok = c0 + 4 * srq < a.Cin;
-                    const bool wr = cur.co0 == 0;
-                    const long zdelta = reinterpret_cast<const char*>(a.zout) - reinterpret_cast<const char*>(a.in);
-                    char* zbase = const_cast<char*>(cur.origin) + zdelta + (long)c0 * 4;
-#pragma unroll
-                    for (int u = 0; u < WN_NIT; ++u) {
-                        const int j = stid + u * 256;
-                        const int hrow = j / (4 * WN_Q);
-                        const int hz = hrow / HY, hy = hrow - hz * HY;
-                        const bool inner = wr && j < WN_NITEM && hz >= 1 && hz <= 4 && hy >= 1 && hy <= TY;      // a voxel row of the tile itself
-#pragma unroll
-                        for (int tt = 0; tt < 4; ++tt) {
-                            const bool ok = cok && ((cur.rmask >> (u * 4 + tt)) & 1u);
-                            auto act = [&](float v, float s_, float h_) { const float t_ = v * s_ + h_; return t_ > 0.f ? t_ : t_ * a.slope; };
-                            float4 v = raw[u][tt];
-                            v = ok ? make_float4(act(v.x, sc.x, sh.x), act(v.y, sc.y, sh.y), act(v.z, sc.z, sh.z), act(v.w, sc.w, sh.w))
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-                            raw[u][tt] = v;
-                            if ((tt == 1 || tt == 2) && inner && ok) *reinterpret_cast<float4*>(zbase + (roff[u] + tt * ps_bytes)) = v;
-                        }
-                    }
-                }
                 w2_store_transformed(xs, raw, tid);
             } else {
                 w2_stage_scalar(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, cur.z0, cur.y0, cur.x0, a.D, a.H, a.W, tid);
@@ -627,11 +258,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
 #pragma unroll
             for (int dz = 0; dz < 3; ++dz, ++it) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of slab `it` have landed
-                if (chunk == 0 && dz == 0 && sched != nullptr && tid == 0) {
-                    asm volatile("" : "+v"(grabbed));                // (the queue atomic issued at the tile's start has returned with the wait above)
-                    const int t_ = queue_lo(xcc) + grabbed;
-                    *next_slot = t_ < queue_lo(xcc + 1) ? t_ : -1;     // -1: this XCD's queue is dry - look at the others when the tile ends
-                }
                 __syncthreads();                        // all pieces landed, staged rows visible, everybody has left ws[buf ^ 1]
                 const float* xa = pa + dz * W2_PS;
                 const float* xb_ = pb + dz * W2_PS;
@@ -640,17 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
                 // the next tile; and (dz == 2) the next halo chunk of this tile, or chunk 0 of the next tile
                 const bool tile_end = dz == 2 && last_chunk;
                 if (tile_end) {
-                    if (sched != nullptr) {
-                        next_work = __builtin_amdgcn_readfirstlane(*next_slot);
-                        if (next_work < 0) {            // (only once an XCD's own queue has run dry)
-                            __syncthreads();
-                            if (tid == 0) *next_slot = steal();
-                            __syncthreads();
-                            next_work = __builtin_amdgcn_readfirstlane(*next_slot);
-                        }
-                    } else {
-                        next_work = work + nwg;
-                    }
+                    next_work = work + nwg;
                     has_next = next_work < nwork;
                 }
                 if (tile_end && has_next) nxt = describe(next_work);
@@ -716,8 +332,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         // Fast path (whole tile inside the volume, all 32 couts real, channels-last 16-byte aligned output - every tile of the BASELINE layers):
         // lane = (channel quad q, row half, row group): the four waves' partial rows are fetched with ds_read_b128 (all issued before the first
         // use), the y inverse transform is done on float4s, and each voxel leaves as one 128-byte line written by 8 lanes x 16 bytes.
-        // (BNR / INAFF: the host launches these instantiations only when every tile qualifies; BNR without bias, both without the eval-mode store)
-        const bool fast = BNR || INAFF || (a.out_cs == 1 && (a.out_ps & 3) == 0 && (a.out_bs & 3) == 0 && (((uintptr_t)a.out) & 15) == 0 && co0 + NT <= a.Cout &&
+        // (BNR: the host launches this instantiation only when every tile qualifies; without bias and without the eval-mode store)
+        const bool fast = BNR || (a.out_cs == 1 && (a.out_ps & 3) == 0 && (a.out_bs & 3) == 0 && (((uintptr_t)a.out) & 15) == 0 && co0 + NT <= a.Cout &&
                           z0 + 4 <= a.D && y0 + TY <= a.H && x0 + TX <= a.W &&
                           (a.bias == nullptr || (((uintptr_t)a.bias) & 15) == 0) &&
                           (a.coef == nullptr || ((((uintptr_t)a.coef) & 15) == 0 && (a.Cout & 3) == 0)));
@@ -730,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 b4 = zero4, sc4 = zero4, sh4 = zero4, s4 = zero4, q4 = zero4;        // fast path: four channels per lane
         float bias1 = 0.f, fsc1 = 1.f, fsh1 = 0.f, ssum = 0.f, ssq = 0.f;             // general path: channel co0 + i
-        const bool fuse = !BNR && !INAFF && a.coef != nullptr;
+        const bool fuse = !BNR && a.coef != nullptr;
         const bool cok = co0 + ei < a.Cout;
         // data-gradient launch with the BatchNorm-backward reduction of the unit in front fused in (host: every tile takes the fast path)
         const bool bnr = BNR && fast;        // (own instantiation: its extra epilogue registers stay out of the plain kernel)
@@ -889,7 +505,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2_mfma(ConvArgs a) {
         cur = nxt;
         work = next_work;
     }
-    finish();
 }
 
 // packing for the (y, x) Winograd kernel: wp[k/8][dz][py][px][n][k%8] = sum_dy sum_dx G[py][dy] G[px][dx] g[dz][dy][dx]
@@ -974,58 +589,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PulpoPack
 }  // namespace
 
 // ================================================================================================ C ABI
-PULPO_API size_t pulpo_conv3d_k3_packed_wino_floats(int K, int N) { return (size_t)((K + WN_CH - 1) / WN_CH) * 9 * 4 * WN_CH * npad(N); }
-
-PULPO_API int pulpo_conv3d_k3_pack_weight_wino(const float* w, float* wp, int Cin, int Cout, int dgrad, void* stream) {
-    PULPO_REQUIRE(w && wp && Cin > 0 && Cout > 0, "conv3d_k3_pack_weight_wino: bad arguments");
-    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
-    const long total = (long)pulpo_conv3d_k3_packed_wino_floats(K, N);
-    const int nb = (int)std::min<long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wp, Cin, Cout, npad(N), dgrad, total);
-    return pulpo::check_launch("pack_weight_wino");
-}
-
-template <int NT, bool VEC>
-static int launch_wino(const ConvArgs& a, int nblk, hipStream_t st) {
-    constexpr size_t lds = (size_t)(WN_HZ * WN_PS + 2 * 4 * WN_CH * NT) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino_mfma<NT, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(conv3d wino): %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((conv3d_k3_wino_mfma<NT, VEC>), dim3(nblk), dim3(256), lds, st, a);
-    return pulpo::check_launch("conv3d_k3_wino_mfma");
-}
-
-// same contract as pulpo_conv3d_k3_fwd / _fwd_bn_lrelu (coef nullable) with weights from pulpo_conv3d_k3_pack_weight_wino;
-// only for shapes where pulpo_conv3d_k3_algo() returns 1
-PULPO_API int pulpo_conv3d_k3_fwd_wino(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
-                                       const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats,
-                                       int B, int D, int H, int W, int K, int N, void* stream) {
-    PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_wino: null pointer");
-    PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd_wino: bad dims");
-    PULPO_REQUIRE(conv_tz(D, H, W) == 4, "conv3d_k3_fwd_wino: volume %dx%dx%d is not tiled 4x8x8 (see pulpo_conv3d_k3_algo)", D, H, W);
-    PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd_wino: batch statistics are not available from the fused eval-mode epilogue");
-    ConvArgs a{};
-    a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
-    a.wp = wp; a.bias = bias;
-    a.out = out; a.out_bs = out_bs; a.out_ps = out_ps; a.out_cs = out_cs;
-    a.stats = stats;
-    a.coef = coef; a.slope = slope;
-    a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
-    a.ntz = pulpo::cdiv(D, 4); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
-    const int NT = 32;                 // 64-wide tiles need 128 accumulator registers and measured slower (2 instead of 3 waves per SIMD)
-    a.ncot = pulpo::cdiv(N, NT);
-    a.ksplit = 1; a.part = nullptr;
-    const long nblk_l = (long)B * a.ntz * a.nty * a.ntx * a.ncot;
-    PULPO_REQUIRE(nblk_l < (1L << 31), "conv3d_k3_fwd_wino: grid too large");
-    const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0);
-    hipStream_t st = (hipStream_t)stream;
-    return vec ? launch_wino<32, true>(a, (int)nblk_l, st) : launch_wino<32, false>(a, (int)nblk_l, st);
-}
-
-// ---- (y, x) Winograd variant: same contract as the x-only entry points
+// ---- (y, x) Winograd: same contract as pulpo_conv3d_k3_fwd / _fwd_bn_lrelu (coef nullable), own weight packing
 PULPO_API size_t pulpo_conv3d_k3_packed_wino2_floats(int K, int N) { return (size_t)((K + WN_CH - 1) / WN_CH) * 3 * 16 * WN_CH * npad(N); }
 
 PULPO_API int pulpo_conv3d_k3_pack_weight_wino2(const float* w, float* wp, int Cin, int Cout, int dgrad, void* stream) {
@@ -1044,52 +608,25 @@ PULPO_API int pulpo_conv3d_k3_pack_weights_multi(const PulpoPackJob* jobs, int n
     return pulpo::check_launch("pack_weights_multi");
 }
 
-static unsigned next_sched_slot() {                    // one launch counter for all instantiations (the main and the autograd thread both launch)
-    static std::atomic<unsigned> n{0};
-    return n.fetch_add(1);
-}
-
-template <bool VEC, bool BNR = false, bool INAFF = false>
+template <bool VEC, bool BNR = false>
 static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
     constexpr size_t lds = (size_t)(W2_XS + 2 * 16 * WN_CH * 32) * sizeof(float);
     static_assert(lds >= (size_t)(4 * 2 * 2 * 16 * 64 + 4 * 2 * 32) * sizeof(float), "exchange buffer must fit");
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino2_mfma<VEC, BNR, INAFF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino2_mfma<VEC, BNR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(conv3d wino2): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    {
-        static int pct = -1;                            // diagnostic: PULPO_CONV_STAGGER = start-up offset of a CU's second workgroup, % of a tile time
-        if (pct < 0) { const char* e = getenv("PULPO_CONV_STAGGER"); pct = e ? atoi(e) : 0; }
-        const long clocks = ((long)((a.Cin + WN_CH - 1) / WN_CH) * 96 * 64 * 2 + 20000) * pct / 100;
-        const_cast<ConvArgs&>(a).stagger = (int)(clocks / (64 * 127));
-    }
-    {
-        // PULPO_CONV_DYNAMIC: 0 (default) static deal of the tiles; 1 queues per XCD; 2 one queue.  Measured on the 160^3 step (three runs
-        // each on one box): 38.08 / 38.30 / 38.07 ms - no gain over the static deal, the single queue at 1.7x the HBM fetches of the kernel
-        // (neighbouring tiles no longer share an XCD's L2), the per-XCD queues at the static deal's traffic but with the helping phase
-        // at the end.  Kept as switches: with a collective's kernels holding CUs (multi-GPU runs) a queue lets late workgroups take less.
-        static int dynamic = -1;
-        if (dynamic < 0) { const char* e = getenv("PULPO_CONV_DYNAMIC"); dynamic = e ? atoi(e) : 0; }
-        static int* sched_base = nullptr;
-        if (dynamic && sched_base == nullptr) {
-            hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&sched_base), HIP_SYMBOL(g_wino2_sched));
-            if (e != hipSuccess) return pulpo::fail((int)e, "hipGetSymbolAddress(wino2 scheduler): %s", hipGetErrorString(e));
-        }
-        const_cast<ConvArgs&>(a).sched = dynamic ? sched_base + (next_sched_slot() % W2_SCHED_SLOTS) * W2_SCHED_WORDS : nullptr;
-        const_cast<ConvArgs&>(a).sched_single = dynamic == 2;
-    }
     // persistent workgroups: two per CU (LDS and registers admit exactly two)
-    hipLaunchKernelGGL((conv3d_k3_wino2_mfma<VEC, BNR, INAFF>), dim3(std::min(nblk, 512)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3d_k3_wino2_mfma<VEC, BNR>), dim3(std::min(nblk, 512)), dim3(256), lds, st, a);
     return pulpo::check_launch("conv3d_k3_wino2_mfma");
 }
 
 static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
                           float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, const float* bn_y, int64_t bn_y_bs,
-                          int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream,
-                          const float* in_coef = nullptr, float* zout = nullptr);
+                          int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream);
 
 static int wino2_pipe_enabled() {                      // PULPO_W2_PIPE=0 keeps the round-2 kernel for every operand (A/B switch)
     static int pipe = -1;
@@ -1136,35 +673,9 @@ PULPO_API int pulpo_conv3d_k3_dgrad_wino2_bnred(const float* in, int64_t in_bs, 
                           W, K, N, stream);
 }
 
-// 1 when pulpo_conv3d_k3_fwd_wino2_prenorm accepts the shape
-PULPO_API int pulpo_conv3d_k3_fwd_wino2_prenorm_ok(int B, int D, int H, int W, int K, int N) {
-    // N == 32: with several cout tiles every one of them would repeat the operand's BatchNorm arithmetic while staging - measured slower
-    // than the separate pass from two cout tiles up (scripts/prenorm_probe.py); with one it saves the pass's read of y
-    return B > 0 && conv_tz(D, H, W) == 4 && D % 4 == 0 && H % TY == 0 && W % TX == 0 && N == 32 && K > 4 && K % 4 == 0 &&
-           K <= 4 * W2_COEF_QUADS;
-}
-
-// Forward convolution of a ConvUnit whose input is the output z = lrelu(bn(y)) of the ConvUnit in front, reading that unit's PRE-NORM
-// tensor y instead (in = y, channels-last, 16-byte aligned): BatchNorm + LeakyReLU (in_coef = the producing unit's coefficient block from
-// pulpo_bn_fwd_finalize) are applied to the operand while it is staged, and z is written to zout (same strides as y) on the way, for the
-// backward pass.  Replaces the producing unit's pulpo_bn_lrelu_apply pass (a read of y and a write of z) by the write alone.
-PULPO_API int pulpo_conv3d_k3_fwd_wino2_prenorm(const float* y_in, int64_t in_bs, int64_t in_ps, const float* in_coef, float slope, float* zout,
-                                                const float* wp, const float* bias, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs,
-                                                float* stats, int B, int D, int H, int W, int K, int N, void* stream) {
-    PULPO_REQUIRE(y_in && in_coef && zout, "conv3d_k3_fwd_wino2_prenorm: null pointer");
-    PULPO_REQUIRE(pulpo_conv3d_k3_fwd_wino2_prenorm_ok(B, D, H, W, K, N), "conv3d_k3_fwd_wino2_prenorm: shape %dx%dx%d, %d -> %d channels not accepted",
-                  D, H, W, K, N);
-    PULPO_REQUIRE(in_ps % 4 == 0 && in_bs % 4 == 0 && (((uintptr_t)y_in | (uintptr_t)zout | (uintptr_t)in_coef) & 15) == 0 && out_cs == 1 &&
-                      out_ps % 4 == 0 && out_bs % 4 == 0 && (((uintptr_t)out) & 15) == 0 && (bias == nullptr || (((uintptr_t)bias) & 15) == 0),
-                  "conv3d_k3_fwd_wino2_prenorm: operands and output must be channels-last and 16-byte aligned");
-    return fwd_wino2_impl(y_in, in_bs, in_ps, 1, wp, bias, nullptr, slope, out, out_bs, out_ps, out_cs, stats, nullptr, 0, 0, nullptr, B, D, H, W, K, N,
-                          stream, in_coef, zout);
-}
-
 static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
                           float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, const float* bn_y, int64_t bn_y_bs,
-                          int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream, const float* in_coef,
-                          float* zout) {
+                          int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream) {
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_wino2: null pointer");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd_wino2: bad dims");
     PULPO_REQUIRE(conv_tz(D, H, W) == 4, "conv3d_k3_fwd_wino2: volume %dx%dx%d is not tiled 4x8x8 (see pulpo_conv3d_k3_algo)", D, H, W);
@@ -1176,7 +687,6 @@ static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t
     a.stats = stats;
     a.coef = coef; a.slope = slope;
     a.bn_y = bn_y; a.bn_y_bs = bn_y_bs; a.bn_y_ps = bn_y_ps; a.bn_coef = bn_coef;
-    a.in_coef = in_coef; a.zout = zout;
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
     a.ntz = pulpo::cdiv(D, 4); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
     a.ncot = pulpo::cdiv(N, 32);
@@ -1185,16 +695,12 @@ static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t
     PULPO_REQUIRE(nblk_l < (1L << 31), "conv3d_k3_fwd_wino2: grid too large");
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
-    // channels-last operands without the operand-side BatchNorm: the pipelined kernel (conv3d_wino2p.hip); PULPO_W2_PIPE=0 keeps the round-2 kernel
+    // channels-last operands: the pipelined kernel (conv3d_wino2p.hip); PULPO_W2_PIPE=0 keeps the round-2 kernel
     const int pipe = wino2_pipe_enabled();
     if (bn_y != nullptr) {
         PULPO_REQUIRE(vec, "conv3d_k3_dgrad_wino2_bnred: the gradient operand must be channels-last, 16-byte aligned, with a multiple of 4 channels");
         if (pipe && wino2p_ok(a)) return launch_wino2p(a, (int)nblk_l, true, st);
         return launch_wino2<true, true>(a, (int)nblk_l, st);
-    }
-    if (in_coef != nullptr) {
-        PULPO_REQUIRE(vec, "conv3d_k3_fwd_wino2_prenorm: the operand must be channels-last, 16-byte aligned, with a multiple of 4 channels");
-        return launch_wino2<true, false, true>(a, (int)nblk_l, st);
     }
     if (vec && pipe && wino2p_ok(a)) return launch_wino2p(a, (int)nblk_l, false, st);
     return vec ? launch_wino2<true>(a, (int)nblk_l, st) : launch_wino2<false>(a, (int)nblk_l, st);

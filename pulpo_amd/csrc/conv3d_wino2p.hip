@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
     STAMP(0, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));        // HW_REG_HW_ID
     STAMP(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));       // HW_REG_XCC_ID
     STAMP(2, __builtin_amdgcn_s_memtime());
-    int tile_no = 0;
+    [[maybe_unused]] int tile_no = 0;
     int work = pulpo::xcd_remap(blockIdx.x, nwg);
     Tile cur = describe(work);
     int cb = 0;                                         // image being read

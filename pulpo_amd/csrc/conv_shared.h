@@ -59,14 +59,7 @@ struct ConvArgs {
     const float* bn_y;
     long bn_y_bs, bn_y_ps;
     const float* bn_coef;
-    // Winograd (y, x) kernel reading the PRE-NORM output y of the ConvUnit in front (in = y): BatchNorm + LeakyReLU of that unit are applied
-    // to the operand while it is staged (coefficients in_coef: scale at [2 Cin], shift at [3 Cin]), and the activated tensor z - which the
-    // backward pass needs as the weight gradient's operand - is written to zout (same strides as `in`) by the workgroups of cout tile 0
-    const float* in_coef;
-    float* zout;
-    int* sched;                   // Winograd (y, x) kernel: device words of its tile scheduler ([0..7] per-XCD queue heads, [8] finished workgroups); null = static deal
-    int sched_single;             // 1: one queue for the whole chip instead of one per XCD (A/B switch PULPO_CONV_DYNAMIC=2)
-    int stagger;                  // Winograd (y, x) kernel: start-up delay (units of 64 x 127 clocks) of the second workgroup of every CU, 0 = none
+    int stagger;                  // pipelined (y, x) kernel: diagnostic start-up delay (units of 64 x 127 clocks) of the second half of the grid, 0 = none
 };
 
 

@@ -53,14 +53,13 @@ class ConvUnit(nn.Module):
             nn.LeakyReLU(negative_slope=0.2, inplace=True),
         )
 
-    def forward(self, x: torch.Tensor, defer_apply: bool = False) -> torch.Tensor:
-        """defer_apply: only for a caller that hands the result straight to another ConvUnit (ConvSequence) - see ops.APPLY_ON_LOAD"""
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
         conv, bn = self._op[0], self._op[1]
         use_batch_stats = self.training or bn.running_mean is None
         # running statistics and num_batches_tracked are updated inside the BatchNorm finalize kernel
         return ops.conv_bn_lrelu(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                  training=use_batch_stats, momentum=bn.momentum, eps=bn.eps,
-                                 num_batches_tracked=bn.num_batches_tracked if self.training else None, defer_apply=defer_apply)
+                                 num_batches_tracked=bn.num_batches_tracked if self.training else None)
 
 
 class ConvSequence(nn.Module):
@@ -73,13 +72,7 @@ class ConvSequence(nn.Module):
         self._op = nn.Sequential(*units)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        # every unit but the last hands its result to the next unit and to nobody else: its BatchNorm + LeakyReLU may be applied by that
-        # unit's convolution as it reads the operand (training mode with gradients, 3-D; ops.conv_bn_lrelu decides)
-        units = list(self._op)
-        chain = torch.is_grad_enabled() and x.dim() == 5 and self.training
-        for k, unit in enumerate(units):
-            x = unit(x, defer_apply=chain and k + 1 < len(units))
-        return x
+        return self._op(x)
 
 
 class MuSigmaBlock(nn.Module):

@@ -191,7 +191,7 @@ def _trace_end(start, name: str, flops: float, nbytes: float = 0.0):
 # 4-5: operands rounded to bf16 while staged, fp32 accumulation; activations, statistics, losses and gradients stay fp32).
 # Layers with <= 4 reduction channels (the 2-channel image input) always run the fp32 kernel.
 CONV_PRECISION = "fp32"
-# None: the library's choice per shape (pulpo_conv3d_k3_algo); "direct" | "wino" | "wino2": force that forward / data-gradient kernel
+# None: the library's choice per shape (pulpo_conv3d_k3_algo); "direct" | "wino2": force that forward / data-gradient kernel
 # wherever a Winograd kernel would be eligible (A/B runs and the full-size consistency test)
 CONV_ALGO = None
 
@@ -316,14 +316,13 @@ def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None, register: bool = 
         return wp
     algo = lib.query("pulpo_conv3d_k3_algo", *shape, K, N) if shape is not None else 0
     if CONV_ALGO is not None and algo != 0:            # diagnostic override; only among the kernels valid for this shape
-        algo = {"direct": 0, "wino": 1, "wino2": 2}[CONV_ALGO]
-    if algo in (1, 2):
-        name = "wino" if algo == 1 else "wino2"
-        wp = torch.empty(lib.query(f"pulpo_conv3d_k3_packed_{name}_floats", K, N), device=w.device, dtype=torch.float32)
-        lib.call(f"pulpo_conv3d_k3_pack_weight_{name}", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
-        wp._pulpo_algo = name
+        algo = {"direct": 0, "wino2": 2}[CONV_ALGO]
+    if algo == 2:
+        wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_wino2_floats", K, N), device=w.device, dtype=torch.float32)
+        lib.call("pulpo_conv3d_k3_pack_weight_wino2", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
+        wp._pulpo_algo = "wino2"
         if register:
-            if algo == 2 and w.is_contiguous():
+            if w.is_contiguous():
                 _register_pack(w, wp, Cin, Cout, dgrad, 2)
             else:
                 _UNREFRESHABLE_PACKS = True
@@ -339,29 +338,6 @@ def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None, register: bool = 
     return wp
 
 
-def _prenorm_conv_ok(x: torch.Tensor, y_prev: torch.Tensor, wp: torch.Tensor, out: torch.Tensor, K: int, N: int) -> bool:
-    """can the forward convolution read the producing unit's pre-norm tensor (pulpo_conv3d_k3_fwd_wino2_prenorm)?"""
-    if not APPLY_ON_LOAD or getattr(wp, "_pulpo_algo", "") != "wino2" or y_prev.shape != x.shape or y_prev.stride() != x.stride():
-        return False
-    B, _, D, H, W = x.shape
-    xb, xp, xc = grid_strides(x)
-    ob, op, oc = grid_strides(out)
-    return (xc == 1 and xp % 4 == 0 and xb % 4 == 0 and x.data_ptr() % 16 == 0 and y_prev.data_ptr() % 16 == 0 and oc == 1 and op % 4 == 0
-            and ob % 4 == 0 and out.data_ptr() % 16 == 0 and bool(lib.query("pulpo_conv3d_k3_fwd_wino2_prenorm_ok", B, D, H, W, K, N)))
-
-
-def _conv_raw_prenorm(y_prev: torch.Tensor, coef_prev: torch.Tensor, z: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
-                      out: torch.Tensor, K: int, N: int, stats: torch.Tensor) -> None:
-    """out = conv(lrelu(bn(y_prev))) with z = lrelu(bn(y_prev)) written on the way (see include/pulpo_hip.h)"""
-    B, _, D, H, W = z.shape
-    yb, yp, _ = grid_strides(y_prev)
-    ob, op, oc = grid_strides(out)
-    t0 = _trace_begin()
-    lib.call("pulpo_conv3d_k3_fwd_wino2_prenorm", _ptr(y_prev), yb, yp, _ptr(coef_prev), LRELU_SLOPE, _ptr(z), _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc,
-             _ptr(stats), B, D, H, W, K, N, _stream())
-    _trace_end(t0, "conv3d_k3_wino2_mfma<true>", 54.0 * K * N * B * D * H * W, 4.0 * (2 * K + N) * B * D * H * W)
-
-
 def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, K: int, N: int,
               stats: Optional[torch.Tensor], coef: Optional[torch.Tensor] = None):
     """coef: eval-mode BatchNorm coefficients -> BatchNorm + LeakyReLU are applied by the convolution's store (one kernel per ConvUnit)"""
@@ -371,13 +347,12 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
     algo = getattr(wp, "_pulpo_algo", "bf16" if wp.dtype == torch.int16 else "direct")
     bf16 = algo == "bf16"
     vec_ok = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0
-    if algo in ("wino", "wino2"):
+    if algo == "wino2":
         t0 = _trace_begin()
-        lib.call(f"pulpo_conv3d_k3_fwd_{algo}", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc, _ptr(stats),
+        lib.call("pulpo_conv3d_k3_fwd_wino2", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc, _ptr(stats),
                  B, D, H, W, K, N, _stream())
-        tmpl = f"<32,{'true' if vec_ok else 'false'}>" if algo == "wino" else f"<{'true' if vec_ok else 'false'}>"
-        kname = f"conv3d_k3_{algo}_mfma{tmpl}"
-        if algo == "wino2" and vec_ok and t0 is not None and lib.query("pulpo_conv3d_k3_wino2_pipelined", D, H, W, K, xp):
+        kname = f"conv3d_k3_wino2_mfma<{'true' if vec_ok else 'false'}>"
+        if vec_ok and t0 is not None and lib.query("pulpo_conv3d_k3_wino2_pipelined", D, H, W, K, xp):
             kname = "conv3d_k3_wino2p_mfma<false>"
         _trace_end(t0, kname, 54.0 * K * N * B * D * H * W, 4.0 * (K + N) * B * D * H * W)
         return
@@ -516,14 +491,6 @@ def join_async_wgrad():
 # the producer's y, and the producer takes them only if the gradient it is given IS that kernel's output, untouched (same storage, same
 # version: a gradient that autograd accumulated from several consumers is a different tensor or carries a bumped version).
 BN_REDUCE_IN_DGRAD = os.environ.get("PULPO_BN_REDUCE_IN_DGRAD", "1") != "0"      # (A/B switch)
-# The forward counterpart: inside a ConvSequence the BatchNorm + LeakyReLU of unit u is applied by unit u+1's convolution while it stages
-# its operand (pulpo_conv3d_k3_fwd_wino2_prenorm), which also writes z_u for the backward pass; unit u then runs no apply pass of its own
-# (`defer_apply`: the tensor it returns is filled by its consumer - network_blocks.ConvSequence is the only caller that may ask for that).
-# OFF by default: measured slower in the step (37.5 -> 37.8 ms at 160^3).  Every cout tile of the consumer repeats the operand's arithmetic
-# (so only 32-cout consumers are accepted at all), and the z stores issued while staging sit in front of the `s_waitcnt vmcnt(0)` with
-# which the kernel waits for its weight DMA - on gfx950 stores count in vmcnt - so every chunk waits for their write acknowledgements
-# (scripts/prenorm_probe.py: 1.32 ms against 1.18 + 0.21 ms for 32->32 at 160^3 stand-alone, a gain that the step does not keep).
-APPLY_ON_LOAD = os.environ.get("PULPO_APPLY_ON_LOAD", "0") != "0"
 _BN_TILE_PARTS: dict = {}
 
 
@@ -572,7 +539,7 @@ class _ConvBNLReLU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool, momentum: float, eps: float,
-                bn_src=None, lazy_in=None, defer_apply: bool = False):
+                bn_src=None):
         _require_gpu(x, weight, bias, gamma, beta)
         ctx.bn_src = bn_src
         x = as_grid(x)
@@ -582,18 +549,10 @@ class _ConvBNLReLU(torch.autograd.Function):
         wp = _pack_weight(weight, dgrad=False, shape=(B, D, H, W), both=bool(training and ctx.needs_input_grad[0]))
         y = new_cl(B, Cout, D, H, W, dev)
         coef = torch.empty(8 * Cout, device=dev, dtype=torch.float32)      # [4][C] floats + [2][C] doubles
-        if lazy_in is not None and not (training and _prenorm_conv_ok(x, lazy_in[0], wp, y, Cin, Cout)):
-            # the producer left its output unfilled for a consumer that could apply its BatchNorm on load; this one cannot: fill it now
-            lib.call("pulpo_bn_lrelu_apply", _ptr(lazy_in[0]), lazy_in[0].stride(4), _ptr(x), x.stride(4), _ptr(lazy_in[1]), B * D * H * W, Cin,
-                     LRELU_SLOPE, _stream())
-            lazy_in = None
         if training:
             ntile = lib.query("pulpo_conv3d_k3_fwd_bf16_stat_tiles" if wp._pulpo_algo == "bf16" else "pulpo_conv3d_k3_stat_tiles", B, D, H, W)
             stats = torch.empty(ntile * 2 * Cout, device=dev, dtype=torch.float32)
-            if lazy_in is not None:
-                _conv_raw_prenorm(lazy_in[0], lazy_in[1], x, wp, bias, y, Cin, Cout, stats)
-            else:
-                _conv_raw(x, wp, bias, y, Cin, Cout, stats)
+            _conv_raw(x, wp, bias, y, Cin, Cout, stats)
             nsd = lib.query("pulpo_bn_fwd_finalize_scratch_doubles", ntile, Cout)
             scratch = torch.empty(nsd, device=dev, dtype=torch.float64) if nsd else None
             lib.call("pulpo_bn_fwd_finalize", _ptr(stats), ntile, Cout, float(B * D * H * W), _ptr(gamma), _ptr(beta), _ptr(running_mean),
@@ -606,15 +565,13 @@ class _ConvBNLReLU(torch.autograd.Function):
                 return y
             _conv_raw(x, wp, bias, y, Cin, Cout, None)
         z = new_cl(B, Cout, D, H, W, dev)
-        ctx.deferred = bool(defer_apply and training and APPLY_ON_LOAD)
-        if not ctx.deferred:
-            t0 = _hbm_begin()
-            lib.call("pulpo_bn_lrelu_apply", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
-            _hbm_end(t0, "bn_lrelu_apply", 8.0 * Cout * B * D * H * W)            # read y, write z
+        t0 = _hbm_begin()
+        lib.call("pulpo_bn_lrelu_apply", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
+        _hbm_end(t0, "bn_lrelu_apply", 8.0 * Cout * B * D * H * W)            # read y, write z
         ctx.save_for_backward(x, weight, y, coef)
         ctx.training = training
         ctx.params = (weight, bias, gamma, beta)      # for DIRECT_PARAM_GRADS (their .grad slots)
-        _TLS.produced = (y, coef, ctx.deferred)      # read back by conv_bn_lrelu (the Function returns tensors only)
+        _TLS.produced = (y, coef)                    # read back by conv_bn_lrelu (the Function returns tensors only)
         return z
 
     @staticmethod
@@ -672,30 +629,22 @@ class _ConvBNLReLU(torch.autograd.Function):
                 _conv_raw(dy, wpt, None, dx, Cout, Cin, None)
         if defer_w:
             _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, w_p)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None,
-                  defer_apply: bool = False):
-    """ConvUnit forward.  In training mode running_mean / running_var / num_batches_tracked are updated in place by the kernel.
-    defer_apply (ConvSequence only, see APPLY_ON_LOAD): the returned tensor may be left unfilled; the next conv_bn_lrelu call that receives it
-    - and nobody else may - fills it."""
+def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None):
+    """ConvUnit forward.  In training mode running_mean / running_var / num_batches_tracked are updated in place by the kernel."""
     if _is2d(x):
         return conv_bn_lrelu(_lift(x), _lift_w3(weight), bias, gamma, beta, running_mean, running_var, training, momentum, eps,
                              num_batches_tracked).squeeze(2)
     src = getattr(x, "_pulpo_bn_src", None)          # x is the untouched output of another ConvUnit: (y, coef, version at production)
     bn_src = src[:2] if (src is not None and src[2] == x._version and training and torch.is_grad_enabled()) else None
-    lazy = getattr(x, "_pulpo_lazy", None)           # x was left unfilled by its producer: (y, coef) to make it from
-    if lazy is not None:
-        del x._pulpo_lazy
     z = _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
-                           float(eps), bn_src, lazy, bool(defer_apply))
+                           float(eps), bn_src)
     produced = getattr(_TLS, "produced", None)
     _TLS.produced = None
     if produced is not None:
         z._pulpo_bn_src = (produced[0], produced[1], z._version)
-        if produced[2]:
-            z._pulpo_lazy = (produced[0], produced[1])
     return z
 
 

@@ -15,10 +15,8 @@ from pulpo_amd.build import CSRC, FLAGS, HIPCC, OBJ, build_library  # noqa: E402
 ABL = os.path.join(OBJ, "abl")
 # name: (unit, PULPO_ABL value, extra env at run time, conv_bench args)
 VARIANTS = {
-    "wino2_stamps": ("conv3d_wino", 9, {}, None),
-    "wino2_stamps_stagger50": ("conv3d_wino", 9, {"PULPO_CONV_STAGGER": "50"}, None),
-    "wino2_base": ("conv3d_wino", 0, {}, ["--only", "fwd"]),
-    "wino2_stagger50": ("conv3d_wino", 0, {"PULPO_CONV_STAGGER": "50"}, ["--only", "fwd"]),
+    "wino2_stamps": ("conv3d_wino", 9, {"PULPO_W2_PIPE": "0"}, None),
+    "wino2_base": ("conv3d_wino", 0, {"PULPO_W2_PIPE": "0"}, ["--only", "fwd"]),
     "wgrad_base": ("conv3d_wgrad", 0, {}, ["--only", "wgrad"]),
     "wgrad_nodma": ("conv3d_wgrad", 11, {}, ["--only", "wgrad"]),
     "wgrad_nomfma": ("conv3d_wgrad", 12, {}, ["--only", "wgrad"]),

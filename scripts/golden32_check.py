@@ -12,7 +12,7 @@ FB = ["samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs
 def rel(a, b):
     a, b = a.detach().double().cpu(), torch.as_tensor(b).double()
     return float((a - b).norm() / (b.norm() + 1e-30))
-for algo in ("direct", "wino", "wino2"):
+for algo in ("direct", "wino2"):
     for wg in ("1", "0"):
         Tl, L, n0, B, *size = [int(v) for v in g["cfg"]]
         model = models.PULPo(Tl, L, 0.1, size, feedback=FB, n0=n0)

@@ -42,7 +42,7 @@ def _clean_kernel_switches():
     if mod is not None:
         assert mod.CONV_ALGO is None, f"ops.CONV_ALGO leaked from an earlier test: {mod.CONV_ALGO!r}"
         assert mod.CONV_PRECISION == "fp32", f"ops.CONV_PRECISION leaked from an earlier test: {mod.CONV_PRECISION!r}"
-        fusion = (mod.BN_REDUCE_IN_DGRAD, mod.APPLY_ON_LOAD)
+        fusion = mod.BN_REDUCE_IN_DGRAD
     yield
     mod = sys.modules.get("pulpo_amd.ops")
     if mod is not None:
@@ -51,6 +51,6 @@ def _clean_kernel_switches():
         mod.set_conv_precision("fp32")
         assert leaked == (None, "fp32"), f"test left ops.CONV_ALGO / CONV_PRECISION = {leaked!r}"
         if fusion is not None:
-            now = (mod.BN_REDUCE_IN_DGRAD, mod.APPLY_ON_LOAD)
-            mod.BN_REDUCE_IN_DGRAD, mod.APPLY_ON_LOAD = fusion
-            assert now == fusion, f"test left ops.BN_REDUCE_IN_DGRAD / APPLY_ON_LOAD = {now!r}"
+            now = mod.BN_REDUCE_IN_DGRAD
+            mod.BN_REDUCE_IN_DGRAD = fusion
+            assert now == fusion, f"test left ops.BN_REDUCE_IN_DGRAD = {now!r}"

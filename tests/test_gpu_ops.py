@@ -102,6 +102,32 @@ def test_vecint_backward_lds_tiled_scatter_vs_oracle(ops, size, amp):
     assert rel_l2(gv, gr) < max(1e-4, 3.0 * rel_l2(g32, gr))
 
 
+@pytest.mark.parametrize("B,size", [(1, (20, 20, 20)), (2, (10, 10, 10)), (1, (12, 14, 10)), (1, (6, 7, 5)), (2, (16, 24, 20))])
+def test_vecint_forward_fused_in_lds_equals_the_step_by_step_kernels(ops, B, size):
+    """fields of <= 8192 voxels (the 20^3 and 10^3 pyramid levels and BASELINE config 5's coarse levels) run all seven squaring steps in ONE
+    launch with the field resident in LDS (vecint_fwd_lds_kernel; network_blocks.py:160-177): compared with the operator evaluated step by
+    step through the warp kernel (v / 2^7, then seven times v + warp(v, v)) - the same arithmetic, to fp32 rounding at worst - and with the
+    float64 oracle; the backward pass (which reads the intermediate fields the fused kernel saved) against autograd through the oracle"""
+    gen = torch.Generator().manual_seed(B * 100 + size[0])
+    v = torch.randn(B, 3, *size, generator=gen) * 2.0
+    up = torch.randn(B, 3, *size, generator=gen)
+    vg = v.cuda().requires_grad_(True)
+    out = ops.vecint(vg, 7)
+    gv, = torch.autograd.grad((out * up.cuda()).sum(), [vg])
+    with torch.no_grad():
+        w = v.cuda() * (1.0 / 128.0)
+        for _ in range(7):
+            w = w + ops.warp3d(w, w)
+    assert float((out - w).abs().max()) <= 1e-5 * max(1.0, float(w.abs().max()))      # (measured 1e-6: contraction / add order of seven squarings)
+    vr = v.double().requires_grad_(True)
+    ref = O.vecint(vr, 7)
+    gr, = torch.autograd.grad((ref * up.double()).sum(), [vr])
+    assert rel_l2(out, ref) < 1e-5
+    v32 = v.clone().requires_grad_(True)
+    g32, = torch.autograd.grad((O.vecint(v32, 7) * up).sum(), [v32])
+    assert rel_l2(gv, gr) < max(1e-4, 3.0 * rel_l2(g32, gr))
+
+
 # ================================================================================================ resampling
 def test_resample_golden(ops, golden):
     g = golden("resample")
@@ -291,15 +317,18 @@ def test_eval_mode_fused_epilogue_equals_separate_passes(ops, precision, Cin, Co
         O.CONV_PRECISION = "fp32"
 
 
-@pytest.mark.parametrize("algo", ["wino2", "wino"])
 @pytest.mark.parametrize("B,Cin,Cout,size", [(1, 32, 32, (64, 64, 64)), (1, 64, 64, (64, 64, 64)), (2, 16, 96, (64, 56, 80)), (1, 20, 12, (64, 64, 70)),
-                                            (1, 96, 32, (68, 61, 67)), (2, 192, 192, (20, 20, 20)), (1, 8, 40, (24, 20, 17))])
-def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size, algo):
-    """volumes of >= 40^3 voxels take a Winograd kernel for forward and data gradient (pulpo_conv3d_k3_algo: 2 = F(2x2,3x3) in (y, x),
-    1 = F(2,3) along x only) and the Winograd-x weight-gradient kernel: same fp32 tolerance against the fp64 convolution as the
-    direct kernels; ragged H / W (odd sizes: half-filled blocks) included"""
+                                            (1, 96, 32, (68, 61, 67)), (2, 192, 192, (20, 20, 20)), (1, 8, 40, (24, 20, 17)),
+                                            (1, 288, 192, (20, 20, 20)), (1, 128, 192, (20, 20, 20))])
+def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size):
+    """volumes of >= 20^3 voxels with depth % 4 == 0 take the F(2x2,3x3) Winograd kernels for forward and data gradient
+    (pulpo_conv3d_k3_algo = 2: the pipelined conv3d_k3_wino2p_mfma for operands with a multiple of 8 channels, the round-2
+    conv3d_k3_wino2_mfma otherwise - Cin = 20 forward, Cout = 12 data gradient here) and for the weight gradient: same fp32 tolerance
+    against the fp64 convolution as the direct kernels; ragged H / W (odd sizes: half-filled blocks) and the 20^3 level's 128 / 192 / 288
+    channel layers included"""
     from pulpo_amd._lib import lib
-    assert lib.query("pulpo_conv3d_k3_algo", B, *size, Cin, Cout) in (1, 2)
+    assert lib.query("pulpo_conv3d_k3_algo", B, *size, Cin, Cout) == 2
+    assert lib.query("pulpo_conv3d_k3_wino2_pipelined", *size, Cin, Cin) == int(Cin % 8 == 0)
     gen = torch.Generator().manual_seed(B * 1000 + Cin * 10 + Cout)
     x = torch.randn(B, Cin, *size, generator=gen)
     w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (27 * Cin) ** 0.5
@@ -310,12 +339,8 @@ def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size, algo):
     gref = torch.autograd.grad((ref * up.double()).sum(), [xr, wr, br])
     xd = x.cuda().contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
     wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
-    ops.CONV_ALGO = algo                      # "wino2" is the library's default choice; "wino" (x only) stays selectable
-    try:
-        out = ops.conv3d_k3(xd, wd, bd)
-        gx, gw, gb = torch.autograd.grad((out * up.cuda()).sum(), [xd, wd, bd])
-    finally:
-        ops.CONV_ALGO = None
+    out = ops.conv3d_k3(xd, wd, bd)
+    gx, gw, gb = torch.autograd.grad((out * up.cuda()).sum(), [xd, wd, bd])
     assert rel_l2(out, ref) < 2e-6
     assert rel_l2(gx, gref[0]) < 2e-6
     assert rel_l2(gw, gref[1]) < 1e-5
@@ -464,83 +489,6 @@ def test_bn_backward_reduction_inside_the_data_gradient_kernel(ops, chans, size)
                 continue                     # conv bias in front of a training-mode BatchNorm: exact gradient 0, computed value is rounding noise
             assert rel_l2(a, b) < 2e-5
             assert rel_l2(a, r) < 2e-3 and rel_l2(b, r) < 2e-3      # (fp32 vs float64 through three units: LeakyReLU branch flips near 0)
-
-
-@pytest.mark.parametrize("chans,size,fused_links", [((16, 32, 64, 32), (24, 32, 40), 1), ((32, 32, 32), (32, 32, 32), 1), ((8, 96, 96), (20, 24, 24), 0),
-                                                   ((32, 32, 32), (18, 20, 22), 0), ((32, 48, 32, 32), (24, 24, 24), 2)])
-def test_batchnorm_applied_while_the_next_convolution_stages_its_operand(ops, chans, size, fused_links):
-    """(opt-in path, ops.APPLY_ON_LOAD / PULPO_APPLY_ON_LOAD=1; off by default because it measured slower in the step)
-    Inside a ConvSequence the BatchNorm + LeakyReLU of a unit is applied by the next unit's convolution as it reads the operand, which
-    also writes the activated tensor for the backward pass (pulpo_conv3d_k3_fwd_wino2_prenorm).  Checked: the fused kernel runs on exactly
-    the links whose shapes allow it (whole tiles, one 32-wide cout tile; the others fall back to a separate pass that fills the tensor), and the
-    module's output, every saved activation's effect - all gradients - and the BatchNorm buffers equal the separate-pass path bit for bit."""
-    from pulpo_amd.network_blocks import ConvSequence
-    gen = torch.Generator().manual_seed(sum(chans) + size[0])
-    x = torch.randn(1, chans[0], *size, generator=gen).cuda()
-    up = torch.randn(1, chans[-1], *size, generator=gen).cuda()
-
-    class Chain(torch.nn.Module):                      # a ConvSequence whose units change the channel count freely
-        def __init__(self):
-            super().__init__()
-            from pulpo_amd.network_blocks import ConvUnit
-            self._op = torch.nn.Sequential(*[ConvUnit(size, chans[u], chans[u + 1]) for u in range(len(chans) - 1)])
-        forward = ConvSequence.forward
-
-    torch.manual_seed(3)
-    ref_mod = Chain().cuda().train()
-    state = {k: v.clone() for k, v in ref_mod.state_dict().items()}
-
-    default = ops.APPLY_ON_LOAD
-
-    def run(on):
-        ops.APPLY_ON_LOAD = on
-        mod = Chain().cuda().train()
-        mod.load_state_dict(state)
-        calls = []
-        orig = ops._conv_raw_prenorm
-        ops._conv_raw_prenorm = lambda *a: (calls.append(1), orig(*a))[1]
-        try:
-            xg = x.clone().requires_grad_(True)
-            out = mod(xg)
-            grads = torch.autograd.grad((out * up).sum(), [xg] + list(mod.parameters()))
-        finally:
-            ops._conv_raw_prenorm = orig
-            ops.APPLY_ON_LOAD = default
-        return out.detach(), grads, {k: v.clone() for k, v in mod.state_dict().items()}, len(calls)
-
-    out1, g1, st1, n1 = run(True)
-    out0, g0, st0, n0 = run(False)
-    assert n0 == 0 and n1 == fused_links, (n0, n1)
-    assert torch.equal(out1, out0)
-    for a, b in zip(g1, g0):
-        assert rel_l2(a, b) < 2e-6                     # (weight gradients are atomic sums: equal up to the order of the adds)
-    for k in st0:
-        assert torch.equal(st1[k], st0[k]), k
-
-
-def test_alternative_kernel_builds_behind_environment_switches():
-    """kernel variants that are chosen once per process from the environment (the four-wave weight-gradient kernel, the tile queues of the
-    persistent Winograd kernel) stay parity-checked: a child process per setting runs one forward / data-gradient / weight-gradient
-    comparison against float64"""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, torch, torch.nn.functional as F\n"
-        f"sys.path.insert(0, {root!r})\n"
-        "from pulpo_amd import ops\n"
-        "g = torch.Generator().manual_seed(7)\n"
-        "x = torch.randn(1, 32, 24, 32, 40, generator=g); w = torch.randn(64, 32, 3, 3, 3, generator=g) / 30; up = torch.randn(1, 64, 24, 32, 40, generator=g)\n"
-        "xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)\n"
-        "ref = F.conv3d(xr, wr, padding=1); gr = torch.autograd.grad((ref * up.double()).sum(), [xr, wr])\n"
-        "xd = x.cuda().contiguous(memory_format=torch.channels_last_3d).requires_grad_(True); wd = w.cuda().requires_grad_(True)\n"
-        "out = ops.conv3d_k3(xd, wd); gx, gw = torch.autograd.grad((out * up.cuda().contiguous(memory_format=torch.channels_last_3d)).sum(), [xd, wd])\n"
-        "rel = lambda a, b: float((a.detach().cpu().double() - b).norm() / b.norm())\n"
-        "print('REL', rel(out, ref.detach()), rel(gx, gr[0]), rel(gw, gr[1]))\n")
-    for env in ({"PULPO_WGRAD_WAVES8": "0"}, {"PULPO_CONV_DYNAMIC": "1"}, {"PULPO_CONV_DYNAMIC": "2"}):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, (env, r.stderr[-2000:])
-        vals = [float(v) for v in r.stdout.split("REL")[1].split()]
-        assert vals[0] < 2e-6 and vals[1] < 2e-6 and vals[2] < 1e-5, (env, vals)
 
 
 def test_conv_linearity_at_full_channel_width(ops):

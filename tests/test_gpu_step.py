@@ -74,8 +74,8 @@ STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16", "step_fullres_T3L2_n2_
 
 
 # (case, forward / data-gradient kernel): None = the library's per-shape default (F(2x2,3x3) Winograd where eligible, which on these
-# fixtures is the 32^3 case only); that case is also pinned with the x-only Winograd and the direct kernels forced
-STEP_ALGO_CASES = [(c, None) for c in STEP_CASES] + [("step_T3L2_n8_32", "wino"), ("step_T3L2_n8_32", "direct")]
+# fixtures is the 32^3 case only); that case is also pinned with the direct kernels forced
+STEP_ALGO_CASES = [(c, None) for c in STEP_CASES] + [("step_T3L2_n8_32", "direct")]
 
 
 @pytest.mark.parametrize("case,algo", STEP_ALGO_CASES)
@@ -810,7 +810,7 @@ def test_headline_160_stepper_equals_autograd(api):
 def test_headline_config_160_direct_and_winograd_kernels_agree(api):
     """BASELINE config 3 / the metric's workload at FULL size (160^3, T5/L4, n0 = 32, B = 1): no oracle run fits the test budget
     (11 s per CPU step), so the size-independent property is the agreement of independent kernels - the direct implicit-GEMM
-    convolution (pinned against the reference goldens at small sizes) and the two Winograd kernels - on every output dictionary and the
+    convolution (pinned against the reference goldens at small sizes) and the Winograd kernels - on every output dictionary and the
     loss terms of one training-mode forward, plus finite gradients and a bitwise reproducible forward."""
     models, nb = api
     from pulpo_amd import ops
@@ -825,14 +825,14 @@ def test_headline_config_160_direct_and_winograd_kernels_agree(api):
     bn_state = {k: v.clone() for k, v in model.state_dict().items()}
     res = {}
     try:
-        for algo in ("direct", "wino", "wino2"):
+        for algo in ("direct", "wino2"):
             ops.CONV_ALGO = algo
             model.load_state_dict(bn_state)                 # same BatchNorm running statistics going in
             with torch.no_grad():
                 outs, _, losses, _ = model._forward_and_losses(x, y)
             res[algo] = ([{l: v.clone() for l, v in d.items()} for d in outs], [float(v) for v in losses])
         ops.CONV_ALGO = None
-        for algo in ("wino", "wino2"):
+        for algo in ("wino2",):
             for name, d0, d1 in zip(OUT, res["direct"][0], res[algo][0]):
                 for l in d0:
                     err = float((d0[l] - d1[l]).abs().max()) / max(1.0, float(d0[l].abs().max()))
@@ -1032,7 +1032,10 @@ def test_bench_self_launch_two_ranks_without_torchrun():
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "32", "32", "32", "--levels", "3", "2",
            "--no-cpu-baseline"]
     for inject, expect in (("", None), ("all", "falling back"), ("1", "starting all ranks again")):
-        r = subprocess.run(cmd, env=dict(base, PULPO_BENCH_INJECT_FAILURE=inject), capture_output=True, text=True, timeout=900, cwd=root)
+        # (one rank failing: its peer sits in the gloo collective of the step until the failed rank's vote times out - with RCCL the
+        #  collective is enqueued and the host goes on to the vote; the rehearsal shortens the 300 s default of that time-out)
+        r = subprocess.run(cmd, env=dict(base, PULPO_BENCH_INJECT_FAILURE=inject, PULPO_BENCH_AGREE_TIMEOUT_S="20"), capture_output=True, text=True,
+                           timeout=900, cwd=root)
         assert r.returncode == 0, (inject, r.stdout[-1500:], r.stderr[-3000:])
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, (inject, r.stdout[-1500:])
