@@ -59,6 +59,7 @@ struct ConvArgs {
     const float* bn_y;
     long bn_y_bs, bn_y_ps;
     const float* bn_coef;
+    int tile_order;               // pipelined (y, x) kernel: 0 = tiles in linear order (x fastest), 1 = in 4 x 4 x 4 blocks (see describe())
     int stagger;                  // pipelined (y, x) kernel: diagnostic start-up delay (units of 64 x 127 clocks) of the second half of the grid, 0 = none
 };
 

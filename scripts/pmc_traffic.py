@@ -5,8 +5,11 @@ usage: python scripts/pmc_traffic.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE
 The two counters do not fit one pass on gfx950 (TCC has 4 slots: FETCH_SIZE costs 3, WRITE_SIZE 2), so they come from two runs of
 the same command.  Units: rocprofv3 reports both in KiB.  Correction applied as MI355X_MICROARCH.md prescribes: FETCH_SIZE reads
 one half of the bytes of fully coalesced 16 B/lane streams - that applies to the LDS-DMA wgrad kernel and the elementwise
-float4 kernels (factor 2 below); the forward/dgrad convolutions gather 32- or 64-byte runs per voxel, an access width the guide calls
-uncalibrated, so its FETCH_SIZE is reported raw (factor 1) and is a lower bound.
+float4 kernels (factor 2 below).  The forward / data-gradient convolutions gather a 32-byte run per voxel and chunk pass, a width the
+guide calls uncalibrated: scripts/probes/fetch_calib.hip reads a known byte count with exactly that pattern (profiles/r3_fetch_calibration.md)
+and finds the same factor 2.000 (line fills of 128 bytes tallied at 64) - and, at the convolution's launch geometry, every line crossing
+the fabric 2.9 times (the halo tiles of the 64 workgroups of an XCD exceed its 4 MiB L2 between chunk passes), which is traffic, not a
+counter artefact.  Factor 2 for every kernel since round 3.
 """
 import csv, glob, json, re, sys
 from collections import defaultdict
@@ -33,8 +36,7 @@ def collect(d: str, counter: str):
     return tot, cnt
 
 
-FETCH_FACTOR = [(re.compile(r"conv3d_k3_wgrad_mfma<true|conv3d_k3_wgrad_wino|conv3d_k3_wgrad_w2"), 2.0), (re.compile(r"conv3d_k3_(wino2?_)?mfma"), 1.0),
-                (re.compile(r"conv3d_k3_wgrad_mfma<false"), 1.0)]
+FETCH_FACTOR = [(re.compile(r"conv3d_k3_"), 2.0)]        # (calibrated for the 32-byte gathers of conv3d_k3_wino2p_mfma; the streaming kernels by the guide)
 
 
 def main():
