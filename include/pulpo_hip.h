@@ -207,6 +207,12 @@ int pulpo_kl_bwd(const float* mu, const float* sigma, const float* mu1, const fl
                  float* gsigma, int64_t n, void* stream);
 int pulpo_l2reg_fwd(const float* df, int64_t nplanes, int D, int H, int W, float* partial, void* stream);
 int pulpo_l2reg_bwd(const float* df, const float* gscale, float coef, float* gdf, int64_t nplanes, int D, int H, int W, void* stream);
+/* sum_l w_l * term_l of the Hierarchical* losses (src/losses.py:262-276, 305-325, 343-355) and models.py:161-162's `kl * beta` in one launch:
+ * levels[i] = w[i] * terms[i] (* scale if scaled), total[0] = (sum_i w[i] * terms[i]) (* scale if scaled), summed in index order like the
+ * reference's `loss = loss + all_levels[l]`.  Device arrays of n floats (total: 1); n <= 64.  Backward: gterms[i] = (gtotal[0] + glevels[i]) *
+ * scale * w[i]; gtotal / glevels nullable (= 0). */
+int pulpo_weighted_sum_fwd(const float* terms, const float* weights, int n, float scale, int scaled, float* levels, float* total, void* stream);
+int pulpo_weighted_sum_bwd(const float* gtotal, const float* glevels, const float* weights, int n, float scale, float* gterms, void* stream);
 
 /* ------------------------------------------------------------------- alternative losses / evaluation metrics
  *   sqdiff: L2_loss (src/losses.py:79-83); dice: Soft_dice_loss (:137-145);

@@ -222,11 +222,23 @@ class PULPoPrior(nn.Module):
     """standard-normal prior on every level (reference pulpo.py:323-341).  The tensors carry a marker so that the KL
     kernel can skip reading them."""
 
+    def __init__(self) -> None:
+        super().__init__()
+        self._constants = {}
+
     def forward(self, posterior_mus: Dict[int, torch.Tensor], posterior_sigmas: Dict[int, torch.Tensor]):
         prior_mus, prior_sigmas = {}, {}
         for l in posterior_mus.keys():
-            prior_mus[l] = torch.zeros_like(posterior_mus[l], dtype=torch.float32)
-            prior_sigmas[l] = torch.ones_like(posterior_sigmas[l], dtype=torch.float32)
-            prior_mus[l]._pulpo_std_normal = True
-            prior_sigmas[l]._pulpo_std_normal = True
+            # constants: made once per (shape, device) and handed out again (two fill kernels per level and step otherwise); the KL kernel
+            # never reads them (marker), callers must not write to them
+            key = (tuple(posterior_mus[l].shape), posterior_mus[l].device)
+            cached = self._constants.get(key)
+            if cached is None:
+                cached = (torch.zeros_like(posterior_mus[l], dtype=torch.float32), torch.ones_like(posterior_sigmas[l], dtype=torch.float32))
+                cached[0]._pulpo_std_normal = True
+                cached[1]._pulpo_std_normal = True
+                if len(self._constants) > 32:
+                    self._constants.clear()
+                self._constants[key] = cached
+            prior_mus[l], prior_sigmas[l] = cached
         return prior_mus, prior_sigmas

@@ -290,3 +290,40 @@ PULPO_API int pulpo_l2reg_bwd(const float* df, const float* gscale, float coef, 
     hipLaunchKernelGGL(l2reg_bwd_kernel, dim3(eblocks(nplanes * D * H * W)), dim3(256), 0, (hipStream_t)stream, df, gscale, coef, gdf, (long)nplanes, D, H, W);
     return pulpo::check_launch("l2reg_bwd");
 }
+
+// ---- weighted sum of per-level loss terms (HierarchicalKLLoss / ...ReconstructionLoss / ...Regularization, src/losses.py:262-276, 305-325,
+// 343-355: all_levels[l] = w_l * term_l, loss = 0 + all_levels[0] + all_levels[1] + ..., and models.py:161-162's kl * beta): ONE launch
+// instead of a mul and an add kernel per level.  Same operation order as the reference's scalar arithmetic (fp32 products, summed in level
+// order, the post-scale applied to the sum and to every level term), so the values are bit-identical to the torch expressions.
+namespace {
+__global__ void weighted_sum_fwd_kernel(const float* __restrict__ t, const float* __restrict__ w, int n, float scale, int scaled, float* __restrict__ levels,
+                                        float* __restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const float v = w[i] * t[i];
+            s += v;
+            levels[i] = scaled ? v * scale : v;
+        }
+        total[0] = scaled ? s * scale : s;
+    }
+}
+// g_t[i] = (g_total + g_levels[i]) * scale * w[i]   (either upstream gradient may be absent: the per-level outputs are normally only logged)
+__global__ void weighted_sum_bwd_kernel(const float* __restrict__ gtotal, const float* __restrict__ glevels, const float* __restrict__ w, int n, float scale,
+                                        float* __restrict__ gt) {
+    const int i = threadIdx.x;
+    if (blockIdx.x == 0 && i < n) gt[i] = ((gtotal ? gtotal[0] : 0.f) + (glevels ? glevels[i] : 0.f)) * scale * w[i];
+}
+}  // namespace
+
+PULPO_API int pulpo_weighted_sum_fwd(const float* terms, const float* weights, int n, float scale, int scaled, float* levels, float* total, void* stream) {
+    PULPO_REQUIRE(terms && weights && levels && total && n > 0 && n <= 64, "weighted_sum_fwd: bad arguments");
+    hipLaunchKernelGGL(weighted_sum_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, terms, weights, n, scale, scaled, levels, total);
+    return pulpo::check_launch("weighted_sum_fwd");
+}
+
+PULPO_API int pulpo_weighted_sum_bwd(const float* gtotal, const float* glevels, const float* weights, int n, float scale, float* gterms, void* stream) {
+    PULPO_REQUIRE((gtotal || glevels) && weights && gterms && n > 0 && n <= 64, "weighted_sum_bwd: bad arguments");
+    hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gtotal, glevels, weights, n, scale, gterms);
+    return pulpo::check_launch("weighted_sum_bwd");
+}

@@ -98,6 +98,24 @@ def _apply_pyramid(weight_dict: Dict[int, float], similarity_pyramid: bool) -> D
     return weight_dict
 
 
+def _weighted(weight_dict: Dict[int, float], terms: Dict[int, torch.Tensor], scale=None):
+    """(sum_l w_l * term_l, {l: w_l * term_l}) - losses.py:262-276 / 305-325 / 343-355.  Device scalars: one kernel for the whole sum
+    (ops.weighted_sum, bit-identical to the reference's per-level mul / add chain); anything else: that chain itself."""
+    levels = list(weight_dict.keys())
+    vals = [terms[l] for l in levels]
+    if all(isinstance(v, torch.Tensor) and v.is_cuda and v.numel() == 1 and v.dtype == torch.float32 for v in vals):
+        total, per_level = ops.weighted_sum(vals, [weight_dict[l] for l in levels], scale)
+        return total, dict(zip(levels, per_level))
+    total, all_levels = 0.0, {}
+    for l in levels:
+        all_levels[l] = weight_dict[l] * terms[l]
+        total = total + all_levels[l]
+    if scale is not None:
+        total = total * scale
+        all_levels = {l: scale * v for l, v in all_levels.items()}
+    return total, all_levels
+
+
 class HierarchicalKLLoss(nn.Module):
     """sum_l w_l * KL_l; also returns the per-level terms (losses.py:225-276)"""
 
@@ -108,18 +126,17 @@ class HierarchicalKLLoss(nn.Module):
         if KL_divergence == KL_nondiagonal:          # one instance per level (reference losses.py:242-243)
             self.KL_divergence = {key: KL_nondiagonal(inshape=level_sizes[key]).loss for key in level_sizes.keys()}
 
-    def forward(self, prior_mus, prior_sigmas, posterior_mus, posterior_sigmas):
+    def forward(self, prior_mus, prior_sigmas, posterior_mus, posterior_sigmas, scale=None):
+        """scale (not in the reference's signature; models.py applies `* beta` to the results, :161-162): folded into the same launch"""
         assert self.weight_dict.keys() == prior_mus.keys()
         assert prior_mus.keys() == prior_sigmas.keys() == posterior_mus.keys() == posterior_sigmas.keys()
-        kl_loss = 0.0
-        all_levels = {}
-        for l, w in self.weight_dict.items():
+        terms = {}
+        for l in self.weight_dict:
             if isinstance(self.KL_divergence, dict):   # argument order of the reference for the non-diagonal class (losses.py:267-269)
-                all_levels[l] = w * self.KL_divergence[l](prior_mus[l], prior_sigmas[l], posterior_mus[l], posterior_sigmas[l])
+                terms[l] = self.KL_divergence[l](prior_mus[l], prior_sigmas[l], posterior_mus[l], posterior_sigmas[l])
             else:
-                all_levels[l] = w * self.KL_divergence(posterior_mus[l], posterior_sigmas[l], prior_mus[l], prior_sigmas[l])
-            kl_loss = kl_loss + all_levels[l]
-        return kl_loss, all_levels
+                terms[l] = self.KL_divergence(posterior_mus[l], posterior_sigmas[l], prior_mus[l], prior_sigmas[l])
+        return _weighted(self.weight_dict, terms, scale)
 
 
 class HierarchicalReconstructionLoss(nn.Module):
@@ -134,12 +151,18 @@ class HierarchicalReconstructionLoss(nn.Module):
         self.mode = "trilinear" if ndims == 3 else "bilinear"
 
     def forward(self, y_hat, y, y_hat_seg=None, seg_y=None, gamma: float = 0.05, dice_factor: int = 1):
+        single = len(self.recon_loss) == 1 and self.recon_loss[0] in ("mse", "ncc", "dice")
         loss = 0.0
-        all_levels = {}
+        all_levels, terms = {}, {}
         for l, w in self.weight_dict.items():
             size = y_hat[l].shape[2:]
             # F.interpolate(y, size) of the reference; the identity resize at full resolution is skipped
             y_target = y if tuple(size) == tuple(y.shape[2:]) else ops.resize_trilinear(y, size)
+            if single and self.recon_loss[0] != "dice":
+                # one term per level (the default, ["ncc"]): weighting and summation of all levels in one launch; x / 1 is x
+                terms[l] = (NCC_loss(y_hat[l], y_target, gamma=gamma, win_size=self.window_size[l]) if self.recon_loss[0] == "ncc"
+                            else L2_loss(y_hat[l], y_target))
+                continue
             term = 0.0
             if "mse" in self.recon_loss:
                 term = term + w * L2_loss(y_hat[l], y_target)
@@ -151,6 +174,8 @@ class HierarchicalReconstructionLoss(nn.Module):
                 term = term + w * Soft_dice_loss(y_hat_seg[l], seg_target, dice_factor=dice_factor)
             all_levels[l] = term / len(self.recon_loss)
             loss = loss + all_levels[l]
+        if terms:
+            return _weighted(self.weight_dict, terms)
         return loss, all_levels
 
 
@@ -164,9 +189,4 @@ class HierarchicalRegularization(nn.Module):
 
     def forward(self, dfs: Dict[int, torch.Tensor], lamb: float = 0):
         assert self.weight_dict.keys() == dfs.keys()
-        total_loss = 0.0
-        all_levels = {}
-        for l, w in self.weight_dict.items():
-            all_levels[l] = w * self.regularizer(dfs[l], lamb)
-            total_loss = total_loss + all_levels[l]
-        return total_loss, all_levels
+        return _weighted(self.weight_dict, {l: self.regularizer(dfs[l], lamb) for l in self.weight_dict})

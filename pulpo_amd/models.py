@@ -123,9 +123,7 @@ class PULPo(ABC, LightningModule):
             y_hat_seg = self.transform_segmentation(final_dfs, seg_x)
         else:
             y_hat_seg = {k: None for k in final_dfs}
-        kl, kl_levels = self.hierarchical_kl_loss(prior_mus, prior_sigmas, mus, sigmas)
-        kl = kl * self.beta
-        kl_levels = {n: self.beta * v for n, v in kl_levels.items()}
+        kl, kl_levels = self.hierarchical_kl_loss(prior_mus, prior_sigmas, mus, sigmas, scale=self.beta)       # (kl * beta, beta * levels: models.py:161-162)
         rec, rec_levels = self.hierarchical_recon_loss(y_hat, y, y_hat_seg, seg_y, gamma=self.hparams.gamma, dice_factor=self.hparams.dice_factor)
         reg, reg_levels = self.hierarchical_regularization(final_dfs, lamb=self.hparams.lamb)
         total = kl + rec + reg

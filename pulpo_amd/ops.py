@@ -1011,6 +1011,52 @@ def l2_reg(df, lamb: float = 0.0):
     return _L2Reg.apply(df, float(lamb))
 
 
+class _WeightedSum(torch.autograd.Function):
+    """(sum_i w_i t_i, [w_0 t_0, ..., w_{n-1} t_{n-1}]) (optionally * scale): the per-level weighting and summation of the Hierarchical*
+    losses as ONE launch (and one in the backward pass) instead of a mul + an add kernel per level and their autograd counterparts"""
+
+    @staticmethod
+    def forward(ctx, terms, weights_dev, scale):
+        _require_gpu(terms, weights_dev)
+        n = terms.numel()
+        levels = torch.empty(n, device=terms.device, dtype=torch.float32)
+        total = torch.empty((), device=terms.device, dtype=torch.float32)
+        lib.call("pulpo_weighted_sum_fwd", _ptr(terms), _ptr(weights_dev), n, 1.0 if scale is None else float(scale), int(scale is not None),
+                 _ptr(levels), _ptr(total), _stream())
+        ctx.save_for_backward(weights_dev)
+        ctx.scale = 1.0 if scale is None else float(scale)
+        ctx.set_materialize_grads(False)
+        return total, levels
+
+    @staticmethod
+    def backward(ctx, gtotal, glevels):
+        (weights_dev,) = ctx.saved_tensors
+        n = weights_dev.numel()
+        if gtotal is None and glevels is None:
+            return None, None, None
+        gt = torch.empty(n, device=weights_dev.device, dtype=torch.float32)
+        lib.call("pulpo_weighted_sum_bwd", _ptr(gtotal.contiguous() if gtotal is not None else None),
+                 _ptr(glevels.contiguous() if glevels is not None else None), _ptr(weights_dev), n, ctx.scale, _ptr(gt), _stream())
+        return gt, None, None
+
+
+_WEIGHT_VECTORS: dict = {}
+
+
+def weighted_sum(terms, weights, scale=None):
+    """terms: list of 0-d device tensors, weights: list of python floats -> (sum, [w_i * term_i]) as 0-d views of one device vector.
+    scale (optional) multiplies the sum and every level term afterwards (models.py:161-162: kl_loss * beta)."""
+    dev = terms[0].device
+    key = (tuple(float(w) for w in weights), dev)
+    wd = _WEIGHT_VECTORS.get(key)
+    if wd is None:
+        if len(_WEIGHT_VECTORS) > 64:
+            _WEIGHT_VECTORS.clear()
+        wd = _WEIGHT_VECTORS[key] = torch.tensor(key[0], device=dev, dtype=torch.float32)
+    total, levels = _WeightedSum.apply(torch.stack([t.reshape(()).float() for t in terms]), wd, scale)
+    return total, [levels[i] for i in range(len(terms))]
+
+
 # ------------------------------------------------------------------------------------------------ alternative losses / metrics
 class _SqDiff(torch.autograd.Function):
     """L2_loss: spatial sum of squared differences, mean over batch and channels"""
