@@ -28,21 +28,25 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
     }
 }
 
-// stage 1 (large tile counts only): slice-wise double-precision column sums  part[S][ncol],  grid = (ceil(ncol/32), S)
-__global__ __launch_bounds__(1024) void colsum_slices_kernel(const float* __restrict__ rows, int nrow, int ncol, double* __restrict__ part) {
-    __shared__ double red[32][33];
+// stage 1 (large tile counts only): slice-wise double-precision column sums  part[S][ncol],  grid = (ceil(ncol/32), S), block = (32, 8).
+// 256 threads at a handful of registers: the kernel runs in the backward pass BESIDE the persistent weight-gradient kernels of the other
+// stream and only starts on a CU where its whole workgroup fits (a 1024-thread build waited ~100 us per launch for a CU the bf16 weight
+// gradient had left: 3.4 ms per bf16 step).
+constexpr int CS_RY = 8;
+__global__ __launch_bounds__(32 * CS_RY) void colsum_slices_kernel(const float* __restrict__ rows, int nrow, int ncol, double* __restrict__ part) {
+    __shared__ double red[CS_RY][33];
     const int cx = threadIdx.x, ry = threadIdx.y;
     const int c = blockIdx.x * 32 + cx;
     const int S = gridDim.y, sl = blockIdx.y;
     double s = 0.0;
     if (c < ncol)
-        for (int r = sl * 32 + ry; r < nrow; r += 32 * S) s += (double)rows[(long)r * ncol + c];
+        for (int r = sl * CS_RY + ry; r < nrow; r += CS_RY * S) s += (double)rows[(long)r * ncol + c];
     red[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && c < ncol) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) t += red[k][cx];
+        for (int k = 0; k < CS_RY; ++k) t += red[k][cx];
         part[(long)sl * ncol + c] = t;
     }
 }
@@ -356,7 +360,7 @@ PULPO_API int pulpo_bn_fwd_finalize(const float* stats, int ntile, int C, double
     int nrow = ntile;
     if (ntile > 2048) {
         PULPO_REQUIRE(scratch != nullptr, "bn_fwd_finalize: scratch required for %d tiles", ntile);
-        hipLaunchKernelGGL(colsum_slices_kernel, dim3(pulpo::cdiv(2 * C, 32), 32), dim3(32, 32), 0, st, stats, ntile, 2 * C, scratch);
+        hipLaunchKernelGGL(colsum_slices_kernel, dim3(pulpo::cdiv(2 * C, 32), 32), dim3(32, CS_RY), 0, st, stats, ntile, 2 * C, scratch);
         int rc = pulpo::check_launch("bn stats slices");
         if (rc) return rc;
         part = scratch;
@@ -423,7 +427,7 @@ PULPO_API int pulpo_bn_bwd_finalize(const float* tile_part, int ntile, int C, co
     int nrow = ntile;
     if (pulpo_bn_bwd_finalize_scratch_doubles(ntile, C) != 0) {
         PULPO_REQUIRE(scratch != nullptr, "bn_bwd_finalize: scratch required for %d tiles", ntile);
-        hipLaunchKernelGGL(colsum_slices_kernel, dim3(pulpo::cdiv(2 * C, 32), 32), dim3(32, 32), 0, st, tile_part, ntile, 2 * C, scratch);
+        hipLaunchKernelGGL(colsum_slices_kernel, dim3(pulpo::cdiv(2 * C, 32), 32), dim3(32, CS_RY), 0, st, tile_part, ntile, 2 * C, scratch);
         int rc = pulpo::check_launch("bn backward tile slices");
         if (rc) return rc;
         partd = scratch;
