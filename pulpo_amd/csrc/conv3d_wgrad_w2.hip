@@ -25,6 +25,9 @@
 #ifndef PULPO_ABL
 #define PULPO_ABL 0          // diagnostic builds (scripts/ablate.py): 21 no matrix instructions, 22 no staging writes, 23 no global loads, 24 no barrier per plane step
 #endif
+#ifndef PULPO_ABLX
+#define PULPO_ABLX 0         // diagnostic builds of the eight-wave kernel (bit mask): 1 no barrier per plane step, 2 no staging writes, 4 no global loads,
+#endif                       // 8 no flush, 16 no operand combinations
 #include <stdlib.h>
 
 namespace {
@@ -356,50 +359,55 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2x(Wgrad2Args a) {
     float* const x_dst = VX + (4 * x_q) * W2G_VROW + x_hy * 4 + x_xb;          // + (px * 4 + slot) * VSLOT + c * VROW
     float* const e_dst = EX + (4 * e_q) * W2G_EROW + e_y * 4 + e_xb;           // + (px * 2 + slot) * ESLOT + c * EROW
 
+    // Operand planes are read through buffer descriptors (as in conv3d_wino2p.hip): per column, every thread holds the byte offsets of its
+    // taps in plane 0 of the column's batch element - OOB (beyond num_records: the load returns zeros) where the tap lies outside the volume or
+    // the thread has no item - and a plane step adds the plane's offset as the instruction's scalar offset.  No branch, no zero-initialised
+    // destination, no 64-bit address arithmetic inside the loop.  (host: volume bytes < 2^31)
+    constexpr unsigned OOB = 0x80000000u;
+    const int x_bytes = (int)((long)a.D * a.H * a.W * a.in_ps * 4), e_bytes = (int)((long)a.D * a.H * a.W * a.go_ps * 4);
     int cb = 0, y0 = 0, x0 = 0;                           // current column
-    unsigned x_ok = 0;                                    // in-volume bits of the four x taps (row in range), e_ok likewise (two taps)
-    unsigned e_ok = 0;
-    const float* x_src = a.in;                            // tap 0 of this thread's X item in plane 0 of the column
-    const float* e_src = a.go;
+    unsigned x_off[4], e_off[2];
+    __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t e_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.go), 0, e_bytes, 0x00020000);
     auto set_column = [&](int col) {
         int t = col;
         const int tx_ = t % a.ntx; t /= a.ntx;
         const int ty_ = t % a.nty;
         cb = t / a.nty;
         y0 = ty_ * 8; x0 = tx_ * 8;
+        x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + (long)cb * a.in_bs), 0, x_bytes, 0x00020000);
+        e_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.go + (long)cb * a.go_bs), 0, e_bytes, 0x00020000);
         const int gy = y0 - 1 + x_hy;
-        x_ok = 0;
-        if (x_item && x_cok && (unsigned)gy < (unsigned)a.H)
+        const bool xrow = x_item && x_cok && (unsigned)gy < (unsigned)a.H;
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4)
-                if ((unsigned)(x0 - 1 + 2 * x_xb + t4) < (unsigned)a.W) x_ok |= 1u << t4;
-        x_src = a.in + (long)cb * a.in_bs + ((long)gy * a.W + (x0 - 1 + 2 * x_xb)) * a.in_ps + ci0 + 4 * x_q;
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const int gx = x0 - 1 + 2 * x_xb + t4;
+            x_off[t4] = (xrow && (unsigned)gx < (unsigned)a.W) ? (unsigned)((gy * a.W + gx) * (int)a.in_ps + ci0 + 4 * x_q) * 4u : OOB;
+        }
         const int ey = y0 + e_y;
-        e_ok = 0;
-        if (e_item && e_cok && ey < a.H)
+        const bool erow = e_item && e_cok && ey < a.H;
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-                if (x0 + 2 * e_xb + t2 < a.W) e_ok |= 1u << t2;
-        e_src = a.go + (long)cb * a.go_bs + ((long)ey * a.W + (x0 + 2 * e_xb)) * a.go_ps + co0 + 4 * e_q;
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int gx = x0 + 2 * e_xb + t2;
+            e_off[t2] = (erow && gx < a.W) ? (unsigned)((ey * a.W + gx) * (int)a.go_ps + co0 + 4 * e_q) * 4u : OOB;
+        }
     };
-    const long x_plane = (long)a.H * a.W * a.in_ps, e_plane = (long)a.H * a.W * a.go_ps;
+    const unsigned x_plane = (unsigned)((long)a.H * a.W * a.in_ps * 4), e_plane = (unsigned)((long)a.H * a.W * a.go_ps * 4);
 
     float4 xr[4], er[2];                                  // raw registers of the plane being fetched
     auto issue_x = [&](int zp) {                          // input plane zp (zeros outside the volume)
-        const bool zok = (unsigned)zp < (unsigned)a.D;
+        const unsigned zmask = (unsigned)zp < (unsigned)a.D ? 0u : OOB;          // (wave-uniform)
+        const unsigned zo = zmask ? 0u : (unsigned)zp * x_plane;
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-            xr[t4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (zok && ((x_ok >> t4) & 1u)) xr[t4] = *reinterpret_cast<const float4*>(x_src + (long)zp * x_plane + (long)t4 * a.in_ps);
-        }
+        for (int t4 = 0; t4 < 4; ++t4)
+            xr[t4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)(x_off[t4] | zmask), (int)zo, 0));
     };
     auto issue_e = [&](int zp) {                          // output-gradient plane zp
-        const bool zok = (unsigned)zp < (unsigned)a.D;
+        const unsigned zmask = (unsigned)zp < (unsigned)a.D ? 0u : OOB;
+        const unsigned zo = zmask ? 0u : (unsigned)zp * e_plane;
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            er[t2] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (zok && ((e_ok >> t2) & 1u)) er[t2] = *reinterpret_cast<const float4*>(e_src + (long)zp * e_plane + (long)t2 * a.go_ps);
-        }
+        for (int t2 = 0; t2 < 2; ++t2)
+            er[t2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(e_rs, (int)(e_off[t2] | zmask), (int)zo, 0));
     };
     // point px of the x-transformed item -> LDS (transposed: one ds_write_b32 per channel)
     auto write_x = [&](int px, int slot) {
@@ -474,7 +482,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2x(Wgrad2Args a) {
         }
 #pragma unroll 1
         for (int j = zs; j < ze; ++j) {
+#if !(PULPO_ABLX & 1)
             __syncthreads();                              // staged planes visible; everybody has finished the previous iteration's reads
+#endif
             const int xs_slot = (j + 3) & 3, es = j & 1;
             // four groups (g, pl) of 12 MFMAs, ONE register set of operand rows (the other wave of the SIMD covers the LDS round trip - see
             // profiles/r2_mfma_probe.md - and the registers saved keep two such waves at 2 x 208).  The planes fetched during the previous step
@@ -494,24 +504,39 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2x(Wgrad2Args a) {
                     bv[dz] = *reinterpret_cast<const float4*>(vb + off);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // the group's sixteen operand combinations first, then its twelve MFMAs back to back (a v_fma -> MFMA dependency in front of
+                // every MFMA stalls the issue: conv3d_wino2p.hip, same finding)
                 const float ev[4] = {fmaf(c1, e1.x, c0 * e0.x), fmaf(c1, e1.y, c0 * e0.y), fmaf(c1, e1.z, c0 * e0.z), fmaf(c1, e1.w, c0 * e0.w)};
+                float vv[3][4];
 #pragma unroll
                 for (int dz = 0; dz < 3; ++dz) {
                     const float4 pa_ = av[dz], pb_ = bv[dz];
-                    const float v4[4] = {fmaf(sa, pb_.x, pa_.x), fmaf(sa, pb_.y, pa_.y), fmaf(sa, pb_.z, pa_.z), fmaf(sa, pb_.w, pa_.w)};
+                    vv[dz][0] = fmaf(sa, pb_.x, pa_.x); vv[dz][1] = fmaf(sa, pb_.y, pa_.y); vv[dz][2] = fmaf(sa, pb_.z, pa_.z); vv[dz][3] = fmaf(sa, pb_.w, pa_.w);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) acc[pl][dz] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[s_], ev[s_], acc[pl][dz], 0, 0, 0);
+                for (int dz = 0; dz < 3; ++dz) {
+#pragma unroll
+#if PULPO_ABLX & 16
+                    for (int s_ = 0; s_ < 4; ++s_) acc[pl][dz] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[dz].x, e0.x, acc[pl][dz], 0, 0, 0);      // (no combinations)
+#else
+                    for (int s_ = 0; s_ < 4; ++s_) acc[pl][dz] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[dz][s_], ev[s_], acc[pl][dz], 0, 0, 0);
+#endif
                     if (dz == 0 && gi < 2) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (gi == 0) touch_raw();
+#if !(PULPO_ABLX & 2)
                         write_x(2 * gi, xs_slot);
                         write_x(2 * gi + 1, xs_slot);
                         write_e(2 * gi, es ^ 1);
                         write_e(2 * gi + 1, es ^ 1);
+#endif
+#if !(PULPO_ABLX & 4)
                         if (gi == 1) {
                             issue_x(j + 3);
                             issue_e(j + 2);
                         }
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -522,6 +547,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2x(Wgrad2Args a) {
         __syncthreads();                                  // (the next segment's warm-up overwrites the rings)
     }
 
+#if PULPO_ABLX & 8
+    if (acc[0][0][0] + acc[1][1][3] + acc[0][2][7] + acc[1][0][9] + acc[0][1][11] + acc[1][2][15] != 12345.678f) return;      // (no flush)
+#endif
     // ---- flush: dw[dz][ky][kx] = sum_py sum_px G[py][ky] G[px][kx] M[py][px][dz], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].  The px sum
     // is in-lane (this wave's two px), the (py, px-half) sum meets in LDS, one dz at a time: X[wave][kx][r][lane] (8 x 3 x 1024 floats = 96 KB)
     __syncthreads();
@@ -591,7 +619,9 @@ int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, lo
     // 11 % faster alone (step-weighted 9.24 against 10.26 ms) and 0.6 ms per 160^3 training step (37.5 -> 36.9 ms)
     static int waves8 = -1;
     if (waves8 < 0) { const char* e = getenv("PULPO_WGRAD_WAVES8"); waves8 = e ? atoi(e) : 1; }
-    if (waves8) {
+    // (the eight-wave kernel addresses its operands with 32-bit buffer offsets: volumes of 2 GiB and more take the four-wave kernel)
+    const bool small = (long)D * H * W * in_ps * 4 < (1L << 31) && (long)D * H * W * go_ps * 4 < (1L << 31);
+    if (waves8 && small) {
         static bool attr8 = false;
         if (!attr8) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_w2x<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2G_LDS);

@@ -22,7 +22,8 @@
 #ifndef PULPO_ABL
 #define PULPO_ABL 0          // diagnostic builds (scripts/ablate.py): timings only, results are garbage.  Bits: 1 no epilogue, 2 no halo staging,
 #endif                       // 4 no weight re-loads, 8 no chunk barrier, 16 no MFMAs (one v_fma each), 32 no operand-row reads inside the loop, 64 phase stamps,
-                             // 128 no output stores (fast path)
+                             // 128 no output stores (fast path), 256 no y combination (one operand row per row tile, no v_fma: the loop of a 2-D-staged image),
+                             // 512 staging without transform + LDS writes (loads and their waits only), 1024 staging without loads (transform + writes only)
 
 #if PULPO_ABL & 64
 // g_stamps[block][0] = HW_REG_HW_ID, [1] = HW_REG_XCC_ID, [2] = start clock, [3 + 2k] / [4 + 2k] = main-loop end / tile end of the block's k-th tile
@@ -251,7 +252,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
                 for (int m = 0; m < 2; ++m) {
                     const int off = ((2 * m + dz) * P_PLROWS + px * P_PL) * 4;
                     ra[slot][m] = *reinterpret_cast<const float4*>(pa + off);
+#if !(PULPO_ABL & 256)
                     rb[slot][m] = *reinterpret_cast<const float4*>(pb + off);
+#endif
                 }
             };
             fetch_a(0, 0, 0);
@@ -281,7 +284,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
                         for (int m = 0; m < 2; ++m) {
                             const float a_ = s2 == 0 ? ra[sl][m].x : s2 == 1 ? ra[sl][m].y : s2 == 2 ? ra[sl][m].z : ra[sl][m].w;
                             const float b_ = s2 == 0 ? rb[sl][m].x : s2 == 1 ? rb[sl][m].y : s2 == 2 ? rb[sl][m].z : rb[sl][m].w;
+#if PULPO_ABL & 256
+                            av[s2][m] = a_; (void)b_;
+#else
                             av[s2][m] = fmaf(sa, b_, a_);
+#endif
                         }
                     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -305,12 +312,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
                         if (s2 == 0) {                  // behind the step's first MFMAs: their 128 pipe clocks cover the issue of the side work
                             __builtin_amdgcn_sched_barrier(0);
                             if (stage) {
+#if !(PULPO_ABL & 1024)
                                 if (s == P_LD0) { load_raw(st_rs, st_c0, 0, 0); load_raw(st_rs, st_c0, 0, 1); }
                                 if (s == P_LD0 + 1) { load_raw(st_rs, st_c0, 0, 2); load_raw(st_rs, st_c0, 0, 3); }
                                 if (s == P_LD1) { load_raw(st_rs, st_c0, 1, 0); load_raw(st_rs, st_c0, 1, 1); }
                                 if (s == P_LD1 + 1) { load_raw(st_rs, st_c0, 1, 2); load_raw(st_rs, st_c0, 1, 3); }
+#endif
+#if PULPO_ABL & 512
+                                if (s == P_XF0 || s == P_XF1) asm volatile("" : : "v"(raw[0].x), "v"(raw[1].x), "v"(raw[2].x), "v"(raw[3].x));      // (wait only)
+#else
                                 if (s == P_XF0) store_item(img_w, 0);
                                 if (s == P_XF1) store_item(img_w, 1);
+#endif
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }

@@ -35,6 +35,10 @@ VARIANTS = {
     "p_nomfma": ("conv3d_wino2p", 16, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
     "p_bare": ("conv3d_wino2p", 1 + 2 + 4 + 8, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
     "p_bare_noreads": ("conv3d_wino2p", 1 + 2 + 4 + 8 + 32, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "p_nocomb": ("conv3d_wino2p", 256, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "p_nocomb_nostage": ("conv3d_wino2p", 256 + 2, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "p_stage_loads_only": ("conv3d_wino2p", 512, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    "p_stage_writes_only": ("conv3d_wino2p", 1024, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
     "p_stamps": ("conv3d_wino2p", 64, {}, None),
     "p_stamps_nostore": ("conv3d_wino2p", 64 + 128, {}, None),
     "p_nostore": ("conv3d_wino2p", 128, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
