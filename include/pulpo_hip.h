@@ -61,9 +61,12 @@ int pulpo_conv3d_k3_fwd_bn_lrelu(const float* in, int64_t in_bs, int64_t in_ps, 
 int pulpo_conv3d_k3_algo(int B, int D, int H, int W, int K, int N);
 size_t pulpo_conv3d_k3_packed_wino2_floats(int K, int N);
 int pulpo_conv3d_k3_pack_weight_wino2(const float* w /*[Cout][Cin][3][3][3]*/, float* wp, int Cin, int Cout, int dgrad, void* stream);
+/* scratch: pulpo_conv3d_k3_fwd_wino2_scratch_floats() floats, > 0 for volumes with fewer (voxel tile, channel tile) pairs than resident
+ * workgroups (the 20^3 level): the reduction channels are split over several work items (partial slabs + ordered reduce, deterministic) */
+size_t pulpo_conv3d_k3_fwd_wino2_scratch_floats(int B, int D, int H, int W, int K, int N);
 int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
-                              float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W,
-                              int K, int N, void* stream);
+                              float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats,
+                              float* scratch /*nullable if the query is 0*/, int B, int D, int H, int W, int K, int N, void* stream);
 /* 1 when the _wino2 entry points run the pipelined kernel (conv3d_wino2p.hip: double-buffered halo images, weights global -> registers) for a
  * channels-last 16-byte-aligned operand: K % 8 == 0 and D*H*W*in_ps*4 < 2^31.  Otherwise (and with PULPO_W2_PIPE=0) the round-2 kernel runs.
  * Same results either way (network_blocks.py:23). */

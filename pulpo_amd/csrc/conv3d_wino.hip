@@ -624,10 +624,6 @@ static int launch_wino2(const ConvArgs& a, int nblk, hipStream_t st) {
     return pulpo::check_launch("conv3d_k3_wino2_mfma");
 }
 
-static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
-                          float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, const float* bn_y, int64_t bn_y_bs,
-                          int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream);
-
 static int wino2_pipe_enabled() {                      // PULPO_W2_PIPE=0 keeps the round-2 kernel for every operand (A/B switch)
     static int pipe = -1;
     if (pipe < 0) { const char* e = getenv("PULPO_W2_PIPE"); pipe = e ? atoi(e) : 1; }
@@ -642,14 +638,43 @@ PULPO_API int pulpo_conv3d_k3_wino2_pipelined(int D, int H, int W, int K, int64_
     return wino2_pipe_enabled() && wino2p_ok(a);
 }
 
-PULPO_API int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
-                                        const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats,
-                                        int B, int D, int H, int W, int K, int N, void* stream) {
-    return fwd_wino2_impl(in, in_bs, in_ps, in_cs, wp, bias, coef, slope, out, out_bs, out_ps, out_cs, stats, nullptr, 0, 0, nullptr, B, D, H, W, K, N,
-                          stream);
+// Small volumes (the 20^3 pyramid level: 45 voxel tiles x 4 - 9 channel tiles for 512 resident workgroups) leave most compute units with one
+// workgroup: the pipelined kernel then splits the reduction channels of every (voxel tile, channel tile) over `ks` work items that store
+// partial slabs, and splitk_reduce_kernel adds the slabs in fixed order (deterministic) while it produces the BatchNorm partial sums.
+// Measured on MI355X (scripts/conv_bench.py, 20^3, PULPO_W2P_KSPLIT = 1 / 2 / 3 / 4 / 8): 192 -> 192 150 / 139 / 136 / 157 / 170 us,
+// 288 -> 192 218 / 187 / 180 / 205 / 228 us, 128 -> 192 110 / 111 / 116 / 127 / 149 us, 192 -> 288 (405 items) 149 / 174 / 184 / 193 / 215 us:
+// three splits pay from 192 reduction channels up while the items fill at most about half of the slots, nothing else does.
+// PULPO_W2P_KSPLIT=<n> forces the split (1 = off) for measurements.
+static int wino2p_ksplit(int B, int D, int H, int W, int K, int N) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("PULPO_W2P_KSPLIT"); force = e ? atoi(e) : 0; }
+    if (!wino2_pipe_enabled() || K % 8 != 0) return 1;
+    const long items = (long)B * pulpo::cdiv(D, 4) * pulpo::cdiv(H, TY) * pulpo::cdiv(W, TX) * pulpo::cdiv(N, 32);
+    const int nchunk = K / 8;
+    if (force > 0) return std::min(force, nchunk);
+    return (items <= 288 && nchunk >= 24) ? 3 : 1;
 }
 
-// 1 when pulpo_conv3d_k3_dgrad_wino2_bnred accepts the shape: every voxel tile whole (4 x 8 x 8) and every channel tile full (32)
+// floats of scratch pulpo_conv3d_k3_fwd_wino2 needs for the shape (0: none, scratch may be NULL)
+PULPO_API size_t pulpo_conv3d_k3_fwd_wino2_scratch_floats(int B, int D, int H, int W, int K, int N) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || K <= 0 || N <= 0) return 0;
+    const int ks = wino2p_ksplit(B, D, H, W, K, N);
+    return ks > 1 ? (size_t)ks * B * D * H * W * N : 0;
+}
+
+static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
+                          float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, const float* bn_y,
+                          int64_t bn_y_bs, int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream);
+
+PULPO_API int pulpo_conv3d_k3_fwd_wino2(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
+                                        const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats,
+                                        float* scratch, int B, int D, int H, int W, int K, int N, void* stream) {
+    return fwd_wino2_impl(in, in_bs, in_ps, in_cs, wp, bias, coef, slope, out, out_bs, out_ps, out_cs, stats, scratch, nullptr, 0, 0, nullptr, B, D, H,
+                          W, K, N, stream);
+}
+
+// 1 when pulpo_conv3d_k3_dgrad_wino2_bnred accepts the shape: every voxel tile whole (4 x 8 x 8) and every channel tile full (32).  (It
+// never splits the reduction channels: the BatchNorm-backward sums come out of the convolution's own epilogue.)
 PULPO_API int pulpo_conv3d_k3_dgrad_wino2_bnred_ok(int B, int D, int H, int W, int K, int N) {
     return B > 0 && K > 0 && N > 0 && conv_tz(D, H, W) == 4 && D % 4 == 0 && H % TY == 0 && W % TX == 0 && N % 32 == 0;
 }
@@ -669,13 +694,13 @@ PULPO_API int pulpo_conv3d_k3_dgrad_wino2_bnred(const float* in, int64_t in_bs, 
     PULPO_REQUIRE(out_ps % 4 == 0 && out_bs % 4 == 0 && (((uintptr_t)out) & 15) == 0 && bn_y_ps % 4 == 0 && bn_y_bs % 4 == 0 &&
                       (((uintptr_t)bn_y) & 15) == 0 && (((uintptr_t)bn_coef) & 15) == 0,
                   "conv3d_k3_dgrad_wino2_bnred: output, pre-norm tensor and coefficients must be channels-last and 16-byte aligned");
-    return fwd_wino2_impl(in, in_bs, in_ps, in_cs, wp, nullptr, nullptr, slope, out, out_bs, out_ps, 1, part, bn_y, bn_y_bs, bn_y_ps, bn_coef, B, D, H,
-                          W, K, N, stream);
+    return fwd_wino2_impl(in, in_bs, in_ps, in_cs, wp, nullptr, nullptr, slope, out, out_bs, out_ps, 1, part, nullptr, bn_y, bn_y_bs, bn_y_ps, bn_coef,
+                          B, D, H, W, K, N, stream);
 }
 
 static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
-                          float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, const float* bn_y, int64_t bn_y_bs,
-                          int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream) {
+                          float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, const float* bn_y,
+                          int64_t bn_y_bs, int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream) {
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_wino2: null pointer");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd_wino2: bad dims");
     PULPO_REQUIRE(conv_tz(D, H, W) == 4, "conv3d_k3_fwd_wino2: volume %dx%dx%d is not tiled 4x8x8 (see pulpo_conv3d_k3_algo)", D, H, W);
@@ -702,6 +727,17 @@ static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t
         if (pipe && wino2p_ok(a)) return launch_wino2p(a, (int)nblk_l, true, st);
         return launch_wino2<true, true>(a, (int)nblk_l, st);
     }
-    if (vec && pipe && wino2p_ok(a)) return launch_wino2p(a, (int)nblk_l, false, st);
+    if (vec && pipe && wino2p_ok(a)) {
+        const int ks = wino2p_ksplit(B, D, H, W, K, N);
+        if (ks == 1) return launch_wino2p(a, (int)nblk_l, false, st);
+        PULPO_REQUIRE(scratch != nullptr, "conv3d_k3_fwd_wino2: scratch of pulpo_conv3d_k3_fwd_wino2_scratch_floats() floats required");
+        PULPO_REQUIRE(nblk_l * ks < (1L << 31), "conv3d_k3_fwd_wino2: grid too large");
+        a.ksplit = ks; a.part = scratch;
+        a.stats = nullptr; a.coef = nullptr;            // both are the reduction's
+        const int rc = launch_wino2p(a, (int)(nblk_l * ks), false, st);
+        if (rc != 0) return rc;
+        return pulpo_conv::launch_splitk_reduce(scratch, ks, out, (long)out_bs, (long)out_ps, (long)out_cs, B, (long)D * H * W, N,
+                                                pulpo_conv3d_k3_stat_tiles(B, D, H, W), stats, coef, slope, st);
+    }
     return vec ? launch_wino2<true>(a, (int)nblk_l, st) : launch_wino2<false>(a, (int)nblk_l, st);
 }

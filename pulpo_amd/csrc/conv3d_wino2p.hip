@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kk = lane >> 5;
     const int nchunk = (a.Cin + CH - 1) / CH;
-    const int nwork = a.B * a.ntz * a.nty * a.ntx * a.ncot;
+    const int ksplit = a.ksplit;                        // > 1: the chunks of a (tile, cout tile) pair are split over ksplit work items, each storing a partial slab
+    const int nwork = a.B * a.ntz * a.nty * a.ntx * a.ncot * ksplit;
     const int nwg = gridDim.x;
     const unsigned ps_bytes = (unsigned)a.in_ps * 4u;
 
@@ -99,10 +100,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
     const int in_bytes = (int)((long)a.D * a.H * a.W * a.in_ps * 4);
     struct Tile {
         int tile_lin, b, z0, y0, x0, co0;
-        unsigned wbase;              // byte offset of (chunk 0, dz 0, point (py, 0), cout co0) in the packed weights
+        unsigned wbase;              // byte offset of (chunk c0, dz 0, point (py, 0), cout co0) in the packed weights
+        int c0, c1, ks;              // chunk range [c0, c1) of this work item and its split index (0 .. ksplit - 1)
     };
     auto describe = [&](int work) {
         Tile t;
+        t.ks = work % ksplit;                           // (splits of a pair are neighbours: they share the halo in L2)
+        work /= ksplit;
+        t.c0 = nchunk * t.ks / ksplit; t.c1 = nchunk * (t.ks + 1) / ksplit;
         const int cot = work % a.ncot;
         int q = work / a.ncot;
         int tx_, ty_, tz_;
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
         t.tile_lin = ((t.b * a.ntz + tz_) * a.nty + ty_) * a.ntx + tx_;        // row of the statistics buffer: the canonical order either way
         t.z0 = tz_ * 4; t.y0 = ty_ * TY; t.x0 = tx_ * TX;
         t.co0 = cot * NT;
-        t.wbase = (unsigned)((py * 4) * a.NPad + t.co0) * (CH * 4u);
+        t.wbase = (unsigned)((py * 4) * a.NPad + t.co0) * (CH * 4u) + (unsigned)t.c0 * 3u * (16u * CH * a.NPad * 4u);
         return t;
     };
     // byte offsets of this thread's eight (item, tap) loads of a tile's halo, channel 4 rq of chunk 0, relative to the batch element; OOB where
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) load_raw(rs0, 0u, u, tt);
+            for (int tt = 0; tt < 4; ++tt) load_raw(rs0, (unsigned)cur.c0 * CH * 4u, u, tt);
             store_item(smem, u);
         }
     }
@@ -230,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
 
         unsigned wnext = cur.wbase + w_it_stride;       // weights of iteration it + 1
         int it = 0;
-        for (int chunk = 0; chunk < nchunk; ++chunk) {
-            const bool last_chunk = chunk + 1 == nchunk;
+        for (int chunk = cur.c0; chunk < cur.c1; ++chunk) {
+            const bool last_chunk = chunk + 1 == cur.c1;
             if (last_chunk) {
                 next_work = work + nwg;
                 has_next = next_work < nwork;
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
             // what is staged underneath this chunk's MFMAs: the tile's next chunk, or chunk 0 of the next tile (after the last tile: the
             // tile's own chunk 0 again, into an image nobody reads - cheaper than a branch around every piece of the side work)
             if (last_chunk) halo_offsets(has_next ? nxt : cur);
-            const unsigned st_c0 = last_chunk ? 0u : (unsigned)(chunk + 1) * CH * 4u;
+            const unsigned st_c0 = (unsigned)(last_chunk ? (has_next ? nxt.c0 : cur.c0) : chunk + 1) * CH * 4u;
             const __amdgpu_buffer_rsrc_t st_rs = in_rsrc(last_chunk ? nxt.b : cur.b);
             const float* img_r = smem + cb * P_IMG;
             float* img_w = smem + (cb ^ 1) * P_IMG;
@@ -348,14 +353,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
         // a time; the exchange buffer is the image the last chunk was read from (the next tile's chunk 0 already sits in the other one)
         float* R = smem + (cb ^ 1) * P_IMG;                 // [py][ox][r][lane]
         float* red = R + P_RH;                              // [4 waves][2][NT]
-        float* out_b = a.out + (long)cur.b * a.out_bs;
+        // split-K work items store their partial sums into slab `ks` of a.part ([ksplit][B * V][Cout], dense channels-last; bias from split 0
+        // only); pulpo_conv::launch_splitk_reduce adds the slabs up in fixed order and produces the BatchNorm partials / the eval-mode store
+        const bool split = ksplit > 1;
+        const long o_ps = split ? (long)a.Cout : a.out_ps, o_cs = split ? 1L : a.out_cs;
+        float* out_b = split ? a.part + ((long)cur.ks * a.B + cur.b) * ((long)a.D * a.H * a.W) * a.Cout : a.out + (long)cur.b * a.out_bs;
         const int z0 = cur.z0, y0 = cur.y0, x0 = cur.x0, co0 = cur.co0;
-        // Fast path (whole tile inside the volume, all 32 couts real, channels-last 16-byte aligned output - every tile of the BASELINE layers):
-        // lane = (channel quad q, row half, row group): the four waves' partial rows are fetched with ds_read_b128, the y inverse transform is
-        // done on float4s, and each voxel leaves as one 128-byte line written by 8 lanes x 16 bytes.
-        // (BNR: the host launches this instantiation only when every tile qualifies; without bias and without the eval-mode store)
-        const bool fast = BNR || (a.out_cs == 1 && (a.out_ps & 3) == 0 && (a.out_bs & 3) == 0 && (((uintptr_t)a.out) & 15) == 0 && co0 + NT <= a.Cout &&
-                                  z0 + 4 <= a.D && y0 + TY <= a.H && x0 + TX <= a.W);
+        // Fast path (all 32 couts real, channels-last 16-byte aligned output - every tile of the BASELINE layers): lane = (channel quad q, row
+        // half, row group): the four waves' partial rows are fetched with ds_read_b128, the y inverse transform is done on float4s, and each
+        // voxel leaves as one 128-byte line written by 8 lanes x 16 bytes; voxels of a ragged tile outside the volume are masked per store.
+        // (BNR: the host launches this instantiation only when every tile is whole; without bias and without the eval-mode store)
+        const bool whole = BNR || (z0 + 4 <= a.D && y0 + TY <= a.H && x0 + TX <= a.W);
+        const bool fast = BNR || (o_cs == 1 && (o_ps & 3) == 0 && (split || (a.out_bs & 3) == 0) && (((uintptr_t)out_b) & 15) == 0 && co0 + NT <= a.Cout);
         // (the lane id passes through an opaque asm: what the epilogue derives from it is computed here and not hoisted above the main loop)
         int elane = lane;
         asm volatile("" : "+v"(elane));
@@ -364,17 +373,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 s4 = zero4, q4 = zero4;
         float ssum = 0.f, ssq = 0.f;
-        const bool fuse = !BNR && a.coef != nullptr;
+        const bool fuse = !BNR && !split && a.coef != nullptr;
         const bool cok = co0 + ei < a.Cout;
+        const bool with_bias = !split || cur.ks == 0;
+        float* const stats = split ? nullptr : a.stats;
         const bool bnr = BNR && fast;
         // fast path: four channels per lane; general path: channel co0 + i.  From the workgroup's table in LDS: [0] the bias (BNR: the channel
         // means rounded to fp32 - pulpo_bn_bwd_finalize corrects for the rounding), [1] / [2] scale and shift of the eval-mode store (BNR: of
         // the unit whose BatchNorm-backward sums this launch delivers)
-        const float4 b4 = BNR ? zero4 : *reinterpret_cast<const float4*>(tab + co0 + 4 * q);
+        const float4 b4 = (BNR || !with_bias) ? zero4 : *reinterpret_cast<const float4*>(tab + co0 + 4 * q);
         const float4 bm4 = *reinterpret_cast<const float4*>(tab + co0 + 4 * q);
         const float4 sc4 = *reinterpret_cast<const float4*>(tab + ctab + co0 + 4 * q);
         const float4 sh4 = *reinterpret_cast<const float4*>(tab + 2 * ctab + co0 + 4 * q);
-        const float bias1 = tab[co0 + ei], fsc1 = tab[ctab + co0 + ei], fsh1 = tab[2 * ctab + co0 + ei];
+        const float bias1 = with_bias ? tab[co0 + ei] : 0.f, fsc1 = tab[ctab + co0 + ei], fsh1 = tab[2 * ctab + co0 + ei];
         const float* bn_b = bnr ? a.bn_y + (long)cur.b * a.bn_y_bs + co0 + 4 * q : nullptr;
         STAMP(4 + 6 * tile_no, __builtin_amdgcn_s_memtime());
 #pragma unroll
@@ -418,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
                     const int gz = z0 + 2 * m + (row >> 4), gy = y0 + 2 * ((row >> 2) & 3), gx = x0 + 2 * (row & 3) + ox;
                     const long vox = (long)(gz * a.H + gy) * a.W + gx;
+                    const bool in0 = whole || (gz < a.D && gy < a.H && gx < a.W), in1 = whole || (gz < a.D && gy + 1 < a.H && gx < a.W);
                     const float4 t0 = tq[h][0], t1 = tq[h][1], t2 = tq[h][2], t3 = tq[h][3];
                     float4 v0 = make_float4(t0.x + t1.x + t2.x + b4.x, t0.y + t1.y + t2.y + b4.y, t0.z + t1.z + t2.z + b4.z, t0.w + t1.w + t2.w + b4.w);
                     float4 v1 = make_float4(t1.x - t2.x - t3.x + b4.x, t1.y - t2.y - t3.y + b4.y, t1.z - t2.z - t3.z + b4.z, t1.w - t2.w - t3.w + b4.w);
@@ -438,9 +450,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
                         red1(v1.y, yv[h][1].y, sc4.y, sh4.y, bm4.y, s4.y, q4.y);
                         red1(v1.z, yv[h][1].z, sc4.z, sh4.z, bm4.z, s4.z, q4.z);
                         red1(v1.w, yv[h][1].w, sc4.w, sh4.w, bm4.w, s4.w, q4.w);
-                    } else {
+                    } else if (whole) {
                         s4.x += v0.x + v1.x; s4.y += v0.y + v1.y; s4.z += v0.z + v1.z; s4.w += v0.w + v1.w;
                         q4.x += v0.x * v0.x + v1.x * v1.x; q4.y += v0.y * v0.y + v1.y * v1.y; q4.z += v0.z * v0.z + v1.z * v1.z; q4.w += v0.w * v0.w + v1.w * v1.w;
+                    } else {
+                        if (in0) { s4.x += v0.x; s4.y += v0.y; s4.z += v0.z; s4.w += v0.w; q4.x += v0.x * v0.x; q4.y += v0.y * v0.y; q4.z += v0.z * v0.z; q4.w += v0.w * v0.w; }
+                        if (in1) { s4.x += v1.x; s4.y += v1.y; s4.z += v1.z; s4.w += v1.w; q4.x += v1.x * v1.x; q4.y += v1.y * v1.y; q4.z += v1.z * v1.z; q4.w += v1.w * v1.w; }
                     }
                     if (fuse) {
                         auto act = [&](float v, float sc, float sh) { const float tt = v * sc + sh; return tt > 0.f ? tt : tt * a.slope; };
@@ -451,8 +466,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
                     if (v0.x == 12345.678f && v1.y == 9876.54f)
 #endif
                     {
-                        *reinterpret_cast<float4*>(obase + vox * a.out_ps) = v0;
-                        *reinterpret_cast<float4*>(obase + (vox + a.W) * a.out_ps) = v1;
+                        if (in0) *reinterpret_cast<float4*>(obase + vox * o_ps) = v0;
+                        if (in1) *reinterpret_cast<float4*>(obase + (vox + a.W) * o_ps) = v1;
                     }
                 }
             } else {
@@ -473,12 +488,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
                         if (gy < a.H) {
                             ssum += v0; ssq += v0 * v0;
                             if (fuse) { const float tt = v0 * fsc1 + fsh1; v0 = tt > 0.f ? tt : tt * a.slope; }
-                            out_b[vox * a.out_ps + (long)(co0 + ei) * a.out_cs] = v0;
+                            out_b[vox * o_ps + (long)(co0 + ei) * o_cs] = v0;
                         }
                         if (gy + 1 < a.H) {
                             ssum += v1; ssq += v1 * v1;
                             if (fuse) { const float tt = v1 * fsc1 + fsh1; v1 = tt > 0.f ? tt : tt * a.slope; }
-                            out_b[(vox + a.W) * a.out_ps + (long)(co0 + ei) * a.out_cs] = v1;
+                            out_b[(vox + a.W) * o_ps + (long)(co0 + ei) * o_cs] = v1;
                         }
                     }
                 }
@@ -487,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
         STAMP(7 + 6 * tile_no, __builtin_amdgcn_s_memtime());
         // per-tile BatchNorm partial sums: reduce over the lanes that hold the same channel(s), then over the four waves.  The barrier also
         // separates the exchange buffer's last reads from the next tile's staging into the same image, so it is taken without statistics too.
-        if (a.stats != nullptr) {
+        if (stats != nullptr) {
             if (fast) {
 #pragma unroll
                 for (int o = 8; o <= 32; o <<= 1) {
@@ -508,12 +523,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
             }
         }
         __syncthreads();
-        if (a.stats != nullptr && tid < 2 * NT) {
+        if (stats != nullptr && tid < 2 * NT) {
             const int which = tid / NT, c = tid - which * NT;
             if (co0 + c < a.Cout) {
                 const float tot = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] + red[(2 * 2 + which) * NT + c] +
                                   red[(3 * 2 + which) * NT + c];
-                a.stats[((long)cur.tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
+                stats[((long)cur.tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
             }
         }
 #if PULPO_ABL & 1

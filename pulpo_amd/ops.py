@@ -348,9 +348,11 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
     bf16 = algo == "bf16"
     vec_ok = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0
     if algo == "wino2":
+        nscr = lib.query("pulpo_conv3d_k3_fwd_wino2_scratch_floats", B, D, H, W, K, N)
+        scratch = torch.empty(nscr, device=x.device, dtype=torch.float32) if nscr else None
         t0 = _trace_begin()
         lib.call("pulpo_conv3d_k3_fwd_wino2", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc, _ptr(stats),
-                 B, D, H, W, K, N, _stream())
+                 _ptr(scratch), B, D, H, W, K, N, _stream())
         kname = f"conv3d_k3_wino2_mfma<{'true' if vec_ok else 'false'}>"
         if vec_ok and t0 is not None and lib.query("pulpo_conv3d_k3_wino2_pipelined", D, H, W, K, xp):
             kname = "conv3d_k3_wino2p_mfma<false>"

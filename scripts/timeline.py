@@ -47,3 +47,41 @@ for n, (c, d, o) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
 g = sorted(queues[main]); gaps = [g[i + 1][0] - max(x[1] for x in g[: i + 1][-3:]) for i in range(len(g) - 1)]
 pos = [x for x in gaps if x > 0]
 print(f"main-queue gaps: {sum(pos)/1e6:.2f} ms in {len(pos)} gaps (median {sorted(pos)[len(pos)//2]/1e3:.1f} us)")
+# ---- exposed time: the parts of the window in which NO matrix-bound convolution kernel runs on either queue, by what the main queue runs then
+MATRIX = ("conv3d_k3_wino2p", "conv3d_k3_wino2_", "conv3d_k3_wgrad", "conv3d_k3_mfma")
+mat = sorted((s, e) for s, e, q, n in ev if n.startswith(MATRIX))
+merged = []
+for s, e in mat:
+    if merged and s <= merged[-1][1]: merged[-1][1] = max(merged[-1][1], e)
+    else: merged.append([s, e])
+holes = [(t0, merged[0][0])] + [(merged[i][1], merged[i + 1][0]) for i in range(len(merged) - 1)] + [(merged[-1][1], t1)]
+holes = [(s, e) for s, e in holes if e > s]
+hole_ms = sum(e - s for s, e in holes) / 1e6
+print(f"no matrix kernel on either queue: {hole_ms:.2f} ms of {span:.1f} ms ({hole_ms / nsteps * 2:.2f} ms per step if the window holds {nsteps / 2:.1f} steps), {len(holes)} holes")
+import bisect
+hs = [h[0] for h in holes]
+def in_holes(s, e):
+    tot = 0
+    i = max(0, bisect.bisect_right(hs, s) - 1)
+    while i < len(holes) and holes[i][0] < e:
+        tot += max(0, min(e, holes[i][1]) - max(s, holes[i][0])); i += 1
+    return tot
+exp = collections.defaultdict(lambda: [0, 0])
+covered = []
+for s, e, q, n in ev:
+    if n.startswith(MATRIX): continue
+    d = in_holes(s, e)
+    if d > 0:
+        exp[n][0] += 1; exp[n][1] += d; covered.append((s, e))
+print("  kernel, launches touching a hole, ms inside holes (kernels on both queues; concurrent ones count twice)")
+for n, (c, d) in sorted(exp.items(), key=lambda kv: -kv[1][1])[:30]:
+    print(f"  {n:50s} {c:5d} {d/1e6:8.2f}")
+# idle inside holes
+cov = 0
+if covered:
+    covered.sort(); cm = []
+    for s, e in covered:
+        if cm and s <= cm[-1][1]: cm[-1][1] = max(cm[-1][1], e)
+        else: cm.append([s, e])
+    cov = sum(in_holes(s, e) for s, e in cm)
+print(f"  nothing running at all inside the holes: {hole_ms - cov/1e6:.2f} ms")

@@ -325,10 +325,12 @@ def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size):
     (pulpo_conv3d_k3_algo = 2: the pipelined conv3d_k3_wino2p_mfma for operands with a multiple of 8 channels, the round-2
     conv3d_k3_wino2_mfma otherwise - Cin = 20 forward, Cout = 12 data gradient here) and for the weight gradient: same fp32 tolerance
     against the fp64 convolution as the direct kernels; ragged H / W (odd sizes: half-filled blocks) and the 20^3 level's 128 / 192 / 288
-    channel layers included"""
+    channel layers (split-K work items where the tiles are few) included"""
     from pulpo_amd._lib import lib
     assert lib.query("pulpo_conv3d_k3_algo", B, *size, Cin, Cout) == 2
     assert lib.query("pulpo_conv3d_k3_wino2_pipelined", *size, Cin, Cin) == int(Cin % 8 == 0)
+    if (B, Cin, size) == (1, 288, (20, 20, 20)):                     # few tiles, many reduction channels: three split-K work items per tile
+        assert lib.query("pulpo_conv3d_k3_fwd_wino2_scratch_floats", B, *size, Cin, Cout) == 3 * B * 8000 * Cout
     gen = torch.Generator().manual_seed(B * 1000 + Cin * 10 + Cout)
     x = torch.randn(B, Cin, *size, generator=gen)
     w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (27 * Cin) ** 0.5
