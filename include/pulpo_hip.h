@@ -190,8 +190,10 @@ int pulpo_warp3d_fwd(const float* df, const float* img, float* out, int B, int C
 int pulpo_warp3d_bwd(const float* df, const float* img, const float* gout, float* gdf, float* gimg, int B, int C, int Dg, int Hg, int Wg, int Di,
                      int Hi, int Wi, void* stream);
 int pulpo_vecint_fwd(const float* v, float* work, int B, int D, int H, int W, int nsteps, void* stream);
-int pulpo_vecint_bwd(const float* work, const float* gout, float* gin, float* tmp /*2 field buffers*/, int B, int D, int H, int W, int nsteps,
-                     void* stream);
+/* tmp: pulpo_vecint_bwd_tmp_floats() floats (one zero-filled buffer per step for fields of 16^3 and up, two otherwise) */
+size_t pulpo_vecint_bwd_tmp_floats(int B, int D, int H, int W, int nsteps);
+int pulpo_vecint_bwd(const float* work, const float* gout, float* gin, float* tmp /*nullable if the query is 0*/, int B, int D, int H, int W,
+                     int nsteps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------ losses
  * ncc:   NCC_loss (src/losses.py:85-135); I = y_true, J = y_pred, planar (B,1,D,H,W); N = B*D*H*W.

@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void grad_finish_multi_kernel(const PulpoGradJ
 
 PULPO_API int pulpo_grad_finish_multi(const PulpoGradJob* jobs, int njobs, void* stream) {
     PULPO_REQUIRE(jobs && njobs > 0, "grad_finish_multi: bad arguments");
-    hipLaunchKernelGGL(grad_finish_multi_kernel, dim3(48, njobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    hipLaunchKernelGGL(grad_finish_multi_kernel, dim3(192, njobs), dim3(256), 0, (hipStream_t)stream, jobs);
     return pulpo::check_launch("grad_finish_multi");
 }
 

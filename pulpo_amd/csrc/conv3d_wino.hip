@@ -604,7 +604,7 @@ PULPO_API int pulpo_conv3d_k3_pack_weight_wino2(const float* w, float* wp, int C
 // jobs: DEVICE array; kind 0 = the layout of pulpo_conv3d_k3_pack_weight, 2 = of pulpo_conv3d_k3_pack_weight_wino2, 3 = of pulpo_conv3d_k3_pack_weight_bf16
 PULPO_API int pulpo_conv3d_k3_pack_weights_multi(const PulpoPackJob* jobs, int njobs, void* stream) {
     PULPO_REQUIRE(jobs && njobs > 0, "conv3d_k3_pack_weights_multi: bad arguments");
-    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(32, njobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(160, njobs), dim3(256), 0, (hipStream_t)stream, jobs);
     return pulpo::check_launch("pack_weights_multi");
 }
 

@@ -53,33 +53,49 @@ __global__ __launch_bounds__(32 * CS_RY) void colsum_slices_kernel(const float* 
 
 // stats (fp32 tile partials [ntile][2][C], or - when part != nullptr - their double slice sums [nslice][2][C])
 //   -> coef = [4][C] floats (mean, rstd, scale, shift) + [2][C] doubles (mean, rstd); running statistics update
-__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(const float* __restrict__ stats, const double* __restrict__ part, int nrow, int C,
+// block = (8 channels, 128 row lanes), grid = ceil(C / 8): up to 2048 tile rows are walked in 16 passes of independent loads (the 32 x 32
+// layout took 64 passes on 2 - 9 workgroups: 11 us per launch on the forward pass's critical path, 35 launches per step)
+constexpr int FIN_CG = 8, FIN_RL = 128;
+__global__ __launch_bounds__(FIN_CG * FIN_RL) void bn_fwd_finalize_kernel(const float* __restrict__ stats, const double* __restrict__ part, int nrow, int C,
                                                                  double count, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                  long long* __restrict__ num_batches_tracked, float momentum, float eps,
                                                                  float* __restrict__ coef) {
-    __shared__ double red[2][32][33];
+    __shared__ double red[2][FIN_RL][FIN_CG + 1];
     const int cx = threadIdx.x, ry = threadIdx.y;
-    const int c = blockIdx.x * 32 + cx;
+    const int c = blockIdx.x * FIN_CG + cx;
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int r = ry; r < nrow; r += 32) {
-            if (part != nullptr) {
+    if (c < C) {
+        if (part != nullptr) {
+            for (int r = ry; r < nrow; r += FIN_RL) {
                 s += part[((long)r * 2 + 0) * C + c];
                 q += part[((long)r * 2 + 1) * C + c];
-            } else {
+            }
+        } else {
+#pragma unroll 4
+            for (int r = ry; r < nrow; r += FIN_RL) {
                 s += (double)stats[((long)r * 2 + 0) * C + c];
                 q += (double)stats[((long)r * 2 + 1) * C + c];
             }
         }
+    }
     red[0][ry][cx] = s;
     red[1][ry][cx] = q;
+    __syncthreads();
+    // 128 -> 8 row lanes, then one thread per channel
+    if (ry < 8) {
+        double ts = 0.0, tq = 0.0;
+#pragma unroll
+        for (int k = 0; k < FIN_RL / 8; ++k) { ts += red[0][ry + 8 * k][cx]; tq += red[1][ry + 8 * k][cx]; }
+        red[0][ry][cx] = ts;
+        red[1][ry][cx] = tq;
+    }
     __syncthreads();
     if (blockIdx.x == 0 && cx == 0 && ry == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;
     if (ry == 0 && c < C) {
         double ts = 0.0, tq = 0.0;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) { ts += red[0][k][cx]; tq += red[1][k][cx]; }
+        for (int k = 0; k < 8; ++k) { ts += red[0][k][cx]; tq += red[1][k][cx]; }
         const double mean = ts / count;
         double var = tq / count - mean * mean;      // biased batch variance
         if (var < 0.0) var = 0.0;
@@ -347,7 +363,9 @@ PULPO_API int pulpo_colsum(const float* partials, int nrow, int ncol, float* out
     return pulpo::check_launch("colsum");
 }
 
-PULPO_API size_t pulpo_bn_fwd_finalize_scratch_doubles(int ntile, int C) { return ntile > 2048 ? (size_t)32 * 2 * C : 0; }
+// (slices of the first stage: 128 - the 16000 tile rows of a 160^3 layer then take 16 passes per thread of its 256 workgroups)
+constexpr int FWD_SLICES = 128;
+PULPO_API size_t pulpo_bn_fwd_finalize_scratch_doubles(int ntile, int C) { return ntile > 2048 ? (size_t)FWD_SLICES * 2 * C : 0; }
 
 // scratch: pulpo_bn_fwd_finalize_scratch_doubles(ntile, C) doubles (may be NULL when that is 0).
 // num_batches_tracked (nullable): int64 counter of nn.BatchNorm3d, incremented here.
@@ -360,13 +378,13 @@ PULPO_API int pulpo_bn_fwd_finalize(const float* stats, int ntile, int C, double
     int nrow = ntile;
     if (ntile > 2048) {
         PULPO_REQUIRE(scratch != nullptr, "bn_fwd_finalize: scratch required for %d tiles", ntile);
-        hipLaunchKernelGGL(colsum_slices_kernel, dim3(pulpo::cdiv(2 * C, 32), 32), dim3(32, CS_RY), 0, st, stats, ntile, 2 * C, scratch);
+        hipLaunchKernelGGL(colsum_slices_kernel, dim3(pulpo::cdiv(2 * C, 32), FWD_SLICES), dim3(32, CS_RY), 0, st, stats, ntile, 2 * C, scratch);
         int rc = pulpo::check_launch("bn stats slices");
         if (rc) return rc;
         part = scratch;
-        nrow = 32;
+        nrow = FWD_SLICES;
     }
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(pulpo::cdiv(C, 32)), dim3(32, 32), 0, st, stats, part, nrow, C, count, gamma, beta,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(pulpo::cdiv(C, FIN_CG)), dim3(FIN_CG, FIN_RL), 0, st, stats, part, nrow, C, count, gamma, beta,
                        running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, coef);
     return pulpo::check_launch("bn_fwd_finalize");
 }

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
 // is a fraction of the final field (v / 2^(nsteps-k)), so almost every corner a voxel scatters to lies inside the box of its own tile -
 // those adds are LDS atomics, the rest go to memory as before.  The box then leaves with one memory atomic per touched cell: 4-7 memory
 // atomics per voxel instead of 27 (24 corner adds + 3 displacement-gradient adds), which is what bounded warp_bwd_kernel here.
-// gp must hold the identity path (g) on entry, as for warp_bwd_kernel<true>.
+// gp must be all zero on entry: the identity path (g itself) is added to the voxel's own cell of the box and leaves with it (no copy of g
+// into gp in front of every step; pulpo_vecint_bwd zeroes the buffers of all steps with one fill).
 template <int R>
 __global__ __launch_bounds__(256) void vecint_bwd_tile_kernel(const float* __restrict__ cur, const float* __restrict__ gout, float* __restrict__ gp,
                                                                 int B, int D, int H, int W, int ntz, int nty, int ntx) {
@@ -158,9 +159,11 @@ __global__ __launch_bounds__(256) void vecint_bwd_tile_kernel(const float* __res
         const int lz0 = cz.i0 - z0 + R, lz1 = cz.i1 - z0 + R, ly0 = cy.i0 - y0 + R, ly1 = cy.i1 - y0 + R, lx0 = cx.i0 - x0 + R, lx1 = cx.i1 - x0 + R;
         const bool inbox = lz0 >= 0 && lz1 < BZ && ly0 >= 0 && ly1 < BY && lx0 >= 0 && lx1 < BX;
         float gz = 0.f, gy = 0.f, gx = 0.f;
+        float gid[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float g = gout[((long)b * 3 + c) * V + v];
+            gid[c] = g;
             const float* s = cur + ((long)b * 3 + c) * V;
             const float s000 = s[o00 + cx.i0], s001 = s[o00 + cx.i1], s010 = s[o01 + cx.i0], s011 = s[o01 + cx.i1];
             const float s100 = s[o10 + cx.i0], s101 = s[o10 + cx.i1], s110 = s[o11 + cx.i0], s111 = s[o11 + cx.i1];
@@ -192,9 +195,9 @@ __global__ __launch_bounds__(256) void vecint_bwd_tile_kernel(const float* __res
         }
         // the displacement-gradient term lands on the voxel itself: into its (always in-box) cell
         const int own = ((z - z0 + R) * BY + (y - y0 + R)) * BX + (x - x0 + R);
-        atomicAdd(box + own, gz * cz.dscale);
-        atomicAdd(box + BV + own, gy * cy.dscale);
-        atomicAdd(box + 2 * BV + own, gx * cx.dscale);
+        atomicAdd(box + own, gid[0] + gz * cz.dscale);
+        atomicAdd(box + BV + own, gid[1] + gy * cy.dscale);
+        atomicAdd(box + 2 * BV + own, gid[2] + gx * cx.dscale);
     }
     __syncthreads();
     for (int j = tid; j < 3 * BV; j += 256) {
@@ -330,28 +333,46 @@ PULPO_API int pulpo_vecint_fwd(const float* v, float* work, int B, int D, int H,
     return 0;
 }
 
-// gin = d loss / d v given gout = d loss / d work[nsteps].  tmp: 2 buffers of B*3*D*H*W floats.
+// floats of scratch pulpo_vecint_bwd needs: one buffer per step for the tiled scatter (zeroed by one fill), two for the plain scatter.
+// (A one-launch variant with the gradient in LDS, as for the forward pass, was measured at 20^3: one compute unit takes 135 us per step
+// for the 27 LDS atomics and 24 gathers per voxel that the tiled kernel spreads over 45 workgroups in 15 us.)
+PULPO_API size_t pulpo_vecint_bwd_tmp_floats(int B, int D, int H, int W, int nsteps) {
+    if (B <= 0 || D < 1 || H < 1 || W < 1 || nsteps <= 0) return 0;
+    const size_t n = (size_t)B * 3 * D * H * W;
+    return (D >= 16 && H >= 16 && W >= 16) ? (size_t)nsteps * n : 2 * n;
+}
+
+// gin = d loss / d v given gout = d loss / d work[nsteps].  tmp: pulpo_vecint_bwd_tmp_floats() floats (NULL when that is 0).
 PULPO_API int pulpo_vecint_bwd(const float* work, const float* gout, float* gin, float* tmp, int B, int D, int H, int W, int nsteps, void* stream) {
-    PULPO_REQUIRE(work && gout && gin && tmp && B > 0 && D >= 1 && H > 1 && W > 1 && nsteps >= 0, "vecint_bwd: bad arguments");
+    PULPO_REQUIRE(work && gout && gin && B > 0 && D >= 1 && H > 1 && W > 1 && nsteps >= 0, "vecint_bwd: bad arguments");
+    PULPO_REQUIRE(tmp || pulpo_vecint_bwd_tmp_floats(B, D, H, W, nsteps) == 0, "vecint_bwd: scratch of pulpo_vecint_bwd_tmp_floats() floats required");
     hipStream_t st = (hipStream_t)stream;
     const long n = (long)B * 3 * D * H * W, total = (long)B * D * H * W;
+    const float scale = 1.0f / (float)(1 << nsteps);
+    const bool tiled = D >= 16 && H >= 16 && W >= 16;   // (smaller fields: a handful of tiles, the plain scatter is as fast)
+    if (tiled && nsteps > 0) {
+        hipError_t e = hipMemsetAsync(tmp, 0, sizeof(float) * n * nsteps, st);
+        if (e != hipSuccess) return pulpo::fail((int)e, "vecint_bwd fill: %s", hipGetErrorString(e));
+    }
     const float* g = gout;
     for (int k = nsteps - 1; k >= 0; --k) {
-        float* gp = tmp + (long)(k & 1) * n;
         // v_{k+1} = v_k + warp(v_k, v_k):  g_k = g_{k+1} (identity) + scatter (image role) + d/d field
-        hipError_t e = hipMemcpyAsync(gp, g, sizeof(float) * n, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return pulpo::fail((int)e, "vecint_bwd copy: %s", hipGetErrorString(e));
         const float* cur = work + (long)k * n;
-        if (D >= 16 && H >= 16 && W >= 16) {           // (smaller fields: a handful of tiles, the plain scatter is as fast)
+        float* gp;
+        if (tiled) {
+            gp = tmp + (long)k * n;
             const int ntz = pulpo::cdiv(D, 4), nty = pulpo::cdiv(H, 8), ntx = pulpo::cdiv(W, 8);
             hipLaunchKernelGGL(vecint_bwd_tile_kernel<1>, dim3((unsigned)((long)B * ntz * nty * ntx)), dim3(256), 0, st, cur, g, gp, B, D, H, W, ntz, nty, ntx);
         } else {
+            gp = tmp + (long)(k & 1) * n;
+            hipError_t e = hipMemcpyAsync(gp, g, sizeof(float) * n, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return pulpo::fail((int)e, "vecint_bwd copy: %s", hipGetErrorString(e));
             hipLaunchKernelGGL(warp_bwd_kernel<true>, dim3(eblocks(total)), dim3(256), 0, st, cur, cur, g, gp, gp, B, D, H, W, D, H, W, 3);
         }
         int rc = pulpo::check_launch("vecint_bwd step");
         if (rc) return rc;
         g = gp;
     }
-    hipLaunchKernelGGL(scale_kernel, dim3(eblocks(n)), dim3(256), 0, st, g, gin, 1.0f / (float)(1 << nsteps), n);
+    hipLaunchKernelGGL(scale_kernel, dim3(eblocks(n)), dim3(256), 0, st, g, gin, scale, n);
     return pulpo::check_launch("vecint_bwd scale");
 }

@@ -896,7 +896,8 @@ class _VecInt(torch.autograd.Function):
         g = planar(g)
         _, B, _, D, H, W = work.shape
         gin = torch.empty((B, 3, D, H, W), device=g.device, dtype=torch.float32)
-        tmp = torch.empty((2, B, 3, D, H, W), device=g.device, dtype=torch.float32)
+        ntmp = lib.query("pulpo_vecint_bwd_tmp_floats", B, D, H, W, ctx.nsteps)
+        tmp = torch.empty(ntmp, device=g.device, dtype=torch.float32) if ntmp else None
         lib.call("pulpo_vecint_bwd", _ptr(work), _ptr(g), _ptr(gin), _ptr(tmp), B, D, H, W, ctx.nsteps, _stream())
         return gin, None
 
