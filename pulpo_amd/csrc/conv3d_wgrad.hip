@@ -623,19 +623,23 @@ __global__ __launch_bounds__(256) void grad_finish_multi_kernel(const PulpoGradJ
             __syncthreads();
         }
     } else {
-        __shared__ double red[8][33];
-        const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-        for (int c0 = blockIdx.x * 32; c0 < j.b; c0 += gridDim.x * 32) {
+        // 8 columns x 32 row lanes per workgroup (up to 2048 rows over 32 - 288 columns: with 32 columns x 8 row lanes a single workgroup
+        // per 32 columns walked 256 dependent passes - most of this launch's 170 us)
+        __shared__ double red[32][9];
+        const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+        for (int c0 = blockIdx.x * 8; c0 < j.b; c0 += gridDim.x * 8) {
             const int c = c0 + cx;
             double s_ = 0.0;
-            if (c < j.b)
-                for (int r = ry; r < j.a; r += 8) s_ += (double)j.src[(long)r * j.b + c];
+            if (c < j.b) {
+#pragma unroll 4
+                for (int r = ry; r < j.a; r += 32) s_ += (double)j.src[(long)r * j.b + c];
+            }
             red[ry][cx] = s_;
             __syncthreads();
             if (ry == 0 && c < j.b) {
                 double t = 0.0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) t += red[k][cx];
+                for (int k = 0; k < 32; ++k) t += red[k][cx];
                 j.dst[c] += (float)t;
             }
             __syncthreads();

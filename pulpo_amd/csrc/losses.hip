@@ -106,6 +106,112 @@ __global__ __launch_bounds__(256) void ncc_final_kernel(const float* __restrict_
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
+// ---- marching form of the strided passes (windows up to 11): a thread walks a segment of one line along the axis and keeps the window's
+// 2 PAD + 1 values of every channel in registers, so each input value is loaded once (the kernels above re-read it for each of the 9 taps:
+// at 160^3 the D pass's working set - 9 planes x 5 channels, 4.6 MB - exceeds an XCD's L2 and the pass ran at 0.9 TB/s).  The window
+// is summed in ascending position order with zeros outside the volume: bit-identical to the tap loops above.
+//   MODE 0: out = box(in)                                  (nch = NCH channels)
+//   MODE 1: S = box(in), partial[block] = sum of cc        (ncc_final_kernel)
+//   MODE 2: gJ = k0 (box(a) + 2 J box(b) + I box(c))       (ncc_bwd_final_kernel)
+// Work items = (segment, group of 256 lines), distributed over the workgroups in a strided loop.
+template <int NCH, int PAD, int MODE>
+__global__ __launch_bounds__(256) void box_march_kernel(const float* __restrict__ in, float* __restrict__ out, long N, long nlines, int extent,
+                                                          long stride, int seglen, int nseg, float nwin, float* __restrict__ partial,
+                                                          const float* __restrict__ I, const float* __restrict__ J, const float* __restrict__ gscale,
+                                                          float coef) {
+    constexpr int WIN = 2 * PAD + 1;
+    __shared__ float sh[4];
+    const long nlg = (nlines + 255) / 256;
+    const long nitem = nlg * nseg;
+    float local = 0.f;
+    [[maybe_unused]] const float k0 = MODE == 2 ? coef * (gscale != nullptr ? gscale[0] : 1.f) : 0.f;
+    for (long item = blockIdx.x; item < nitem; item += gridDim.x) {
+        const long lg = item % nlg;
+        const int seg = (int)(item / nlg);
+        const long line = lg * 256 + threadIdx.x;
+        if (line >= nlines) continue;
+        const long outer = line / stride, inner = line - outer * stride;
+        const long base = outer * extent * stride + inner;
+        const int p0 = seg * seglen, p1 = min(extent, p0 + seglen);
+        float ring[NCH][WIN];
+#pragma unroll
+        for (int j = 0; j < WIN - 1; ++j) {
+            const int pos = p0 - PAD + j;
+            const bool ok = pos >= 0 && pos < extent;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) ring[c][j] = ok ? in[c * N + base + pos * stride] : 0.f;
+        }
+        for (int t0 = p0; t0 < p1; t0 += WIN) {
+#pragma unroll
+            for (int u = 0; u < WIN; ++u) {
+                const int p = t0 + u;
+                if (p < p1) {
+                    const int slot = (u + WIN - 1) % WIN;
+                    const int pos = p + PAD;
+                    const bool ok = pos < extent;
+                    float sum[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        ring[c][slot] = ok ? in[c * N + base + pos * stride] : 0.f;
+                        float acc = 0.f;
+#pragma unroll
+                        for (int j = 0; j < WIN; ++j) acc += ring[c][(u + j) % WIN];
+                        sum[c] = acc;
+                    }
+                    const long e = base + p * stride;
+                    if constexpr (MODE == 0) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) out[c * N + e] = sum[c];
+                    } else if constexpr (MODE == 1) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) out[c * N + e] = sum[c];
+                        // losses.py:125-132, same expression order
+                        const float uI = sum[0] / nwin, uJ = sum[1] / nwin;
+                        const float cross = sum[4] - uJ * sum[0] - uI * sum[1] + uI * uJ * nwin;
+                        const float Iv = sum[2] - 2.f * uI * sum[0] + uI * uI * nwin;
+                        const float Jv = sum[3] - 2.f * uJ * sum[1] + uJ * uJ * nwin;
+                        local += cross * cross / (Iv * Jv + 1e-8f);
+                    } else {
+                        out[e] = k0 * (sum[0] + 2.f * J[e] * sum[1] + I[e] * sum[2]);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (MODE == 1) {
+        const float t = block_sum_256(local, sh);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
+// segment length for the marching kernels: about 1024 work items where the lines allow, segments of at least 2 PAD positions
+static inline void march_segments(long nlines, int extent, int pad, int& seglen, int& nseg) {
+    const long nlg = (nlines + 255) / 256;
+    const long want = std::max<long>(1, (1024 + nlg - 1) / nlg);
+    nseg = (int)std::max<long>(1, std::min<long>(want, extent / std::max(1, 2 * pad)));
+    seglen = (extent + nseg - 1) / nseg;
+    nseg = (extent + seglen - 1) / seglen;
+}
+
+template <int NCH, int MODE>
+static int launch_march(int pad, int grid, hipStream_t st, const float* in, float* out, long N, int extent, long stride, float nwin, float* partial,
+                        const float* I, const float* J, const float* gscale, float coef) {
+    const long nlines = N / extent;
+    int seglen, nseg;
+    march_segments(nlines, extent, pad, seglen, nseg);
+#define PULPO_MARCH(P) hipLaunchKernelGGL((box_march_kernel<NCH, P, MODE>), dim3(grid), dim3(256), 0, st, in, out, N, nlines, extent, stride, seglen, nseg, nwin, partial, I, J, gscale, coef)
+    switch (pad) {
+        case 1: PULPO_MARCH(1); break;
+        case 2: PULPO_MARCH(2); break;
+        case 3: PULPO_MARCH(3); break;
+        case 4: PULPO_MARCH(4); break;
+        case 5: PULPO_MARCH(5); break;
+        default: return -1;
+    }
+#undef PULPO_MARCH
+    return pulpo::check_launch("ncc box march");
+}
+
 // backward stage 1: from the saved box sums form the three fields that get box-filtered again
 __global__ __launch_bounds__(256) void ncc_abc_kernel(const float* __restrict__ S, float* __restrict__ A, long N, float nwin) {
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
@@ -231,9 +337,14 @@ PULPO_API int pulpo_ncc_fwd(const float* I, const float* J, float* S, float* T, 
     hipLaunchKernelGGL(box_x_kernel<0>, dim3(eblocks(nrows * segs * 64)), dim3(256), 0, st, I, J, T1, N, nrows, W, pad, 5, segs);
     int rc = pulpo::check_launch("ncc box_x");
     if (rc) return rc;
-    hipLaunchKernelGGL(box_axis_kernel, dim3(eblocks(N)), dim3(256), 0, st, T1, T2, N, 5, H, (long)W, pad);
-    rc = pulpo::check_launch("ncc box_y");
+    const bool march = pad >= 1 && pad <= 5;            // windows 3 .. 11 (the model's: 9, 7, 5, 3 from the finest level down)
+    if (march && H > 1) rc = launch_march<5, 0>(pad, eblocks(N, 1024), st, T1, T2, N, H, (long)W, 0.f, nullptr, nullptr, nullptr, nullptr, 0.f);
+    else {
+        hipLaunchKernelGGL(box_axis_kernel, dim3(eblocks(N)), dim3(256), 0, st, T1, T2, N, 5, H, (long)W, pad);
+        rc = pulpo::check_launch("ncc box_y");
+    }
     if (rc) return rc;
+    if (march) return launch_march<5, 1>(pad, pulpo_loss_blocks(N), st, T2, S, N, D, (long)H * W, ncc_window_count(win, D), partial, nullptr, nullptr, nullptr, 0.f);
     hipLaunchKernelGGL(ncc_final_kernel, dim3(pulpo_loss_blocks(N)), dim3(256), 0, st, T2, S, N, D, (long)H * W, pad, ncc_window_count(win, D), partial);
     return pulpo::check_launch("ncc final");
 }
@@ -255,9 +366,14 @@ PULPO_API int pulpo_ncc_bwd(const float* I, const float* J, const float* S, floa
     hipLaunchKernelGGL(box_x_kernel<1>, dim3(eblocks(nrows * segs * 64)), dim3(256), 0, st, T1, nullptr, T2, N, nrows, W, pad, 3, segs);
     rc = pulpo::check_launch("ncc bwd box_x");
     if (rc) return rc;
-    hipLaunchKernelGGL(box_axis_kernel, dim3(eblocks(N)), dim3(256), 0, st, T2, T1, N, 3, H, (long)W, pad);
-    rc = pulpo::check_launch("ncc bwd box_y");
+    const bool march = pad >= 1 && pad <= 5;
+    if (march && H > 1) rc = launch_march<3, 0>(pad, eblocks(N, 1024), st, T2, T1, N, H, (long)W, 0.f, nullptr, nullptr, nullptr, nullptr, 0.f);
+    else {
+        hipLaunchKernelGGL(box_axis_kernel, dim3(eblocks(N)), dim3(256), 0, st, T2, T1, N, 3, H, (long)W, pad);
+        rc = pulpo::check_launch("ncc bwd box_y");
+    }
     if (rc) return rc;
+    if (march) return launch_march<3, 2>(pad, eblocks(N, 1024), st, T1, gJ, N, D, (long)H * W, 0.f, nullptr, I, J, gscale, coef);
     hipLaunchKernelGGL(ncc_bwd_final_kernel, dim3(eblocks(N)), dim3(256), 0, st, T1, I, J, gscale, coef, gJ, N, D, (long)H * W, pad);
     return pulpo::check_launch("ncc bwd final");
 }
