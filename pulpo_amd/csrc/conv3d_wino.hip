@@ -652,7 +652,18 @@ static int wino2p_ksplit(int B, int D, int H, int W, int K, int N) {
     const long items = (long)B * pulpo::cdiv(D, 4) * pulpo::cdiv(H, TY) * pulpo::cdiv(W, TX) * pulpo::cdiv(N, 32);
     const int nchunk = K / 8;
     if (force > 0) return std::min(force, nchunk);
+    if (items <= 96 && nchunk >= 8) return std::min(nchunk / 4, 6);          // the 10^3 level: 12 voxel tiles (see wino2_ragged_depth_ok)
     return (items <= 288 && nchunk >= 24) ? 3 : 1;
+}
+
+// The 10^3 level (192 -> 192 channels, 12 tiles of 4 x 8 x 8 with the last depth tile half empty): the direct kernel took 70 us per launch
+// there (27 barrier-separated weight taps per 16-channel chunk on 1 - 2 chunks per workgroup).  The pipelined kernel masks every access
+// by the volume's extent, so a ragged depth tile costs only its empty rows; statistics then always come from the split-K reduction,
+// whose row count (pulpo_conv3d_k3_stat_tiles) does not depend on the tiling.
+int pulpo_conv::wino2_ragged_depth_ok(int B, int D, int H, int W, int K, int N) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PULPO_W2P_RAGGED_DEPTH"); on = e ? atoi(e) : 1; }      // (A/B switch)
+    return on && D >= 8 && (long)D * H * W >= 1000 && K % 8 == 0 && wino2_pipe_enabled() && wino2p_ksplit(B, D, H, W, K, N) > 1;
 }
 
 // floats of scratch pulpo_conv3d_k3_fwd_wino2 needs for the shape (0: none, scratch may be NULL)
@@ -703,7 +714,8 @@ static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t
                           int64_t bn_y_bs, int64_t bn_y_ps, const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream) {
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_wino2: null pointer");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd_wino2: bad dims");
-    PULPO_REQUIRE(conv_tz(D, H, W) == 4, "conv3d_k3_fwd_wino2: volume %dx%dx%d is not tiled 4x8x8 (see pulpo_conv3d_k3_algo)", D, H, W);
+    PULPO_REQUIRE(conv_tz(D, H, W) == 4 || (bn_y == nullptr && wino2_ragged_depth_ok(B, D, H, W, K, N)),
+                  "conv3d_k3_fwd_wino2: volume %dx%dx%d is not tiled 4x8x8 (see pulpo_conv3d_k3_algo)", D, H, W);
     PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd_wino2: batch statistics are not available from the fused eval-mode epilogue");
     ConvArgs a{};
     a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
@@ -722,6 +734,8 @@ static int fwd_wino2_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t
     hipStream_t st = (hipStream_t)stream;
     // channels-last operands: the pipelined kernel (conv3d_wino2p.hip); PULPO_W2_PIPE=0 keeps the round-2 kernel
     const int pipe = wino2_pipe_enabled();
+    PULPO_REQUIRE(conv_tz(D, H, W) == 4 || (vec && wino2p_ok(a)),
+                  "conv3d_k3_fwd_wino2: a volume of depth %d needs a channels-last, 16-byte aligned operand (pipelined kernel, split-K)", D);
     if (bn_y != nullptr) {
         PULPO_REQUIRE(vec, "conv3d_k3_dgrad_wino2_bnred: the gradient operand must be channels-last, 16-byte aligned, with a multiple of 4 channels");
         if (pipe && wino2p_ok(a)) return launch_wino2p(a, (int)nblk_l, true, st);

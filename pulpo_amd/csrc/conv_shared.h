@@ -10,6 +10,8 @@ constexpr int HY = TY + 2, HX = TX + 2;
 // z extent of the forward voxel tile for a volume (both precisions use the same tiling, so the BatchNorm partial-statistics
 // rows written by either kernel are pulpo_conv3d_k3_stat_tiles() many)
 int conv_tz(int D, int H, int W);
+// (y, x) Winograd kernel on a volume whose depth is NOT a multiple of 4 (the 10^3 level): pipelined kernel with split-K work items only
+int wino2_ragged_depth_ok(int B, int D, int H, int W, int K, int N);
 
 __host__ __device__ inline int npad(int N) { return (N + 63) & ~63; }
 // Cin chunk of the direct kernel's weight packing (conv3d.hip pick_ch)

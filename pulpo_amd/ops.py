@@ -348,6 +348,10 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
     bf16 = algo == "bf16"
     vec_ok = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0
     if algo == "wino2":
+        if (D % 4 or D * H * W < 8000) and not vec_ok:     # (volumes below 20^3 - the 10^3 level - run on the pipelined kernel only: channels-last operand)
+            x = to_cl(x)
+            xb, xp, xc = grid_strides(x)
+            vec_ok = True
         nscr = lib.query("pulpo_conv3d_k3_fwd_wino2_scratch_floats", B, D, H, W, K, N)
         scratch = torch.empty(nscr, device=x.device, dtype=torch.float32) if nscr else None
         t0 = _trace_begin()

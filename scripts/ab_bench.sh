@@ -1,4 +1,5 @@
-# same-box A/B: the committed tree in _ab/ against the working tree
+# same-box A/B: a copy of the committed tree in _ab/ (git archive HEAD | tar -x -C _ab; python -m pulpo_amd.build there) against the working tree;
+# usage (on the GPU box): bash scripts/ab_bench.sh [repetitions]
 set -e
 R=$GRAFT_REPO_ROOT
 N=${1:-3}

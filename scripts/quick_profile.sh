@@ -7,5 +7,6 @@ F=$(find $O/pq -name "*kernel_stats.csv" | head -1)
 python scripts/summarize_profile.py $F $O/q_summary.md 10 "work tree" > /dev/null
 T=$(find $O/pq -name "*kernel_trace.csv" | head -1)
 python scripts/timeline.py $T 10 > $O/q_timeline.txt 2>&1
+python scripts/percall.py $T ${PERCALL:-vecint_bwd_tile} > $O/q_percall.txt 2>&1
 rm -rf $O/pq
 head -60 $O/q_summary.md

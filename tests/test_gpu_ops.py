@@ -320,13 +320,15 @@ def test_eval_mode_fused_epilogue_equals_separate_passes(ops, precision, Cin, Co
 
 @pytest.mark.parametrize("B,Cin,Cout,size", [(1, 32, 32, (64, 64, 64)), (1, 64, 64, (64, 64, 64)), (2, 16, 96, (64, 56, 80)), (1, 20, 12, (64, 64, 70)),
                                             (1, 96, 32, (68, 61, 67)), (2, 192, 192, (20, 20, 20)), (1, 8, 40, (24, 20, 17)),
-                                            (1, 288, 192, (20, 20, 20)), (1, 128, 192, (20, 20, 20))])
+                                            (1, 288, 192, (20, 20, 20)), (1, 128, 192, (20, 20, 20)), (1, 192, 192, (10, 10, 10)),
+                                            (2, 96, 64, (10, 12, 9))])
 def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size):
     """volumes of >= 20^3 voxels with depth % 4 == 0 take the F(2x2,3x3) Winograd kernels for forward and data gradient
     (pulpo_conv3d_k3_algo = 2: the pipelined conv3d_k3_wino2p_mfma for operands with a multiple of 8 channels, the round-2
     conv3d_k3_wino2_mfma otherwise - Cin = 20 forward, Cout = 12 data gradient here) and for the weight gradient: same fp32 tolerance
     against the fp64 convolution as the direct kernels; ragged H / W (odd sizes: half-filled blocks) and the 20^3 level's 128 / 192 / 288
-    channel layers (split-K work items where the tiles are few) included"""
+    channel layers (split-K work items where the tiles are few) included, and the 10^3 level, whose depth is not a multiple of 4
+    (ragged depth tile: pipelined kernel with split-K only)"""
     from pulpo_amd._lib import lib
     assert lib.query("pulpo_conv3d_k3_algo", B, *size, Cin, Cout) == 2
     assert lib.query("pulpo_conv3d_k3_wino2_pipelined", *size, Cin, Cin) == int(Cin % 8 == 0)
