@@ -593,7 +593,8 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
 
 // deferred parameter-gradient jobs of a whole backward pass in ONE launch (grid = (blocks per job, jobs)):
 //   kind 0: dw[co][ci][27] += packed[tap][ci][co] and packed := 0   (a = Cin, b = Cout, c = NPad)     - weight gradients of pulpo_conv3d_k3_wgrad(accumulate = 2)
-//   kind 1: dst[col] += sum_r src[r][col]                          (a = rows, b = columns)          - conv-bias gradients from the BatchNorm backward partials
+//   kind 1: dst[col] += sum_r src[r * stride + col]                (a = rows, b = columns, c = row stride or 0 = b)  - conv-bias gradients from the
+//           BatchNorm backward partials; column ranges of the 1x1x1 heads' partial rows (weights and biases of mu / sigma / velocity heads)
 __global__ __launch_bounds__(256) void grad_finish_multi_kernel(const PulpoGradJob* __restrict__ jobs) {
     const PulpoGradJob j = jobs[blockIdx.y];
     if (j.kind == 0) {
@@ -627,12 +628,13 @@ __global__ __launch_bounds__(256) void grad_finish_multi_kernel(const PulpoGradJ
         // per 32 columns walked 256 dependent passes - most of this launch's 170 us)
         __shared__ double red[32][9];
         const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+        const long rs = j.c > 0 ? j.c : j.b;           // row stride of src (c = 0: the rows are dense)
         for (int c0 = blockIdx.x * 8; c0 < j.b; c0 += gridDim.x * 8) {
             const int c = c0 + cx;
             double s_ = 0.0;
             if (c < j.b) {
 #pragma unroll 4
-                for (int r = ry; r < j.a; r += 32) s_ += (double)j.src[(long)r * j.b + c];
+                for (int r = ry; r < j.a; r += 32) s_ += (double)j.src[(long)r * rs + c];
             }
             red[ry][cx] = s_;
             __syncthreads();

@@ -429,7 +429,7 @@ def reset_param_grad_buffers(module: Optional[torch.nn.Module] = None) -> None:
     _BN_TILE_PARTS.clear()
     if module is not None:
         for p_ in module.parameters():
-            for name in ("_pulpo_wgrad_scratch", "_pulpo_dbias_part"):
+            for name in ("_pulpo_wgrad_scratch", "_pulpo_dbias_part", "_pulpo_heads_part"):
                 if hasattr(p_, name):
                     delattr(p_, name)
 
@@ -693,8 +693,12 @@ def conv3d_k3(x, weight, bias=None):
 # ------------------------------------------------------------------------------------------------ 1x1x1 heads
 class _Heads(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, Wt, bias, eps, nout: int):
+    def forward(ctx, h, Wt, bias, eps, nout: int, params=None):
+        """params: the leaf parameters Wt / bias were assembled from, as ((tensor, first row of Wt, rows), ...) for the weights and
+        ((tensor, first element of bias, elements), ...) for the biases: inside the data-parallel stepper their gradients are finished by
+        flush_param_grads() straight from the backward kernel's partial rows (no column sum, no split, no AccumulateGrad add per parameter)"""
         _require_gpu(h, Wt, bias, eps)
+        ctx.params = params
         h = to_cl(h)
         B, C, D, H, W = h.shape
         V = D * H * W
@@ -720,11 +724,29 @@ class _Heads(torch.autograd.Function):
         dh = new_cl(B, C, D, H, W, dev)
         nblk = lib.query("pulpo_heads_bwd_blocks", B, V, C)
         rowlen = nout * C + nout
-        part = torch.empty(nblk * rowlen, device=dev, dtype=torch.float32)
+        # inside the stepper: the partial rows go to a persistent buffer (stable address: the finishing launch's job table is cached) and
+        # flush_param_grads() adds their column sums to the parameters' .grad; a head applied twice in a step takes the immediate path
+        slots = None
+        if ctx.params is not None and DIRECT_PARAM_GRADS and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            wparts, bparts = ctx.params
+            slots = [(_grad_slot(t), off, n) for t, off, n in wparts] + [(_grad_slot(t), off, n) for t, off, n in bparts]
+            if not all(sl is not None for sl, _, _ in slots):
+                slots = None
+        part = _persistent_buffer(ctx.params[0][0][0], "_pulpo_heads_part", nblk * rowlen, zero=False) if slots is not None else None
+        if part is None or _pending_src(part):
+            slots = None
+            part = torch.empty(nblk * rowlen, device=dev, dtype=torch.float32)
         lib.call("pulpo_heads_bwd", _ptr(h), h.stride(4), _ptr(Wt), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(eps), _ptr(sigma), _ptr(dh),
                  dh.stride(4), _ptr(part), nout, B, V, C, _stream())
+        if slots is not None:
+            nw = len(ctx.params[0])
+            for k, (sl, off, n) in enumerate(slots):
+                col0, ncol = (off * C, n * C) if k < nw else (nout * C + off, n)
+                _PENDING_GRAD_JOBS.append((part.data_ptr() + 4 * col0, sl.data_ptr(), 1, nblk, ncol, rowlen))
+            _PENDING_KEEPALIVE.append(part)
+            return dh, None, None, None, None, None
         tot = _colsum(part, nblk, rowlen)
-        return dh, tot[: nout * C].view(nout, C), tot[nout * C:], None, None
+        return dh, tot[: nout * C].view(nout, C), tot[nout * C:], None, None, None
 
 
 def mu_sigma_sample(h, w_mu, b_mu, w_sigma, b_sigma, eps):
@@ -741,7 +763,7 @@ def mu_sigma_sample(h, w_mu, b_mu, w_sigma, b_sigma, eps):
         return _unlift_field(mu), _unlift_field(sigma), _unlift_field(z)
     Wt = torch.cat([w_mu.reshape(3, C), w_sigma.reshape(3, C)], dim=0)
     bias = torch.cat([b_mu, b_sigma], dim=0)
-    return _Heads.apply(h, Wt, bias, eps, 6)
+    return _Heads.apply(h, Wt, bias, eps, 6, (((w_mu, 0, 3), (w_sigma, 3, 3)), ((b_mu, 0, 3), (b_sigma, 3, 3))))
 
 
 def conv1x1_to3(h, w, b):
@@ -750,7 +772,7 @@ def conv1x1_to3(h, w, b):
         C = w.shape[1]
         Wt = torch.cat([w.new_zeros(1, C), w.reshape(2, C)], dim=0)
         return _unlift_field(_Heads.apply(_lift(h), Wt, torch.cat([b.new_zeros(1), b]), None, 3))
-    return _Heads.apply(h, w.reshape(3, w.shape[1]), b, None, 3)
+    return _Heads.apply(h, w.reshape(3, w.shape[1]), b, None, 3, (((w, 0, 3),), ((b, 0, 3),)))
 
 
 # ------------------------------------------------------------------------------------------------ resampling

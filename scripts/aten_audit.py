@@ -27,6 +27,13 @@ SKIP = ("aten.empty", "aten.view", "aten._unsafe_view", "aten.as_strided", "aten
 class Audit(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
+        if name.startswith(("aten._to_copy", "aten.copy_", "aten._local_scalar_dense", "aten.item")):
+            # host <-> device traffic: every one of these is a blit kernel (or a synchronisation) inside the step
+            allt = [a for a in list(args) + list((kwargs or {}).values()) if isinstance(a, torch.Tensor)]
+            devs = {str(t.device.type) for t in allt} | ({str(kwargs["device"]).split(":")[0]} if kwargs and kwargs.get("device") is not None else set())
+            if len(devs) > 1 or name.startswith(("aten._local_scalar_dense", "aten.item")):
+                fr = [f"{os.path.basename(f.filename)}:{f.lineno}" for f in traceback.extract_stack() if ("pulpo_amd" in f.filename or "/src/" in f.filename)][-3:]
+                log[("H<->D " + name, ", ".join(f"{tuple(t.shape)}@{t.device.type}" for t in allt[:2]), " <- ".join(reversed(fr)))] += 1
         if not name.startswith(SKIP):
             ts = [a for a in args if isinstance(a, torch.Tensor) and a.is_cuda]
             for a in args:
