@@ -4,6 +4,8 @@
 //   mix 1: fp32 MFMA + one ds_read_b128 per 2 MFMAs + one v_fma per MFMA            (the (y, x) Winograd kernel's inner loop, roughly)
 //   mix 2: bf16 MFMAs only (v_mfma_f32_32x32x16_bf16)
 //   mix 3: six bf16 MFMAs per six ds_read_b128                                      (fp32 products from three-term bf16 splits)
+//   mix 4: eight fp32 MFMAs (eight accumulators) per six ds_read_b128 and twenty v_fma  (Winograd F(2,3) along z as well: operands = y and z
+//          combinations of six rows formed at read time, two z points x four k-steps per point step)
 // For every mix and 1 / 2 / 4 waves per SIMD on all CUs: MFMA instructions per second, the implied TFLOP/s, and - from s_memtime around the
 // loop - shader clocks per MFMA and wave, i.e. pipe clocks per MFMA = that / (waves per SIMD), and the clock the chip held.
 #include <hip/hip_runtime.h>
@@ -15,7 +17,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
 template <int MIX>
-__global__ __launch_bounds__(256) void probe(float* out, unsigned long long* clk, int iters) {
+__global__ __launch_bounds__(256, 2) void probe(float* out, unsigned long long* clk, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     for (int j = tid; j < 8192; j += blockDim.x) lds[j] = (float)(j & 15) * 0.001f;
@@ -23,6 +25,10 @@ __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* clk
     f32x16 acc[4];
     for (int p = 0; p < 4; ++p)
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    [[maybe_unused]] f32x16 acc8[8];
+    if constexpr (MIX == 4)
+        for (int p = 0; p < 8; ++p)
+            for (int r = 0; r < 16; ++r) acc8[p][r] = 0.f;
     float a = 1.0f + lane * 1e-3f, b = 0.5f;
     const float* rp = lds + lane * 4;
     float4 v = *reinterpret_cast<const float4*>(rp);
@@ -37,6 +43,24 @@ __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* clk
                 if ((p & 1) == 0) v = *reinterpret_cast<const float4*>(rp + ((it * 4 + p) & 255) * 16);
                 const float x = __builtin_fmaf(-1.f, v.x, v.y);
                 acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, b, acc[p], 0, 0, 0);
+            }
+        } else if constexpr (MIX == 4) {
+            float4 r6[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) r6[k] = *reinterpret_cast<const float4*>(rp + ((it * 6 + k) & 255) * 16);
+            // y combinations of the three planes, then the two z combinations
+            float pz[3][4], op[2][4];
+#pragma unroll
+            for (int z = 0; z < 3; ++z) {
+                pz[z][0] = __builtin_fmaf(-1.f, r6[2 * z + 1].x, r6[2 * z].x); pz[z][1] = __builtin_fmaf(-1.f, r6[2 * z + 1].y, r6[2 * z].y);
+                pz[z][2] = __builtin_fmaf(-1.f, r6[2 * z + 1].z, r6[2 * z].z); pz[z][3] = __builtin_fmaf(-1.f, r6[2 * z + 1].w, r6[2 * z].w);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { op[0][k] = __builtin_fmaf(-1.f, pz[2][k], pz[0][k]); op[1][k] = __builtin_fmaf(1.f, pz[2][k], pz[1][k]); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc8[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(op[0][k], b, acc8[k], 0, 0, 0);
+                acc8[4 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(op[1][k], b, acc8[4 + k], 0, 0, 0);
             }
         } else if constexpr (MIX == 2) {
             bf16x8 x, y;
@@ -61,8 +85,12 @@ __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* clk
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.f;
-    for (int p = 0; p < 4; ++p)
-        for (int r = 0; r < 16; ++r) s += acc[p][r];
+    if constexpr (MIX != 4)
+        for (int p = 0; p < 4; ++p)
+            for (int r = 0; r < 16; ++r) s += acc[p][r];
+    if constexpr (MIX == 4)
+        for (int p = 0; p < 8; ++p)
+            for (int r = 0; r < 16; ++r) s += acc8[p][r];
     out[blockIdx.x * blockDim.x + tid] = s + v.x;
     if (lane == 0) clk[blockIdx.x * (blockDim.x / 64) + tid / 64] = t1 - t0;
 }
@@ -106,5 +134,6 @@ int main() {
     run<1>("fp32 32x32x2 + LDS read + fma", 4, 2.0 * 32 * 32 * 2);
     run<2>("bf16 32x32x16, MFMA only", 4, 2.0 * 32 * 32 * 16);
     run<3>("bf16 x6 per 6 ds_read_b128", 6, 2.0 * 32 * 32 * 16);
+    run<4>("fp32 x8 per 6 ds_read_b128 + 20 fma", 8, 2.0 * 32 * 32 * 2);
     return 0;
 }
