@@ -33,6 +33,7 @@
 namespace {
 
 using namespace pulpo_conv;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int W2G_VROW = 44, W2G_EROW = 36;                       // floats per (px, slot, channel) row
 constexpr int W2G_VSLOT = 32 * W2G_VROW, W2G_ESLOT = 32 * W2G_EROW; // floats per (px, slot)
@@ -412,12 +413,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2x(Wgrad2Args a) {
     // point px of the x-transformed item -> LDS (transposed: one ds_write_b32 per channel)
     auto write_x = [&](int px, int slot) {
         if (x_item) {
-            const float4 d0 = xr[0], d1 = xr[1], d2 = xr[2], d3 = xr[3];
-            float4 v;
-            if (px == 0) v = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
-            else if (px == 1) v = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
-            else if (px == 2) v = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
-            else v = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+            // (two-wide vector arithmetic: v_pk_add_f32)
+            const float4 pa_ = px == 0 ? xr[0] : px == 2 ? xr[2] : xr[1], pb_ = px == 0 ? xr[2] : px == 1 ? xr[2] : px == 2 ? xr[1] : xr[3];
+            const f32x2 sg = px == 1 ? f32x2{1.f, 1.f} : f32x2{-1.f, -1.f};
+            const f32x2 lo = f32x2{pa_.x, pa_.y} + sg * f32x2{pb_.x, pb_.y}, hi = f32x2{pa_.z, pa_.w} + sg * f32x2{pb_.z, pb_.w};
+            const float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
             float* o = x_dst + (px * 4 + slot) * W2G_VSLOT;
             o[0] = v.x; o[W2G_VROW] = v.y; o[2 * W2G_VROW] = v.z; o[3 * W2G_VROW] = v.w;
         }
@@ -427,9 +427,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2x(Wgrad2Args a) {
             const float4 d0 = er[0], d1 = er[1];
             float4 v;
             if (px == 0) v = d0;
-            else if (px == 1) v = make_float4(d0.x + d1.x, d0.y + d1.y, d0.z + d1.z, d0.w + d1.w);
-            else if (px == 2) v = make_float4(d0.x - d1.x, d0.y - d1.y, d0.z - d1.z, d0.w - d1.w);
-            else v = make_float4(-d1.x, -d1.y, -d1.z, -d1.w);
+            else if (px == 3) v = make_float4(-d1.x, -d1.y, -d1.z, -d1.w);
+            else {
+                const f32x2 sg = px == 1 ? f32x2{1.f, 1.f} : f32x2{-1.f, -1.f};
+                const f32x2 lo = f32x2{d0.x, d0.y} + sg * f32x2{d1.x, d1.y}, hi = f32x2{d0.z, d0.w} + sg * f32x2{d1.z, d1.w};
+                v = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
             float* o = e_dst + (px * 2 + slot) * W2G_ESLOT;
             o[0] = v.x; o[W2G_EROW] = v.y; o[2 * W2G_EROW] = v.z; o[3 * W2G_EROW] = v.w;
         }
@@ -506,12 +509,18 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2x(Wgrad2Args a) {
                 __builtin_amdgcn_sched_barrier(0);
                 // the group's sixteen operand combinations first, then its twelve MFMAs back to back (a v_fma -> MFMA dependency in front of
                 // every MFMA stalls the issue: conv3d_wino2p.hip, same finding)
-                const float ev[4] = {fmaf(c1, e1.x, c0 * e0.x), fmaf(c1, e1.y, c0 * e0.y), fmaf(c1, e1.z, c0 * e0.z), fmaf(c1, e1.w, c0 * e0.w)};
+                // (two-wide vector arithmetic: v_pk_mul_f32 / v_pk_fma_f32 - ten instructions per group instead of twenty)
+                const f32x2 c0v = {c0, c0}, c1v = {c1, c1}, sav = {sa, sa};
+                const f32x2 e01 = __builtin_elementwise_fma(c1v, f32x2{e1.x, e1.y}, c0v * f32x2{e0.x, e0.y});
+                const f32x2 e23 = __builtin_elementwise_fma(c1v, f32x2{e1.z, e1.w}, c0v * f32x2{e0.z, e0.w});
+                const float ev[4] = {e01.x, e01.y, e23.x, e23.y};
                 float vv[3][4];
 #pragma unroll
                 for (int dz = 0; dz < 3; ++dz) {
                     const float4 pa_ = av[dz], pb_ = bv[dz];
-                    vv[dz][0] = fmaf(sa, pb_.x, pa_.x); vv[dz][1] = fmaf(sa, pb_.y, pa_.y); vv[dz][2] = fmaf(sa, pb_.z, pa_.z); vv[dz][3] = fmaf(sa, pb_.w, pa_.w);
+                    const f32x2 v01 = __builtin_elementwise_fma(sav, f32x2{pb_.x, pb_.y}, f32x2{pa_.x, pa_.y});
+                    const f32x2 v23 = __builtin_elementwise_fma(sav, f32x2{pb_.z, pb_.w}, f32x2{pa_.z, pa_.w});
+                    vv[dz][0] = v01.x; vv[dz][1] = v01.y; vv[dz][2] = v23.x; vv[dz][3] = v23.y;
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -39,6 +39,7 @@ PULPO_API int pulpo_debug_read_stamps(void* dst, size_t bytes) {
 namespace {
 
 using namespace pulpo_conv;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int P_CH = 8, P_NT = 32;
 constexpr int P_PL = HY * 4;                     // rows of one px slice of a plane: (hy, x-pair)
@@ -283,18 +284,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
 #if PULPO_W2P_FMA_BATCH
                     // the step's eight y combinations first, then eight MFMAs back to back (no VALU -> MFMA dependency stall between them)
                     float av[4][2];
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            const float a_ = s2 == 0 ? ra[sl][m].x : s2 == 1 ? ra[sl][m].y : s2 == 2 ? ra[sl][m].z : ra[sl][m].w;
-                            const float b_ = s2 == 0 ? rb[sl][m].x : s2 == 1 ? rb[sl][m].y : s2 == 2 ? rb[sl][m].z : rb[sl][m].w;
 #if PULPO_ABL & 256
-                            av[s2][m] = a_; (void)b_;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) { av[0][m] = ra[sl][m].x; av[1][m] = ra[sl][m].y; av[2][m] = ra[sl][m].z; av[3][m] = ra[sl][m].w; }
 #else
-                            av[s2][m] = fmaf(sa, b_, a_);
+                    // (two-wide vector arithmetic: four v_pk_fma_f32 per step instead of eight v_fma_f32)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const f32x2 sav = {sa, sa};
+                        const f32x2 lo = __builtin_elementwise_fma(sav, f32x2{rb[sl][m].x, rb[sl][m].y}, f32x2{ra[sl][m].x, ra[sl][m].y});
+                        const f32x2 hi = __builtin_elementwise_fma(sav, f32x2{rb[sl][m].z, rb[sl][m].w}, f32x2{ra[sl][m].z, ra[sl][m].w});
+                        av[0][m] = lo.x; av[1][m] = lo.y; av[2][m] = hi.x; av[3][m] = hi.y;
+                    }
 #endif
-                        }
                     __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
