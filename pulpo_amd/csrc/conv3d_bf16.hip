@@ -555,7 +555,14 @@ PULPO_API int pulpo_conv3d_k3_wgrad_bf16(const float* in, int64_t in_bs, int64_t
     a.ncit = pulpo::cdiv(Cin, CH); a.ncot = pulpo::cdiv(Cout, 32);
     const int ntile = B * a.ntz * a.nty * a.ntx;
     const int npair = a.ncit * a.ncot;
-    a.nsplit = std::min(std::max(1, 512 / npair), ntile);        // two resident workgroups per CU: one stages while the other multiplies
+    // ONE resident workgroup per CU.  The kernel holds 242 registers per wave: two workgroups per CU (the round-1 choice: one stages while the
+    // other multiplies) take 484 of a SIMD's 512, and no kernel of the main stream starts on a CU until a workgroup retires - every
+    // BatchNorm-backward launch of the step then waited ~100 us for one (colsum_slices 109 instead of 8 us: 3 ms per bf16 step).  Measured
+    // per 160^3 bf16 step for 512 / 448 / 384 / 320 / 256 / 192 / 128 workgroups: 23.1 / 20.3 / 20.3 / 20.2 / 20.3 / 21.0 / 24.4 ms.
+    // PULPO_WGRAD_BF16_WGS overrides (A/B switch).
+    static int wgs = -1;
+    if (wgs < 0) { const char* e = getenv("PULPO_WGRAD_BF16_WGS"); wgs = e ? atoi(e) : 256; }
+    a.nsplit = std::min(std::max(1, wgs / npair), ntile);
     const bool deferred = accumulate == 2;                 // see pulpo_conv3d_k3_wgrad
     if (!deferred) {
         hipError_t e = hipMemsetAsync(scratch, 0, pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout) * sizeof(float), st);

@@ -203,6 +203,7 @@ class DataParallelStepper:
         dev0 = next(model.parameters()).device
         self.async_wgrad = bool(async_wgrad) and dev0.type == "cuda" and os.environ.get("PULPO_ASYNC_WGRAD", "1") != "0"
         self._side = torch.cuda.Stream(device=dev0) if self.async_wgrad else None
+        self._one = None
         params, ranges, triggers = _gradient_buckets(model)
         self.arena = FlatArena(model, params)
         off = self.arena.offsets + [self.arena.numel]
@@ -254,7 +255,9 @@ class DataParallelStepper:
             ops.DIRECT_PARAM_GRADS = True          # conv / BN backward kernels add straight into the arena's .grad views
             ops.ASYNC_WGRAD_STREAM = self._side if self.async_wgrad else None
             try:
-                loss.backward()
+                if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype:
+                    self._one = torch.ones((), device=loss.device, dtype=loss.dtype)       # (backward() would fill a fresh one per step)
+                loss.backward(self._one)
             except BaseException:
                 ops.reset_param_grad_buffers(self.model)        # deferred gradient sums of an interrupted backward pass are void
                 raise
