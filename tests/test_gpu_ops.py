@@ -201,6 +201,26 @@ def test_conv_unit_golden(ops, golden, tag):
     close(oe, g[tag + "_out_eval"], atol=2e-5)
 
 
+@pytest.mark.parametrize("size,cin,cout", [((10, 10, 10), 192, 192), ((20, 20, 20), 288, 192), ((32, 32, 32), 32, 64)])
+def test_conv_unit_eval_mode_fused_store_equals_the_separate_passes(ops, size, cin, cout):
+    """inference (no gradient): the convolution's store applies the eval-mode BatchNorm + LeakyReLU (one kernel per ConvUnit) - on the
+    split-K shapes (10^3, 20^3 with >= 192 reduction channels) the ordered reduction of the partial slabs does it.  Same values as the
+    path that keeps the pre-norm tensor for a backward pass (convolution, then bn_lrelu_apply)."""
+    gen = torch.Generator().manual_seed(cin + size[0])
+    x = torch.randn(1, cin, *size, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=gen) / (27 * cin) ** 0.5).cuda()
+    b, gam, bet = torch.randn(cout, generator=gen).cuda(), torch.rand(cout, generator=gen).cuda() + 0.5, torch.randn(cout, generator=gen).cuda()
+    rm, rv = torch.randn(cout, generator=gen).cuda() * 0.1, torch.rand(cout, generator=gen).cuda() + 0.5
+    with torch.no_grad():
+        fused = ops.conv_bn_lrelu(x, w, b, gam, bet, rm, rv, training=False)
+    xg = x.clone().requires_grad_(True)
+    plain = ops.conv_bn_lrelu(xg, w, b, gam, bet, rm, rv, training=False)
+    assert float((fused - plain.detach()).abs().max()) <= 2e-6 * float(plain.detach().abs().max())
+    ref = F.leaky_relu(F.batch_norm(F.conv3d(x.cpu().double(), w.cpu().double(), b.cpu().double(), padding=1), rm.cpu().double(), rv.cpu().double(),
+                                    gam.cpu().double(), bet.cpu().double(), False, 0.1, 1e-5), 0.2)
+    assert rel_l2(fused, ref) < 3e-6
+
+
 CONV_CASES = [
     # B, Cin, Cout, size, channels-last input?
     (1, 2, 32, (9, 11, 13), False),
