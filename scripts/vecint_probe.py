@@ -9,7 +9,7 @@ lib.load()
 sizes = [int(s) for s in sys.argv[1:]] or [80, 40, 20, 10]
 for S in sizes:
     torch.manual_seed(S)
-    v = (torch.randn(1, 3, S, S, S, device="cuda") * 2.0).requires_grad_(True)
+    v = (torch.randn(1, 3, S, S, S, device="cuda") * float(os.environ.get("AMP", "2.0"))).requires_grad_(True)
     up = torch.randn(1, 3, S, S, S, device="cuda")
     def fwd(): return ops.vecint(v, 7)
     out = fwd()
