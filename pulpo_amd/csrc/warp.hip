@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
 // LDS: a workgroup owns a 4 x 8 x 8 voxel tile and keeps a (4+2R) x (8+2R) x (8+2R) x 3 accumulation box around it; a step's displacement
 // is a fraction of the final field (v / 2^(nsteps-k)), so almost every corner a voxel scatters to lies inside the box of its own tile -
 // those adds are LDS atomics, the rest go to memory as before.  The box then leaves with one memory atomic per touched cell: 4-7 memory
-// atomics per voxel instead of 27 (24 corner adds + 3 displacement-gradient adds), which is what bounded warp_bwd_kernel here.
+// atomics per voxel instead of 27 (24 corner adds + 3 displacement-gradient adds), which is what bounded warp_bwd_kernel here.  Round 3:
+// the LDS atomics themselves (about one lane per two clocks) had become the bound - neighbouring lanes now merge their contributions to
+// shared cells before the add (along x, then along y: see below), 607 -> 335 us per seven steps at 80^3.
 // gp must be all zero on entry: the identity path (g itself) is added to the voxel's own cell of the box and leaves with it (no copy of g
 // into gp in front of every step; pulpo_vecint_bwd zeroes the buffers of all steps with one fill).
 template <int R>
@@ -146,54 +148,92 @@ __global__ __launch_bounds__(256) void vecint_bwd_tile_kernel(const float* __res
     for (int j = tid; j < 3 * BV; j += 256) box[j] = 0.f;
     __syncthreads();
     const int z = z0 + (tid >> 6), y = y0 + ((tid >> 3) & 7), x = x0 + (tid & 7);
-    if (z < D && y < H && x < W) {
-        const long v = ((long)z * H + y) * W + x;
-        const float* d = cur + (long)b * 3 * V + v;
-        const Corner cz = sample_coord((float)z, d[0], D, D);
-        const Corner cy = sample_coord((float)y, d[V], H, H);
-        const Corner cx = sample_coord((float)x, d[2 * V], W, W);
-        const float wz0 = 1.f - cz.f, wy0 = 1.f - cy.f, wx0 = 1.f - cx.f;
-        const long o00 = ((long)cz.i0 * H + cy.i0) * W, o01 = ((long)cz.i0 * H + cy.i1) * W;
-        const long o10 = ((long)cz.i1 * H + cy.i0) * W, o11 = ((long)cz.i1 * H + cy.i1) * W;
-        // box coordinates of the corners (negative / too large = outside the box)
-        const int lz0 = cz.i0 - z0 + R, lz1 = cz.i1 - z0 + R, ly0 = cy.i0 - y0 + R, ly1 = cy.i1 - y0 + R, lx0 = cx.i0 - x0 + R, lx1 = cx.i1 - x0 + R;
-        const bool inbox = lz0 >= 0 && lz1 < BZ && ly0 >= 0 && ly1 < BY && lx0 >= 0 && lx1 < BX;
-        float gz = 0.f, gy = 0.f, gx = 0.f;
-        float gid[3];
+    // (straight-line code with a `valid` predicate instead of a branch around the voxel's work: the lanes of a wave - one z-plane of the
+    //  tile, 8 rows of 8 voxels - exchange contributions below)
+    const bool valid = z < D && y < H && x < W;
+    const long v = valid ? ((long)z * H + y) * W + x : 0;
+    const float* d = cur + (long)b * 3 * V + v;
+    const Corner cz = sample_coord((float)z, valid ? d[0] : 0.f, D, D);
+    const Corner cy = sample_coord((float)y, valid ? d[V] : 0.f, H, H);
+    const Corner cx = sample_coord((float)x, valid ? d[2 * V] : 0.f, W, W);
+    const float wz0 = 1.f - cz.f, wy0 = 1.f - cy.f, wx0 = 1.f - cx.f;
+    const long o00 = ((long)cz.i0 * H + cy.i0) * W, o01 = ((long)cz.i0 * H + cy.i1) * W;
+    const long o10 = ((long)cz.i1 * H + cy.i0) * W, o11 = ((long)cz.i1 * H + cy.i1) * W;
+    // box coordinates of the corners (negative / too large = outside the box)
+    const int lz0 = cz.i0 - z0 + R, lz1 = cz.i1 - z0 + R, ly0 = cy.i0 - y0 + R, ly1 = cy.i1 - y0 + R, lx0 = cx.i0 - x0 + R, lx1 = cx.i1 - x0 + R;
+    const bool inbox = valid && lz0 >= 0 && lz1 < BZ && ly0 >= 0 && ly1 < BY && lx0 >= 0 && lx1 < BX;
+    // Neighbouring lanes of a row mostly scatter to overlapping cells: for a smooth field the "x1" corners of voxel x are the "x0" corners of
+    // voxel x + 1.  Where that holds (same z / y cells, both in the box) the right neighbour TAKES the left one's four x1 contributions per
+    // channel into its own x0 adds, and the left one skips them: 12 + 3 instead of 24 + 3 LDS atomics per voxel - which retire about one lane
+    // per two clocks and are what bounds this kernel (scripts/vecint_probe.py).  Sums are the same up to the order of the additions.
+    const int key = inbox ? (((lz0 * 32 + lz1) * 32 + ly0) * 32 + ly1) : -1;
+    const int key_l = __shfl_up(key, 1, 64), lx1_l = __shfl_up(lx1, 1, 64);
+    const bool take = inbox && (tid & 7) != 0 && key_l == key && lx1_l == lx0;
+    const int take_r = __shfl_down((int)take, 1, 64);          // (every lane takes part in the exchange: no short-circuit in front of it)
+    const bool give = (tid & 7) != 7 && take_r != 0;
+    // ... and the same along y (lanes 8 apart), separately for the x0 corners and for the x1 corners a lane still holds: the lane of row
+    // y + 1 takes the dy = 1 contributions of row y into its dy = 0 adds.  An interior voxel of a smooth field is left with 2 of its 8
+    // corner adds per channel.
+    const int row = (tid >> 3) & 7;
+    const int ky0 = inbox ? ((lz0 * 32 + lz1) * 32 + lx0) : -1, ky1 = (inbox && !give) ? ((lz0 * 32 + lz1) * 32 + lx1) : -1;
+    const int ky0_u = __shfl_up(ky0, 8, 64), ky1_u = __shfl_up(ky1, 8, 64), ly1_u = __shfl_up(ly1, 8, 64);
+    const bool take_y0 = row != 0 && ky0 >= 0 && ky0_u == ky0 && ly1_u == ly0;
+    const bool take_y1 = row != 0 && ky1 >= 0 && ky1_u == ky1 && ly1_u == ly0;
+    const int ty0_d = __shfl_down((int)take_y0, 8, 64), ty1_d = __shfl_down((int)take_y1, 8, 64);
+    const bool give_y0 = row != 7 && ty0_d != 0, give_y1 = row != 7 && ty1_d != 0;
+    float gz = 0.f, gy = 0.f, gx = 0.f;
+    float gid[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float g = gout[((long)b * 3 + c) * V + v];
-            gid[c] = g;
+    for (int c = 0; c < 3; ++c) {
+        const float g = valid ? gout[((long)b * 3 + c) * V + v] : 0.f;
+        gid[c] = g;
+        if (valid) {
             const float* s = cur + ((long)b * 3 + c) * V;
             const float s000 = s[o00 + cx.i0], s001 = s[o00 + cx.i1], s010 = s[o01 + cx.i0], s011 = s[o01 + cx.i1];
             const float s100 = s[o10 + cx.i0], s101 = s[o10 + cx.i1], s110 = s[o11 + cx.i0], s111 = s[o11 + cx.i1];
             gz += g * (wy0 * wx0 * (s100 - s000) + wy0 * cx.f * (s101 - s001) + cy.f * wx0 * (s110 - s010) + cy.f * cx.f * (s111 - s011));
             gy += g * (wz0 * wx0 * (s010 - s000) + wz0 * cx.f * (s011 - s001) + cz.f * wx0 * (s110 - s100) + cz.f * cx.f * (s111 - s101));
             gx += g * (wz0 * wy0 * (s001 - s000) + wz0 * cy.f * (s011 - s010) + cz.f * wy0 * (s101 - s100) + cz.f * cy.f * (s111 - s110));
-            if (inbox) {
-                float* q = box + c * BV;
-                const int p00 = (lz0 * BY + ly0) * BX, p01 = (lz0 * BY + ly1) * BX, p10 = (lz1 * BY + ly0) * BX, p11 = (lz1 * BY + ly1) * BX;
-                atomicAdd(q + p00 + lx0, g * wz0 * wy0 * wx0);
-                atomicAdd(q + p00 + lx1, g * wz0 * wy0 * cx.f);
-                atomicAdd(q + p01 + lx0, g * wz0 * cy.f * wx0);
-                atomicAdd(q + p01 + lx1, g * wz0 * cy.f * cx.f);
-                atomicAdd(q + p10 + lx0, g * cz.f * wy0 * wx0);
-                atomicAdd(q + p10 + lx1, g * cz.f * wy0 * cx.f);
-                atomicAdd(q + p11 + lx0, g * cz.f * cy.f * wx0);
-                atomicAdd(q + p11 + lx1, g * cz.f * cy.f * cx.f);
-            } else {
-                float* q = gp + ((long)b * 3 + c) * V;
-                atomicAdd(q + o00 + cx.i0, g * wz0 * wy0 * wx0);
-                atomicAdd(q + o00 + cx.i1, g * wz0 * wy0 * cx.f);
-                atomicAdd(q + o01 + cx.i0, g * wz0 * cy.f * wx0);
-                atomicAdd(q + o01 + cx.i1, g * wz0 * cy.f * cx.f);
-                atomicAdd(q + o10 + cx.i0, g * cz.f * wy0 * wx0);
-                atomicAdd(q + o10 + cx.i1, g * cz.f * wy0 * cx.f);
-                atomicAdd(q + o11 + cx.i0, g * cz.f * cy.f * wx0);
-                atomicAdd(q + o11 + cx.i1, g * cz.f * cy.f * cx.f);
-            }
         }
-        // the displacement-gradient term lands on the voxel itself: into its (always in-box) cell
+        float a000 = g * wz0 * wy0 * wx0, a010 = g * wz0 * cy.f * wx0, a100 = g * cz.f * wy0 * wx0, a110 = g * cz.f * cy.f * wx0;       // x0 corners
+        const float a001 = g * wz0 * wy0 * cx.f, a011 = g * wz0 * cy.f * cx.f, a101 = g * cz.f * wy0 * cx.f, a111 = g * cz.f * cy.f * cx.f;   // x1 corners
+        const float t00 = __shfl_up(a001, 1, 64), t01 = __shfl_up(a011, 1, 64), t10 = __shfl_up(a101, 1, 64), t11 = __shfl_up(a111, 1, 64);
+        if (take) { a000 += t00; a010 += t01; a100 += t10; a110 += t11; }
+        float b001 = a001, b101 = a101;
+        const float u010 = __shfl_up(a010, 8, 64), u110 = __shfl_up(a110, 8, 64), u011 = __shfl_up(a011, 8, 64), u111 = __shfl_up(a111, 8, 64);
+        if (take_y0) { a000 += u010; a100 += u110; }
+        if (take_y1) { b001 += u011; b101 += u111; }
+        if (inbox) {
+            float* q = box + c * BV;
+            const int p00 = (lz0 * BY + ly0) * BX, p01 = (lz0 * BY + ly1) * BX, p10 = (lz1 * BY + ly0) * BX, p11 = (lz1 * BY + ly1) * BX;
+            atomicAdd(q + p00 + lx0, a000);
+            atomicAdd(q + p10 + lx0, a100);
+            if (!give_y0) {
+                atomicAdd(q + p01 + lx0, a010);
+                atomicAdd(q + p11 + lx0, a110);
+            }
+            if (!give) {
+                atomicAdd(q + p00 + lx1, b001);
+                atomicAdd(q + p10 + lx1, b101);
+                if (!give_y1) {
+                    atomicAdd(q + p01 + lx1, a011);
+                    atomicAdd(q + p11 + lx1, a111);
+                }
+            }
+        } else if (valid) {
+            float* q = gp + ((long)b * 3 + c) * V;
+            atomicAdd(q + o00 + cx.i0, a000);
+            atomicAdd(q + o00 + cx.i1, a001);
+            atomicAdd(q + o01 + cx.i0, a010);
+            atomicAdd(q + o01 + cx.i1, a011);
+            atomicAdd(q + o10 + cx.i0, a100);
+            atomicAdd(q + o10 + cx.i1, a101);
+            atomicAdd(q + o11 + cx.i0, a110);
+            atomicAdd(q + o11 + cx.i1, a111);
+        }
+    }
+    if (valid) {
+        // the displacement-gradient term and the identity path land on the voxel itself: into its (always in-box) cell
         const int own = ((z - z0 + R) * BY + (y - y0 + R)) * BX + (x - x0 + R);
         atomicAdd(box + own, gid[0] + gz * cz.dscale);
         atomicAdd(box + BV + own, gid[1] + gy * cy.dscale);
