@@ -173,6 +173,10 @@ int pulpo_heads_bwd(const float* h, int64_t ps, const float* Wt, const float* g0
  * feedback_up2: the x2 up-sampling + torch.cat of the feedback tensors (pulpo.py:195-206), planar sources -> channels-last out */
 int pulpo_avgpool2_fwd(const float* in, int64_t ips, float* out, int64_t ops, int B, int D, int H, int W, int C, void* stream);
 int pulpo_avgpool2_bwd(const float* gout, int64_t gops, float* gin, int64_t gips, int B, int D, int H, int W, int C, void* stream);
+/* gin = add + avgpool2_bwd(gout): the gradient of a tensor that is pooled AND used as a skip connection (components/pulpo.py:58, 77), both
+ * contributions in one pass instead of a pooling backward and autograd's accumulation add; add: channels-last with voxel stride aps */
+int pulpo_avgpool2_bwd_add(const float* gout, int64_t gops, const float* add, int64_t aps, float* gin, int64_t gips, int B, int D, int H, int W,
+                           int C, void* stream);
 int pulpo_resize_trilinear_fwd(const float* in, const float* add, float* out, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                                float mult, void* stream);
 int pulpo_resize_trilinear_bwd(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo, float mult,

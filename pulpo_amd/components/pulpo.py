@@ -55,7 +55,9 @@ class DownPath(nn.Module):
         h = torch.cat([x, y], dim=1)            # two planar volumes side by side; read in place by the first conv
         acts = {0: self.down_blocks[0](h)}
         for k in range(1, self.total_levels):
-            acts[k] = self.down_blocks[k](ops.avg_pool2(acts[k - 1]))
+            # (the activation is pooled AND handed out as a skip connection: one operator, so that its two gradients meet in one kernel)
+            acts[k - 1], pooled = ops.avg_pool2_skip(acts[k - 1])
+            acts[k] = self.down_blocks[k](pooled)
         return acts
 
 

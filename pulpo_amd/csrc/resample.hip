@@ -43,9 +43,11 @@ __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restri
     }
 }
 
+// (add, nullable: a second gradient of the same tensor - the pooled activation is also a skip connection - summed in the same pass:
+//  gin = add + up(gout) / count, the operand order of autograd's own accumulation)
 template <int VEC>
 __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ gout, long gops, float* __restrict__ gin, long gips, int B,
-                                                             int D, int H, int W, int Do, int Ho, int Wo, int C) {
+                                                             int D, int H, int W, int Do, int Ho, int Wo, int C, const float* __restrict__ add, long aps) {
     const int CV = C / VEC;
     const long total = (long)B * D * H * W * CV;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -60,11 +62,14 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
         const float inv = 1.f / (float)cnt;
         const float* s = gout + ((((long)b * Do + oz) * Ho + oy) * Wo + ox) * gops + c;
         float* d = gin + ((((long)b * D + z) * H + y) * W + x) * gips + c;
+        const float* q = add != nullptr ? add + ((((long)b * D + z) * H + y) * W + x) * aps + c : nullptr;
         if constexpr (VEC == 4) {
             const float4 t = *reinterpret_cast<const float4*>(s);
-            *reinterpret_cast<float4*>(d) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+            float4 r = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+            if (q != nullptr) { const float4 u = *reinterpret_cast<const float4*>(q); r = make_float4(u.x + r.x, u.y + r.y, u.z + r.z, u.w + r.w); }
+            *reinterpret_cast<float4*>(d) = r;
         } else {
-            d[0] = s[0] * inv;
+            d[0] = q != nullptr ? q[0] + s[0] * inv : s[0] * inv;
         }
     }
 }
@@ -251,14 +256,28 @@ PULPO_API int pulpo_avgpool2_fwd(const float* in, int64_t ips, float* out, int64
     return pulpo::check_launch("avgpool2_fwd");
 }
 
-PULPO_API int pulpo_avgpool2_bwd(const float* gout, int64_t gops, float* gin, int64_t gips, int B, int D, int H, int W, int C, void* stream) {
+static int avgpool2_bwd_impl(const float* gout, int64_t gops, const float* add, int64_t aps, float* gin, int64_t gips, int B, int D, int H, int W, int C,
+                             void* stream) {
     PULPO_REQUIRE(gout && gin && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "avgpool2_bwd: bad arguments");
     const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    const bool v4 = C % 4 == 0 && gips % 4 == 0 && gops % 4 == 0 && ((((uintptr_t)gin) | ((uintptr_t)gout)) & 15) == 0;
+    const bool v4 = C % 4 == 0 && gips % 4 == 0 && gops % 4 == 0 && ((((uintptr_t)gin) | ((uintptr_t)gout)) & 15) == 0 &&
+                    (add == nullptr || (aps % 4 == 0 && (((uintptr_t)add) & 15) == 0));
     const long items = (long)B * D * H * W * (C / (v4 ? 4 : 1));
-    if (v4) hipLaunchKernelGGL(avgpool2_bwd_kernel<4>, dim3(eblocks(items)), dim3(256), 0, (hipStream_t)stream, gout, gops, gin, gips, B, D, H, W, Do, Ho, Wo, C);
-    else hipLaunchKernelGGL(avgpool2_bwd_kernel<1>, dim3(eblocks(items)), dim3(256), 0, (hipStream_t)stream, gout, gops, gin, gips, B, D, H, W, Do, Ho, Wo, C);
+    if (v4) hipLaunchKernelGGL(avgpool2_bwd_kernel<4>, dim3(eblocks(items)), dim3(256), 0, (hipStream_t)stream, gout, gops, gin, gips, B, D, H, W, Do, Ho, Wo, C, add, (long)aps);
+    else hipLaunchKernelGGL(avgpool2_bwd_kernel<1>, dim3(eblocks(items)), dim3(256), 0, (hipStream_t)stream, gout, gops, gin, gips, B, D, H, W, Do, Ho, Wo, C, add, (long)aps);
     return pulpo::check_launch("avgpool2_bwd");
+}
+
+PULPO_API int pulpo_avgpool2_bwd(const float* gout, int64_t gops, float* gin, int64_t gips, int B, int D, int H, int W, int C, void* stream) {
+    return avgpool2_bwd_impl(gout, gops, nullptr, 0, gin, gips, B, D, H, W, C, stream);
+}
+
+// gin = add + avgpool2_bwd(gout): `add` = the other gradient of a tensor that is pooled AND used as a skip connection (channels-last, voxel
+// stride aps: e.g. a channel slice of a concatenation's gradient), batch stride = D*H*W*aps
+PULPO_API int pulpo_avgpool2_bwd_add(const float* gout, int64_t gops, const float* add, int64_t aps, float* gin, int64_t gips, int B, int D, int H, int W,
+                                     int C, void* stream) {
+    PULPO_REQUIRE(add != nullptr, "avgpool2_bwd_add: null pointer");
+    return avgpool2_bwd_impl(gout, gops, add, aps, gin, gips, B, D, H, W, C, stream);
 }
 
 // planar tensors: in (nplanes, Di, Hi, Wi) -> out (nplanes, Do, Ho, Wo); out = mult * interpolate(in) (+ add, nullable:

@@ -130,6 +130,36 @@ def test_vecint_forward_fused_in_lds_equals_the_step_by_step_kernels(ops, B, siz
 
 
 # ================================================================================================ resampling
+@pytest.mark.parametrize("size,C", [((8, 12, 10), 16), ((7, 9, 5), 8), ((6, 6, 6), 1)])
+def test_avg_pool_with_skip_gradient_meets_the_pooled_one_in_one_kernel(ops, size, C):
+    """DownPath hands an activation to the next level (pooled) and to the decoder (skip connection): ops.avg_pool2_skip returns both and its
+    backward pass forms skip gradient + pooling backward in one pass - here with the skip gradient a channel slice of a concatenation's
+    gradient, as in the model (components/pulpo.py:58, 77).  Same values as the separate operators (the sum is one fp32 addition either
+    way: bit-identical); odd sizes (ceil-mode windows) and the single-channel case, which takes the separate operators"""
+    gen = torch.Generator().manual_seed(C + size[0])
+    x = torch.randn(2, C, *size, generator=gen).cuda()
+    x = x.contiguous(memory_format=torch.channels_last_3d) if C > 1 else x
+    other = torch.randn(2, 4, *size, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    wcat = torch.randn(2, C + 4, *size, generator=gen).cuda()
+    psize = [(s + 1) // 2 for s in size]
+    wp = torch.randn(2, C, *psize, generator=gen).cuda()
+    res = []
+    for fused in (False, True):
+        xg = x.clone().requires_grad_(True)
+        h = xg * 1.0
+        if fused:
+            skip, pooled = ops.avg_pool2_skip(h)
+        else:
+            skip, pooled = h, ops.avg_pool2(h)
+        loss = (torch.cat([other, skip], dim=1) * wcat).sum() + (pooled * wp).sum()
+        g, = torch.autograd.grad(loss, [xg])
+        res.append((pooled.detach(), g))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    ref = F.avg_pool3d(x.cpu().double(), 2, 2, ceil_mode=True)
+    assert rel_l2(res[1][0], ref) < 1e-6
+
+
 def test_resample_golden(ops, golden):
     g = golden("resample")
     x = dev(g["rt_x"]).requires_grad_(True)
