@@ -144,6 +144,11 @@ int pulpo_bn_fwd_finalize(const float* stats, int ntile, int C, double count, co
 int pulpo_bn_eval_coef(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
                        float* coef, void* stream);
 int pulpo_bn_lrelu_apply(const float* y, int64_t yps, float* z, int64_t zps, const float* coef, int64_t npix, int C, float slope, void* stream);
+/* the same pass for the last ConvUnit of an encoder level, whose output is pooled for the next level (components/pulpo.py:58): writes z AND
+ * pooled = AvgPool3d(2, 2, ceil_mode=True)(z) while y is read once; _ok() = 1 when the float4 path applies (else: the two separate passes) */
+int pulpo_bn_lrelu_apply_pool2_ok(int C, int64_t yps, int64_t zps, int64_t pps);
+int pulpo_bn_lrelu_apply_pool2(const float* y, int64_t yps, float* z, int64_t zps, float* pooled, int64_t pps, const float* coef, int B, int D, int H,
+                               int W, int C, float slope, void* stream);
 int pulpo_bn_bwd_blocks(int64_t npix, int C);
 int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, int64_t npix, int C, float slope,
                               float* partial /*[blocks][2C]*/, void* stream);

@@ -53,11 +53,11 @@ class DownPath(nn.Module):
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> Dict[int, torch.Tensor]:
         h = torch.cat([x, y], dim=1)            # two planar volumes side by side; read in place by the first conv
-        acts = {0: self.down_blocks[0](h)}
+        acts = {0: self.down_blocks[0](h, pool_after=self.total_levels > 1)}
         for k in range(1, self.total_levels):
             # (the activation is pooled AND handed out as a skip connection: one operator, so that its two gradients meet in one kernel)
             acts[k - 1], pooled = ops.avg_pool2_skip(acts[k - 1])
-            acts[k] = self.down_blocks[k](pooled)
+            acts[k] = self.down_blocks[k](pooled, pool_after=k + 1 < self.total_levels)
         return acts
 
 

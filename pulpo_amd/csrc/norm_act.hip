@@ -174,6 +174,41 @@ __global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(const float* __rest
     }
 }
 
+// z = leaky_relu(y * scale + shift) AND pooled = AvgPool3d(2, 2, ceil_mode)(z) in one pass (the last ConvUnit of an encoder level: its
+// output is pooled for the next level, components/pulpo.py:58): a thread owns one pooled voxel x four channels, i.e. up to eight voxels of
+// y / z; same expressions and the same summation order (z, y, x) as bn_lrelu_apply_kernel followed by avgpool2_fwd_kernel.
+__global__ __launch_bounds__(256) void bn_lrelu_apply_pool2_kernel(const float* __restrict__ y, long yps, float* __restrict__ z, long zps,
+                                                                     float* __restrict__ pooled, long pps, const float* __restrict__ coef, int B,
+                                                                     int D, int H, int W, int Do, int Ho, int Wo, int C, float slope) {
+    const int CV = C / 4;
+    const long total = (long)B * Do * Ho * Wo * CV;
+    const float* scale = coef + 2 * C;
+    const float* shift = coef + 3 * C;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % CV) * 4;
+        long p = e / CV;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho); p /= Ho;
+        const int oz = (int)(p % Do);
+        const int b = (int)(p / Do);
+        const int z1 = min(2 * oz + 2, D), y1 = min(2 * oy + 2, H), x1 = min(2 * ox + 2, W);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int zz = 2 * oz; zz < z1; ++zz)
+            for (int yy = 2 * oy; yy < y1; ++yy)
+                for (int xx = 2 * ox; xx < x1; ++xx) {
+                    const long vox = (((long)b * D + zz) * H + yy) * W + xx;
+                    const float4 v = *reinterpret_cast<const float4*>(y + vox * yps + c);
+                    auto act = [&](float a, float s_, float h_) { const float t = a * s_ + h_; return t > 0.f ? t : t * slope; };
+                    const float4 r = make_float4(act(v.x, sc.x, sh.x), act(v.y, sc.y, sh.y), act(v.z, sc.z, sh.z), act(v.w, sc.w, sh.w));
+                    *reinterpret_cast<float4*>(z + vox * zps + c) = r;
+                    acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+                }
+        const float inv = 1.f / (float)((z1 - 2 * oz) * (y1 - 2 * oy) * (x1 - 2 * ox));   // ceil_mode: divisor = in-bounds taps
+        *reinterpret_cast<float4*>(pooled + ((((long)b * Do + oz) * Ho + oy) * Wo + ox) * pps + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+}
+
 // pass 1 of the backward: partial[blk][0][c] = sum dbn, partial[blk][1][c] = sum dbn * (y - m32)
 //   dbn = dz * (bn_out > 0 ? 1 : slope),  bn_out = y*scale + shift,  m32 = the batch mean rounded to fp32 (coef[c])
 // All fp32: the difference of two floats carries a relative error of 2^-24 however close they are, and what the ROUNDED mean leaves out is
@@ -406,6 +441,20 @@ PULPO_API int pulpo_bn_lrelu_apply(const float* y, int64_t yps, float* z, int64_
     else
         hipLaunchKernelGGL(bn_lrelu_apply_kernel<1>, dim3(stream_blocks(npix * C)), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope);
     return pulpo::check_launch("bn_lrelu_apply");
+}
+
+// 1 when pulpo_bn_lrelu_apply_pool2 accepts the operands (float4 path: C % 4 == 0, 16-byte aligned rows)
+PULPO_API int pulpo_bn_lrelu_apply_pool2_ok(int C, int64_t yps, int64_t zps, int64_t pps) { return C % 4 == 0 && yps % 4 == 0 && zps % 4 == 0 && pps % 4 == 0; }
+
+PULPO_API int pulpo_bn_lrelu_apply_pool2(const float* y, int64_t yps, float* z, int64_t zps, float* pooled, int64_t pps, const float* coef, int B, int D,
+                                         int H, int W, int C, float slope, void* stream) {
+    PULPO_REQUIRE(y && z && pooled && coef && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bn_lrelu_apply_pool2: bad arguments");
+    PULPO_REQUIRE(pulpo_bn_lrelu_apply_pool2_ok(C, yps, zps, pps) && ((((uintptr_t)y) | ((uintptr_t)z) | ((uintptr_t)pooled) | ((uintptr_t)coef)) & 15) == 0,
+                  "bn_lrelu_apply_pool2: operands must be channels-last, 16-byte aligned, C %% 4 == 0");
+    const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    hipLaunchKernelGGL(bn_lrelu_apply_pool2_kernel, dim3(stream_blocks((long)B * Do * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, (long)yps, z,
+                       (long)zps, pooled, (long)pps, coef, B, D, H, W, Do, Ho, Wo, C, slope);
+    return pulpo::check_launch("bn_lrelu_apply_pool2");
 }
 
 // number of partial rows the two backward passes write (caller allocates partial[nblk][2C] and partial2[nblk][C])

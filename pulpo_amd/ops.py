@@ -545,7 +545,7 @@ class _ConvBNLReLU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool, momentum: float, eps: float,
-                bn_src=None):
+                bn_src=None, pool_after: bool = False):
         _require_gpu(x, weight, bias, gamma, beta)
         ctx.bn_src = bn_src
         x = as_grid(x)
@@ -571,13 +571,22 @@ class _ConvBNLReLU(torch.autograd.Function):
                 return y
             _conv_raw(x, wp, bias, y, Cin, Cout, None)
         z = new_cl(B, Cout, D, H, W, dev)
-        t0 = _hbm_begin()
-        lib.call("pulpo_bn_lrelu_apply", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
-        _hbm_end(t0, "bn_lrelu_apply", 8.0 * Cout * B * D * H * W)            # read y, write z
+        pooled = None
+        if pool_after and lib.query("pulpo_bn_lrelu_apply_pool2_ok", Cout, y.stride(4), z.stride(4), Cout):
+            # the caller pools this output next (DownPath): z and AvgPool(z) from one read of y; avg_pool2_skip() picks the pooled tensor up
+            pooled = new_cl(B, Cout, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, dev)
+            t0 = _hbm_begin()
+            lib.call("pulpo_bn_lrelu_apply_pool2", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(pooled), pooled.stride(4), _ptr(coef), B, D, H, W, Cout,
+                     LRELU_SLOPE, _stream())
+            _hbm_end(t0, "bn_lrelu_apply", 8.0 * Cout * B * D * H * W)
+        else:
+            t0 = _hbm_begin()
+            lib.call("pulpo_bn_lrelu_apply", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
+            _hbm_end(t0, "bn_lrelu_apply", 8.0 * Cout * B * D * H * W)            # read y, write z
         ctx.save_for_backward(x, weight, y, coef)
         ctx.training = training
         ctx.params = (weight, bias, gamma, beta)      # for DIRECT_PARAM_GRADS (their .grad slots)
-        _TLS.produced = (y, coef)                    # read back by conv_bn_lrelu (the Function returns tensors only)
+        _TLS.produced = (y, coef, pooled)            # read back by conv_bn_lrelu (the Function returns tensors only)
         return z
 
     @staticmethod
@@ -635,22 +644,27 @@ class _ConvBNLReLU(torch.autograd.Function):
                 _conv_raw(dy, wpt, None, dx, Cout, Cin, None)
         if defer_w:
             _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, w_p)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
-def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None):
-    """ConvUnit forward.  In training mode running_mean / running_var / num_batches_tracked are updated in place by the kernel."""
+def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None,
+                  pool_after: bool = False):
+    """ConvUnit forward.  In training mode running_mean / running_var / num_batches_tracked are updated in place by the kernel.
+    pool_after: the caller applies avg_pool2_skip() to the result next - where the shapes allow, the pooled tensor is produced by the same
+    pass that writes the result and waits on it (`_pulpo_pooled`)."""
     if _is2d(x):
         return conv_bn_lrelu(_lift(x), _lift_w3(weight), bias, gamma, beta, running_mean, running_var, training, momentum, eps,
                              num_batches_tracked).squeeze(2)
     src = getattr(x, "_pulpo_bn_src", None)          # x is the untouched output of another ConvUnit: (y, coef, version at production)
     bn_src = src[:2] if (src is not None and src[2] == x._version and training and torch.is_grad_enabled()) else None
     z = _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
-                           float(eps), bn_src)
+                           float(eps), bn_src, bool(pool_after))
     produced = getattr(_TLS, "produced", None)
     _TLS.produced = None
     if produced is not None:
         z._pulpo_bn_src = (produced[0], produced[1], z._version)
+        if produced[2] is not None:
+            z._pulpo_pooled = (produced[2], z._version)
     return z
 
 
@@ -810,14 +824,17 @@ class _AvgPool2Skip(torch.autograd.Function):
     strided slice of the concatenation's gradient (101 us at 80^3 x 64 channels at 1 TB/s in torch's generic strided kernel)"""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, ready=None):
         _require_gpu(x)
         ctx.set_materialize_grads(False)
         xc = to_cl(x)
         B, C, D, H, W = xc.shape
-        out = new_cl(B, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, x.device) if C > 1 else \
-            torch.empty((B, 1, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32)
-        lib.call("pulpo_avgpool2_fwd", _ptr(xc), xc.stride(4), _ptr(out), out.stride(4), B, D, H, W, C, _stream())
+        if ready is not None:                          # AvgPool(x) already written by the pass that wrote x (conv_bn_lrelu(pool_after=True))
+            out = ready
+        else:
+            out = new_cl(B, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, x.device) if C > 1 else \
+                torch.empty((B, 1, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32)
+            lib.call("pulpo_avgpool2_fwd", _ptr(xc), xc.stride(4), _ptr(out), out.stride(4), B, D, H, W, C, _stream())
         ctx.shape = (B, C, D, H, W)
         # (the alias keeps x's exact strides - view_as() would renumber the batch stride of a B = 1 tensor, and torch.cat then no longer
         #  recognises the channels-last layout of its inputs)
@@ -827,23 +844,24 @@ class _AvgPool2Skip(torch.autograd.Function):
     def backward(ctx, gskip, gpool):
         B, C, D, H, W = ctx.shape
         if gpool is None:
-            return gskip
+            return gskip, None
         g = to_cl(gpool)
         gin = new_cl(B, C, D, H, W, g.device) if C > 1 else torch.empty((B, 1, D, H, W), device=g.device, dtype=torch.float32)
         if gskip is not None:
             sb, sp, sc = grid_strides(gskip)
             if _dense_grid(gskip) and sc == 1 and sb == D * H * W * sp and C > 1 and gskip.dtype == torch.float32:
                 lib.call("pulpo_avgpool2_bwd_add", _ptr(g), g.stride(4), _ptr(gskip), sp, _ptr(gin), gin.stride(4), B, D, H, W, C, _stream())
-                return gin
+                return gin, None
         lib.call("pulpo_avgpool2_bwd", _ptr(g), g.stride(4), _ptr(gin), gin.stride(4), B, D, H, W, C, _stream())
-        return gin if gskip is None else gskip + gin
+        return (gin if gskip is None else gskip + gin), None
 
 
 def avg_pool2_skip(x):
     """(x, AvgPool(x)) where x goes on to other consumers as well; see _AvgPool2Skip"""
     if _is2d(x):
         return x, avg_pool2(x)
-    return _AvgPool2Skip.apply(x)
+    ready = getattr(x, "_pulpo_pooled", None)
+    return _AvgPool2Skip.apply(x, ready[0] if (ready is not None and ready[1] == x._version) else None)
 
 
 class _Resize(torch.autograd.Function):

@@ -160,6 +160,30 @@ def test_avg_pool_with_skip_gradient_meets_the_pooled_one_in_one_kernel(ops, siz
     assert rel_l2(res[1][0], ref) < 1e-6
 
 
+@pytest.mark.parametrize("size,cin,cout", [((16, 16, 16), 8, 16), ((10, 9, 7), 4, 8)])
+def test_last_unit_of_an_encoder_level_writes_the_pooled_tensor_too(ops, size, cin, cout):
+    """DownPath pools the output of every level's ConvSequence (components/pulpo.py:58): the last unit's BatchNorm / LeakyReLU pass writes
+    AvgPool(z) along with z (pulpo_bn_lrelu_apply_pool2) and ops.avg_pool2_skip picks it up instead of reading z again.  Same z, same
+    pooled tensor, same gradients as the separate passes (same expressions, same summation order); even and odd (ceil-mode) sizes"""
+    from pulpo_amd.network_blocks import ConvSequence
+    x = torch.randn(1, cin, *size, generator=torch.Generator().manual_seed(3)).cuda()
+    res = []
+    for fused in (False, True):
+        torch.manual_seed(11)
+        seq = ConvSequence(list(size), cin, cout, 2).cuda().train()
+        xg = x.clone().requires_grad_(True)
+        z = seq(xg, pool_after=fused)
+        assert hasattr(z, "_pulpo_pooled") == fused
+        skip, pooled = ops.avg_pool2_skip(z)
+        loss = (skip * skip).sum() + (pooled * torch.arange(pooled.numel(), device="cuda").view_as(pooled).float().sin()).sum()
+        grads = torch.autograd.grad(loss, [xg] + list(seq.parameters()))
+        res.append((z.detach(), pooled.detach(), grads))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert rel_l2(res[1][2][0], res[0][2][0]) < 1e-6
+    ref = F.avg_pool3d(res[0][0].cpu().double(), 2, 2, ceil_mode=True)
+    assert rel_l2(res[1][1], ref) < 1e-6
+
+
 def test_resample_golden(ops, golden):
     g = golden("resample")
     x = dev(g["rt_x"]).requires_grad_(True)
