@@ -150,6 +150,11 @@ int pulpo_bn_lrelu_apply_pool2_ok(int C, int64_t yps, int64_t zps, int64_t pps);
 int pulpo_bn_lrelu_apply_pool2(const float* y, int64_t yps, float* z, int64_t zps, float* pooled, int64_t pps, const float* coef, int B, int D, int H,
                                int W, int C, float slope, void* stream);
 int pulpo_bn_bwd_blocks(int64_t npix, int C);
+/* gin = (add +) avgpool2_bwd(gout) AND the partial rows of pulpo_bn_lrelu_bwd_reduce for the ConvUnit whose output was pooled, in one pass
+ * (the last unit of every encoder level: pooling backward, autograd's accumulation add and the BatchNorm-backward reduction read its
+ * gradient three times otherwise); partial: pulpo_bn_bwd_blocks(B*D*H*W, C) rows of 2C floats; add nullable */
+int pulpo_avgpool2_bwd_bnred(const float* gout, int64_t gops, const float* add, int64_t aps, float* gin, int64_t gips, const float* y, int64_t yps,
+                             const float* coef, float slope, float* partial, int B, int D, int H, int W, int C, void* stream);
 int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, int64_t npix, int C, float slope,
                               float* partial /*[blocks][2C]*/, void* stream);
 /* rows [nrow][2][C] = (sum dbn, sum dbn * (y - fp32 batch mean)): the block partials of pulpo_bn_lrelu_bwd_reduce (nrow = pulpo_bn_bwd_blocks)

@@ -214,10 +214,20 @@ __global__ __launch_bounds__(256) void bn_lrelu_apply_pool2_kernel(const float* 
 // All fp32: the difference of two floats carries a relative error of 2^-24 however close they are, and what the ROUNDED mean leaves out is
 // added back in double by bn_bwd_finalize_kernel (sum dbn * xhat = rstd * (sum dbn * (y - m32) - (mean - m32) * sum dbn)).  No doubles per
 // element: a wave needs 40 instead of 64 registers, so that two instead of one fit on a SIMD beside the weight-gradient kernel.
-template <int VEC>
+// POOL: dz is not read but PRODUCED here - the gradient of an activation that was pooled (gpool: gradient of the pooled tensor, spread over
+// each 2 x 2 x 2 window with the ceil-mode divisor, the arithmetic of avgpool2_bwd_kernel) and possibly also used as a skip connection
+// (add, nullable) - and written to dzout on the way: the pooling backward, autograd's accumulation and this reduction in one pass.
+struct PoolGrad {
+    const float* gpool; long gpps;
+    const float* add; long aps;
+    float* dzout; long dzops;
+    int D, H, W, Do, Ho, Wo;
+};
+
+template <int VEC, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* __restrict__ dz, long dzps, const float* __restrict__ y,
                                                                     long yps, const float* __restrict__ coef, long npix, int C,
-                                                                    float slope, float* __restrict__ partial) {
+                                                                    float slope, float* __restrict__ partial, PoolGrad pg = PoolGrad{}) {
     extern __shared__ float red[];                 // [RB][2][C]
     const int CV = C / VEC, RB = blockDim.x / CV;
     const int col = threadIdx.x % CV, row = threadIdx.x / CV;
@@ -232,7 +242,28 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* _
         Vec<VEC>::ld(coef + c, m32);
         for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
             float g[VEC], v[VEC];
-            Vec<VEC>::ld(dz + p * dzps + c, g);
+            if constexpr (POOL) {
+                long q = p;
+                const int x_ = (int)(q % pg.W); q /= pg.W;
+                const int y_ = (int)(q % pg.H); q /= pg.H;
+                const int z_ = (int)(q % pg.D);
+                const long b_ = q / pg.D;
+                const int oz = z_ >> 1, oy = y_ >> 1, ox = x_ >> 1;
+                const int cnt = (min(2 * oz + 2, pg.D) - 2 * oz) * (min(2 * oy + 2, pg.H) - 2 * oy) * (min(2 * ox + 2, pg.W) - 2 * ox);
+                const float inv = 1.f / (float)cnt;
+                Vec<VEC>::ld(pg.gpool + (((b_ * pg.Do + oz) * pg.Ho + oy) * pg.Wo + ox) * pg.gpps + c, g);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) g[k] *= inv;
+                if (pg.add != nullptr) {
+                    float u[VEC];
+                    Vec<VEC>::ld(pg.add + p * pg.aps + c, u);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) g[k] = u[k] + g[k];
+                }
+                Vec<VEC>::st(pg.dzout + p * pg.dzops + c, g);
+            } else {
+                Vec<VEC>::ld(dz + p * dzps + c, g);
+            }
             Vec<VEC>::ld(y + p * yps + c, v);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
@@ -477,6 +508,26 @@ PULPO_API int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const flo
     if (v4) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<4>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, npix, C, slope, partial);
     else hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, npix, C, slope, partial);
     return pulpo::check_launch("bn_lrelu_bwd_reduce");
+}
+
+// gin = (add +) avgpool2_bwd(gout) AND the first pass of the BatchNorm / LeakyReLU backward of the ConvUnit whose output was pooled (y, coef:
+// that unit's pre-norm tensor and coefficient block): partial rows as pulpo_bn_lrelu_bwd_reduce writes them (same voxel-to-row assignment,
+// same sums).  The last unit of every encoder level (components/pulpo.py:58): its gradient is read once instead of written, read, read.
+// Channels-last float4 operands only (C % 4 == 0, 16-byte aligned rows); add nullable.
+PULPO_API int pulpo_avgpool2_bwd_bnred(const float* gout, int64_t gops, const float* add, int64_t aps, float* gin, int64_t gips, const float* y,
+                                       int64_t yps, const float* coef, float slope, float* partial, int B, int D, int H, int W, int C, void* stream) {
+    PULPO_REQUIRE(gout && gin && y && coef && partial && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "avgpool2_bwd_bnred: bad arguments");
+    PULPO_REQUIRE(C % 4 == 0 && C / 4 <= 256 && gops % 4 == 0 && gips % 4 == 0 && yps % 4 == 0 && (add == nullptr || aps % 4 == 0) &&
+                      ((((uintptr_t)gout) | ((uintptr_t)gin) | ((uintptr_t)y) | ((uintptr_t)coef) | ((uintptr_t)add)) & 15) == 0,
+                  "avgpool2_bwd_bnred: operands must be channels-last, 16-byte aligned, C %% 4 == 0");
+    const long npix = (long)B * D * H * W;
+    const int nblk = pulpo_bn_bwd_blocks(npix, C);
+    const int RB = std::max(1, 256 / (C / 4));
+    const size_t lds = (size_t)RB * 2 * C * sizeof(float);
+    PoolGrad pg{gout, (long)gops, add, (long)aps, gin, (long)gips, D, H, W, (D + 1) / 2, (H + 1) / 2, (W + 1) / 2};
+    hipLaunchKernelGGL((bn_lrelu_bwd_reduce_kernel<4, true>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, nullptr, 0L, y, (long)yps, coef, npix, C, slope,
+                       partial, pg);
+    return pulpo::check_launch("avgpool2_bwd_bnred");
 }
 
 // dbeta / dgamma: [C] each, written (accumulate = 0) or added to (accumulate = 1, e.g. the parameters' .grad storage).

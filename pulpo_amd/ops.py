@@ -824,9 +824,12 @@ class _AvgPool2Skip(torch.autograd.Function):
     strided slice of the concatenation's gradient (101 us at 80^3 x 64 channels at 1 TB/s in torch's generic strided kernel)"""
 
     @staticmethod
-    def forward(ctx, x, ready=None):
+    def forward(ctx, x, ready=None, bn_y=None, bn_coef=None):
+        """bn_y / bn_coef: x is the untouched output of a ConvUnit, these are its pre-norm tensor and coefficient block - the backward pass then
+        also delivers that unit's BatchNorm-backward partial sums (see _BN_TILE_PARTS)"""
         _require_gpu(x)
         ctx.set_materialize_grads(False)
+        ctx.bn = (bn_y, bn_coef) if (bn_y is not None and BN_REDUCE_IN_DGRAD) else None
         xc = to_cl(x)
         B, C, D, H, W = xc.shape
         if ready is not None:                          # AvgPool(x) already written by the pass that wrote x (conv_bn_lrelu(pool_after=True))
@@ -844,16 +847,29 @@ class _AvgPool2Skip(torch.autograd.Function):
     def backward(ctx, gskip, gpool):
         B, C, D, H, W = ctx.shape
         if gpool is None:
-            return gskip, None
+            return gskip, None, None, None
         g = to_cl(gpool)
         gin = new_cl(B, C, D, H, W, g.device) if C > 1 else torch.empty((B, 1, D, H, W), device=g.device, dtype=torch.float32)
+        skip_ok = False
         if gskip is not None:
             sb, sp, sc = grid_strides(gskip)
-            if _dense_grid(gskip) and sc == 1 and sb == D * H * W * sp and C > 1 and gskip.dtype == torch.float32:
-                lib.call("pulpo_avgpool2_bwd_add", _ptr(g), g.stride(4), _ptr(gskip), sp, _ptr(gin), gin.stride(4), B, D, H, W, C, _stream())
-                return gin, None
+            skip_ok = _dense_grid(gskip) and sc == 1 and sb == D * H * W * sp and C > 1 and gskip.dtype == torch.float32 and sp % 4 == 0 \
+                and gskip.data_ptr() % 16 == 0
+        if ctx.bn is not None and C % 4 == 0 and C // 4 <= 256 and (gskip is None or skip_ok) and g.stride(4) % 4 == 0 and g.data_ptr() % 16 == 0:
+            # the producing ConvUnit's first BatchNorm-backward pass rides along: this kernel has every element of its gradient in registers
+            y, coef = ctx.bn
+            if tuple(y.shape) == (B, C, D, H, W) and y.stride(1) == 1 and y.stride(4) % 4 == 0 and y.data_ptr() % 16 == 0 and _dense_grid(y):
+                nblk = lib.query("pulpo_bn_bwd_blocks", B * D * H * W, C)
+                part = torch.empty(nblk * 2 * C, device=g.device, dtype=torch.float32)
+                lib.call("pulpo_avgpool2_bwd_bnred", _ptr(g), g.stride(4), _ptr(gskip), grid_strides(gskip)[1] if gskip is not None else 0, _ptr(gin),
+                         gin.stride(4), _ptr(y), y.stride(4), _ptr(coef), LRELU_SLOPE, _ptr(part), B, D, H, W, C, _stream())
+                _BN_TILE_PARTS[y.data_ptr()] = (part, nblk, coef.data_ptr(), gin.data_ptr(), gin._version, tuple(gin.shape), tuple(gin.stride()))
+                return gin, None, None, None
+        if skip_ok:
+            lib.call("pulpo_avgpool2_bwd_add", _ptr(g), g.stride(4), _ptr(gskip), grid_strides(gskip)[1], _ptr(gin), gin.stride(4), B, D, H, W, C, _stream())
+            return gin, None, None, None
         lib.call("pulpo_avgpool2_bwd", _ptr(g), g.stride(4), _ptr(gin), gin.stride(4), B, D, H, W, C, _stream())
-        return (gin if gskip is None else gskip + gin), None
+        return (gin if gskip is None else gskip + gin), None, None, None
 
 
 def avg_pool2_skip(x):
@@ -861,7 +877,9 @@ def avg_pool2_skip(x):
     if _is2d(x):
         return x, avg_pool2(x)
     ready = getattr(x, "_pulpo_pooled", None)
-    return _AvgPool2Skip.apply(x, ready[0] if (ready is not None and ready[1] == x._version) else None)
+    src = getattr(x, "_pulpo_bn_src", None)          # x is the untouched output of a ConvUnit: (y, coef, version at production)
+    src = src if (src is not None and src[2] == x._version and torch.is_grad_enabled()) else None
+    return _AvgPool2Skip.apply(x, ready[0] if (ready is not None and ready[1] == x._version) else None, src[0] if src else None, src[1] if src else None)
 
 
 class _Resize(torch.autograd.Function):

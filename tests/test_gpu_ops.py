@@ -182,6 +182,21 @@ def test_last_unit_of_an_encoder_level_writes_the_pooled_tensor_too(ops, size, c
     assert rel_l2(res[1][2][0], res[0][2][0]) < 1e-6
     ref = F.avg_pool3d(res[0][0].cpu().double(), 2, 2, ceil_mode=True)
     assert rel_l2(res[1][1], ref) < 1e-6
+    # the backward pass of avg_pool2_skip also delivers the last unit's BatchNorm-backward sums (pulpo_avgpool2_bwd_bnred): same partial
+    # rows as the separate reduction pass, hence the same gradients for every parameter
+    ops.BN_REDUCE_IN_DGRAD = False
+    try:
+        torch.manual_seed(11)
+        seq = ConvSequence(list(size), cin, cout, 2).cuda().train()
+        xg = x.clone().requires_grad_(True)
+        skip, pooled = ops.avg_pool2_skip(seq(xg, pool_after=True))
+        loss = (skip * skip).sum() + (pooled * torch.arange(pooled.numel(), device="cuda").view_as(pooled).float().sin()).sum()
+        plain = torch.autograd.grad(loss, [xg] + list(seq.parameters()))
+    finally:
+        ops.BN_REDUCE_IN_DGRAD = True
+    scale = max(float(g.abs().max()) for g in plain)
+    for a_, b_ in zip(res[1][2], plain):
+        assert float((a_ - b_).abs().max()) <= 2e-5 * scale
 
 
 def test_resample_golden(ops, golden):
