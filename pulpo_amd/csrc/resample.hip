@@ -158,13 +158,32 @@ __global__ __launch_bounds__(256) void resize_up2_bwd_kernel(const float* __rest
         const int z = (int)(p % Di);
         const long pl = p / Di;
         const float* g = gout + pl * (long)Do * Ho * Wo;
+        // the four candidate taps per axis and their weights once per voxel (12 instead of 84 source-index evaluations); same products and
+        // the same summation order as the plain triple loop
+        float wz4[4], wy4[4], wx4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oz = 2 * z - 1 + k, oy = 2 * y - 1 + k, ox = 2 * x - 1 + k;
+            wz4[k] = (oz >= 0 && oz < Do) ? up2_weight(oz, z, Di) : 0.f;
+            wy4[k] = (oy >= 0 && oy < Ho) ? up2_weight(oy, y, Hi) : 0.f;
+            wx4[k] = (ox >= 0 && ox < Wo) ? up2_weight(ox, x, Wi) : 0.f;
+        }
         float acc = 0.f;
-        for (int oz = max(2 * z - 1, 0); oz <= min(2 * z + 2, Do - 1); ++oz) {
-            const float wz = up2_weight(oz, z, Di);
-            for (int oy = max(2 * y - 1, 0); oy <= min(2 * y + 2, Ho - 1); ++oy) {
-                const float wzy = wz * up2_weight(oy, y, Hi);
-                for (int ox = max(2 * x - 1, 0); ox <= min(2 * x + 2, Wo - 1); ++ox)
-                    acc += wzy * up2_weight(ox, x, Wi) * g[((long)oz * Ho + oy) * Wo + ox];
+#pragma unroll
+        for (int kz = 0; kz < 4; ++kz) {
+            const int oz = 2 * z - 1 + kz;
+            if (oz < 0 || oz >= Do) continue;
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const int oy = 2 * y - 1 + ky;
+                if (oy < 0 || oy >= Ho) continue;
+                const float wzy = wz4[kz] * wy4[ky];
+                const float* row = g + ((long)oz * Ho + oy) * Wo;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const int ox = 2 * x - 1 + kx;
+                    if (ox >= 0 && ox < Wo) acc += wzy * wx4[kx] * row[ox];
+                }
             }
         }
         gin[e] = acc * mult;
