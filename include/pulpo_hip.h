@@ -30,7 +30,11 @@
 extern "C" {
 #endif
 
-/* ---------------------------------------------------------------------------------------------- runtime */
+/* ---------------------------------------------------------------------------------------------- runtime
+ * PULPO_ABI_VERSION is bumped whenever a prototype below changes its argument list or a buffer contract, or an entry point is removed
+ * (history: INTEGRATION.md "ABI history").  pulpo_abi_version() returns the value the library was built with: a client compares it with
+ * the header it was compiled against before the first call (pulpo_amd/_lib.py does). */
+#define PULPO_ABI_VERSION 3
 int pulpo_abi_version(void);
 const char* pulpo_last_error(void);
 

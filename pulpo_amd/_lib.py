@@ -58,6 +58,14 @@ def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
     return protos
 
 
+def header_abi_version(path: str = HEADER) -> int:
+    """PULPO_ABI_VERSION of include/pulpo_hip.h (the version this binding was written against)"""
+    m = re.search(r"^\s*#\s*define\s+PULPO_ABI_VERSION\s+(\d+)", open(path).read(), flags=re.M)
+    if m is None:
+        raise RuntimeError(f"{path} does not define PULPO_ABI_VERSION")
+    return int(m.group(1))
+
+
 class PulpoHipError(RuntimeError):
     pass
 
@@ -84,8 +92,11 @@ class _Lib:
             f.argtypes = argtypes
             self._fn[name] = f
         self._dll = dll
-        if self._fn["pulpo_abi_version"]() != 1:
-            raise PulpoHipError("ABI version mismatch between include/pulpo_hip.h and libpulpo_hip.so")
+        built, want = self._fn["pulpo_abi_version"](), header_abi_version()
+        if built != want:
+            self._dll, self._fn = None, {}
+            raise PulpoHipError(f"ABI version mismatch: {LIB_PATH} was built as version {built}, include/pulpo_hip.h is version {want} "
+                                "(rebuild with `python -m pulpo_amd.build --force`)")
         return dll
 
     def raw(self, name: str):

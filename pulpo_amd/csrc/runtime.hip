@@ -1,5 +1,6 @@
 // Error reporting + ABI version for the PULPo HIP library.
 #include "common.h"
+#include "../../include/pulpo_hip.h"
 #include <stdarg.h>
 
 namespace pulpo {
@@ -16,5 +17,5 @@ int fail(int code, const char* fmt, ...) {
 }
 }  // namespace pulpo
 
-PULPO_API int pulpo_abi_version(void) { return 1; }
+PULPO_API int pulpo_abi_version(void) { return PULPO_ABI_VERSION; }
 PULPO_API const char* pulpo_last_error(void) { return pulpo::err_buf(); }
