@@ -64,6 +64,11 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "infer", "mc8"],
                     help="train (the metric: fwd+bwd+all-reduce+Adam), infer (eval-mode predict_deterministic) or mc8 (8-sample Monte-Carlo "
                          "uncertainty maps of one pair, BASELINE config 5) - the latter two are reported under their own metric names")
+    ap.add_argument("--loop", default="stepper", choices=["stepper", "lightning", "plain-autograd"],
+                    help="who drives the training step: stepper = dp.DataParallelStepper.step (default); lightning = the LightningModule hooks of "
+                         "src.models.PULPo called in pytorch_lightning 1.8's order (pulpo_amd/_lightning.py::HookOrderTrainer - what an unchanged "
+                         "train.py runs); plain-autograd = loss.backward() + torch.optim.Adam with every fast-path switch off (one GPU only)")
+    ap.add_argument("--no-loops", action="store_true", help="do not time the other two loops after the measurement (one GPU, train mode)")
     ap.add_argument("--host-input", action="store_true",
                     help="feed every step from host memory through pulpo_amd.prefetch.DevicePrefetcher (PCIe-inclusive rate; the default "
                          "keeps the pair resident in HBM as the metric prescribes)")
@@ -144,7 +149,7 @@ def launch_ranks(args) -> int:
     rc = _spawn_ranks(n, {})
     if rc == EXIT_OVERLAP_FAILED:
         print("[bench launcher] starting all ranks again with the plain stepper (PULPO_DP_OVERLAP=0 PULPO_ASYNC_WGRAD=0)", file=sys.stderr)
-        rc = _spawn_ranks(n, {"PULPO_DP_OVERLAP": "0", "PULPO_ASYNC_WGRAD": "0"})
+        rc = _spawn_ranks(n, {"PULPO_DP_OVERLAP": "0", "PULPO_ASYNC_WGRAD": "0", "PULPO_BENCH_RELAUNCHED": "1"})     # (the line says so: stepper.fallback)
     return rc
 
 
@@ -173,8 +178,16 @@ def plumbing_only(args) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert float(got[0]) == float(world)
+    names = [None] * world
+    if world > 1:
+        dist.all_gather_object(names, f"cpu (rank {rank})")
+    else:
+        names = ["cpu (rank 0)"]
     if rank == 0:
         print(json.dumps({"metric": "plumbing only (no kernels run; not a measurement)", "valid": False, "value": None, "unit": "volume-pairs/s",
+                          "loop": "none", "stepper": {"overlap": False, "async_wgrad": False,
+                                                      "fallback": "relaunched" if os.environ.get("PULPO_BENCH_RELAUNCHED") == "1" else "none"},
+                          "dist": {"backend": dist.get_backend() if world > 1 else None, "world": world, "devices": names},
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(1, args.steps) * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
                           "config": {"workload": "launcher / rendezvous / barrier / max-over-ranks rehearsal", "global_batch": world,
@@ -269,6 +282,31 @@ def pmc_traffic(kernel: str) -> dict:
                               "gathers by scripts/probes/fetch_calib.hip, profiles/r3_fetch_calibration.md)"}
 
 
+def make_loop(kind: str, model):
+    """-> (run(batch) -> loss, the dp.DataParallelStepper behind it or None, the name reported in the line's "loop" field)"""
+    from pulpo_amd import dp
+    if kind == "stepper":
+        stepper = dp.DataParallelStepper(model)
+        return stepper.step, stepper, "stepper"
+    if kind == "lightning":
+        from pulpo_amd._lightning import HookOrderTrainer
+        trainer = HookOrderTrainer()
+        trainer.attach(model)                       # configure_optimizers() -> dp.ArenaAdam; every step goes through the module's hooks
+        eng = model._engine()
+        if eng is None:
+            raise SystemExit("bench: --loop lightning with PULPO_LIGHTNING_FAST=0 is the plain-autograd loop; ask for that one")
+        return (lambda batch: trainer.run_batch(batch, 0)), eng, "lightning-hooks"
+    opt = torch.optim.Adam(model.parameters(), lr=float(model.hparams.lr))          # the reference's optimizer as it stands (models.py:398-400)
+
+    def run(batch):
+        opt.zero_grad()
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+    return run, None, "plain-autograd"
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -297,8 +335,11 @@ def main():
     T, L = args.levels
     size, B = list(args.size), args.batch
     torch.manual_seed(0)
+    if args.loop == "plain-autograd" and world > 1:
+        raise SystemExit("bench: --loop plain-autograd has no gradient exchange; one GPU only")
     model = PULPo(T, L, 0.1, size, feedback=FEEDBACK, n0=32).to(dev).train()
-    stepper = dp.DataParallelStepper(model)
+    run_step, stepper, loop_name = make_loop(args.loop, model)       # stepper: the dp.DataParallelStepper that owns arena / streams (None: plain autograd)
+    fallback = "relaunched" if os.environ.get("PULPO_BENCH_RELAUNCHED") == "1" else "none"
     from pulpo_amd import synthetic
     x, y = (synthetic.oasis_like_pair if args.data == "oasis" else synthetic.uniform_pair)(size, B, 1234 + rank, dev)
     empty = torch.empty((0,), device=dev)
@@ -330,10 +371,10 @@ def main():
         feed = iter(DevicePrefetcher((host_batch for _ in range(args.warmup + args.steps + 8)), dev))
 
         def one_step():
-            return stepper.step(next(feed))
+            return run_step(next(feed))
     else:
         def one_step():
-            return stepper.step(batch)
+            return run_step(batch)
 
     # Insurance for the multi-rank RCCL runs, which a one-GPU box cannot rehearse: the first step with the overlapped gradient exchange /
     # second-stream weight gradients is tried, and the outcome is agreed on by ALL ranks before anybody goes on - a flag all-reduce over a
@@ -341,7 +382,7 @@ def main():
     # the peer never joins.  All ranks failed (a deterministic failure is the same everywhere and leaves no half-issued collective): every
     # rank switches to the plain single-all-reduce stepper.  Some failed: nothing in this process can be trusted any more - every rank
     # exits with EXIT_OVERLAP_FAILED and the launcher starts the job again with PULPO_DP_OVERLAP=0 PULPO_ASYNC_WGRAD=0.
-    if world > 1 and not infer and args.warmup > 0 and (stepper.overlap or stepper.async_wgrad):
+    if world > 1 and not infer and args.warmup > 0 and stepper is not None and (stepper.overlap or stepper.async_wgrad):
         import datetime
         side = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("PULPO_BENCH_AGREE_TIMEOUT_S", "300"))))
         ok = 1.0
@@ -366,7 +407,10 @@ def main():
                 print("[bench] every rank failed alike: falling back to overlap=False, async_wgrad=False on all ranks", file=sys.stderr)
             ops.ASYNC_WGRAD_STREAM = None
             ops.DIRECT_PARAM_GRADS = False
-            stepper = dp.DataParallelStepper(model, overlap=False, async_wgrad=False)
+            ops.reset_param_grad_buffers(model)
+            stepper.overlap, stepper.async_wgrad = False, False          # the same engine, plain: one all-reduce after backward, weight gradients in line
+            stepper._works, stepper._launched, stepper._armed = [], 0, False
+            fallback = "in-place"
         else:
             print(f"[bench] rank {rank}: {world - n_ok} of {world} ranks failed their first step; leaving with code {EXIT_OVERLAP_FAILED}", file=sys.stderr)
             sys.stderr.flush()
@@ -379,6 +423,8 @@ def main():
         ops.HBM_TRACE = []
         ops.CONV_TRACE_STRIDE = 7        # every 7th conv launch of the timed region is bracketed (the launch count per step is not a multiple of 7)
     ops.CONV_TRACE_STRIDE_USED = ops.CONV_TRACE_STRIDE
+    if stepper is not None and world > 1:
+        stepper.exchange_events = []        # HIP events around the waits for the gradient exchange: what of it is NOT hidden under the backward pass
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
@@ -390,7 +436,12 @@ def main():
     # bracket there includes the time it shares the CUs.  Two extra, untimed steps with that overlap switched off give the same
     # kernels' stand-alone durations (reported as roofline["serialized"]; the throughput value is NOT taken from these steps).
     trace_serial = None
-    if trace is not None and not infer and world == 1 and stepper.async_wgrad:
+    exchange_ms = None
+    if stepper is not None and stepper.exchange_events:
+        exchange_ms = sum(a_.elapsed_time(b_) for a_, b_ in stepper.exchange_events) / len(stepper.exchange_events)
+    if stepper is not None:
+        stepper.exchange_events = None
+    if trace is not None and not infer and world == 1 and stepper is not None and stepper.async_wgrad:
         stepper.async_wgrad = False
         one_step()
         torch.cuda.synchronize()
@@ -407,6 +458,35 @@ def main():
         dt = float(t.item())
     if not bool(torch.isfinite(loss)):
         raise SystemExit("bench: non-finite loss")
+    devices = [None] * world
+    mine = f"{torch.cuda.get_device_name(dev)} (cuda:{local})"
+    if world > 1:
+        dist.all_gather_object(devices, mine)
+    else:
+        devices = [mine]
+    # the other two loops on fresh models of the same seed, a few steps each (one GPU, train mode): what an unchanged train.py gets
+    # ("lightning-hooks") and what it got before the hooks existed ("plain-autograd"), beside the measured loop
+    loops_ms = None
+    if world == 1 and not infer and not args.no_loops and not args.host_input:
+        loops_ms = {loop_name: dt / args.steps * 1e3}
+        n_ab = max(3, min(args.steps, 10))
+        for other, name2 in (("stepper", "stepper"), ("lightning", "lightning-hooks"), ("plain-autograd", "plain-autograd")):
+            if name2 in loops_ms:
+                continue
+            torch.manual_seed(0)
+            m2 = PULPo(T, L, 0.1, size, feedback=FEEDBACK, n0=32).to(dev).train()
+            run2, _, _ = make_loop(other, m2)
+            for _ in range(2):
+                run2(batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_ab):
+                run2(batch)
+            torch.cuda.synchronize()
+            loops_ms[name2] = (time.perf_counter() - t1) / n_ab * 1e3
+            del m2, run2
+            ops.invalidate_weight_packs()
+            torch.cuda.empty_cache()
 
     if rank == 0:
         pairs = world * B * args.steps
@@ -473,6 +553,14 @@ def main():
             + ", default-initialised weights (manual_seed 0)",
             "config": {"workload": f"{size[0]}x{size[1]}x{size[2]} synthetic pair, {L}-level pyramid (total_levels {T}), {'bf16 conv operands' if bf16 else 'fp32'}, batch {B} per GPU, "
                                    + ("eval-mode forward (mu path, no sampling)" if infer else "fwd+bwd+grad all-reduce+Adam"), "global_batch": world * B, "parallelism": f"dp{world}"},
+            "loop": loop_name,
+            "loops_ms_per_step": loops_ms,
+            "stepper": None if stepper is None else {"overlap": bool(stepper.overlap and world > 1), "async_wgrad": bool(stepper.async_wgrad),
+                                                     "buckets": len(stepper.buckets) if (stepper.overlap and world > 1) else 1, "fallback": fallback,
+                                                     "exposed_exchange_ms_per_step": exchange_ms},
+            "dist": {"backend": dist.get_backend() if world > 1 else None, "world": dist.get_world_size() if world > 1 else 1, "devices": devices},
+            "parity_note": "outputs / losses within 1e-4 of the CPU oracle at this size; whole-step parameter gradients on the statistical criterion of "
+                           "DESIGN.md section 4 (6e-3 per parameter at 160^3 against SURVEY 8(c)'s suggested 5e-3, 1e-2 on the 32^3 reference golden against 1e-3)",
             "roofline": roof,
             "hbm_rooflines": hbm_roof,
             "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated(dev) / 1e9,

@@ -222,25 +222,32 @@ class Autoencoder(nn.Module):
 
 class PULPoPrior(nn.Module):
     """standard-normal prior on every level (reference pulpo.py:323-341).  The tensors carry a marker so that the KL
-    kernel can skip reading them."""
+    kernel can skip reading them.
+
+    What is handed out are zero-stride views (`expand`) of one cached 0 and one cached 1 per device: no fill kernel per level and step,
+    nothing to go stale, and an in-place write by a caller raises (torch refuses to write through an expanded view) instead of silently
+    corrupting every later step's prior."""
 
     def __init__(self) -> None:
         super().__init__()
         self._constants = {}
 
+    def _apply(self, fn, *args, **kwargs):
+        self._constants = {}                  # .to() / .cuda(): cached scalars of the old device are dropped
+        return super()._apply(fn, *args, **kwargs)
+
+    def __deepcopy__(self, memo):
+        return PULPoPrior()
+
     def forward(self, posterior_mus: Dict[int, torch.Tensor], posterior_sigmas: Dict[int, torch.Tensor]):
         prior_mus, prior_sigmas = {}, {}
         for l in posterior_mus.keys():
-            # constants: made once per (shape, device) and handed out again (two fill kernels per level and step otherwise); the KL kernel
-            # never reads them (marker), callers must not write to them
-            key = (tuple(posterior_mus[l].shape), posterior_mus[l].device)
-            cached = self._constants.get(key)
+            dev = posterior_mus[l].device
+            cached = self._constants.get(dev)
             if cached is None:
-                cached = (torch.zeros_like(posterior_mus[l], dtype=torch.float32), torch.ones_like(posterior_sigmas[l], dtype=torch.float32))
-                cached[0]._pulpo_std_normal = True
-                cached[1]._pulpo_std_normal = True
-                if len(self._constants) > 32:
-                    self._constants.clear()
-                self._constants[key] = cached
-            prior_mus[l], prior_sigmas[l] = cached
+                cached = self._constants[dev] = (torch.zeros((), device=dev, dtype=torch.float32), torch.ones((), device=dev, dtype=torch.float32))
+            mu0, sigma1 = cached[0].expand(posterior_mus[l].shape), cached[1].expand(posterior_sigmas[l].shape)
+            mu0._pulpo_std_normal = True
+            sigma1._pulpo_std_normal = True
+            prior_mus[l], prior_sigmas[l] = mu0, sigma1
         return prior_mus, prior_sigmas

@@ -415,20 +415,27 @@ namespace {
 __global__ void weighted_sum_fwd_kernel(const float* __restrict__ t, const float* __restrict__ w, int n, float scale, int scaled, float* __restrict__ levels,
                                         float* __restrict__ total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        // explicit round-to-nearest products and sums: the library is built with the compiler's default -ffp-contract=fast, under which
+        // `s += w * t` may become fma(w, t, s) - one rounding instead of the two of the reference's `w * term` and `+=` kernels
         float s = 0.f;
         for (int i = 0; i < n; ++i) {
-            const float v = w[i] * t[i];
-            s += v;
-            levels[i] = scaled ? v * scale : v;
+            const float v = __fmul_rn(w[i], t[i]);
+            s = __fadd_rn(s, v);
+            levels[i] = scaled ? __fmul_rn(v, scale) : v;
         }
-        total[0] = scaled ? s * scale : s;
+        total[0] = scaled ? __fmul_rn(s, scale) : s;
     }
 }
 // g_t[i] = (g_total + g_levels[i]) * scale * w[i]   (either upstream gradient may be absent: the per-level outputs are normally only logged)
 __global__ void weighted_sum_bwd_kernel(const float* __restrict__ gtotal, const float* __restrict__ glevels, const float* __restrict__ w, int n, float scale,
                                         float* __restrict__ gt) {
     const int i = threadIdx.x;
-    if (blockIdx.x == 0 && i < n) gt[i] = ((gtotal ? gtotal[0] : 0.f) + (glevels ? glevels[i] : 0.f)) * scale * w[i];
+    // autograd's chain for total = (sum_i w_i t_i) * scale and level_i = (w_i t_i) * scale: every path is g * scale * w_i, the paths are added
+    if (blockIdx.x == 0 && i < n) {
+        const float a = gtotal ? __fmul_rn(__fmul_rn(gtotal[0], scale), w[i]) : 0.f;
+        const float b = glevels ? __fmul_rn(__fmul_rn(glevels[i], scale), w[i]) : 0.f;
+        gt[i] = __fadd_rn(a, b);
+    }
 }
 }  // namespace
 

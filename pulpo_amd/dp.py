@@ -212,6 +212,8 @@ class DataParallelStepper:
         self._works: List = []
         self._launched = 0
         self._armed = False
+        self._in_backward = False
+        self.exchange_events: Optional[List] = None      # bench.py: [] -> (start, end) HIP events around the waits for the gradient exchange
         if self.overlap:
             for i, trig in enumerate(triggers):
                 if trig is not None:
@@ -229,7 +231,8 @@ class DataParallelStepper:
     def _make_forward_hook(self, i: int):
         def fwd_hook(_module, _inputs, output):
             if self._armed and isinstance(output, torch.Tensor) and output.requires_grad:
-                output.register_hook(lambda g, i=i: self._launch_upto(i))
+                # (a backward pass that does not go through self.backward() exchanges its gradients in one piece, in reduce_and_update)
+                output.register_hook(lambda g, i=i: self._launch_upto(i) if self._in_backward else None)
         return fwd_hook
 
     def _launch_upto(self, i: int) -> None:
@@ -244,37 +247,114 @@ class DataParallelStepper:
             self._launched += 1
         return None
 
-    def step(self, batch) -> torch.Tensor:
-        from . import ops
+    # ---- the pieces of a step.  step() below strings them together; the LightningModule hooks of pulpo_amd.models.PULPo call the same
+    # ---- pieces from Lightning's own loop (training_step -> optimizer_zero_grad -> backward -> optimizer.step), so that an unchanged
+    # ---- train.py runs the path bench.py times.
+    def zero_grad(self) -> None:
         self.arena.zero_grad()
+
+    def arm(self, on: bool = True) -> None:
+        """the next forward pass registers the bucket triggers of the overlapped gradient exchange (multi-rank only)"""
+        self._armed = bool(on) and self.overlap and world() > 1
+
+    def backward(self, loss: torch.Tensor, direct: bool = True) -> None:
+        """loss.backward() with the parameter gradients written straight into the arena, the weight gradients on the side stream and ONE
+        finishing launch for all deferred parameter gradients.  direct=False: parameter gradients through autograd's AccumulateGrad (what a
+        DistributedDataParallel wrapper needs to see), everything else alike."""
+        from . import ops
         self._works, self._launched = [], 0
-        self._armed = self.overlap and world() > 1
         ops._BN_TILE_PARTS.clear()                 # (BatchNorm-backward sums a data-gradient kernel left for a unit whose backward never ran)
+        ops.DIRECT_PARAM_GRADS = bool(direct)      # conv / BN backward kernels add straight into the arena's .grad views
+        ops.ASYNC_WGRAD_STREAM = self._side if (self.async_wgrad and direct) else None
+        self._in_backward = True
         try:
-            loss = self.model.training_step(batch, 0)
-            ops.DIRECT_PARAM_GRADS = True          # conv / BN backward kernels add straight into the arena's .grad views
-            ops.ASYNC_WGRAD_STREAM = self._side if self.async_wgrad else None
-            try:
-                if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype:
-                    self._one = torch.ones((), device=loss.device, dtype=loss.dtype)       # (backward() would fill a fresh one per step)
-                loss.backward(self._one)
-            except BaseException:
-                ops.reset_param_grad_buffers(self.model)        # deferred gradient sums of an interrupted backward pass are void
-                raise
-            finally:
-                ops.DIRECT_PARAM_GRADS = False
-                ops.join_async_wgrad()             # (also finishes the deferred weight / bias gradients in one launch)
-                ops.ASYNC_WGRAD_STREAM = None
+            if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype:
+                self._one = torch.ones((), device=loss.device, dtype=loss.dtype)       # (backward() would fill a fresh one per step)
+            loss.backward(self._one)
+        except BaseException:
+            ops.reset_param_grad_buffers(self.model)        # deferred gradient sums of an interrupted backward pass are void
+            raise
         finally:
+            self._in_backward = False
             self._armed = False
-        if self.overlap and world() > 1:
+            ops.DIRECT_PARAM_GRADS = False
+            ops.join_async_wgrad()             # (also finishes the deferred weight / bias gradients in one launch)
+            ops.ASYNC_WGRAD_STREAM = None
+
+    def reduce_and_update(self, reduced_elsewhere: bool = False) -> None:
+        """gradient exchange (what is left of it) + fused Adam.  reduced_elsewhere: a DistributedDataParallel wrapper has already averaged
+        the gradients (Lightning's ddp strategy): no exchange here, no 1/world scale."""
+        if reduced_elsewhere:
+            self.opt.step(1.0)
+            return
+        ev = None
+        if self.exchange_events is not None and world() > 1 and self.arena.grad.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if self.overlap and world() > 1 and self._launched > 0:       # buckets already travelling: issue the rest, wait for all
             self._launch_upto(len(self.buckets) - 1)
             for w in self._works:
                 w.wait()
         else:
             allreduce_sum_(self.arena.grad)
+        self._works, self._launched = [], 0
+        if ev is not None:
+            ev[1].record()
+            self.exchange_events.append(ev)
         self.opt.step(1.0 / world())
+
+    def step(self, batch) -> torch.Tensor:
+        self.zero_grad()
+        self.arm()
+        try:
+            loss = self.model.training_step(batch, 0)
+            self.backward(loss)
+        finally:
+            self._armed = False
+        self.reduce_and_update()
         return loss.detach()
+
+    def describe(self) -> dict:
+        return {"overlap": bool(self.overlap and world() > 1), "async_wgrad": bool(self.async_wgrad), "buckets": len(self.buckets)}
+
+
+class ArenaAdam(torch.optim.Adam):
+    """What `PULPo.configure_optimizers()` returns on a GPU: a torch.optim.Adam (same param_groups, same state_dict layout, same defaults
+    as the reference's optimizer, models.py:398-400) whose step is the fused HIP Adam over the flat arenas and whose zero_grad is one fill.
+    It owns the DataParallelStepper the LightningModule hooks drive (`engine`); used without those hooks - `opt.zero_grad();
+    loss.backward(); opt.step()` - it is plain autograd accumulation into the arena's gradient views + the fused update."""
+
+    def __init__(self, model: nn.Module, lr: float = 1e-4, **stepper_kw):
+        super().__init__([p for p in model.parameters() if p.requires_grad], lr=lr)
+        self.engine = DataParallelStepper(model, lr=lr, **stepper_kw)
+        self.reduced_elsewhere = False          # set by the module's hooks when a DistributedDataParallel wrapper averages the gradients
+
+    def zero_grad(self, set_to_none: bool = True) -> None:      # noqa: ARG002  (the gradient views stay attached: one fill of the arena)
+        self.engine.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        g = self.param_groups[0]                # a learning-rate scheduler writes here
+        fa = self.engine.opt
+        fa.lr, fa.betas, fa.eps = float(g["lr"]), tuple(g["betas"]), float(g["eps"])
+        if g.get("weight_decay", 0) or g.get("amsgrad") or g.get("maximize"):
+            raise ValueError("ArenaAdam: weight_decay / amsgrad / maximize are not part of the reference's optimizer (models.py:399)")
+        self.engine.reduce_and_update(reduced_elsewhere=self.reduced_elsewhere)
+        return loss
+
+    def state_dict(self) -> dict:
+        sd = self.engine.opt.state_dict()
+        sd["param_groups"][0].update({k: v for k, v in self.param_groups[0].items() if k not in ("params",) and k in sd["param_groups"][0]})
+        return sd
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.engine.opt.load_state_dict(sd)
+        fa = self.engine.opt
+        self.param_groups[0].update(lr=fa.lr, betas=tuple(fa.betas), eps=fa.eps)
 
 
 def init_from_env(backend: Optional[str] = None) -> int:

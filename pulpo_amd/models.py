@@ -11,6 +11,7 @@ arithmetic:
 from __future__ import annotations
 
 import math
+import os
 from abc import ABC
 from typing import Dict, List, Optional
 
@@ -186,6 +187,9 @@ class PULPo(ABC, LightningModule):
     def training_step(self, batch, batch_idx):
         x, y, seg_x, seg_y, lm1, lm2, mask1, mask2 = batch
         self._check_previous_step_for_nan()
+        eng = self._engine()
+        if eng is not None and torch.is_grad_enabled():
+            eng.arm(not self._ddp_wrapped())          # multi-rank: this forward pass registers the triggers of the bucketed gradient exchange
         outs, priors, (total, kl, rec, reg), levels = self._forward_and_losses(x, y, seg_x, seg_y)
         self.log_dict({"train/kl_loss": kl, "train/reconstruction_loss": rec, "train/regularization_loss": reg, "train/total_loss": total},
                       on_step=True, on_epoch=True, prog_bar=True)
@@ -256,5 +260,42 @@ class PULPo(ABC, LightningModule):
             level_seg[0] = seg
         return {k: self.autoencoder.decoders[k].spatial_transform(dfs[k], level_seg[k]) for k in dfs}
 
+    # ------------------------------------------------------------------------------------------------ optimizer + Lightning's backward hooks
+    # The reference leaves the step to Lightning: `return total_loss` (models.py:196) -> Lightning's closure runs optimizer_zero_grad,
+    # on_before_backward, backward, on_after_backward and hands the closure to `optimizer.step` of what configure_optimizers returned
+    # (models.py:398-400; pytorch_lightning 1.8 loops/optimization/optimizer_loop.py).  The overrides below make that loop run the step
+    # bench.py times: parameter gradients straight into the flat arena, weight gradients on the side stream, one finishing launch, fused
+    # Adam, in-place re-pack of the weights - the same pieces `dp.DataParallelStepper.step` strings together.  PULPO_LIGHTNING_FAST=0
+    # switches all of it off (plain autograd + torch.optim.Adam).
     def configure_optimizers(self):
-        return torch.optim.Adam(self.parameters(), lr=self.hparams.lr)
+        first = next(self.parameters())
+        if not first.is_cuda or os.environ.get("PULPO_LIGHTNING_FAST", "1") == "0":
+            self._pulpo_optimizer = None
+            return torch.optim.Adam(self.parameters(), lr=self.hparams.lr)     # (a model that is not on the GPU cannot step anyway: construction only)
+        from .dp import ArenaAdam
+        opt = ArenaAdam(self, lr=float(self.hparams.lr))
+        self._pulpo_optimizer = opt                # (a plain attribute: neither a sub-module nor part of the state dict)
+        return opt
+
+    def _engine(self):
+        opt = getattr(self, "_pulpo_optimizer", None)
+        return None if opt is None else opt.engine
+
+    def _ddp_wrapped(self) -> bool:
+        """is a DistributedDataParallel wrapper (Lightning's ddp strategies) reducing the gradients?  It needs them from autograd's
+        AccumulateGrad nodes, so the direct-to-arena path is off and the optimizer neither exchanges nor rescales them."""
+        tr = getattr(self, "_trainer", None) or getattr(self, "trainer", None)
+        wrapped = getattr(getattr(tr, "strategy", None), "model", None)
+        return isinstance(wrapped, torch.nn.parallel.DistributedDataParallel)
+
+    def optimizer_zero_grad(self, epoch, batch_idx, optimizer, *args, **kwargs):
+        optimizer.zero_grad()                      # (ArenaAdam: one fill, the gradient views stay attached)
+
+    def backward(self, loss, *args, **kwargs):
+        eng = self._engine()
+        if eng is None:
+            return loss.backward(*[a for a in args if torch.is_tensor(a)], **kwargs)      # (PL 1.x passes (optimizer, optimizer_idx) first)
+        ddp = self._ddp_wrapped()
+        self._pulpo_optimizer.reduced_elsewhere = ddp
+        eng.backward(loss, direct=not ddp)
+

@@ -139,31 +139,40 @@ def _grad_slot(p: torch.Tensor) -> Optional[torch.Tensor]:
 CONV_TRACE = None
 CONV_TRACE_STRIDE = 1          # > 1: bracket only every n-th launch (a stride co-prime with the launches per step samples every layer)
 CONV_TRACE_STRIDE_USED = 1     # the stride of the last timed trace (bench.py scales sampled totals with it)
-_trace_counter = 0
+_trace_rng = __import__("random").Random(0)     # which launches are bracketed: an unbiased 1-in-stride draw (a fixed stride can lock onto the
+                                                # same launches of every step when the launch count per step is a multiple of it)
+
+
+def _sampled() -> bool:
+    return CONV_TRACE_STRIDE <= 1 or _trace_rng.random() * CONV_TRACE_STRIDE < 1.0
 
 
 def _trace_begin():
-    global _trace_counter
-    if CONV_TRACE is None:
-        return None
-    _trace_counter += 1
-    if _trace_counter % CONV_TRACE_STRIDE:
+    if CONV_TRACE is None or not _sampled():
         return None
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()
     return ev
 
 
-# HBM-bound kernels (BatchNorm / LeakyReLU passes): same bracket, algorithmic BYTES instead of FLOP
+# HBM-bound kernels (BatchNorm / LeakyReLU passes, warp, VecInt, NCC, pooling / resizing, heads, KL, regulariser, Adam): same bracket,
+# algorithmic BYTES instead of FLOP
 HBM_TRACE = None
 
 
-def _hbm_begin():
-    global _trace_counter
-    if HBM_TRACE is None:
+_HBM_SEEN: dict = {}
+
+
+def _hbm_begin(name: str):
+    """brackets the first launches of every kernel class (a class with one launch per step - Adam - must not depend on the draw) and a
+    1-in-stride draw of the rest"""
+    trace = HBM_TRACE
+    if trace is None:
         return None
-    _trace_counter += 1
-    if _trace_counter % CONV_TRACE_STRIDE:
+    if not trace:
+        _HBM_SEEN.clear()
+    n = _HBM_SEEN[name] = _HBM_SEEN.get(name, 0) + 1
+    if n > 2 and not _sampled():
         return None
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()
@@ -171,7 +180,7 @@ def _hbm_begin():
 
 
 def _hbm_end(start, name: str, nbytes: float):
-    if start is None:
+    if start is None or HBM_TRACE is None:
         return
     end = torch.cuda.Event(enable_timing=True)
     end.record()
@@ -575,12 +584,12 @@ class _ConvBNLReLU(torch.autograd.Function):
         if pool_after and lib.query("pulpo_bn_lrelu_apply_pool2_ok", Cout, y.stride(4), z.stride(4), Cout):
             # the caller pools this output next (DownPath): z and AvgPool(z) from one read of y; avg_pool2_skip() picks the pooled tensor up
             pooled = new_cl(B, Cout, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, dev)
-            t0 = _hbm_begin()
+            t0 = _hbm_begin("bn_lrelu_apply")
             lib.call("pulpo_bn_lrelu_apply_pool2", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(pooled), pooled.stride(4), _ptr(coef), B, D, H, W, Cout,
                      LRELU_SLOPE, _stream())
             _hbm_end(t0, "bn_lrelu_apply", 8.0 * Cout * B * D * H * W)
         else:
-            t0 = _hbm_begin()
+            t0 = _hbm_begin("bn_lrelu_apply")
             lib.call("pulpo_bn_lrelu_apply", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
             _hbm_end(t0, "bn_lrelu_apply", 8.0 * Cout * B * D * H * W)            # read y, write z
         ctx.save_for_backward(x, weight, y, coef)
@@ -603,7 +612,7 @@ class _ConvBNLReLU(torch.autograd.Function):
         tiles = _take_bn_tile_parts(y, coef, dz)
         if tiles is None:
             part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
-            t0 = _hbm_begin()
+            t0 = _hbm_begin("bn_lrelu_bwd_reduce")
             lib.call("pulpo_bn_lrelu_bwd_reduce", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE, _ptr(part), _stream())
             _hbm_end(t0, "bn_lrelu_bwd_reduce", 8.0 * Cout * npix)                # read dz, y
         w_p, b_p, g_p, be_p = ctx.params
@@ -625,7 +634,7 @@ class _ConvBNLReLU(torch.autograd.Function):
             defer_b = False                          # for flush_param_grads() - this pass takes the immediate path into the same slot
         if not defer_b:
             part2 = torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
-        t0 = _hbm_begin()
+        t0 = _hbm_begin("bn_lrelu_bwd_apply")
         lib.call("pulpo_bn_lrelu_bwd_apply", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4), npix, Cout,
                  LRELU_SLOPE, _ptr(part2), _stream())
         _hbm_end(t0, "bn_lrelu_bwd_apply", 12.0 * Cout * npix)                # read dz, y; write dy
@@ -719,8 +728,10 @@ class _Heads(torch.autograd.Function):
         dev = h.device
         outs = [torch.empty((B, 3, D, H, W), device=dev, dtype=torch.float32) for _ in range(1 if nout == 3 else 3)]
         epsc = planar(eps) if eps is not None else None
+        t0 = _hbm_begin("heads_fwd")
         lib.call("pulpo_heads_fwd", _ptr(h), h.stride(4), _ptr(Wt), _ptr(bias), _ptr(epsc), _ptr(outs[0]), _ptr(outs[1]) if nout == 6 else None,
                  _ptr(outs[2]) if nout == 6 else None, nout, B, V, C, _stream())
+        _hbm_end(t0, "heads_fwd", 4.0 * B * V * (C + (12 if nout == 6 else 3)))       # read h (+ eps), write mu / sigma / z (or the field)
         ctx.nout = nout
         ctx.save_for_backward(h, Wt, epsc, outs[1] if nout == 6 else None)
         return outs[0] if nout == 3 else tuple(outs)
@@ -750,8 +761,10 @@ class _Heads(torch.autograd.Function):
         if part is None or _pending_src(part):
             slots = None
             part = torch.empty(nblk * rowlen, device=dev, dtype=torch.float32)
+        t0 = _hbm_begin("heads_bwd")
         lib.call("pulpo_heads_bwd", _ptr(h), h.stride(4), _ptr(Wt), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(eps), _ptr(sigma), _ptr(dh),
                  dh.stride(4), _ptr(part), nout, B, V, C, _stream())
+        _hbm_end(t0, "heads_bwd", 4.0 * B * V * (2 * C + (15 if nout == 6 else 3)))   # read h, the output gradients (+ eps, sigma), write dh
         if slots is not None:
             nw = len(ctx.params[0])
             for k, (sl, off, n) in enumerate(slots):
@@ -798,7 +811,9 @@ class _AvgPool2(torch.autograd.Function):
         B, C, D, H, W = x.shape
         out = new_cl(B, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, x.device) if C > 1 else \
             torch.empty((B, 1, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32)
+        t0 = _hbm_begin("avgpool2_fwd")
         lib.call("pulpo_avgpool2_fwd", _ptr(x), x.stride(4), _ptr(out), out.stride(4), B, D, H, W, C, _stream())
+        _hbm_end(t0, "avgpool2_fwd", 4.0 * C * (x.numel() // C + out.numel() // C))
         ctx.shape = (B, C, D, H, W)
         return out
 
@@ -861,12 +876,17 @@ class _AvgPool2Skip(torch.autograd.Function):
             if tuple(y.shape) == (B, C, D, H, W) and y.stride(1) == 1 and y.stride(4) % 4 == 0 and y.data_ptr() % 16 == 0 and _dense_grid(y):
                 nblk = lib.query("pulpo_bn_bwd_blocks", B * D * H * W, C)
                 part = torch.empty(nblk * 2 * C, device=g.device, dtype=torch.float32)
+                t0 = _hbm_begin("avgpool2_bwd_bnred")
                 lib.call("pulpo_avgpool2_bwd_bnred", _ptr(g), g.stride(4), _ptr(gskip), grid_strides(gskip)[1] if gskip is not None else 0, _ptr(gin),
                          gin.stride(4), _ptr(y), y.stride(4), _ptr(coef), LRELU_SLOPE, _ptr(part), B, D, H, W, C, _stream())
+                # read the pooled gradient, the skip gradient and y, write the summed gradient
+                _hbm_end(t0, "avgpool2_bwd_bnred", 4.0 * C * (g.numel() // C + (3 if gskip is not None else 2) * B * D * H * W))
                 _BN_TILE_PARTS[y.data_ptr()] = (part, nblk, coef.data_ptr(), gin.data_ptr(), gin._version, tuple(gin.shape), tuple(gin.stride()))
                 return gin, None, None, None
         if skip_ok:
+            t0 = _hbm_begin("avgpool2_bwd_add")
             lib.call("pulpo_avgpool2_bwd_add", _ptr(g), g.stride(4), _ptr(gskip), grid_strides(gskip)[1], _ptr(gin), gin.stride(4), B, D, H, W, C, _stream())
+            _hbm_end(t0, "avgpool2_bwd_add", 4.0 * C * (g.numel() // C + 2 * B * D * H * W))
             return gin, None, None, None
         lib.call("pulpo_avgpool2_bwd", _ptr(g), g.stride(4), _ptr(gin), gin.stride(4), B, D, H, W, C, _stream())
         return (gin if gskip is None else gskip + gin), None, None, None
@@ -891,7 +911,9 @@ class _Resize(torch.autograd.Function):
         Do, Ho, Wo = size
         out = torch.empty((B, C, Do, Ho, Wo), device=x.device, dtype=torch.float32)
         addc = planar(add) if add is not None else None
+        t0 = _hbm_begin("resize_trilinear_fwd")
         lib.call("pulpo_resize_trilinear_fwd", _ptr(x), _ptr(addc), _ptr(out), B * C, Di, Hi, Wi, Do, Ho, Wo, mult, _stream())
+        _hbm_end(t0, "resize_trilinear_fwd", 4.0 * (x.numel() + out.numel() * (2 if addc is not None else 1)))
         ctx.dims = (B, C, Di, Hi, Wi, Do, Ho, Wo)
         ctx.mult = mult
         ctx.has_add = add is not None
@@ -904,7 +926,9 @@ class _Resize(torch.autograd.Function):
         gin = None
         if ctx.needs_input_grad[0]:
             gin = torch.empty((B, C, Di, Hi, Wi), device=g.device, dtype=torch.float32)
+            t0 = _hbm_begin("resize_trilinear_bwd")
             lib.call("pulpo_resize_trilinear_bwd", _ptr(g), _ptr(gin), B * C, Di, Hi, Wi, Do, Ho, Wo, ctx.mult, _stream())
+            _hbm_end(t0, "resize_trilinear_bwd", 4.0 * (g.numel() + gin.numel()))
         return gin, None, None, (g if ctx.has_add and ctx.needs_input_grad[3] else None)
 
 
@@ -927,7 +951,9 @@ class _FeedbackUp2(torch.autograd.Function):
         n = len(srcs)
         ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
         ch = (ctypes.c_int * n)(*chans)
+        t0 = _hbm_begin("feedback_up2_fwd")
         lib.call("pulpo_feedback_up2_fwd", ptrs, ch, n, _ptr(out), out.stride(4), B, Di, Hi, Wi, _stream())
+        _hbm_end(t0, "feedback_up2_fwd", 4.0 * ctot * B * Di * Hi * Wi * 9)             # read the sources, write 8x as many voxels
         ctx.meta = (B, Di, Hi, Wi, chans)
         ctx.keep = srcs      # keep the sources alive until the kernel has been enqueued (same stream: safe afterwards)
         return out
@@ -941,7 +967,9 @@ class _FeedbackUp2(torch.autograd.Function):
               for i, c in enumerate(chans)]
         ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in gs])
         ch = (ctypes.c_int * n)(*chans)
+        t0 = _hbm_begin("feedback_up2_bwd")
         lib.call("pulpo_feedback_up2_bwd", _ptr(g), g.stride(4), ptrs, ch, n, B, Di, Hi, Wi, _stream())
+        _hbm_end(t0, "feedback_up2_bwd", 4.0 * sum(chans) * B * Di * Hi * Wi * 9)
         return tuple(gs)
 
 
@@ -959,7 +987,9 @@ class _Warp(torch.autograd.Function):
         B, _, Dg, Hg, Wg = df.shape
         _, C, Di, Hi, Wi = img.shape
         out = torch.empty((B, C, Dg, Hg, Wg), device=df.device, dtype=torch.float32)
+        t0 = _hbm_begin("warp3d_fwd")
         lib.call("pulpo_warp3d_fwd", _ptr(df), _ptr(img), _ptr(out), B, C, Dg, Hg, Wg, Di, Hi, Wi, _stream())
+        _hbm_end(t0, "warp3d_fwd", 4.0 * (df.numel() + img.numel() + out.numel()))          # (3 + 2C) V 4
         ctx.save_for_backward(df, img)
         return out
 
@@ -971,7 +1001,10 @@ class _Warp(torch.autograd.Function):
         _, C, Di, Hi, Wi = img.shape
         gdf = torch.empty_like(df) if ctx.needs_input_grad[0] else None
         gimg = torch.empty_like(img) if ctx.needs_input_grad[1] else None
+        t0 = _hbm_begin("warp3d_bwd")
         lib.call("pulpo_warp3d_bwd", _ptr(df), _ptr(img), _ptr(g), _ptr(gdf), _ptr(gimg), B, C, Dg, Hg, Wg, Di, Hi, Wi, _stream())
+        _hbm_end(t0, "warp3d_bwd", 4.0 * (df.numel() + img.numel() + g.numel() + (gdf.numel() if gdf is not None else 0)
+                                          + (2 * gimg.numel() if gimg is not None else 0)))      # (image gradient: zero fill + scatter)
         return gdf, gimg
 
 
@@ -989,7 +1022,9 @@ class _VecInt(torch.autograd.Function):
         v = planar(v)
         B, _, D, H, W = v.shape
         work = torch.empty((nsteps + 1, B, 3, D, H, W), device=v.device, dtype=torch.float32)
+        t0 = _hbm_begin("vecint_fwd")
         lib.call("pulpo_vecint_fwd", _ptr(v), _ptr(work), B, D, H, W, nsteps, _stream())
+        _hbm_end(t0, "vecint_fwd", 4.0 * v.numel() * 2 * (nsteps + 1))                       # every step: one read, one write of the field
         ctx.save_for_backward(work)
         ctx.nsteps = nsteps
         return work[nsteps]
@@ -1002,7 +1037,9 @@ class _VecInt(torch.autograd.Function):
         gin = torch.empty((B, 3, D, H, W), device=g.device, dtype=torch.float32)
         ntmp = lib.query("pulpo_vecint_bwd_tmp_floats", B, D, H, W, ctx.nsteps)
         tmp = torch.empty(ntmp, device=g.device, dtype=torch.float32) if ntmp else None
+        t0 = _hbm_begin("vecint_bwd")
         lib.call("pulpo_vecint_bwd", _ptr(work), _ptr(g), _ptr(gin), _ptr(tmp), B, D, H, W, ctx.nsteps, _stream())
+        _hbm_end(t0, "vecint_bwd", 4.0 * gin.numel() * (3 * ctx.nsteps + 2))                 # every step: read the field and the gradient, write a gradient
         return gin, None
 
 
@@ -1027,7 +1064,9 @@ class _NCC(torch.autograd.Function):
         T = torch.empty(10 * N, device=dev, dtype=torch.float32)
         nblk = lib.query("pulpo_loss_blocks", N)
         part = torch.empty(nblk, device=dev, dtype=torch.float32)
+        t0 = _hbm_begin("ncc_fwd")
         lib.call("pulpo_ncc_fwd", _ptr(true), _ptr(pred), _ptr(S), _ptr(T), _ptr(part), B, D, H, W, win, _stream())
+        _hbm_end(t0, "ncc_fwd", 4.0 * 22 * N)                  # 2 images in; three separable passes over 5 box-sum channels (write 5, read 5, write 5, read 5)
         loss = _colsum(part, nblk, 1, -gamma / B)
         ctx.save_for_backward(pred, true, S)
         ctx.win, ctx.gamma = win, gamma
@@ -1041,7 +1080,9 @@ class _NCC(torch.autograd.Function):
         T = torch.empty(6 * N, device=pred.device, dtype=torch.float32)
         gJ = torch.empty_like(pred)
         g = g.contiguous()
+        t0 = _hbm_begin("ncc_bwd")
         lib.call("pulpo_ncc_bwd", _ptr(true), _ptr(pred), _ptr(S), _ptr(T), _ptr(g), -ctx.gamma / B, _ptr(gJ), B, D, H, W, ctx.win, _stream())
+        _hbm_end(t0, "ncc_bwd", 4.0 * 20 * N)                  # 2 images + 5 sums in; three passes over 3 channels (write 3, read 3, write 3, read 3); gradient out
         return gJ, None, None, None
 
 
@@ -1061,7 +1102,9 @@ class _KL(torch.autograd.Function):
         n = mu.numel()
         nblk = lib.query("pulpo_loss_blocks", n)
         part = torch.empty(nblk, device=mu.device, dtype=torch.float32)
+        t0 = _hbm_begin("kl_fwd")
         lib.call("pulpo_kl_fwd", _ptr(mu), _ptr(sigma), _ptr(mu1), _ptr(sigma1), n, _ptr(part), _stream())
+        _hbm_end(t0, "kl_fwd", 4.0 * n * (2 + (mu1 is not None) + (sigma1 is not None)))
         ctx.save_for_backward(mu, sigma, mu1, sigma1)
         return _colsum(part, nblk, 1, 0.5 / mu.shape[0]).reshape(())
 
@@ -1070,8 +1113,10 @@ class _KL(torch.autograd.Function):
         mu, sigma, mu1, sigma1 = ctx.saved_tensors
         gmu, gsg = torch.empty_like(mu), torch.empty_like(sigma)
         g = g.contiguous()
+        t0 = _hbm_begin("kl_bwd")
         lib.call("pulpo_kl_bwd", _ptr(mu), _ptr(sigma), _ptr(mu1), _ptr(sigma1), _ptr(g), 1.0 / mu.shape[0], _ptr(gmu), _ptr(gsg), mu.numel(),
                  _stream())
+        _hbm_end(t0, "kl_bwd", 4.0 * mu.numel() * (4 + (mu1 is not None) + (sigma1 is not None)))
         return gmu, gsg, None, None
 
 
@@ -1096,7 +1141,9 @@ class _L2Reg(torch.autograd.Function):
         n = df.numel()
         nblk = lib.query("pulpo_loss_blocks", n)
         part = torch.empty(nblk, device=df.device, dtype=torch.float32)
+        t0 = _hbm_begin("l2reg_fwd")
         lib.call("pulpo_l2reg_fwd", _ptr(df), B * C, D, H, W, _ptr(part), _stream())
+        _hbm_end(t0, "l2reg_fwd", 4.0 * n)
         coef = lamb * D * H * W / float(B * C * max(D - 1, 1) * (H - 1) * (W - 1))      # D == 1: the 2-D form (no depth difference)
         ctx.save_for_backward(df)
         ctx.coef = coef
@@ -1108,7 +1155,9 @@ class _L2Reg(torch.autograd.Function):
         B, C, D, H, W = df.shape
         gdf = torch.empty_like(df)
         g = g.contiguous()
+        t0 = _hbm_begin("l2reg_bwd")
         lib.call("pulpo_l2reg_bwd", _ptr(df), _ptr(g), ctx.coef, _ptr(gdf), B * C, D, H, W, _stream())
+        _hbm_end(t0, "l2reg_bwd", 8.0 * df.numel())
         return gdf, None
 
 
@@ -1342,7 +1391,9 @@ class StreamingMoments:
 
 def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, gscale: float = 1.0):
     _require_gpu(p, g, m, v)
+    t0 = _hbm_begin("adam_step")
     lib.call("pulpo_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, int(step), gscale, _stream())
+    _hbm_end(t0, "adam_step", 28.0 * p.numel())               # read p, g, m, v; write p, m, v
     refresh_weight_packs()                       # the kernel rewrote parameters through raw pointers: the cached packs follow, in one launch
 
 

@@ -9,7 +9,7 @@ float4 kernels (factor 2 below).  The forward / data-gradient convolutions gathe
 guide calls uncalibrated: scripts/probes/fetch_calib.hip reads a known byte count with exactly that pattern (profiles/r3_fetch_calibration.md)
 and finds the same factor 2.000 (line fills of 128 bytes tallied at 64) - and, at the convolution's launch geometry, every line crossing
 the fabric 2.9 times (the halo tiles of the 64 workgroups of an XCD exceed its 4 MiB L2 between chunk passes), which is traffic, not a
-counter artefact.  Factor 2 for every kernel since round 3.
+counter artefact.  Factor 2 for every kernel except the 4-byte-per-lane convolution instantiations (see FETCH_FACTOR: lower bound there).
 """
 import csv, glob, json, re, sys
 from collections import defaultdict
@@ -36,7 +36,11 @@ def collect(d: str, counter: str):
     return tot, cnt
 
 
-FETCH_FACTOR = [(re.compile(r"conv3d_k3_"), 2.0)]        # (calibrated for the 32-byte gathers of conv3d_k3_wino2p_mfma; the streaming kernels by the guide)
+# factor 2: calibrated for the 32-byte gathers of conv3d_k3_wino2p_mfma / wino2_mfma<true> (scripts/probes/fetch_calib.hip) and, by the
+# guide, for 16 B/lane streams (every float4 kernel, the vectorised weight-gradient kernels).  The kernels that read 4 bytes per lane - the
+# scalar direct convolution of the 2-/3-channel input layers (conv3d_k3_mfma<2|4,...>), the planar-operand instantiations (<..., false>) and
+# the narrow-input weight gradient (wgrad_smallc) - were never calibrated: factor 1, i.e. their traffic figure is a LOWER bound.
+FETCH_FACTOR = [(re.compile(r"conv3d_k3_mfma<(2|4),|conv3d_k3_wgrad_smallc|conv3d_k3_\w+<[^>]*false>"), 1.0), (re.compile(r"conv3d_k3_"), 2.0)]
 
 
 def main():

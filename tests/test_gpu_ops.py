@@ -774,3 +774,103 @@ def test_streaming_mc_moments_single_sample_is_nan_like_torch_std(ops):
     assert bool(torch.isnan(sm.std_map()).all())          # torch.std over one sample is NaN (unbiased estimator), evaluate.py:243
     with pytest.raises(ValueError):
         sm.update(torch.ones(1, 3, 4, 4, 5, device="cuda"))
+
+
+# ================================================================================================ round-4 additions
+@pytest.mark.parametrize("scale", [None, 0.1])
+def test_weighted_sum_is_the_reference_scalar_chain(ops, scale):
+    """ops.weighted_sum (one launch) against the reference's per-level scalar chain `all_levels[l] = w * term; total += all_levels[l]`
+    (losses.py:262-276, 305-325, 343-355) and `kl * beta` (models.py:161-162), evaluated by torch on the same device scalars: forward values
+    EXACTLY equal (explicit round-to-nearest products and sums in the kernel - no fused multiply-add), gradients equal to one rounding."""
+    gen = torch.Generator().manual_seed(3)
+    for n, weights in ((4, [1.0 / 8 * 4, 8.0, 64.0, 512.0]), (4, [0.3, 1.7, 8.0 / 3, 511.9]), (1, [9.0]), (7, [0.37 * (k + 1) for k in range(7)])):
+        vals = (torch.randn(n, generator=gen) * 100).tolist()
+        ta = [torch.tensor(v, device="cuda", requires_grad=True) for v in vals]
+        tb = [torch.tensor(v, device="cuda", requires_grad=True) for v in vals]
+        total, levels = ops.weighted_sum(ta, weights, scale)
+        ref_total, ref_levels = 0.0, []
+        for w, t in zip(weights, tb):
+            ref_levels.append(w * t)
+            ref_total = ref_total + ref_levels[-1]
+        if scale is not None:
+            ref_total = ref_total * scale
+            ref_levels = [scale * v for v in ref_levels]
+        assert float(total) == float(ref_total), (weights, float(total), float(ref_total))
+        for a, b in zip(levels, ref_levels):
+            assert float(a) == float(b)
+        # gradients: through the total only (the training step), and through the total and the per-level outputs together
+        coef = torch.randn(n, generator=gen).tolist()
+        for use_levels in (False, True):
+            for t in ta + tb:
+                t.grad = None
+            obj_a = total * 1.5 + (sum(c * v for c, v in zip(coef, levels)) if use_levels else 0.0)
+            obj_b = ref_total * 1.5 + (sum(c * v for c, v in zip(coef, ref_levels)) if use_levels else 0.0)
+            obj_a.backward(retain_graph=True)
+            obj_b.backward(retain_graph=True)
+            for a, b in zip(ta, tb):
+                np.testing.assert_allclose(float(a.grad), float(b.grad), rtol=2e-7, atol=0)
+
+
+class _TwiceNet(torch.nn.Module):
+    """one ConvUnit and one 1x1x1 head applied TWICE per forward pass - shared weights, the second application optionally on a pooled
+    (smaller) volume - plus a unit applied once in between: what the deferred parameter-gradient jobs of the stepper must survive"""
+
+    def __init__(self, nb, pooled_second: bool):
+        super().__init__()
+        import types
+        self.first = nb.ConvUnit([16, 16, 16], 8, 8)
+        self.shared = nb.ConvUnit([16, 16, 16], 8, 8)
+        self.head = nb.VelocityField([16, 16, 16], 3, 8, 3)          # ConvUnit(3 -> 8), ConvUnit(8 -> 8), 1x1x1 (8 -> 3)
+        self.hparams = types.SimpleNamespace(lr=1e-3)
+        self.pooled_second = pooled_second
+        self.mid_hook = None
+
+    def training_step(self, batch, idx):
+        from pulpo_amd import ops as _ops
+        x, z = batch
+        h = self.shared(self.first(x))
+        if self.mid_hook is not None and h.requires_grad:
+            h.register_hook(self.mid_hook)              # fires between the two backward passes of `shared`
+        h2 = _ops.avg_pool2(h) if self.pooled_second else h
+        h3 = self.shared(h2)
+        f1 = self.head(z)
+        f2 = self.head(f1)                               # the whole VelocityField (two ConvUnits + the head kernel) twice
+        return (h3 * h3).mean() + (f2 * f2).mean() + 0.5 * (f1 * f1).mean() + h.mean()
+
+
+@pytest.mark.parametrize("pooled_second", [False, True])
+@pytest.mark.parametrize("mode", ["async", "inline", "flush-between"])
+def test_unit_and_head_applied_twice_in_one_stepper_step(ops, pooled_second, mode):
+    """advisor (round 3): `_pending_src` - a ConvUnit / 1x1x1 head applied twice inside one DataParallelStepper step accumulates both weight
+    gradients into ONE persistent scratch with ONE finishing job, the second bias / head backward takes the immediate path while the first
+    is still deferred, and a mid-backward flush (the bucket hook of a multi-rank run) clears the pending list in between.  All three must
+    give plain autograd's gradients; also with the weight gradients in line (async_wgrad off)."""
+    from pulpo_amd import dp
+    import src.network_blocks as nb
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 8, 16, 16, 16, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    z = torch.randn(1, 3, 16, 16, 16, generator=gen).cuda()
+
+    def make():
+        torch.manual_seed(4)
+        return _TwiceNet(nb, pooled_second).cuda().train()
+
+    ref = make()
+    ref.training_step((x, z), 0).backward()
+    want = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+    net = make()
+    stepper = dp.DataParallelStepper(net, lr=0.0, async_wgrad=(mode != "inline"))
+    assert stepper.async_wgrad == (mode != "inline")
+    if mode == "flush-between":
+        net.mid_hook = lambda g: (ops.join_async_wgrad(), None)[1]
+    stepper.opt.step = lambda scale: None                # keep the weights: the gradients are what is compared
+    for rep in range(2):                                 # twice: the persistent scratch buffers must come back zeroed
+        stepper.step((x, z))
+        torch.cuda.synchronize()
+        assert not ops._PENDING_GRAD_JOBS and not ops._BN_TILE_PARTS
+        for k, p in net.named_parameters():
+            if k.endswith("_op.0.bias") and not k.endswith("head._op.2.bias"):
+                wmax = float(want[k[:-4] + "weight"].abs().max())       # bias in front of a BatchNorm: rounding noise on both sides
+                assert float((p.grad - want[k]).abs().max()) <= 1e-4 * max(wmax, 1e-6), (rep, k)
+                continue
+            assert rel_l2(p.grad, want[k]) < 2e-5, (rep, k, rel_l2(p.grad, want[k]))

@@ -308,6 +308,41 @@ stepper.step(x)
 assert [i for i, _ in launches] == [0, 1, 2], launches      # two hooks during backward, the rest after it
 for n, p in net.named_parameters():
     assert torch.allclose(p.grad, exp[n], rtol=1e-6, atol=1e-7), n
+# the same pieces in Lightning's order (training_step -> optimizer_zero_grad -> backward -> optimizer.step): forward BEFORE the fill
+launches.clear()
+stepper.arm()
+loss = net.training_step(x, 0)
+stepper.zero_grad()
+stepper.backward(loss)
+stepper.reduce_and_update()
+assert [i for i, _ in launches] == [0, 1, 2], launches
+for n, p in net.named_parameters():
+    assert torch.allclose(p.grad, exp[n], rtol=1e-6, atol=1e-7), n
+# a backward pass that does NOT go through stepper.backward() (manual optimisation, a user's own loop) with the triggers armed: no bucket
+# leaves during it, the whole arena is exchanged in one piece by reduce_and_update()
+launches.clear()
+stepper.arm()
+loss = net.training_step(x, 0)
+stepper.zero_grad()
+loss.backward()
+assert launches == [] and stepper._launched == 0
+stepper.reduce_and_update()
+for n, p in net.named_parameters():
+    assert torch.allclose(p.grad, exp[n], rtol=1e-6, atol=1e-7), n
+# ... and the step after it is a normal overlapped one again (no stale bucket state)
+launches.clear()
+stepper.step(x)
+assert [i for i, _ in launches] == [0, 1, 2], launches
+for n, p in net.named_parameters():
+    assert torch.allclose(p.grad, exp[n], rtol=1e-6, atol=1e-7), n
+# gradients a DistributedDataParallel wrapper has already averaged: no exchange, no 1/world scale
+seen = []
+stepper.opt.step = lambda scale: seen.append(scale)
+before = stepper.arena.grad.clone()
+stepper.reduce_and_update(reduced_elsewhere=True)
+assert seen == [1.0] and torch.equal(stepper.arena.grad, before)
+stepper.reduce_and_update()
+assert seen[-1] == 0.5
 print(f"rank {rank} buckets ok")
 dist.destroy_process_group()
 '''
@@ -393,6 +428,9 @@ def test_bench_gpus_2_starts_its_own_ranks_without_torchrun():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["parallelism"] == "dp2" and d["valid"] is False
+    # the audit fields of a multi-rank record: which loop, which stepper switches, did a fallback happen, what did the process group see
+    assert d["loop"] == "none" and d["stepper"]["fallback"] == "none"
+    assert d["dist"] == {"backend": "gloo", "world": 2, "devices": ["cpu (rank 0)", "cpu (rank 1)"]}
 
 
 def test_bench_launcher_fails_loudly_when_a_rank_dies():
