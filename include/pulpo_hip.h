@@ -195,6 +195,14 @@ int pulpo_resize_trilinear_fwd(const float* in, const float* add, float* out, in
                                float mult, void* stream);
 int pulpo_resize_trilinear_bwd(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo, float mult,
                                void* stream);
+/* the same with explicit source-coordinate steps per output voxel (scale_* <= 0: in / out, as above).  F.interpolate(scale_factor = f) - what
+ * ResizeTransform calls, src/network_blocks.py:141-147 - maps coordinates with 1 / f whatever floor(in * f) is, so for sizes where in * f is
+ * not an integer (a factor < 1 on odd sizes, non-integer factors) it differs from the size-ratio mapping of F.interpolate(size = ...)
+ * (components/pulpo.py:202, losses.py:313).  Since ABI 3. */
+int pulpo_resize_trilinear_scaled_fwd(const float* in, const float* add, float* out, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho,
+                                      int Wo, float scale_d, float scale_h, float scale_w, float mult, void* stream);
+int pulpo_resize_trilinear_scaled_bwd(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                      float scale_d, float scale_h, float scale_w, float mult, void* stream);
 int pulpo_feedback_up2_fwd(const float* const* srcs /*host array of device ptrs*/, const int* chans /*host*/, int nsrc, float* out, int64_t ops,
                            int B, int Di, int Hi, int Wi, void* stream);
 int pulpo_feedback_up2_bwd(const float* gout, int64_t gops, float* const* gsrcs /*host array, entries may be NULL*/, const int* chans, int nsrc,

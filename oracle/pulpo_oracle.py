@@ -559,10 +559,13 @@ def init_state_dict(cfg: Cfg, seed: int = 0) -> Dict[str, Tensor]:
     for l in range(L):
         k = l + o
         d = f"autoencoder.decoders.{l}"
-        unit(d + ".velocity_field._op.0", cfg.zdim, cfg.n0)
-        for i in range(1, cfg.cp_depth - 1):
-            unit(d + f".velocity_field._op.{i}", cfg.n0, cfg.n0)
-        conv(d + f".velocity_field._op.{cfg.cp_depth - 1}", cfg.n0, 3, 1)
+        if cfg.cp_depth == 1:                          # a bare (unpadded) 3x3x3 convolution, network_blocks.py:74-75
+            conv(d + ".velocity_field._op.0", cfg.zdim, 3, 3)
+        elif cfg.cp_depth >= 2:                        # (depth 0: nn.Identity, no parameters - network_blocks.py:76-77)
+            unit(d + ".velocity_field._op.0", cfg.zdim, cfg.n0)
+            for i in range(1, cfg.cp_depth - 1):
+                unit(d + f".velocity_field._op.{i}", cfg.n0, cfg.n0)
+            conv(d + f".velocity_field._op.{cfg.cp_depth - 1}", cfg.n0, 3, 1)
         sd[d + ".integrate.transformer.grid"] = identity_grid(sizes[k])
         sd[d + ".spatial_transform.grid"] = identity_grid(cfg.input_size if (l == 0 or cfg.df_resolution == "full_res") else sizes[k])
     return sd

@@ -374,29 +374,43 @@ PULPO_API int pulpo_avgpool2_bwd_add(const float* gout, int64_t gops, const floa
 
 // planar tensors: in (nplanes, Di, Hi, Wi) -> out (nplanes, Do, Ho, Wo); out = mult * interpolate(in) (+ add, nullable:
 // the DFAdder of src/network_blocks.py:152-158 fused into ResizeTransform)
-PULPO_API int pulpo_resize_trilinear_fwd(const float* in, const float* add, float* out, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-                                         float mult, void* stream) {
+// scale_*: source-coordinate step per output voxel along each axis; <= 0 selects in / out (what F.interpolate(size=...) uses).
+// F.interpolate(scale_factor=f) maps with 1 / f instead, whatever floor(in * f) came out as (ResizeTransform, network_blocks.py:138-149).
+PULPO_API int pulpo_resize_trilinear_scaled_fwd(const float* in, const float* add, float* out, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho,
+                                                int Wo, float scale_d, float scale_h, float scale_w, float mult, void* stream) {
     PULPO_REQUIRE(in && out && nplanes > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, "resize_fwd: bad arguments");
-    const float sd = (float)Di / (float)Do, sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+    const float sd = scale_d > 0.f ? scale_d : (float)Di / (float)Do, sh = scale_h > 0.f ? scale_h : (float)Hi / (float)Ho,
+                sw = scale_w > 0.f ? scale_w : (float)Wi / (float)Wo;
     hipLaunchKernelGGL(resize_fwd_kernel, dim3(eblocks(nplanes * Do * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, in, add, out, (long)nplanes, Di,
                        Hi, Wi, Do, Ho, Wo, sd, sh, sw, mult);
     return pulpo::check_launch("resize_fwd");
 }
 
-PULPO_API int pulpo_resize_trilinear_bwd(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo, float mult,
-                                         void* stream) {
+PULPO_API int pulpo_resize_trilinear_fwd(const float* in, const float* add, float* out, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                         float mult, void* stream) {
+    return pulpo_resize_trilinear_scaled_fwd(in, add, out, nplanes, Di, Hi, Wi, Do, Ho, Wo, 0.f, 0.f, 0.f, mult, stream);
+}
+
+PULPO_API int pulpo_resize_trilinear_scaled_bwd(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                                float scale_d, float scale_h, float scale_w, float mult, void* stream) {
     PULPO_REQUIRE(gout && gin && nplanes > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, "resize_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (Do == 2 * Di && Ho == 2 * Hi && Wo == 2 * Wi) {
+    const float sd = scale_d > 0.f ? scale_d : (float)Di / (float)Do, sh = scale_h > 0.f ? scale_h : (float)Hi / (float)Ho,
+                sw = scale_w > 0.f ? scale_w : (float)Wi / (float)Wo;
+    if (Do == 2 * Di && Ho == 2 * Hi && Wo == 2 * Wi && sd == 0.5f && sh == 0.5f && sw == 0.5f) {
         hipLaunchKernelGGL(resize_up2_bwd_kernel, dim3(eblocks(nplanes * Di * Hi * Wi)), dim3(256), 0, st, gout, gin, (long)nplanes, Di, Hi, Wi, mult);
         return pulpo::check_launch("resize_up2_bwd");
     }
     hipError_t e = hipMemsetAsync(gin, 0, sizeof(float) * nplanes * Di * Hi * Wi, st);
     if (e != hipSuccess) return pulpo::fail((int)e, "resize_bwd memset: %s", hipGetErrorString(e));
-    const float sd = (float)Di / (float)Do, sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
     hipLaunchKernelGGL(resize_bwd_atomic_kernel, dim3(eblocks(nplanes * Do * Ho * Wo)), dim3(256), 0, st, gout, gin, (long)nplanes, Di, Hi, Wi, Do,
                        Ho, Wo, sd, sh, sw, mult);
     return pulpo::check_launch("resize_bwd_atomic");
+}
+
+PULPO_API int pulpo_resize_trilinear_bwd(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo, float mult,
+                                         void* stream) {
+    return pulpo_resize_trilinear_scaled_bwd(gout, gin, nplanes, Di, Hi, Wi, Do, Ho, Wo, 0.f, 0.f, 0.f, mult, stream);
 }
 
 // srcs[i]: planar (B, chans[i], Di, Hi, Wi); out: channels-last (B, 2Di, 2Hi, 2Wi, sum chans) with pixel stride ops

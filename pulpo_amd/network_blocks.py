@@ -82,13 +82,15 @@ class ConvSequence(nn.Module):
 
 
 class MuSigmaBlock(nn.Module):
-    """two 1x1x1 convolutions C -> zdim; sigma = softplus (src/network_blocks.py:49-60)"""
+    """two 1x1x1 convolutions C -> zdim; sigma = softplus (src/network_blocks.py:49-60).  zdim == ndims (the reference model's setting,
+    models.py:88) is one launch of the fused head kernel; any other zdim runs the same kernel over groups of three latent channels."""
 
     def __init__(self, input_size: Sequence[int], in_channels: int, zdim: int) -> None:
         super().__init__()
         nd = _ndims(input_size, "MuSigmaBlock")
-        if zdim != nd:
-            raise NotImplementedError("MuSigmaBlock: the HIP head kernel produces zdim == ndims latents (the reference's setting, models.py:88)")
+        if zdim < 1:
+            raise ValueError("MuSigmaBlock: zdim >= 1 expected")
+        self.ndims, self.zdim = nd, zdim
         Conv = nn.Conv3d if nd == 3 else nn.Conv2d
         self._conv_mu = Conv(in_channels, zdim, kernel_size=1)
         self._conv_sigma = nn.Sequential(Conv(in_channels, zdim, kernel_size=1), nn.Softplus())
@@ -172,8 +174,9 @@ class ResizeTransform(nn.Module):
         """`add` (optional) is summed into the result inside the kernel (the DFAdder of the decoder)"""
         if self.factor == 1:
             return x if add is None else x + add
-        # scaling commutes with the (linear) interpolation: one kernel does both orders of the reference
-        return ops.resize_trilinear(x, self.out_size(x), self.factor, add)
+        # scaling commutes with the (linear) interpolation: one kernel does both orders of the reference (factor < 1: resize, then scale;
+        # factor > 1: scale, then resize - network_blocks.py:138-147); coordinates are mapped with 1 / factor, as F.interpolate(scale_factor=)
+        return ops.resize_trilinear(x, self.out_size(x), self.factor, add, scale_factor=self.factor)
 
 
 class DFAdder(nn.Module):

@@ -777,10 +777,12 @@ class _Heads(torch.autograd.Function):
 
 
 def mu_sigma_sample(h, w_mu, b_mu, w_sigma, b_sigma, eps):
-    """MuSigmaBlock + sampler: returns (mu, sigma, z) planar (B,3,D,H,W); eps=None -> z = mu.
-    w_*: (3, C, 1, 1, 1) conv weights (reference src/network_blocks.py:54-57)"""
-    C = w_mu.shape[1]
-    if _is2d(h):
+    """MuSigmaBlock + sampler: returns (mu, sigma, z) planar (B,zdim,D,H,W); eps=None -> z = mu.
+    w_*: (zdim, C, 1, 1, 1) conv weights (reference src/network_blocks.py:54-57).  zdim == 3 on volumes / 2 on slices (zdim = ndims,
+    models.py:88) is ONE launch of the head kernel; any other zdim runs it over groups of three latent channels, the last group padded with
+    zero rows (mu 0, sigma softplus(0), noise 0), which are dropped again."""
+    C, zdim = w_mu.shape[1], w_mu.shape[0]
+    if _is2d(h) and zdim == 2:
         # 2-D: two latent channels -> rows (0, mu_y, mu_x) / (0, sigma_y, sigma_x) of the three-channel head kernel; the padded channel
         # (mu 0, sigma softplus(0), noise 0 -> sample 0) is dropped again
         z1, zb = w_mu.new_zeros(1, C), b_mu.new_zeros(1)
@@ -788,6 +790,25 @@ def mu_sigma_sample(h, w_mu, b_mu, w_sigma, b_sigma, eps):
         bias = torch.cat([zb, b_mu, zb, b_sigma], dim=0)
         mu, sigma, z = _Heads.apply(_lift(h), Wt, bias, _lift_field(eps), 6)
         return _unlift_field(mu), _unlift_field(sigma), _unlift_field(z)
+    if zdim != 3 or _is2d(h):
+        two_d = _is2d(h)
+        h5 = _lift(h) if two_d else h
+        e5 = (_lift(eps) if two_d else eps) if eps is not None else None
+        mus, sigmas, zs = [], [], []
+        for c0 in range(0, zdim, 3):
+            n = min(3, zdim - c0)
+            pad_w, pad_b = w_mu.new_zeros(3 - n, C), b_mu.new_zeros(3 - n)
+            Wt = torch.cat([w_mu[c0:c0 + n].reshape(n, C), pad_w, w_sigma[c0:c0 + n].reshape(n, C), pad_w], dim=0)
+            bias = torch.cat([b_mu[c0:c0 + n], pad_b, b_sigma[c0:c0 + n], pad_b], dim=0)
+            eg = None
+            if e5 is not None:
+                eg = e5[:, c0:c0 + n]
+                if n < 3:
+                    eg = torch.cat([eg, eg.new_zeros((eg.shape[0], 3 - n) + tuple(eg.shape[2:]))], dim=1)
+            mu, sigma, z = _Heads.apply(h5, Wt, bias, eg, 6)
+            mus.append(mu[:, :n]); sigmas.append(sigma[:, :n]); zs.append(z[:, :n])
+        out = [torch.cat(t, dim=1) if len(t) > 1 else t[0].contiguous() for t in (mus, sigmas, zs)]
+        return tuple(o.squeeze(2) for o in out) if two_d else tuple(out)
     Wt = torch.cat([w_mu.reshape(3, C), w_sigma.reshape(3, C)], dim=0)
     bias = torch.cat([b_mu, b_sigma], dim=0)
     return _Heads.apply(h, Wt, bias, eps, 6, (((w_mu, 0, 3), (w_sigma, 3, 3)), ((b_mu, 0, 3), (b_sigma, 3, 3))))
@@ -904,7 +925,7 @@ def avg_pool2_skip(x):
 
 class _Resize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, size, mult: float, add):
+    def forward(ctx, x, size, mult: float, add, scale):
         _require_gpu(x, add)
         x = planar(x)
         B, C, Di, Hi, Wi = x.shape
@@ -912,10 +933,11 @@ class _Resize(torch.autograd.Function):
         out = torch.empty((B, C, Do, Ho, Wo), device=x.device, dtype=torch.float32)
         addc = planar(add) if add is not None else None
         t0 = _hbm_begin("resize_trilinear_fwd")
-        lib.call("pulpo_resize_trilinear_fwd", _ptr(x), _ptr(addc), _ptr(out), B * C, Di, Hi, Wi, Do, Ho, Wo, mult, _stream())
+        lib.call("pulpo_resize_trilinear_scaled_fwd", _ptr(x), _ptr(addc), _ptr(out), B * C, Di, Hi, Wi, Do, Ho, Wo, *scale, mult, _stream())
         _hbm_end(t0, "resize_trilinear_fwd", 4.0 * (x.numel() + out.numel() * (2 if addc is not None else 1)))
         ctx.dims = (B, C, Di, Hi, Wi, Do, Ho, Wo)
         ctx.mult = mult
+        ctx.scale = scale
         ctx.has_add = add is not None
         return out
 
@@ -927,16 +949,20 @@ class _Resize(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gin = torch.empty((B, C, Di, Hi, Wi), device=g.device, dtype=torch.float32)
             t0 = _hbm_begin("resize_trilinear_bwd")
-            lib.call("pulpo_resize_trilinear_bwd", _ptr(g), _ptr(gin), B * C, Di, Hi, Wi, Do, Ho, Wo, ctx.mult, _stream())
+            lib.call("pulpo_resize_trilinear_scaled_bwd", _ptr(g), _ptr(gin), B * C, Di, Hi, Wi, Do, Ho, Wo, *ctx.scale, ctx.mult, _stream())
             _hbm_end(t0, "resize_trilinear_bwd", 4.0 * (g.numel() + gin.numel()))
-        return gin, None, None, (g if ctx.has_add and ctx.needs_input_grad[3] else None)
+        return gin, None, None, (g if ctx.has_add and ctx.needs_input_grad[3] else None), None
 
 
-def resize_trilinear(x, size, mult: float = 1.0, add=None):
-    """mult * F.interpolate(x, size, 'trilinear', align_corners=False) (+ add)"""
+def resize_trilinear(x, size, mult: float = 1.0, add=None, scale_factor: Optional[float] = None):
+    """mult * F.interpolate(x, size, 'trilinear', align_corners=False) (+ add).  scale_factor: the call being replaced is
+    F.interpolate(x, scale_factor=...) - coordinates are then mapped with 1 / scale_factor on every axis instead of in / out (they differ
+    wherever in * scale_factor is not an integer); `size` is still the output size, floor(in * scale_factor)."""
     if _is2d(x):                                       # bilinear = trilinear over a depth-1 volume
-        return resize_trilinear(_lift(x), [1] + [int(v) for v in size], mult, _lift(add)).squeeze(2)
-    return _Resize.apply(x, tuple(int(s) for s in size), float(mult), add)
+        return resize_trilinear(_lift(x), [1] + [int(v) for v in size], mult, _lift(add), scale_factor).squeeze(2)
+    step = 0.0 if scale_factor is None else float(torch.tensor(1.0 / float(scale_factor), dtype=torch.float32))     # ATen: static_cast<float>(1.0 / scale)
+    scale = (0.0 if x.shape[2] == 1 and int(size[0]) == 1 else step, step, step)       # (the lifted depth axis of a slice keeps its identity mapping)
+    return _Resize.apply(x, tuple(int(s) for s in size), float(mult), add, scale)
 
 
 class _FeedbackUp2(torch.autograd.Function):

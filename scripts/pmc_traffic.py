@@ -40,7 +40,7 @@ def collect(d: str, counter: str):
 # guide, for 16 B/lane streams (every float4 kernel, the vectorised weight-gradient kernels).  The kernels that read 4 bytes per lane - the
 # scalar direct convolution of the 2-/3-channel input layers (conv3d_k3_mfma<2|4,...>), the planar-operand instantiations (<..., false>) and
 # the narrow-input weight gradient (wgrad_smallc) - were never calibrated: factor 1, i.e. their traffic figure is a LOWER bound.
-FETCH_FACTOR = [(re.compile(r"conv3d_k3_mfma<(2|4),|conv3d_k3_wgrad_smallc|conv3d_k3_\w+<[^>]*false>"), 1.0), (re.compile(r"conv3d_k3_"), 2.0)]
+FETCH_FACTOR = [(re.compile(r"conv3d_k3_mfma<(2|4),|conv3d_k3_wgrad_smallc|conv3d_k3_mfma<[^>]*false>|conv3d_k3_wino2_mfma<false|conv3d_k3_wgrad_mfma<false"), 1.0), (re.compile(r"conv3d_k3_"), 2.0)]
 
 
 def main():

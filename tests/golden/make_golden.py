@@ -252,12 +252,12 @@ def weight_dicts(T, L, ndims=3):
 class Step:
     """The reference's training_step assembled from its own component modules (no Lightning)."""
 
-    def __init__(self, T, L, size, n0, seed, df_resolution="level_res"):
+    def __init__(self, T, L, size, n0, seed, df_resolution="level_res", cp_depth=3):
         torch.manual_seed(seed)
         self.T, self.L = T, L
         nd = len(size)                           # 3 (volumes) or 2 (slices, train.py --ndims 2): zdim = ndims (models.py:88)
         self.down = cp.DownPath(T, L, list(size), 2, n0)
-        self.ae = cp.Autoencoder(nb.gauss_sampler, "SVF", T, L, nd, list(size), list(FEEDBACK), df_resolution, n0, 3)
+        self.ae = cp.Autoencoder(nb.gauss_sampler, "SVF", T, L, nd, list(size), list(FEEDBACK), df_resolution, n0, cp_depth)
         self.prior = cp.PULPoPrior()
         window, kl_w, rec_w, reg_w = weight_dicts(T, L, ndims=nd)
         if df_resolution == "full_res":          # models.py:112-115,123
@@ -309,8 +309,8 @@ class Step:
 OUT_NAMES = ["mus", "sigmas", "samples", "velocity_fields", "individual_dfs", "combined_dfs", "final_dfs", "transformed"]
 
 
-def gen_step(name, T, L, size, n0, B, seed, with_grads=True, smooth=False, df_resolution="level_res"):
-    st = Step(T, L, size, n0, seed, df_resolution)
+def gen_step(name, T, L, size, n0, B, seed, with_grads=True, smooth=False, df_resolution="level_res", cp_depth=3):
+    st = Step(T, L, size, n0, seed, df_resolution, cp_depth)
     g = torch.Generator().manual_seed(seed + 2)
     if smooth:
         y = smooth_volume(g, tuple(size), B)
@@ -705,8 +705,66 @@ def gen_models_api(df_resolution, T=3, L=2, size=(16, 16, 16), n0=2, seed=170):
     return float(total)
 
 
+# --------------------------------------------------------------------------- round 4: the corners of the operator surface
+def gen_round4():
+    """VelocityField depth 0 / 1 (network_blocks.py:70-79; depth 1 is an UNPADDED 3x3x3 convolution), ResizeTransform with factor < 1 and
+    with sizes where `scale_factor` and the size ratio disagree (network_blocks.py:138-149: F.interpolate(scale_factor=...) maps
+    coordinates with 1 / scale_factor, not with in / out), MuSigmaBlock with zdim != ndims (network_blocks.py:49-60), a VelocityField
+    fed by such a latent."""
+    g = torch.Generator().manual_seed(180)
+    out = {}
+
+    def with_grads(tag, module, x, extra_inputs=()):
+        x = x.clone().requires_grad_(True)
+        y = module(x)
+        up = torch.randn(y.shape, generator=g)
+        params = list(module.parameters())
+        grads = torch.autograd.grad((y * up).sum(), [x] + params)
+        out.update({f"{tag}.x": npy(x), f"{tag}.up": npy(up), f"{tag}.y": npy(y), f"{tag}.gx": npy(grads[0])})
+        out.update({f"{tag}.sd.{k}": npy(v) for k, v in module.state_dict().items()})
+        for (n, _), gr in zip(module.named_parameters(), grads[1:]):
+            out[f"{tag}.g.{n}"] = npy(gr)
+
+    torch.manual_seed(181)
+    with_grads("vf0", nb.VelocityField([9, 8, 10], 3, 8, 0), torch.randn(2, 3, 9, 8, 10, generator=g))
+    with_grads("vf1", nb.VelocityField([9, 8, 10], 3, 8, 1), torch.randn(2, 3, 9, 8, 10, generator=g))
+    with_grads("vf1_2d", nb.VelocityField([9, 8], 2, 8, 1), torch.randn(2, 2, 9, 8, generator=g))
+    with_grads("rs_half_even", nb.ResizeTransform(2, 3), torch.randn(1, 3, 12, 10, 8, generator=g))
+    with_grads("rs_half_odd", nb.ResizeTransform(2, 3), torch.randn(2, 3, 9, 7, 5, generator=g))
+    with_grads("rs_x1p5", nb.ResizeTransform(1 / 1.5, 3), torch.randn(1, 3, 5, 6, 7, generator=g))
+    with_grads("rs_x0p625", nb.ResizeTransform(1.6, 3), torch.randn(1, 3, 16, 8, 11, generator=g))
+    with_grads("rs_half_2d", nb.ResizeTransform(2, 2), torch.randn(1, 2, 9, 12, generator=g))
+    for zdim in (5, 1):
+        ms = nb.MuSigmaBlock([4, 5, 6], 8, zdim)
+        x = (torch.randn(2, 8, 4, 5, 6, generator=g) * 2).requires_grad_(True)
+        eps = torch.randn(2, zdim, 4, 5, 6, generator=g)
+        mu, sigma = ms(x)
+        z = mu + sigma * eps
+        up = torch.randn(2, zdim, 4, 5, 6, generator=g)
+        grads = torch.autograd.grad((z * up).sum() + (mu * mu).sum() + sigma.sum(), [x] + list(ms.parameters()))
+        t = f"ms{zdim}"
+        out.update({f"{t}.x": npy(x), f"{t}.eps": npy(eps), f"{t}.up": npy(up), f"{t}.mu": npy(mu), f"{t}.sigma": npy(sigma), f"{t}.z": npy(z),
+                    f"{t}.gx": npy(grads[0])})
+        out.update({f"{t}.sd.{k}": npy(v) for k, v in ms.state_dict().items()})
+        for (n, _), gr in zip(ms.named_parameters(), grads[1:]):
+            out[f"{t}.g.{n}"] = npy(gr)
+    vf = nb.VelocityField([4, 5, 6], 5, 8, 3)
+    vf.eval()
+    zz = torch.randn(1, 5, 4, 5, 6, generator=g)
+    out.update({"vf_z5.z": npy(zz), "vf_z5.y": npy(vf(zz))})
+    out.update({"vf_z5.sd." + k: npy(v) for k, v in vf.state_dict().items()})
+    save("blocks_r4", **out)
+
+
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "round4":
+        gen_round4()
+        # cp_depth = 0 (network_blocks.py:73-74: the latent sample IS the velocity field) through the whole step.  cp_depth = 1 cannot run
+        # in the reference's own model: the unpadded convolution shrinks the field by 2 voxels per axis and VecInt's grid no longer fits
+        t = gen_step("step_cp0_T3L2_n2_16", T=3, L=2, size=[16, 16, 16], n0=2, B=1, seed=190, cp_depth=0)
+        print("   total loss", t)
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "2d":
         gen_2d()
         raise SystemExit(0)

@@ -874,3 +874,70 @@ def test_unit_and_head_applied_twice_in_one_stepper_step(ops, pooled_second, mod
                 assert float((p.grad - want[k]).abs().max()) <= 1e-4 * max(wmax, 1e-6), (rep, k)
                 continue
             assert rel_l2(p.grad, want[k]) < 2e-5, (rep, k, rel_l2(p.grad, want[k]))
+
+
+def _load_block(block, g, tag):
+    sd = {k[len(tag) + 4:]: T(v.copy()) for k, v in g.items() if k.startswith(tag + ".sd.")}
+    block.load_state_dict(sd, strict=True)
+    return block.cuda()
+
+
+def test_velocity_field_depth_0_and_1_golden(ops, golden):
+    """VelocityField depth 0 (identity) and depth 1 (a bare, UNPADDED 3x3x3 convolution) - network_blocks.py:70-79 - against the
+    reference's own class (blocks_r4.npz), values and gradients, on volumes and on slices"""
+    import src.network_blocks as nb
+    g = golden("blocks_r4")
+    vf0 = nb.VelocityField([9, 8, 10], 3, 8, 0)
+    x = dev(g["vf0.x"]).requires_grad_(True)
+    y = vf0(x)
+    assert torch.equal(y.detach().cpu(), T(g["vf0.y"]))
+    gx, = torch.autograd.grad((y * dev(g["vf0.up"])).sum(), [x])
+    close(gx, g["vf0.gx"], atol=0)
+    for tag, size, zdim in (("vf1", [9, 8, 10], 3), ("vf1_2d", [9, 8], 2)):
+        vf = _load_block(nb.VelocityField(size, zdim, 8, 1), g, tag).train()
+        x = dev(g[tag + ".x"]).requires_grad_(True)
+        y = vf(x)
+        assert tuple(y.shape) == g[tag + ".y"].shape               # two voxels smaller along every axis
+        close(y, g[tag + ".y"], atol=3e-6)
+        grads = torch.autograd.grad((y * dev(g[tag + ".up"])).sum(), [x] + list(vf.parameters()))
+        close(grads[0], g[tag + ".gx"], atol=1e-5)
+        for (n, _), gr in zip(vf.named_parameters(), grads[1:]):
+            close(gr, g[f"{tag}.g.{n}"], atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag,vel,nd", [("rs_half_even", 2, 3), ("rs_half_odd", 2, 3), ("rs_x1p5", 1 / 1.5, 3), ("rs_x0p625", 1.6, 3), ("rs_half_2d", 2, 2)])
+def test_resize_transform_scale_factor_semantics_golden(ops, golden, tag, vel, nd):
+    """ResizeTransform (network_blocks.py:124-150) with factor < 1 (resize, then scale) and with sizes where floor(in * factor) is not
+    in * factor: F.interpolate(scale_factor=...) maps coordinates with 1 / factor there, not with in / out - against the reference's class"""
+    import src.network_blocks as nb
+    g = golden("blocks_r4")
+    rt = nb.ResizeTransform(vel, nd)
+    x = dev(g[tag + ".x"]).requires_grad_(True)
+    y = rt(x)
+    assert tuple(y.shape) == g[tag + ".y"].shape
+    close(y, g[tag + ".y"], atol=2e-6)
+    gx, = torch.autograd.grad((y * dev(g[tag + ".up"])).sum(), [x])
+    close(gx, g[tag + ".gx"], atol=1e-5)
+
+
+@pytest.mark.parametrize("zdim", [5, 1])
+def test_mu_sigma_block_with_zdim_other_than_ndims_golden(ops, golden, zdim):
+    """MuSigmaBlock(zdim != ndims) (network_blocks.py:49-60; the model itself always builds zdim = ndims, models.py:88, but the class is part
+    of the operator surface): values and every gradient against the reference's class; and a depth-3 VelocityField fed by a 5-channel latent"""
+    import src.network_blocks as nb
+    g = golden("blocks_r4")
+    t = f"ms{zdim}"
+    ms = _load_block(nb.MuSigmaBlock([4, 5, 6], 8, zdim), g, t)
+    x = dev(g[t + ".x"]).requires_grad_(True)
+    mu, sigma, z = ms.sample(x, dev(g[t + ".eps"]))
+    close(mu, g[t + ".mu"], atol=3e-6); close(sigma, g[t + ".sigma"], atol=3e-6); close(z, g[t + ".z"], atol=5e-6)
+    mu2, sigma2 = ms(x)
+    close(mu2, g[t + ".mu"], atol=3e-6); close(sigma2, g[t + ".sigma"], atol=3e-6)
+    grads = torch.autograd.grad((z * dev(g[t + ".up"])).sum() + (mu * mu).sum() + sigma.sum(), [x] + list(ms.parameters()))
+    close(grads[0], g[t + ".gx"], atol=2e-5)
+    for (n, _), gr in zip(ms.named_parameters(), grads[1:]):
+        close(gr, g[f"{t}.g.{n}"], atol=2e-4, rtol=1e-5)
+    if zdim == 5:
+        vf = _load_block(nb.VelocityField([4, 5, 6], 5, 8, 3), g, "vf_z5").eval()
+        with torch.no_grad():
+            close(vf(dev(g["vf_z5.z"])), g["vf_z5.y"], atol=3e-6)

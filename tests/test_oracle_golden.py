@@ -112,6 +112,28 @@ def test_mu_sigma_and_velocity_field(golden):
     close(O.velocity_field(T(g["vf_z"]), vsd, "v", 3, training=False), g["vf_out"], atol=2e-6)
 
 
+def test_operator_surface_corners_round4(golden):
+    """VelocityField depth 0 / 1 (network_blocks.py:70-79), ResizeTransform with factor < 1 and where scale_factor and the size ratio
+    disagree (:138-149), MuSigmaBlock with zdim != ndims (:49-60) - blocks_r4.npz, produced by the reference's own classes"""
+    g = golden("blocks_r4")
+    close(O.velocity_field(T(g["vf0.x"]), {}, "v", 0, training=True), g["vf0.y"], atol=0)
+    sd = {"v." + k[len("vf1.sd."):]: T(v.copy()) for k, v in g.items() if k.startswith("vf1.sd.")}
+    close(O.velocity_field(T(g["vf1.x"]), sd, "v", 1, training=True), g["vf1.y"], atol=2e-6)
+    for tag, vel in (("rs_half_even", 2), ("rs_half_odd", 2), ("rs_x1p5", 1 / 1.5), ("rs_x0p625", 1.6)):
+        x = T(g[tag + ".x"]).requires_grad_(True)
+        y = O.resize_field(x, vel)
+        close(y, g[tag + ".y"], atol=1e-6)
+        gx, = torch.autograd.grad((y * T(g[tag + ".up"])).sum(), [x])
+        close(gx, g[tag + ".gx"], atol=1e-5)
+    for zdim in (5, 1):
+        t = f"ms{zdim}"
+        sd = {"m." + k[len(t) + 4:]: T(v.copy()) for k, v in g.items() if k.startswith(t + ".sd.")}
+        mu, sg = O.mu_sigma(T(g[t + ".x"]), sd, "m")
+        close(mu, g[t + ".mu"]); close(sg, g[t + ".sigma"]); close(mu + sg * T(g[t + ".eps"]), g[t + ".z"])
+    vsd = {"v." + k[len("vf_z5.sd."):]: T(v.copy()) for k, v in g.items() if k.startswith("vf_z5.sd.")}
+    close(O.velocity_field(T(g["vf_z5.z"]), vsd, "v", 3, training=False), g["vf_z5.y"], atol=2e-6)
+
+
 # ------------------------------------------------------------------------------------------------ losses
 @pytest.mark.parametrize("w", [3, 5, 7, 9, 11])
 @pytest.mark.parametrize("kind", ["rand", "smooth"])
@@ -216,12 +238,12 @@ def test_unknown_feedback_item_raises():
 
 
 # ------------------------------------------------------------------------------------------------ full step
-STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16", "step_fullres_T3L2_n2_16", "step_T3L2_n8_32"]
+STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16", "step_fullres_T3L2_n2_16", "step_T3L2_n8_32", "step_cp0_T3L2_n2_16"]
 
 
 def _load_step(g, case=""):
     Tl, L, n0, B, *size = [int(v) for v in g["cfg"]]
-    cfg = O.Cfg(Tl, L, size, n0=n0, df_resolution="full_res" if "fullres" in case else "level_res")
+    cfg = O.Cfg(Tl, L, size, n0=n0, df_resolution="full_res" if "fullres" in case else "level_res", cp_depth=0 if "_cp0_" in case else 3)
     sd = O.init_state_dict(cfg)                       # supplies the (deterministic) grid buffers
     for k, v in g.items():
         if k.startswith("sd0."):
