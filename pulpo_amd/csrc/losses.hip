@@ -430,11 +430,12 @@ __global__ void weighted_sum_fwd_kernel(const float* __restrict__ t, const float
 __global__ void weighted_sum_bwd_kernel(const float* __restrict__ gtotal, const float* __restrict__ glevels, const float* __restrict__ w, int n, float scale,
                                         float* __restrict__ gt) {
     const int i = threadIdx.x;
-    // autograd's chain for total = (sum_i w_i t_i) * scale and level_i = (w_i t_i) * scale: every path is g * scale * w_i, the paths are added
+    // autograd's chain for v_i = w_i t_i, total = (sum_i v_i) * scale, level_i = v_i * scale: the two paths meet at v_i (their gradients,
+    // g_total * scale and g_level_i * scale, are ADDED there) and the sum goes through the product with w_i
     if (blockIdx.x == 0 && i < n) {
-        const float a = gtotal ? __fmul_rn(__fmul_rn(gtotal[0], scale), w[i]) : 0.f;
-        const float b = glevels ? __fmul_rn(__fmul_rn(glevels[i], scale), w[i]) : 0.f;
-        gt[i] = __fadd_rn(a, b);
+        const float a = gtotal ? __fmul_rn(gtotal[0], scale) : 0.f;
+        const float b = glevels ? __fmul_rn(glevels[i], scale) : 0.f;
+        gt[i] = __fmul_rn(__fadd_rn(a, b), w[i]);
     }
 }
 }  // namespace

@@ -800,7 +800,7 @@ def _assert_bn_buffers_follow_the_parameter_noise(model_named_buffers, bn_ref, p
             d = (v.detach() - bn_ref[k]).abs().cpu().numpy()
             db = param_delta[k.replace("_op.1.running_mean", "_op.0.bias")].cpu().numpy()
             dw = param_delta[k.replace("_op.1.running_mean", "_op.0.weight")].flatten(1).sum(1).cpu().numpy()
-            bound = momentum * (db + dw) + 1e-4 * np.abs(bn_ref[k].cpu().numpy()) + 5e-6
+            bound = momentum * (db + dw) + 1e-4 * np.abs(bn_ref[k].cpu().numpy()) + 1e-5        # (rounding of a 4e6-voxel mean, upstream layers' own noise)
             assert (d <= bound).all(), (k, float(d.max()), float(db.max()), float(dw.max()))
             worst = max(worst, float((d / bound).max()))
     return worst
@@ -839,26 +839,29 @@ def test_headline_160_stepper_and_lightning_hooks_equal_autograd(api):
         return m
 
     def snapshot(model):
+        """after the first step: gradients, BatchNorm buffers, the ConvUnit convolutions' parameters (moved once by Adam)"""
         return ({k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None},
-                {k: v.detach().clone() for k, v in model.named_buffers() if "running" in k})
+                {k: v.detach().clone() for k, v in model.named_buffers() if "running" in k},
+                {k: p.detach().clone() for k, p in model.named_parameters() if "_op.0." in k})
 
     # ---- A: plain autograd + torch.optim.Adam
     model = make()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     loss_a = model.training_step(batch, 0)
     loss_a.backward()
-    grads_a, bn_a1 = snapshot(model)
+    grads_a, bn_a1, _ = snapshot(model)
     opt.step()
+    par_a = {k: p.detach().clone() for k, p in model.named_parameters() if "_op.0." in k}
     opt.zero_grad(set_to_none=True)
     loss_a2 = model.training_step(batch, 0).detach()
     bn_a = {k: v.detach().clone() for k, v in model.named_buffers() if "running" in k}
-    par_a = {k: p.detach().clone() for k, p in model.named_parameters() if "_op.0." in k}
     torch.cuda.synchronize()
     l_a, l_a2 = float(loss_a), float(loss_a2)
     del model, opt, loss_a, loss_a2
     torch.cuda.empty_cache()
 
-    def compare(tag, model, l_1, grads, bn_1, l_2):
+    def compare(tag, model, l_1, first, l_2):
+        grads, bn_1, par_1 = first
         assert l_1 == l_a, (tag, l_1, l_a)
         worst = 0.0
         for k, ga in grads_a.items():
@@ -876,7 +879,7 @@ def test_headline_160_stepper_and_lightning_hooks_equal_autograd(api):
         np.testing.assert_allclose(l_2, l_a2, rtol=1e-5)
         for k, v in bn_1.items():                    # after ONE step: nothing but the forward pass has touched them
             np.testing.assert_allclose(v.cpu().numpy(), bn_a1[k].cpu().numpy(), rtol=1e-6, atol=1e-9, err_msg=f"{tag} {k}")
-        delta = {k: (p.detach() - par_a[k]).abs() for k, p in model.named_parameters() if "_op.0." in k}
+        delta = {k: (p - par_a[k]).abs() for k, p in par_1.items()}       # the parameters the SECOND forward pass ran on
         assert max(float(v.max()) for v in delta.values()) <= 2.0e-4 * 1.0001      # one Adam move of at most lr on either side
         ratio = _assert_bn_buffers_follow_the_parameter_noise(model.named_buffers(), bn_a, delta)
         print(f"{tag}: running means after two steps at most {ratio:.2f} of what the parameter noise allows")
@@ -887,10 +890,11 @@ def test_headline_160_stepper_and_lightning_hooks_equal_autograd(api):
     stepper = dp.DataParallelStepper(model, lr=1e-4)
     assert stepper.async_wgrad and ops.BN_REDUCE_IN_DGRAD, "default switches"
     l_b = float(stepper.step(batch))
-    grads_b, bn_b1 = snapshot(model)
+    first_b = snapshot(model)
     l_b2 = float(stepper.step(batch))
     torch.cuda.synchronize()
-    worst_b = compare("stepper", model, l_b, grads_b, bn_b1, l_b2)
+    worst_b = compare("stepper", model, l_b, first_b, l_b2)
+    grads_b = first_b[0]
     del model, stepper
     torch.cuda.empty_cache()
 
@@ -902,10 +906,11 @@ def test_headline_160_stepper_and_lightning_hooks_equal_autograd(api):
     l_c = float(trainer.run_batch(batch, 0))
     assert trainer.calls == ["on_train_batch_start", "optimizer_step", "training_step", "on_before_zero_grad", "optimizer_zero_grad",
                              "on_before_backward", "backward", "on_after_backward", "on_before_optimizer_step", "on_train_batch_end"]
-    grads_c, bn_c1 = snapshot(model)
+    first_c = snapshot(model)
     l_c2 = float(trainer.run_batch(batch, 1))
     torch.cuda.synchronize()
-    worst_c = compare("lightning-hooks", model, l_c, grads_c, bn_c1, l_c2)
+    worst_c = compare("lightning-hooks", model, l_c, first_c, l_c2)
+    grads_c = first_c[0]
     assert l_c == l_b
     for k, gb in grads_b.items():                   # B and C are the same kernels in the same order: atomic order is all that differs
         if float(gb.abs().max()) > 0.0 and not (k.endswith("_op.0.bias") and "velocity_field._op.2" not in k):
