@@ -291,6 +291,47 @@ int pulpo_mc_moments_std(const float* m2, const float* scale /*nullable (B,V)*/,
 int pulpo_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float gscale,
                     void* stream);
 
+/* ------------------------------------------------------------------------- bf16 ACTIVATION STORAGE (BASELINE configs 4-5; since ABI 3)
+ * No counterpart in the reference (fp32 throughout).  On top of the bf16-operand convolutions the multi-channel activation
+ * tensors of a ConvUnit - the pre-norm output y (src/network_blocks.py:23), the output z (:25), pooled / concatenated / up-sampled feature
+ * maps (components/pulpo.py:58, 195-206, 250) - and their gradients may live in HBM as bf16: every kernel below computes in fp32 and
+ * rounds to nearest even on the store; BatchNorm statistics describe the tensor AS STORED.  These are the typed forms of the entry points
+ * above: activation operands are `void*` with a dtype code (0 = fp32, 1 = bf16), strides in ELEMENTS, everything else (coefficients,
+ * partial sums, planar fields, parameters) stays fp32; with code 0 they are the fp32 entry points.  The convolution and weight-gradient
+ * kernels take operand and result in ONE storage type (dt). */
+int pulpo_conv3d_k3_fwd_bf16_t(const void* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias, void* out,
+                               int64_t out_bs, int64_t out_ps, int64_t out_cs, int dt, float* stats, float* scratch, int B, int D, int H, int W,
+                               int K, int N, void* stream);
+int pulpo_conv3d_k3_fwd_bn_lrelu_bf16_t(const void* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias,
+                                        const float* coef, float slope, void* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, int dt,
+                                        float* scratch, int B, int D, int H, int W, int K, int N, void* stream);
+int pulpo_conv3d_k3_wgrad_bf16_t(const void* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const void* dy, int64_t dy_bs, int64_t dy_ps,
+                                 int64_t dy_cs, int dt, float* dw, int accumulate, float* scratch, int B, int D, int H, int W, int Cin, int Cout,
+                                 void* stream);
+int pulpo_bn_lrelu_apply_t(const void* y, int y_dt, int64_t yps, void* z, int z_dt, int64_t zps, const float* coef, int64_t npix, int C, float slope,
+                           void* stream);
+int pulpo_bn_lrelu_apply_pool2_t(const void* y, int y_dt, int64_t yps, void* z, int z_dt, int64_t zps, void* pooled /* z's dtype */, int64_t pps,
+                                 const float* coef, int B, int D, int H, int W, int C, float slope, void* stream);
+int pulpo_bn_lrelu_bwd_reduce_t(const void* dz, int dz_dt, int64_t dzps, const void* y, int y_dt, int64_t yps, const float* coef, int64_t npix, int C,
+                                float slope, float* partial, void* stream);
+int pulpo_bn_lrelu_bwd_apply_t(const void* dz, int dz_dt, int64_t dzps, const void* y, int y_dt, int64_t yps, const float* coef, const double* totd,
+                               void* dy /* y's dtype */, int64_t dyps, int64_t npix, int C, float slope, float* partial2, void* stream);
+int pulpo_avgpool2_bwd_bnred_t(const void* gout, int64_t gops, const void* add, int64_t aps, void* gin, int64_t gips, int g_dt /* gout, add, gin */,
+                               const void* y, int y_dt, int64_t yps, const float* coef, float slope, float* partial, int B, int D, int H, int W,
+                               int C, void* stream);
+int pulpo_heads_fwd_t(const void* h, int h_dt, int64_t ps, const float* Wt, const float* bias, const float* eps, float* o0, float* o1, float* o2,
+                      int nout, int B, int64_t V, int C, void* stream);
+int pulpo_heads_bwd_t(const void* h, int h_dt, int64_t ps, const float* Wt, const float* g0, const float* g1, const float* g2, const float* eps,
+                      const float* sigma, void* dh /* h's dtype */, int64_t dps, float* partial, int nout, int B, int64_t V, int C, void* stream);
+int pulpo_avgpool2_fwd_t(const void* in, int64_t ips, void* out, int64_t ops, int dt, int B, int D, int H, int W, int C, void* stream);
+int pulpo_avgpool2_bwd_t(const void* gout, int64_t gops, const void* add /* nullable */, int64_t aps, void* gin, int64_t gips, int dt, int B, int D,
+                         int H, int W, int C, void* stream);
+int pulpo_feedback_up2_fwd_t(const float* const* srcs /*host array of device ptrs, planar fp32*/, const int* chans /*host*/, int nsrc, void* out,
+                             int dt, int64_t ops, int B, int Di, int Hi, int Wi, void* stream);
+int pulpo_feedback_up2_bwd_t(const void* gout, int dt, int64_t gops, float* const* gsrcs /*host array, entries may be NULL*/, const int* chans,
+                             int nsrc, int B, int Di, int Hi, int Wi, void* stream);
+
+
 #ifdef __cplusplus
 }
 #endif

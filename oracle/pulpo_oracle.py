@@ -90,10 +90,33 @@ def weight_tables(cfg: Cfg) -> Tuple[Dict[int, int], Dict[int, float], Dict[int,
 # gradient, weight gradient) takes its two operands rounded to bf16 (round-to-nearest-even) and accumulates in fp32;
 # GEMMs with <= 4 reduction channels (the image / latent inputs) stay fp32.  Everything else is fp32 as in the reference.
 CONV_PRECISION = "fp32"
+# bf16 ACTIVATION STORAGE (configs 4-5, on top of the bf16 operands; pulpo_amd.ops.ACT_BF16).  Also a definition ("parity unpinned"): the
+# multi-channel activation tensors are ROUNDED to bf16 where the product path stores them - a ConvUnit's pre-norm output y when the
+# bf16-operand kernel produces it (more than 4 reduction channels), every ConvUnit output z, pooled feature maps, the concatenated
+# up-sampled feedback - and so are the gradients that arrive at those tensors in the backward pass; all arithmetic in between is fp32
+# (BatchNorm statistics are those of y AS ROUNDED).  Images, latents, fields, losses, parameters and their gradients are never rounded.
+ACT_PRECISION = "fp32"
 
 
 def _rb(t: Tensor) -> Tensor:
     return t.bfloat16().to(t.dtype)
+
+
+class _StoreBf16(torch.autograd.Function):
+    """a tensor that lives in HBM as bf16: the value is rounded on the way forward, its gradient on the way back"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _rb(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rb(g)
+
+
+def stored(t: Tensor) -> Tensor:
+    """identity in fp32 storage; round-trip through bf16 (value and gradient) under ACT_PRECISION == 'bf16'"""
+    return _StoreBf16.apply(t) if (ACT_PRECISION == "bf16" and CONV_PRECISION == "bf16") else t
 
 
 class _ConvBf16Operands(torch.autograd.Function):
@@ -130,13 +153,15 @@ def conv_unit(h: Tensor, sd: Dict[str, Tensor], prefix: str, training: bool) -> 
     In training mode the running statistics in `sd` are updated in place, as nn.BatchNorm3d does."""
     w, b = sd[prefix + "._op.0.weight"], sd[prefix + "._op.0.bias"]
     h = conv3_k3(h, w, b)
+    if w.shape[1] > 4:
+        h = stored(h)                    # the pre-norm tensor y (fp32 behind the exact-fp32 kernel of the <= 4-channel input layers)
     rm, rv = sd[prefix + "._op.1.running_mean"], sd[prefix + "._op.1.running_var"]
     if training:
         nbt = sd.get(prefix + "._op.1.num_batches_tracked")
         if nbt is not None:
             nbt += 1
     h = F.batch_norm(h, rm, rv, sd[prefix + "._op.1.weight"], sd[prefix + "._op.1.bias"], training=training, momentum=0.1, eps=1e-5)
-    return F.leaky_relu(h, 0.2)
+    return stored(F.leaky_relu(h, 0.2))
 
 
 def conv_sequence(h: Tensor, sd, prefix: str, depth: int, training: bool) -> Tensor:
@@ -422,7 +447,7 @@ def down_path(sd, cfg: Cfg, x: Tensor, y: Tensor, training: bool, prefix: str = 
     h = torch.cat([x, y], dim=1)
     acts = {0: conv_sequence(h, sd, f"{prefix}.down_blocks.0", 3, training)}
     for k in range(1, cfg.total_levels):
-        acts[k] = conv_sequence(pool2(acts[k - 1]), sd, f"{prefix}.down_blocks.{k}", 3, training)
+        acts[k] = conv_sequence(stored(pool2(acts[k - 1])), sd, f"{prefix}.down_blocks.{k}", 3, training)
     return acts
 
 
@@ -468,7 +493,7 @@ def autoencoder(sd, cfg: Cfg, x: Tensor, acts: Dict[int, Tensor], eps: Optional[
                 if item not in OUT_NAMES:
                     raise ValueError(f"Feedback list contains {item}. Not a known option.")
                 fb.append(resize_to(out[item][l + 1], acts[k].shape[2:]))
-            up = conv_sequence(torch.cat(fb, dim=1), sd, f"{prefix}.up_blocks.{k}", 2, training)
+            up = conv_sequence(stored(torch.cat(fb, dim=1)), sd, f"{prefix}.up_blocks.{k}", 2, training)
             h = conv_sequence(torch.cat([up, acts[k]], dim=1), sd, enc + ".sample_merge_block", 2, training)
         mu, sg = mu_sigma(h, sd, enc + ".mu_sigma")
         if eps is None:

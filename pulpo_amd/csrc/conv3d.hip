@@ -14,6 +14,7 @@
 // gradient (conv3d_k3_wino2p_mfma / conv3d_k3_wino2_mfma) and F(2x2,3x3) / F(2,3) along x for the weight gradient
 // (conv3d_k3_wgrad_wino) - fewer matrix instructions, all arithmetic still fp32.
 #include "conv_shared.h"
+#include "act_io.h"
 #include <stdlib.h>
 
 namespace {
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(256, TZv == 4 ? 3 : 2) void conv3d_k3_mfma(ConvArgs
 
 // split-K finish: out = sum_s part[s] in fixed order (deterministic), plus the per-row (sum, sum of squares) BatchNorm partials.
 // Row r of stats covers voxels [r*V/nrow, (r+1)*V/nrow): any partition is fine for the double-precision finalize.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, float* __restrict__ out, long obs, long ops,
+template <typename TO = float>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, TO* __restrict__ out, long obs, long ops,
                                                               long ocs, int B, long V, int C, int nrow, float* __restrict__ stats,
                                                               const float* __restrict__ coef, float slope) {
     // grid = (nrow, ceil(C/32)): one workgroup per (voxel slice, 32-channel group); 32 channels x 8 voxel lanes
@@ -270,10 +272,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             for (int k = 0; k < ksplit; ++k) v += part[((long)k * npix + p) * C + c];
             const long b = p / V, vox = p - b * V;
             if (fuse) {
-                const float t = v * fsc + fsh;
+                const float t = pulpo::as_stored<TO>(v) * fsc + fsh;
                 v = t > 0.f ? t : t * slope;
             }
-            out[b * obs + vox * ops + (long)c * ocs] = v;
+            v = pulpo::as_stored<TO>(v);
+            float v1[1] = {v};
+            pulpo::stv<1>(out + b * obs + vox * ops + (long)c * ocs, v1);
             s += v;
             q += v * v;
         }
@@ -294,7 +298,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // channels-last, 16-byte aligned output with C % 4 == 0: four channels per lane (8 lanes x 16 bytes = one voxel's 128-byte line), 32 voxels
 // per pass, the slabs' loads of a pass independent of each other (the scalar kernel above walks 8 voxels per pass: at the 20^3 / 10^3
 // levels its 20 passes of dependent loads took 15 - 19 us per launch)
-__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ part, int ksplit, float* __restrict__ out, long obs, long ops,
+template <typename TO = float>
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ part, int ksplit, TO* __restrict__ out, long obs, long ops,
                                                                   int B, long V, int C, int nrow, float* __restrict__ stats,
                                                                   const float* __restrict__ coef, float slope) {
     __shared__ float4 red[2][256];
@@ -317,10 +322,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __r
             }
             const long b = p / V, vox = p - b * V;
             if (fuse) {
-                auto act = [&](float x, float sc, float sh) { const float t = x * sc + sh; return t > 0.f ? t : t * slope; };
+                auto act = [&](float x, float sc, float sh) { const float t = pulpo::as_stored<TO>(x) * sc + sh; return t > 0.f ? t : t * slope; };
                 v = make_float4(act(v.x, fsc.x, fsh.x), act(v.y, fsc.y, fsh.y), act(v.z, fsc.z, fsh.z), act(v.w, fsc.w, fsh.w));
             }
-            *reinterpret_cast<float4*>(out + b * obs + vox * ops + c) = v;
+            v = make_float4(pulpo::as_stored<TO>(v.x), pulpo::as_stored<TO>(v.y), pulpo::as_stored<TO>(v.z), pulpo::as_stored<TO>(v.w));
+            const float v4[4] = {v.x, v.y, v.z, v.w};
+            pulpo::stv<4>(out + b * obs + vox * ops + c, v4);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
         }
@@ -390,15 +397,21 @@ int pulpo_conv::conv_tz(int D, int H, int W) {
     return (D % 4 == 0 && (long)D * H * W >= 20L * 20 * 20) ? 4 : 2;
 }
 
-int pulpo_conv::launch_splitk_reduce(const float* part, int ksplit, float* out, long obs, long ops, long ocs, int B, long V, int C, int nrow,
-                                     float* stats, const float* coef, float slope, hipStream_t st) {
-    const bool vec = ocs == 1 && C % 4 == 0 && ops % 4 == 0 && obs % 4 == 0 && (((uintptr_t)out | (uintptr_t)part | (uintptr_t)stats | (uintptr_t)coef) & 15) == 0;
-    if (vec)
-        hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(nrow, pulpo::cdiv(C, 32)), dim3(256), 0, st, part, ksplit, out, obs, ops, B, V, C, nrow, stats,
-                           coef, slope);
-    else
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nrow, pulpo::cdiv(C, 32)), dim3(256), 0, st, part, ksplit, out, obs, ops, ocs, B, V, C, nrow, stats,
-                           coef, slope);
+int pulpo_conv::launch_splitk_reduce(const float* part, int ksplit, void* out, long obs, long ops, long ocs, int B, long V, int C, int nrow,
+                                     float* stats, const float* coef, float slope, hipStream_t st, int out_dt) {
+    const int eb = out_dt ? 2 : 4;
+    const bool vec = ocs == 1 && C % 4 == 0 && ops % 4 == 0 && obs % 4 == 0 && (((uintptr_t)part | (uintptr_t)stats | (uintptr_t)coef) & 15) == 0 &&
+                     ((uintptr_t)out % (4 * eb)) == 0;
+    const dim3 grid(nrow, pulpo::cdiv(C, 32));
+    if (out_dt) {
+        pulpo::bf16_t* o = (pulpo::bf16_t*)out;
+        if (vec) hipLaunchKernelGGL((splitk_reduce_vec_kernel<pulpo::bf16_t>), grid, dim3(256), 0, st, part, ksplit, o, obs, ops, B, V, C, nrow, stats, coef, slope);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<pulpo::bf16_t>), grid, dim3(256), 0, st, part, ksplit, o, obs, ops, ocs, B, V, C, nrow, stats, coef, slope);
+    } else {
+        float* o = (float*)out;
+        if (vec) hipLaunchKernelGGL((splitk_reduce_vec_kernel<float>), grid, dim3(256), 0, st, part, ksplit, o, obs, ops, B, V, C, nrow, stats, coef, slope);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<float>), grid, dim3(256), 0, st, part, ksplit, o, obs, ops, ocs, B, V, C, nrow, stats, coef, slope);
+    }
     return pulpo::check_launch("splitk_reduce");
 }
 

@@ -9,6 +9,7 @@
 // Same tiling, grid order, split-K and BatchNorm partial statistics as conv3d.hip; a 32-channel chunk per pass,
 // LDS tiles [voxel][32 + 8] bf16 (80-byte rows: 16-byte fragments, conflict-free ds_read_b128).
 #include "conv_shared.h"
+#include "act_io.h"
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -26,11 +27,11 @@ constexpr int CH = 32;            // channels per staged chunk = two K=16 MFMA s
 constexpr int CP = CH + 8;        // LDS row length in bf16 elements
 
 struct ConvArgsH {
-    const float* in;
+    const void* in;               // fp32 or bf16 (the kernel's T); strides in elements
     long in_bs, in_ps, in_cs;
     const uint16_t* wp;           // packed bf16 [nchunk][27][NPad][32]
     const float* bias;
-    float* out;
+    void* out;                    // same element type as `in`
     long out_bs, out_ps, out_cs;
     float* stats;
     int B, D, H, W, Cin, Cout, NPad;
@@ -49,11 +50,34 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 __device__ __forceinline__ int tap_halo_offset(int tap) { return ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3; }
 
 // stage the halo tile of channels [c0, c0+32) as bf16 into xs[HV][CP]; zero outside the volume / beyond Cin
-template <bool VEC, int TZv>
-__device__ __forceinline__ void stage_halo_bf16(uint16_t* xs, const float* __restrict__ in, long in_ps, long in_cs, int c0, int Cin, int z0, int y0,
+// T = pulpo::bf16_t: the tensor already holds bf16 - the vector path is one 16-byte load and one 16-byte LDS store per 8-channel piece
+template <bool VEC, int TZv, typename T>
+__device__ __forceinline__ void stage_halo_bf16(uint16_t* xs, const T* __restrict__ in, long in_ps, long in_cs, int c0, int Cin, int z0, int y0,
                                                 int x0, int D, int H, int W, int tid) {
     constexpr int HV = (TZv + 2) * HY * HX;
-    if constexpr (VEC) {
+    if constexpr (VEC && sizeof(T) == 2) {
+        constexpr int Q = CH / 8;
+        constexpr int NIT = (HV * Q + 255) / 256;
+        uint4 v[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int j = tid + u * 256;
+            const int hv = j / Q, q = j - hv * Q;
+            const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (j < HV * Q && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c0 + 8 * q < Cin)
+                v[u] = *reinterpret_cast<const uint4*>(in + ((long)(gz * H + gy) * W + gx) * in_ps + c0 + 8 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int j = tid + u * 256;
+            if (j < HV * Q) {
+                const int hv = j / Q, q = j - hv * Q;
+                *reinterpret_cast<uint4*>(xs + hv * CP + 8 * q) = v[u];
+            }
+        }
+    } else if constexpr (VEC) {
         constexpr int Q = CH / 8;                       // 8-channel pieces per voxel: two float4 in, one 16-byte LDS store out
         constexpr int NIT = (HV * Q + 255) / 256;
         float4 v[NIT][2];
@@ -86,18 +110,18 @@ __device__ __forceinline__ void stage_halo_bf16(uint16_t* xs, const float* __res
             const int hv = j / (CH / 2), c = 2 * (j - hv * (CH / 2));
             const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
             const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            float v0 = 0.f, v1 = 0.f;
+            float v0[1] = {0.f}, v1[1] = {0.f};
             if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-                const float* p = in + ((long)(gz * H + gy) * W + gx) * in_ps;
-                if (c0 + c < Cin) v0 = p[(long)(c0 + c) * in_cs];
-                if (c0 + c + 1 < Cin) v1 = p[(long)(c0 + c + 1) * in_cs];
+                const T* p = in + ((long)(gz * H + gy) * W + gx) * in_ps;
+                if (c0 + c < Cin) pulpo::ldv<1>(p + (long)(c0 + c) * in_cs, v0);
+                if (c0 + c + 1 < Cin) pulpo::ldv<1>(p + (long)(c0 + c + 1) * in_cs, v1);
             }
-            *reinterpret_cast<uint32_t*>(xs + hv * CP + c) = pack2(v0, v1);
+            *reinterpret_cast<uint32_t*>(xs + hv * CP + c) = pack2(v0[0], v1[0]);
         }
     }
 }
 
-template <int NT, bool VEC, int TZv>
+template <int NT, bool VEC, int TZv, typename T = float>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16(ConvArgsH a) {
     constexpr int NN = NT / 32;
     constexpr int MT = TZv / 2;
@@ -127,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16(ConvArgsH a) {
     const int chunk0 = split * cper, chunk1 = min(nchunk_all, chunk0 + cper);
     constexpr int NIT = 27 / TPB;                       // barrier iterations per chunk
     const int it0 = chunk0 * NIT, niter = chunk1 * NIT;
-    const float* in_b = a.in + (long)b * a.in_bs;
+    const T* in_b = reinterpret_cast<const T*>(a.in) + (long)b * a.in_bs;
 
     // weight slab of one tap: NT rows (cout) x 32 k bf16 = NT*4 pieces of 16 bytes; one piece per thread (NT = 64) or per low thread (NT = 32)
     const int wrow = tid >> 2, wpiece = tid & 3;
@@ -174,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16(ConvArgsH a) {
     int buf = 0, it = it0;
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
         __syncthreads();
-        stage_halo_bf16<VEC, TZv>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+        stage_halo_bf16<VEC, TZv, T>(xs, in_b, a.in_ps, a.in_cs, chunk * CH, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
         for (int itc = 0; itc < NIT; ++itc, ++it) {
             store_w(buf);
             __syncthreads();
@@ -209,8 +233,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16(ConvArgsH a) {
         }
     }
 
-    // ---- epilogue: bias, store, per-tile BatchNorm partial statistics (identical to the fp32 kernel)
-    float* out_b = a.out + (long)b * a.out_bs;
+    // ---- epilogue: bias, store, per-tile BatchNorm partial statistics (identical to the fp32 kernel).  bf16 output: neighbouring lanes hold
+    // neighbouring channels of one voxel - the even lane takes its neighbour's value (DPP) and stores both as one packed dword; the
+    // statistics describe the tensor as stored (rounded)
+    T* out_b = reinterpret_cast<T*>(a.out) + (long)b * a.out_bs;
+    constexpr bool HALF = sizeof(T) == 2;
+    const bool pair_ok = HALF && a.out_cs == 1 && (a.Cout & 1) == 0 && a.ksplit == 1;
     float ssum[NN], ssq[NN];
 #pragma unroll
     for (int n = 0; n < NN; ++n) {
@@ -227,17 +255,29 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16(ConvArgsH a) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
                 const int vv = (wave * MT + m) * 32 + row;
                 const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
-                if (cok && gz < a.D && gy < a.H && gx < a.W) {
-                    float val = acc[m][n][r] + bias;
-                    const long vox = (long)(gz * a.H + gy) * a.W + gx;
-                    if (a.ksplit > 1) a.part[(((long)split * a.B + b) * a.D * a.H * a.W + vox) * a.Cout + co] = val;
-                    else {
-                        if (fuse) {
-                            const float t = val * fsc + fsh;
-                            val = t > 0.f ? t : t * a.slope;
-                        }
-                        out_b[vox * a.out_ps + (long)co * a.out_cs] = val;
+                const bool inb = gz < a.D && gy < a.H && gx < a.W;
+                float val = acc[m][n][r] + bias;
+                if (a.ksplit == 1) {
+                    if (fuse) {
+                        const float t = pulpo::as_stored<T>(val) * fsc + fsh;        // (the pre-norm value as the unfused path would have stored it)
+                        val = t > 0.f ? t : t * a.slope;
                     }
+                    val = pulpo::as_stored<T>(val);
+                }
+                const long vox = (long)(gz * a.H + gy) * a.W + gx;
+                if constexpr (HALF) {
+                    const float nb = __shfl_xor(val, 1, 64);               // (all lanes take part)
+                    if (pair_ok) {
+                        if (cok && inb && (i & 1) == 0)
+                            *reinterpret_cast<uint32_t*>(out_b + vox * a.out_ps + co) = pulpo::pack_bf2(val, nb);
+                    } else if (cok && inb && a.ksplit == 1) {
+                        out_b[vox * a.out_ps + (long)co * a.out_cs] = pulpo::f2bf(val);
+                    }
+                } else {
+                    if (cok && inb && a.ksplit == 1) out_b[vox * a.out_ps + (long)co * a.out_cs] = val;
+                }
+                if (cok && inb) {
+                    if (a.ksplit > 1) a.part[(((long)split * a.B + b) * a.D * a.H * a.W + vox) * a.Cout + co] = val;
                     s += val;
                     q += val * val;
                 }
@@ -287,9 +327,9 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, uint16_t* _
 
 // ------------------------------------------------------------------------------------------------ weight gradient
 struct WgradArgsH {
-    const float* in;
+    const void* in;               // fp32 or bf16 (the kernel's T, shared by both operands); strides in elements
     long in_bs, in_ps, in_cs;
-    const float* dy;
+    const void* dy;
     long dy_bs, dy_ps, dy_cs;
     float* dwp;                   // zero-initialised fp32 scratch [27][Cin][NPad], accumulated with float atomics
     int B, D, H, W, Cin, Cout, NPad;
@@ -299,8 +339,8 @@ struct WgradArgsH {
 constexpr int WTZ = 2, WMV = WTZ * TY * TX, WHV = (WTZ + 2) * HY * HX;     // 2x8x8 voxel tiles: 8 K=16 steps (one x-row of voxels per half-wave)
 
 // stage `nvox` voxels x 32 channels [c0, c0+32) as bf16 into dst[nvox][CP]; voxel -> global coordinates through `coord`
-template <bool VEC, int NVOX, bool HALO>
-__device__ __forceinline__ void stage_tile_bf16(uint16_t* dst, const float* __restrict__ src, long ps, long cs, int c0, int C, int z0, int y0, int x0,
+template <bool VEC, int NVOX, bool HALO, typename T>
+__device__ __forceinline__ void stage_tile_bf16(uint16_t* dst, const T* __restrict__ src, long ps, long cs, int c0, int C, int z0, int y0, int x0,
                                                 int D, int H, int W, int tid) {
     auto coord = [&](int v, int& gz, int& gy, int& gx) {
         if constexpr (HALO) {
@@ -310,7 +350,29 @@ __device__ __forceinline__ void stage_tile_bf16(uint16_t* dst, const float* __re
             gz = z0 + (v >> 6); gy = y0 + ((v >> 3) & 7); gx = x0 + (v & 7);
         }
     };
-    if constexpr (VEC) {
+    if constexpr (VEC && sizeof(T) == 2) {
+        constexpr int Q = CH / 8;
+        constexpr int NIT = (NVOX * Q + 255) / 256;
+        uint4 v[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int j = tid + u * 256;
+            const int vv = j / Q, q = j - vv * Q;
+            int gz, gy, gx;
+            coord(vv, gz, gy, gx);
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (j < NVOX * Q && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c0 + 8 * q < C)
+                v[u] = *reinterpret_cast<const uint4*>(src + ((long)(gz * H + gy) * W + gx) * ps + c0 + 8 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int j = tid + u * 256;
+            if (j < NVOX * Q) {
+                const int vv = j / Q, q = j - vv * Q;
+                *reinterpret_cast<uint4*>(dst + vv * CP + 8 * q) = v[u];
+            }
+        }
+    } else if constexpr (VEC) {
         constexpr int Q = CH / 8;
         constexpr int NIT = (NVOX * Q + 255) / 256;
         float4 v[NIT][2];
@@ -343,13 +405,13 @@ __device__ __forceinline__ void stage_tile_bf16(uint16_t* dst, const float* __re
             const int vv = j / (CH / 2), c = 2 * (j - vv * (CH / 2));
             int gz, gy, gx;
             coord(vv, gz, gy, gx);
-            float v0 = 0.f, v1 = 0.f;
+            float v0[1] = {0.f}, v1[1] = {0.f};
             if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-                const float* p = src + ((long)(gz * H + gy) * W + gx) * ps;
-                if (c0 + c < C) v0 = p[(long)(c0 + c) * cs];
-                if (c0 + c + 1 < C) v1 = p[(long)(c0 + c + 1) * cs];
+                const T* p = src + ((long)(gz * H + gy) * W + gx) * ps;
+                if (c0 + c < C) pulpo::ldv<1>(p + (long)(c0 + c) * cs, v0);
+                if (c0 + c + 1 < C) pulpo::ldv<1>(p + (long)(c0 + c + 1) * cs, v1);
             }
-            *reinterpret_cast<uint32_t*>(dst + vv * CP + c) = pack2(v0, v1);
+            *reinterpret_cast<uint32_t*>(dst + vv * CP + c) = pack2(v0[0], v1[0]);
         }
     }
 }
@@ -366,7 +428,7 @@ __device__ __forceinline__ bf16x8 gather8(const uint16_t* p) {          // p[t *
     return __builtin_bit_cast(bf16x8, o);
 }
 
-template <int NTW, bool VEC>
+template <int NTW, bool VEC, typename T = float>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16(WgradArgsH a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_h[];
     uint16_t* xs = smem_h;                     // [WHV][CP]
@@ -407,8 +469,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16(WgradArgsH a) {
         const int b = t / a.ntz;
         const int z0 = tz_ * WTZ, y0 = ty_ * TY, x0 = tx_ * TX;
         __syncthreads();
-        stage_tile_bf16<VEC, WHV, true>(xs, a.in + (long)b * a.in_bs, a.in_ps, a.in_cs, ci0, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
-        stage_tile_bf16<VEC, WMV, false>(dys, a.dy + (long)b * a.dy_bs, a.dy_ps, a.dy_cs, co0, a.Cout, z0, y0, x0, a.D, a.H, a.W, tid);
+        stage_tile_bf16<VEC, WHV, true, T>(xs, reinterpret_cast<const T*>(a.in) + (long)b * a.in_bs, a.in_ps, a.in_cs, ci0, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
+        stage_tile_bf16<VEC, WMV, false, T>(dys, reinterpret_cast<const T*>(a.dy) + (long)b * a.dy_bs, a.dy_ps, a.dy_cs, co0, a.Cout, z0, y0, x0, a.D, a.H, a.W, tid);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < WMV / 16; ++ks) {
@@ -450,17 +512,17 @@ int conv_ksplit_bf16(int B, int D, int H, int W, int K, int N) {
     return (int)std::max<long>(1, std::min<long>(std::min(nchunk, 8), 1024 / nblk));
 }
 
-template <int NT, bool VEC, int TZv>
+template <int NT, bool VEC, int TZv, typename T>
 int launch_bf16(const ConvArgsH& a, int nblk, hipStream_t st) {
     constexpr size_t lds = (size_t)((TZv + 2) * HY * HX * CP + 2 * ((TZv == 4 && NT == 64) ? 3 : 1) * NT * CP) * sizeof(uint16_t);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma_bf16<NT, VEC, TZv>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma_bf16<NT, VEC, TZv, T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(conv3d bf16): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3d_k3_mfma_bf16<NT, VEC, TZv>), dim3(nblk), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3d_k3_mfma_bf16<NT, VEC, TZv, T>), dim3(nblk), dim3(256), lds, st, a);
     return pulpo::check_launch("conv3d_k3_mfma_bf16");
 }
 
@@ -487,12 +549,15 @@ PULPO_API int pulpo_conv3d_k3_fwd_bf16_stat_tiles(int B, int D, int H, int W) {
     return B * pulpo::cdiv(D, conv_tz(D, H, W)) * pulpo::cdiv(H, TY) * pulpo::cdiv(W, TX);
 }
 
-static int conv_fwd_bf16_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias, float* out,
-                              int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, const float* coef, float slope,
+// dt: dtype code of `in` AND `out` (0 fp32: the operands are rounded while they are staged; 1 bf16: activations are stored as bf16, the
+// result is rounded on the store and the BatchNorm partials describe it as stored); strides in elements
+static int conv_fwd_bf16_impl(const void* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias, void* out,
+                              int64_t out_bs, int64_t out_ps, int64_t out_cs, int dt, float* stats, float* scratch, const float* coef, float slope,
                               int B, int D, int H, int W, int K, int N, void* stream) {
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_bf16: null pointer");
     PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd_bf16: batch statistics are not available from the fused eval-mode epilogue");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && K > 0 && N > 0, "conv3d_k3_fwd_bf16: bad dims");
+    PULPO_REQUIRE_DT(dt, "conv3d_k3_fwd_bf16");
     ConvArgsH a;
     a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
     a.wp = wp; a.bias = bias;
@@ -509,41 +574,65 @@ static int conv_fwd_bf16_impl(const float* in, int64_t in_bs, int64_t in_ps, int
     a.part = scratch;
     PULPO_REQUIRE(a.ksplit == 1 || scratch != nullptr, "conv3d_k3_fwd_bf16: scratch of pulpo_conv3d_k3_fwd_bf16_scratch_floats() floats required");
     const int nblk = (int)nblk_l * a.ksplit;
-    const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0);
+    // vector staging: 16-byte pieces = 4 fp32 / 8 bf16 channels
+    const int g = dt ? 8 : 4;
+    const bool vec = (in_cs == 1) && (in_ps % g == 0) && (in_bs % g == 0) && (K % g == 0) && (((uintptr_t)in & 15) == 0);
+    if (dt) PULPO_REQUIRE(out_cs != 1 || (N & 1) || ((out_ps % 2 == 0) && (out_bs % 2 == 0) && (((uintptr_t)out & 3) == 0)),
+                          "conv3d_k3_fwd_bf16: bf16 channels-last output must be 4-byte aligned with even strides");
     hipStream_t st = (hipStream_t)stream;
     int rc;
-#define PULPO_BF16(NTV, VECV) (tz == 4 ? launch_bf16<NTV, VECV, 4>(a, nblk, st) : launch_bf16<NTV, VECV, 2>(a, nblk, st))
-    if (vec) rc = NT == 64 ? PULPO_BF16(64, true) : PULPO_BF16(32, true);
-    else rc = NT == 64 ? PULPO_BF16(64, false) : PULPO_BF16(32, false);
+#define PULPO_BF16(NTV, VECV, TT) (tz == 4 ? launch_bf16<NTV, VECV, 4, TT>(a, nblk, st) : launch_bf16<NTV, VECV, 2, TT>(a, nblk, st))
+#define PULPO_BF16_T(TT)                                                                          \
+    do {                                                                                          \
+        if (vec) rc = NT == 64 ? PULPO_BF16(64, true, TT) : PULPO_BF16(32, true, TT);             \
+        else rc = NT == 64 ? PULPO_BF16(64, false, TT) : PULPO_BF16(32, false, TT);               \
+    } while (0)
+    if (dt) PULPO_BF16_T(pulpo::bf16_t); else PULPO_BF16_T(float);
+#undef PULPO_BF16_T
 #undef PULPO_BF16
     if (rc == 0 && a.ksplit > 1)
         rc = pulpo_conv::launch_splitk_reduce(scratch, a.ksplit, out, (long)out_bs, (long)out_ps, (long)out_cs, B, (long)D * H * W, N,
-                                              pulpo_conv3d_k3_fwd_bf16_stat_tiles(B, D, H, W), stats, coef, slope, st);
+                                              pulpo_conv3d_k3_fwd_bf16_stat_tiles(B, D, H, W), stats, coef, slope, st, dt);
     return rc;
+}
+
+PULPO_API int pulpo_conv3d_k3_fwd_bf16_t(const void* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias, void* out,
+                                         int64_t out_bs, int64_t out_ps, int64_t out_cs, int dt, float* stats, float* scratch, int B, int D, int H,
+                                         int W, int K, int N, void* stream) {
+    return conv_fwd_bf16_impl(in, in_bs, in_ps, in_cs, wp, bias, out, out_bs, out_ps, out_cs, dt, stats, scratch, nullptr, 0.f, B, D, H, W, K, N,
+                              stream);
 }
 
 PULPO_API int pulpo_conv3d_k3_fwd_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias,
                                        float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, float* scratch, int B, int D,
                                        int H, int W, int K, int N, void* stream) {
-    return conv_fwd_bf16_impl(in, in_bs, in_ps, in_cs, wp, bias, out, out_bs, out_ps, out_cs, stats, scratch, nullptr, 0.f, B, D, H, W, K, N,
+    return conv_fwd_bf16_impl(in, in_bs, in_ps, in_cs, wp, bias, out, out_bs, out_ps, out_cs, 0, stats, scratch, nullptr, 0.f, B, D, H, W, K, N,
+                              stream);
+}
+
+PULPO_API int pulpo_conv3d_k3_fwd_bn_lrelu_bf16_t(const void* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp, const float* bias,
+                                                  const float* coef, float slope, void* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, int dt,
+                                                  float* scratch, int B, int D, int H, int W, int K, int N, void* stream) {
+    PULPO_REQUIRE(coef, "conv3d_k3_fwd_bn_lrelu_bf16: null coef");
+    return conv_fwd_bf16_impl(in, in_bs, in_ps, in_cs, wp, bias, out, out_bs, out_ps, out_cs, dt, nullptr, scratch, coef, slope, B, D, H, W, K, N,
                               stream);
 }
 
 PULPO_API int pulpo_conv3d_k3_fwd_bn_lrelu_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const uint16_t* wp,
                                                 const float* bias, const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps,
                                                 int64_t out_cs, float* scratch, int B, int D, int H, int W, int K, int N, void* stream) {
-    PULPO_REQUIRE(coef, "conv3d_k3_fwd_bn_lrelu_bf16: null coef");
-    return conv_fwd_bf16_impl(in, in_bs, in_ps, in_cs, wp, bias, out, out_bs, out_ps, out_cs, nullptr, scratch, coef, slope, B, D, H, W, K, N,
-                              stream);
+    return pulpo_conv3d_k3_fwd_bn_lrelu_bf16_t(in, in_bs, in_ps, in_cs, wp, bias, coef, slope, out, out_bs, out_ps, out_cs, 0, scratch, B, D, H, W, K,
+                                               N, stream);
 }
 
 /* weight gradient with bf16 operands: dw[Cout][Cin][27] (+)= sum_voxels bf16(in[v + tap - 1][ci]) * bf16(dy[v][co]), fp32 accumulation */
 PULPO_API size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
 
-PULPO_API int pulpo_conv3d_k3_wgrad_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
-                                         int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, int B, int D, int H, int W,
-                                         int Cin, int Cout, void* stream) {
+PULPO_API int pulpo_conv3d_k3_wgrad_bf16_t(const void* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const void* dy, int64_t dy_bs, int64_t dy_ps,
+                                           int64_t dy_cs, int dt, float* dw, int accumulate, float* scratch, int B, int D, int H, int W, int Cin,
+                                           int Cout, void* stream) {
     PULPO_REQUIRE(in && dy && scratch && (dw || accumulate == 2), "conv3d_k3_wgrad_bf16: null pointer");
+    PULPO_REQUIRE_DT(dt, "conv3d_k3_wgrad_bf16");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3d_k3_wgrad_bf16: bad dims");
     hipStream_t st = (hipStream_t)stream;
     WgradArgsH a;
@@ -568,20 +657,34 @@ PULPO_API int pulpo_conv3d_k3_wgrad_bf16(const float* in, int64_t in_bs, int64_t
         hipError_t e = hipMemsetAsync(scratch, 0, pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout) * sizeof(float), st);
         if (e != hipSuccess) return pulpo::fail((int)e, "wgrad_bf16 memset: %s", hipGetErrorString(e));
     }
-    const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)in & 15) == 0) &&
-                     (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
+    const int g = dt ? 8 : 4;             // channels per 16-byte piece
+    const bool vec = (in_cs == 1) && (in_ps % g == 0) && (in_bs % g == 0) && (Cin % g == 0) && (((uintptr_t)in & 15) == 0) &&
+                     (dy_cs == 1) && (dy_ps % g == 0) && (dy_bs % g == 0) && (Cout % g == 0) && (((uintptr_t)dy & 15) == 0);
     const int nrt_max = (27 * std::min(Cin, CH) + 31) / 32;
     const int ntw = (nrt_max + 3) / 4;
     constexpr size_t lds = (size_t)(WHV + WMV) * CP * sizeof(uint16_t);
     const int nblk = npair * a.nsplit;
-#define PULPO_WGRAD_H(NTWV, VECV) hipLaunchKernelGGL((conv3d_k3_wgrad_bf16<NTWV, VECV>), dim3(nblk), dim3(256), lds, st, a)
-    if (vec) {
-        if (ntw <= 1) PULPO_WGRAD_H(1, true); else if (ntw <= 2) PULPO_WGRAD_H(2, true); else if (ntw <= 4) PULPO_WGRAD_H(4, true); else PULPO_WGRAD_H(7, true);
-    } else {
-        if (ntw <= 1) PULPO_WGRAD_H(1, false); else if (ntw <= 2) PULPO_WGRAD_H(2, false); else if (ntw <= 4) PULPO_WGRAD_H(4, false); else PULPO_WGRAD_H(7, false);
-    }
+#define PULPO_WGRAD_H(NTWV, VECV, TT) hipLaunchKernelGGL((conv3d_k3_wgrad_bf16<NTWV, VECV, TT>), dim3(nblk), dim3(256), lds, st, a)
+#define PULPO_WGRAD_T(TT)                                                                                                                           \
+    do {                                                                                                                                            \
+        if (vec) {                                                                                                                                  \
+            if (ntw <= 1) PULPO_WGRAD_H(1, true, TT); else if (ntw <= 2) PULPO_WGRAD_H(2, true, TT); else if (ntw <= 4) PULPO_WGRAD_H(4, true, TT); \
+            else PULPO_WGRAD_H(7, true, TT);                                                                                                        \
+        } else {                                                                                                                                    \
+            if (ntw <= 1) PULPO_WGRAD_H(1, false, TT); else if (ntw <= 2) PULPO_WGRAD_H(2, false, TT);                                              \
+            else if (ntw <= 4) PULPO_WGRAD_H(4, false, TT); else PULPO_WGRAD_H(7, false, TT);                                                       \
+        }                                                                                                                                           \
+    } while (0)
+    if (dt) PULPO_WGRAD_T(pulpo::bf16_t); else PULPO_WGRAD_T(float);
+#undef PULPO_WGRAD_T
 #undef PULPO_WGRAD_H
     int rc = pulpo::check_launch("conv3d_k3_wgrad_bf16");
     if (rc || deferred) return rc;
     return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
+}
+
+PULPO_API int pulpo_conv3d_k3_wgrad_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
+                                         int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, int B, int D, int H, int W,
+                                         int Cin, int Cout, void* stream) {
+    return pulpo_conv3d_k3_wgrad_bf16_t(in, in_bs, in_ps, in_cs, dy, dy_bs, dy_ps, dy_cs, 0, dw, accumulate, scratch, B, D, H, W, Cin, Cout, stream);
 }

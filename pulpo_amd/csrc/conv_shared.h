@@ -19,8 +19,9 @@ __host__ __device__ inline int direct_ch(int K) { return K <= 2 ? 2 : K <= 4 ? 4
 
 // out = sum over the ksplit partial slabs (fixed order) + per-row BatchNorm partials; see splitk_reduce_kernel in conv3d.hip
 // (coef != nullptr: eval-mode BatchNorm + LeakyReLU applied to the reduced value, see ConvArgs::coef)
-int launch_splitk_reduce(const float* part, int ksplit, float* out, long obs, long ops, long ocs, int B, long V, int C, int nrow, float* stats,
-                         const float* coef, float slope, hipStream_t st);
+// (out_dt: dtype code of `out`, 0 fp32 / 1 bf16 - rounded on the store, the statistics describe the stored values)
+int launch_splitk_reduce(const float* part, int ksplit, void* out, long obs, long ops, long ocs, int B, long V, int C, int nrow, float* stats,
+                         const float* coef, float slope, hipStream_t st, int out_dt = 0);
 
 // dw[Cout][Cin][27] (+)= packed[27][Cin][NPad]; see unpack_wgrad_kernel in conv3d.hip
 int launch_unpack_wgrad(const float* packed, float* dw, int Cin, int Cout, int accumulate, hipStream_t st);

@@ -5,7 +5,7 @@
 // Input h is channels-last [pixel][C]; outputs are planar (B, 3, D*H*W) like the reference's tensors.
 // HBM-bound (reads C floats, writes 3-9 per voxel): 8 lanes share one voxel, each lane streams float4 channel
 // slices (one 128-byte line per voxel per step), partial dot products are combined with wave shuffles.
-#include "common.h"
+#include "act_io.h"
 
 namespace {
 
@@ -21,8 +21,8 @@ __device__ __forceinline__ float group_sum(float v) {
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
 // NOUT = 3: plain head.  NOUT = 6: rows 0-2 mu, rows 3-5 sigma pre-activation.
-template <int NOUT, bool VEC>
-__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ h, long ps, const float* __restrict__ Wt,
+template <int NOUT, bool VEC, typename TH = float>
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const TH* __restrict__ h, long ps, const float* __restrict__ Wt,
                                                           const float* __restrict__ bias, const float* __restrict__ eps, float* __restrict__ o0,
                                                           float* __restrict__ o1, float* __restrict__ o2, int B, long V, int C) {
     extern __shared__ float wl[];              // [NOUT][C]
@@ -38,19 +38,22 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) acc[j] = 0.f;
         if (live) {
-            const float* hp = h + p * ps;
+            const TH* hp = h + p * ps;
             if constexpr (VEC) {
                 for (int c = 4 * g; c < C; c += 4 * G) {
-                    const float4 x = *reinterpret_cast<const float4*>(hp + c);
+                    float x[4];
+                    pulpo::ldv<4>(hp + c, x);
 #pragma unroll
                     for (int j = 0; j < NOUT; ++j) {
                         const float* w = wl + j * C + c;
-                        acc[j] += x.x * w[0] + x.y * w[1] + x.z * w[2] + x.w * w[3];
+                        acc[j] += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
                     }
                 }
             } else {
                 for (int c = g; c < C; c += G) {
-                    const float x = hp[c];
+                    float x1[1];
+                    pulpo::ldv<1>(hp + c, x1);
+                    const float x = x1[0];
 #pragma unroll
                     for (int j = 0; j < NOUT; ++j) acc[j] += x * wl[j * C + c];
                 }
@@ -83,10 +86,10 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
 //   NOUT == 6 : dmu = g0 + g2 ; dsigma = g1 + g2 * eps ; dpre[3+j] = dsigma * (1 - exp(-sigma))   (softplus' = sigmoid)
 // outputs: dh[pixel][C] ;  partial[blk][NOUT*C + NOUT] = per-block sums for dW and db.
 // Thread (col,row) owns VEC channels and walks the block's pixels, so dW accumulates in NOUT*VEC registers.
-template <int NOUT, int VEC>
-__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ h, long ps, const float* __restrict__ Wt,
+template <int NOUT, int VEC, typename TH = float>
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const TH* __restrict__ h, long ps, const float* __restrict__ Wt,
                                                           const float* __restrict__ g0, const float* __restrict__ g1, const float* __restrict__ g2,
-                                                          const float* __restrict__ eps, const float* __restrict__ sigma, float* __restrict__ dh,
+                                                          const float* __restrict__ eps, const float* __restrict__ sigma, TH* __restrict__ dh,
                                                           long dps, float* __restrict__ partial, int B, long V, int C) {
     extern __shared__ float red[];             // [RB][NOUT*C + NOUT]
     const int CV = C / VEC, RB = blockDim.x / CV;
@@ -121,12 +124,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
                 }
             }
             float x[VEC], o[VEC];
-            if constexpr (VEC == 4) {
-                const float4 t = *reinterpret_cast<const float4*>(h + p * ps + c);
-                x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
-            } else {
-                x[0] = h[p * ps + c];
-            }
+            pulpo::ldv<VEC>(h + p * ps + c, x);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) o[k] = 0.f;
 #pragma unroll
@@ -135,8 +133,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) { o[k] += dpre[j] * w[j][k]; dw[j][k] += dpre[j] * x[k]; }
             }
-            if constexpr (VEC == 4) *reinterpret_cast<float4*>(dh + p * dps + c) = make_float4(o[0], o[1], o[2], o[3]);
-            else dh[p * dps + c] = o[0];
+            pulpo::stv<VEC>(dh + p * dps + c, o);
         }
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) {
@@ -157,23 +154,33 @@ inline int heads_blocks(long npix) { return (int)std::max<long>(1, std::min<long
 
 }  // namespace
 
-// Wt: [NOUT][C] (rows 0-2 = first conv, rows 3-5 = second conv for NOUT == 6); bias: [NOUT]
-PULPO_API int pulpo_heads_fwd(const float* h, int64_t ps, const float* Wt, const float* bias, const float* eps, float* o0, float* o1,
-                              float* o2, int nout, int B, int64_t V, int C, void* stream) {
+// Wt: [NOUT][C] (rows 0-2 = first conv, rows 3-5 = second conv for NOUT == 6); bias: [NOUT].  h_dt: dtype code of h (0 fp32, 1 bf16;
+// stride in elements); the outputs are planar fp32
+PULPO_API int pulpo_heads_fwd_t(const void* h, int h_dt, int64_t ps, const float* Wt, const float* bias, const float* eps, float* o0, float* o1,
+                                float* o2, int nout, int B, int64_t V, int C, void* stream) {
     PULPO_REQUIRE(h && Wt && bias && o0 && B > 0 && V > 0 && C > 0, "heads_fwd: bad arguments");
     PULPO_REQUIRE(nout == 3 || (nout == 6 && o1 && o2), "heads_fwd: nout must be 3 or 6");
+    PULPO_REQUIRE_DT(h_dt, "heads_fwd");
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = C % 4 == 0 && ps % 4 == 0 && (((uintptr_t)h) & 15) == 0;
+    const bool vec = C % 4 == 0 && ps % 4 == 0 && (((uintptr_t)h) % (h_dt ? 8 : 16)) == 0;
     const int nblk = heads_blocks((long)B * V);
     const size_t lds = (size_t)nout * C * sizeof(float);
-    if (nout == 3) {
-        if (vec) hipLaunchKernelGGL((heads_fwd_kernel<3, true>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, bias, eps, o0, o1, o2, B, V, C);
-        else hipLaunchKernelGGL((heads_fwd_kernel<3, false>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, bias, eps, o0, o1, o2, B, V, C);
-    } else {
-        if (vec) hipLaunchKernelGGL((heads_fwd_kernel<6, true>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, bias, eps, o0, o1, o2, B, V, C);
-        else hipLaunchKernelGGL((heads_fwd_kernel<6, false>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, bias, eps, o0, o1, o2, B, V, C);
-    }
+    PULPO_DISPATCH_DT(h_dt, TH, {
+        const TH* hp = (const TH*)h;
+        if (nout == 3) {
+            if (vec) hipLaunchKernelGGL((heads_fwd_kernel<3, true, TH>), dim3(nblk), dim3(256), lds, st, hp, ps, Wt, bias, eps, o0, o1, o2, B, V, C);
+            else hipLaunchKernelGGL((heads_fwd_kernel<3, false, TH>), dim3(nblk), dim3(256), lds, st, hp, ps, Wt, bias, eps, o0, o1, o2, B, V, C);
+        } else {
+            if (vec) hipLaunchKernelGGL((heads_fwd_kernel<6, true, TH>), dim3(nblk), dim3(256), lds, st, hp, ps, Wt, bias, eps, o0, o1, o2, B, V, C);
+            else hipLaunchKernelGGL((heads_fwd_kernel<6, false, TH>), dim3(nblk), dim3(256), lds, st, hp, ps, Wt, bias, eps, o0, o1, o2, B, V, C);
+        }
+    });
     return pulpo::check_launch("heads_fwd");
+}
+
+PULPO_API int pulpo_heads_fwd(const float* h, int64_t ps, const float* Wt, const float* bias, const float* eps, float* o0, float* o1,
+                              float* o2, int nout, int B, int64_t V, int C, void* stream) {
+    return pulpo_heads_fwd_t(h, 0, ps, Wt, bias, eps, o0, o1, o2, nout, B, V, C, stream);
 }
 
 PULPO_API int pulpo_heads_bwd_blocks(int B, int64_t V, int C) {
@@ -183,25 +190,36 @@ PULPO_API int pulpo_heads_bwd_blocks(int B, int64_t V, int C) {
     return (int)std::max<long>(1, std::min<long>((npix + RB * 8 - 1) / (RB * 8), 1024));
 }
 
-// partial: [pulpo_heads_bwd_blocks][nout*C + nout]; reduce with pulpo_colsum -> (dW[nout][C] | db[nout])
-PULPO_API int pulpo_heads_bwd(const float* h, int64_t ps, const float* Wt, const float* g0, const float* g1, const float* g2, const float* eps,
-                              const float* sigma, float* dh, int64_t dps, float* partial, int nout, int B, int64_t V, int C, void* stream) {
+// partial: [pulpo_heads_bwd_blocks][nout*C + nout]; reduce with pulpo_colsum -> (dW[nout][C] | db[nout]).  h and dh share the dtype h_dt.
+PULPO_API int pulpo_heads_bwd_t(const void* h, int h_dt, int64_t ps, const float* Wt, const float* g0, const float* g1, const float* g2,
+                                const float* eps, const float* sigma, void* dh, int64_t dps, float* partial, int nout, int B, int64_t V, int C,
+                                void* stream) {
     PULPO_REQUIRE(h && Wt && dh && partial && B > 0 && V > 0 && C > 0, "heads_bwd: bad arguments");
     PULPO_REQUIRE((nout == 3 && g0) || (nout == 6 && sigma), "heads_bwd: nout must be 3 (with g0) or 6 (with sigma)");
+    PULPO_REQUIRE_DT(h_dt, "heads_bwd");
     hipStream_t st = (hipStream_t)stream;
     const bool v4 = C % 4 == 0;
-    if (v4) PULPO_REQUIRE(ps % 4 == 0 && dps % 4 == 0 && ((((uintptr_t)h) | ((uintptr_t)dh)) & 15) == 0, "heads_bwd: unaligned operands");
+    if (v4) PULPO_REQUIRE(ps % 4 == 0 && dps % 4 == 0 && ((((uintptr_t)h) | ((uintptr_t)dh)) % (h_dt ? 8 : 16)) == 0, "heads_bwd: unaligned operands");
     PULPO_REQUIRE(C / (v4 ? 4 : 1) <= 256, "heads_bwd: too many channels");
     const int nblk = pulpo_heads_bwd_blocks(B, V, C);
     const int RB = std::max(1, 256 / (C / (v4 ? 4 : 1)));
     const size_t lds = (size_t)RB * (nout * C + nout) * sizeof(float);
     PULPO_REQUIRE(lds <= 64 * 1024, "heads_bwd: LDS budget exceeded");
-    if (nout == 3) {
-        if (v4) hipLaunchKernelGGL((heads_bwd_kernel<3, 4>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, g0, g1, g2, eps, sigma, dh, dps, partial, B, V, C);
-        else hipLaunchKernelGGL((heads_bwd_kernel<3, 1>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, g0, g1, g2, eps, sigma, dh, dps, partial, B, V, C);
-    } else {
-        if (v4) hipLaunchKernelGGL((heads_bwd_kernel<6, 4>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, g0, g1, g2, eps, sigma, dh, dps, partial, B, V, C);
-        else hipLaunchKernelGGL((heads_bwd_kernel<6, 1>), dim3(nblk), dim3(256), lds, st, h, ps, Wt, g0, g1, g2, eps, sigma, dh, dps, partial, B, V, C);
-    }
+    PULPO_DISPATCH_DT(h_dt, TH, {
+        const TH* hp = (const TH*)h;
+        TH* dhp = (TH*)dh;
+        if (nout == 3) {
+            if (v4) hipLaunchKernelGGL((heads_bwd_kernel<3, 4, TH>), dim3(nblk), dim3(256), lds, st, hp, ps, Wt, g0, g1, g2, eps, sigma, dhp, dps, partial, B, V, C);
+            else hipLaunchKernelGGL((heads_bwd_kernel<3, 1, TH>), dim3(nblk), dim3(256), lds, st, hp, ps, Wt, g0, g1, g2, eps, sigma, dhp, dps, partial, B, V, C);
+        } else {
+            if (v4) hipLaunchKernelGGL((heads_bwd_kernel<6, 4, TH>), dim3(nblk), dim3(256), lds, st, hp, ps, Wt, g0, g1, g2, eps, sigma, dhp, dps, partial, B, V, C);
+            else hipLaunchKernelGGL((heads_bwd_kernel<6, 1, TH>), dim3(nblk), dim3(256), lds, st, hp, ps, Wt, g0, g1, g2, eps, sigma, dhp, dps, partial, B, V, C);
+        }
+    });
     return pulpo::check_launch("heads_bwd");
+}
+
+PULPO_API int pulpo_heads_bwd(const float* h, int64_t ps, const float* Wt, const float* g0, const float* g1, const float* g2, const float* eps,
+                              const float* sigma, float* dh, int64_t dps, float* partial, int nout, int B, int64_t V, int C, void* stream) {
+    return pulpo_heads_bwd_t(h, 0, ps, Wt, g0, g1, g2, eps, sigma, dh, dps, partial, nout, B, V, C, stream);
 }

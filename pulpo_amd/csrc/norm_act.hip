@@ -3,7 +3,7 @@
 // All kernels are HBM-bound streaming passes over channels-last [pixel][C] activations (pixel stride explicit,
 // so a channel slice of a concatenation buffer is a valid operand).  Reductions are two-stage and deterministic:
 // per-block fp32 partials, then a double-precision column sum.
-#include "common.h"
+#include "act_io.h"
 
 namespace {
 
@@ -131,28 +131,17 @@ __global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float
     cd[C + c] = 1.0 / sqrt((double)rv[c] + (double)eps);
 }
 
+// Vec<VEC>::ld / st on FLOAT arrays (coefficient blocks, LDS tables); activation tensors go through pulpo::ldv / stv (act_io.h), which
+// also read and write bf16 storage
 template <int VEC>
-struct Vec;
-template <>
-struct Vec<4> {
-    using T = float4;
-    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
-    static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-};
-template <>
-struct Vec<1> {
-    static __device__ __forceinline__ void ld(const float* p, float (&v)[1]) { v[0] = *p; }
-    static __device__ __forceinline__ void st(float* p, const float (&v)[1]) { *p = v[0]; }
+struct Vec {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[VEC]) { pulpo::ldv<VEC>(p, v); }
+    static __device__ __forceinline__ void st(float* p, const float (&v)[VEC]) { pulpo::stv<VEC>(p, v); }
 };
 
 // z = leaky_relu(y * scale[c] + shift[c])
-template <int VEC>
-__global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(const float* __restrict__ y, long yps, float* __restrict__ z, long zps,
+template <int VEC, typename TY = float, typename TZ = float>
+__global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(const TY* __restrict__ y, long yps, TZ* __restrict__ z, long zps,
                                                                const float* __restrict__ coef, long npix, int C, float slope) {
     const int CV = C / VEC;
     const long total = npix * CV;
@@ -162,7 +151,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(const float* __rest
         const long p = e / CV;
         const int c = (int)(e - p * CV) * VEC;
         float v[VEC], sc[VEC], sh[VEC];
-        Vec<VEC>::ld(y + p * yps + c, v);
+        pulpo::ldv<VEC>(y + p * yps + c, v);
         Vec<VEC>::ld(scale + c, sc);
         Vec<VEC>::ld(shift + c, sh);
 #pragma unroll
@@ -170,15 +159,16 @@ __global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(const float* __rest
             const float t = v[k] * sc[k] + sh[k];
             v[k] = t > 0.f ? t : t * slope;
         }
-        Vec<VEC>::st(z + p * zps + c, v);
+        pulpo::stv<VEC>(z + p * zps + c, v);
     }
 }
 
 // z = leaky_relu(y * scale + shift) AND pooled = AvgPool3d(2, 2, ceil_mode)(z) in one pass (the last ConvUnit of an encoder level: its
 // output is pooled for the next level, components/pulpo.py:58): a thread owns one pooled voxel x four channels, i.e. up to eight voxels of
 // y / z; same expressions and the same summation order (z, y, x) as bn_lrelu_apply_kernel followed by avgpool2_fwd_kernel.
-__global__ __launch_bounds__(256) void bn_lrelu_apply_pool2_kernel(const float* __restrict__ y, long yps, float* __restrict__ z, long zps,
-                                                                     float* __restrict__ pooled, long pps, const float* __restrict__ coef, int B,
+template <typename TY = float, typename TZ = float>
+__global__ __launch_bounds__(256) void bn_lrelu_apply_pool2_kernel(const TY* __restrict__ y, long yps, TZ* __restrict__ z, long zps,
+                                                                     TZ* __restrict__ pooled, long pps, const float* __restrict__ coef, int B,
                                                                      int D, int H, int W, int Do, int Ho, int Wo, int C, float slope) {
     const int CV = C / 4;
     const long total = (long)B * Do * Ho * Wo * CV;
@@ -192,20 +182,27 @@ __global__ __launch_bounds__(256) void bn_lrelu_apply_pool2_kernel(const float* 
         const int oz = (int)(p % Do);
         const int b = (int)(p / Do);
         const int z1 = min(2 * oz + 2, D), y1 = min(2 * oy + 2, H), x1 = min(2 * ox + 2, W);
-        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sc[4], sh[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+        Vec<4>::ld(scale + c, sc);
+        Vec<4>::ld(shift + c, sh);
         for (int zz = 2 * oz; zz < z1; ++zz)
             for (int yy = 2 * oy; yy < y1; ++yy)
                 for (int xx = 2 * ox; xx < x1; ++xx) {
                     const long vox = (((long)b * D + zz) * H + yy) * W + xx;
-                    const float4 v = *reinterpret_cast<const float4*>(y + vox * yps + c);
-                    auto act = [&](float a, float s_, float h_) { const float t = a * s_ + h_; return t > 0.f ? t : t * slope; };
-                    const float4 r = make_float4(act(v.x, sc.x, sh.x), act(v.y, sc.y, sh.y), act(v.z, sc.z, sh.z), act(v.w, sc.w, sh.w));
-                    *reinterpret_cast<float4*>(z + vox * zps + c) = r;
-                    acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+                    float v[4];
+                    pulpo::ldv<4>(y + vox * yps + c, v);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float t = v[k] * sc[k] + sh[k];
+                        v[k] = pulpo::as_stored<TZ>(t > 0.f ? t : t * slope);        // (the pooled tensor averages z as stored)
+                        acc[k] += v[k];
+                    }
+                    pulpo::stv<4>(z + vox * zps + c, v);
                 }
         const float inv = 1.f / (float)((z1 - 2 * oz) * (y1 - 2 * oy) * (x1 - 2 * ox));   // ceil_mode: divisor = in-bounds taps
-        *reinterpret_cast<float4*>(pooled + ((((long)b * Do + oz) * Ho + oy) * Wo + ox) * pps + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] *= inv;
+        pulpo::stv<4>(pooled + ((((long)b * Do + oz) * Ho + oy) * Wo + ox) * pps + c, acc);
     }
 }
 
@@ -217,17 +214,18 @@ __global__ __launch_bounds__(256) void bn_lrelu_apply_pool2_kernel(const float* 
 // POOL: dz is not read but PRODUCED here - the gradient of an activation that was pooled (gpool: gradient of the pooled tensor, spread over
 // each 2 x 2 x 2 window with the ceil-mode divisor, the arithmetic of avgpool2_bwd_kernel) and possibly also used as a skip connection
 // (add, nullable) - and written to dzout on the way: the pooling backward, autograd's accumulation and this reduction in one pass.
+template <typename TG>
 struct PoolGrad {
-    const float* gpool; long gpps;
-    const float* add; long aps;
-    float* dzout; long dzops;
+    const TG* gpool; long gpps;
+    const TG* add; long aps;
+    TG* dzout; long dzops;
     int D, H, W, Do, Ho, Wo;
 };
 
-template <int VEC, bool POOL = false>
-__global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* __restrict__ dz, long dzps, const float* __restrict__ y,
+template <int VEC, bool POOL = false, typename TG = float, typename TY = float>
+__global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const TG* __restrict__ dz, long dzps, const TY* __restrict__ y,
                                                                     long yps, const float* __restrict__ coef, long npix, int C,
-                                                                    float slope, float* __restrict__ partial, PoolGrad pg = PoolGrad{}) {
+                                                                    float slope, float* __restrict__ partial, PoolGrad<TG> pg = PoolGrad<TG>{}) {
     extern __shared__ float red[];                 // [RB][2][C]
     const int CV = C / VEC, RB = blockDim.x / CV;
     const int col = threadIdx.x % CV, row = threadIdx.x / CV;
@@ -251,20 +249,22 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* _
                 const int oz = z_ >> 1, oy = y_ >> 1, ox = x_ >> 1;
                 const int cnt = (min(2 * oz + 2, pg.D) - 2 * oz) * (min(2 * oy + 2, pg.H) - 2 * oy) * (min(2 * ox + 2, pg.W) - 2 * ox);
                 const float inv = 1.f / (float)cnt;
-                Vec<VEC>::ld(pg.gpool + (((b_ * pg.Do + oz) * pg.Ho + oy) * pg.Wo + ox) * pg.gpps + c, g);
+                pulpo::ldv<VEC>(pg.gpool + (((b_ * pg.Do + oz) * pg.Ho + oy) * pg.Wo + ox) * pg.gpps + c, g);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) g[k] *= inv;
                 if (pg.add != nullptr) {
                     float u[VEC];
-                    Vec<VEC>::ld(pg.add + p * pg.aps + c, u);
+                    pulpo::ldv<VEC>(pg.add + p * pg.aps + c, u);
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) g[k] = u[k] + g[k];
                 }
-                Vec<VEC>::st(pg.dzout + p * pg.dzops + c, g);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) g[k] = pulpo::as_stored<TG>(g[k]);     // (the sums describe the gradient as stored)
+                pulpo::stv<VEC>(pg.dzout + p * pg.dzops + c, g);
             } else {
-                Vec<VEC>::ld(dz + p * dzps + c, g);
+                pulpo::ldv<VEC>(dz + p * dzps + c, g);
             }
-            Vec<VEC>::ld(y + p * yps + c, v);
+            pulpo::ldv<VEC>(y + p * yps + c, v);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float bn = v[k] * sc[k] + sh[k];
@@ -295,10 +295,10 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float* _
 // bits, the (y - m32) factor is centred (a rounding of B does not shift the channel) and everything else rounds without bias.
 // The six per-channel constants live in LDS and are read per element group (6 ds_read_b128 against 48 bytes of HBM traffic): the kernel
 // then needs ~40 instead of 71 registers, i.e. two waves instead of one fit on a SIMD beside the weight-gradient kernel.
-template <int VEC>
-__global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __restrict__ dz, long dzps, const float* __restrict__ y,
+template <int VEC, typename TG = float, typename TY = float>
+__global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const TG* __restrict__ dz, long dzps, const TY* __restrict__ y,
                                                                    long yps, const float* __restrict__ coef, const double* __restrict__ totd,
-                                                                   float* __restrict__ dy, long dyps, long npix, int C,
+                                                                   TY* __restrict__ dy, long dyps, long npix, int C,
                                                                    float slope, float* __restrict__ partial2) {
     extern __shared__ float red[];                 // [RB][C] partial sums, then [6][C] constants: scale, shift, m32, B, C hi, C lo
     const int CV = C / VEC, RB = blockDim.x / CV;
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __
     if (row < RB) {
         for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
             float g[VEC], v[VEC], o[VEC];
-            Vec<VEC>::ld(dz + p * dzps + c, g);
-            Vec<VEC>::ld(y + p * yps + c, v);
+            pulpo::ldv<VEC>(dz + p * dzps + c, g);
+            pulpo::ldv<VEC>(y + p * yps + c, v);
             int cl = c;                                 // (opaque: the constants are to be READ here every time, not kept in registers)
             asm volatile("" : "+v"(cl));
             // three stages, each with its own constants, so that no more than three constant vectors are live at a time
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float* __
                     s0[k] += o[k];
                 }
             }
-            Vec<VEC>::st(dy + p * dyps + c, o);
+            pulpo::stv<VEC>(dy + p * dyps + c, o);
         }
 #pragma unroll
         for (int k = 0; k < VEC; ++k) red[row * C + c + k] = s0[k];
@@ -463,29 +463,59 @@ PULPO_API int pulpo_bn_eval_coef(const float* gamma, const float* beta, const fl
     return pulpo::check_launch("bn_eval_coef");
 }
 
-PULPO_API int pulpo_bn_lrelu_apply(const float* y, int64_t yps, float* z, int64_t zps, const float* coef, int64_t npix, int C, float slope,
-                                   void* stream) {
-    PULPO_REQUIRE(y && z && coef && npix > 0 && C > 0, "bn_lrelu_apply: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    if (vec_ok(y, yps, z, zps, C) && (((uintptr_t)coef & 15) == 0))
-        hipLaunchKernelGGL(bn_lrelu_apply_kernel<4>, dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope);
+// ---- typed entry points: activation tensors are fp32 (dtype code 0) or bf16 (1) in HBM, strides in ELEMENTS; arithmetic is fp32 either way.
+// The untyped names below them are the fp32 forms.
+namespace {
+template <typename TY, typename TZ>
+int apply_t(const TY* y, long yps, TZ* z, long zps, const float* coef, long npix, int C, float slope, hipStream_t st) {
+    pulpo::GroupProbe g(C);
+    g.add(y, yps, sizeof(TY)); g.add(z, zps, sizeof(TZ)); g.add(coef, 8, 4);
+    constexpr bool half = sizeof(TY) == 2 || sizeof(TZ) == 2;
+    if (half && g.ok8)
+        hipLaunchKernelGGL((bn_lrelu_apply_kernel<8, TY, TZ>), dim3(stream_blocks(npix * (C / 8))), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope);
+    else if (g.ok4)
+        hipLaunchKernelGGL((bn_lrelu_apply_kernel<4, TY, TZ>), dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope);
     else
-        hipLaunchKernelGGL(bn_lrelu_apply_kernel<1>, dim3(stream_blocks(npix * C)), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope);
+        hipLaunchKernelGGL((bn_lrelu_apply_kernel<1, TY, TZ>), dim3(stream_blocks(npix * C)), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope);
     return pulpo::check_launch("bn_lrelu_apply");
 }
+}  // namespace
 
-// 1 when pulpo_bn_lrelu_apply_pool2 accepts the operands (float4 path: C % 4 == 0, 16-byte aligned rows)
+PULPO_API int pulpo_bn_lrelu_apply_t(const void* y, int y_dt, int64_t yps, void* z, int z_dt, int64_t zps, const float* coef, int64_t npix, int C,
+                                     float slope, void* stream) {
+    PULPO_REQUIRE(y && z && coef && npix > 0 && C > 0, "bn_lrelu_apply: bad arguments");
+    PULPO_REQUIRE_DT(y_dt, "bn_lrelu_apply"); PULPO_REQUIRE_DT(z_dt, "bn_lrelu_apply");
+    PULPO_DISPATCH_DT(y_dt, TY, PULPO_DISPATCH_DT(z_dt, TZ, return apply_t((const TY*)y, (long)yps, (TZ*)z, (long)zps, coef, (long)npix, C, slope, (hipStream_t)stream)));
+    return -1;
+}
+
+PULPO_API int pulpo_bn_lrelu_apply(const float* y, int64_t yps, float* z, int64_t zps, const float* coef, int64_t npix, int C, float slope,
+                                   void* stream) {
+    return pulpo_bn_lrelu_apply_t(y, 0, yps, z, 0, zps, coef, npix, C, slope, stream);
+}
+
+// 1 when pulpo_bn_lrelu_apply_pool2 accepts the operands (groups of four channels: C % 4 == 0, strides % 4 == 0)
 PULPO_API int pulpo_bn_lrelu_apply_pool2_ok(int C, int64_t yps, int64_t zps, int64_t pps) { return C % 4 == 0 && yps % 4 == 0 && zps % 4 == 0 && pps % 4 == 0; }
+
+PULPO_API int pulpo_bn_lrelu_apply_pool2_t(const void* y, int y_dt, int64_t yps, void* z, int z_dt, int64_t zps, void* pooled, int64_t pps,
+                                           const float* coef, int B, int D, int H, int W, int C, float slope, void* stream) {
+    PULPO_REQUIRE(y && z && pooled && coef && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bn_lrelu_apply_pool2: bad arguments");
+    PULPO_REQUIRE_DT(y_dt, "bn_lrelu_apply_pool2"); PULPO_REQUIRE_DT(z_dt, "bn_lrelu_apply_pool2");
+    const int ey = y_dt ? 2 : 4, ez = z_dt ? 2 : 4;
+    PULPO_REQUIRE(pulpo_bn_lrelu_apply_pool2_ok(C, yps, zps, pps) && (((uintptr_t)y) % (4 * ey)) == 0 && ((((uintptr_t)z) | ((uintptr_t)pooled)) % (4 * ez)) == 0 &&
+                      (((uintptr_t)coef) & 15) == 0,
+                  "bn_lrelu_apply_pool2: operands must be channels-last, aligned to four elements, C %% 4 == 0");
+    const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int nb = stream_blocks((long)B * Do * Ho * Wo * (C / 4));
+    PULPO_DISPATCH_DT(y_dt, TY, PULPO_DISPATCH_DT(z_dt, TZ,
+        hipLaunchKernelGGL((bn_lrelu_apply_pool2_kernel<TY, TZ>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const TY*)y, (long)yps, (TZ*)z, (long)zps,
+                           (TZ*)pooled, (long)pps, coef, B, D, H, W, Do, Ho, Wo, C, slope)));
+    return pulpo::check_launch("bn_lrelu_apply_pool2");
+}
 
 PULPO_API int pulpo_bn_lrelu_apply_pool2(const float* y, int64_t yps, float* z, int64_t zps, float* pooled, int64_t pps, const float* coef, int B, int D,
                                          int H, int W, int C, float slope, void* stream) {
-    PULPO_REQUIRE(y && z && pooled && coef && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bn_lrelu_apply_pool2: bad arguments");
-    PULPO_REQUIRE(pulpo_bn_lrelu_apply_pool2_ok(C, yps, zps, pps) && ((((uintptr_t)y) | ((uintptr_t)z) | ((uintptr_t)pooled) | ((uintptr_t)coef)) & 15) == 0,
-                  "bn_lrelu_apply_pool2: operands must be channels-last, 16-byte aligned, C %% 4 == 0");
-    const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    hipLaunchKernelGGL(bn_lrelu_apply_pool2_kernel, dim3(stream_blocks((long)B * Do * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, (long)yps, z,
-                       (long)zps, pooled, (long)pps, coef, B, D, H, W, Do, Ho, Wo, C, slope);
-    return pulpo::check_launch("bn_lrelu_apply_pool2");
+    return pulpo_bn_lrelu_apply_pool2_t(y, 0, yps, z, 0, zps, pooled, pps, coef, B, D, H, W, C, slope, stream);
 }
 
 // number of partial rows the two backward passes write (caller allocates partial[nblk][2C] and partial2[nblk][C])
@@ -495,39 +525,99 @@ PULPO_API int pulpo_bn_bwd_blocks(int64_t npix, int C) {
     return (int)std::max<long>(1, std::min<long>((npix + RB * 8 - 1) / (RB * 8), 2048));
 }
 
+namespace {
+// channel-group width of a backward pass: 8 when a bf16 tensor takes part and everything allows it, else 4, else 1 (-1: misaligned)
+inline int bwd_group(const pulpo::GroupProbe& g, bool half, int C) {
+    if (half && g.ok8 && C / 8 <= 256) return 8;
+    if (g.ok4) return C / 4 <= 256 ? 4 : -2;
+    if (C % 4 == 0) return -1;
+    return C <= 256 ? 1 : -2;
+}
+
+template <typename TG, typename TY>
+int reduce_t(const TG* dz, long dzps, const TY* y, long yps, const float* coef, long npix, int C, float slope, float* partial, hipStream_t st) {
+    pulpo::GroupProbe g(C);
+    g.add(dz, dzps, sizeof(TG)); g.add(y, yps, sizeof(TY)); g.add(coef, 8, 4);
+    const int vec = bwd_group(g, sizeof(TG) == 2 || sizeof(TY) == 2, C);
+    if (vec == -1) return pulpo::fail(-1, "bn_lrelu_bwd_reduce: operands must be aligned to four elements when C %% 4 == 0");
+    if (vec == -2) return pulpo::fail(-1, "bn_lrelu_bwd_reduce: too many channels (%d)", C);
+    const int nblk = pulpo_bn_bwd_blocks(npix, C);
+    const int RB = std::max(1, 256 / (C / vec));
+    const size_t lds = (size_t)RB * 2 * C * sizeof(float);
+    if (vec == 8) hipLaunchKernelGGL((bn_lrelu_bwd_reduce_kernel<8, false, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, npix, C, slope, partial, PoolGrad<TG>{});
+    else if (vec == 4) hipLaunchKernelGGL((bn_lrelu_bwd_reduce_kernel<4, false, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, npix, C, slope, partial, PoolGrad<TG>{});
+    else hipLaunchKernelGGL((bn_lrelu_bwd_reduce_kernel<1, false, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, npix, C, slope, partial, PoolGrad<TG>{});
+    return pulpo::check_launch("bn_lrelu_bwd_reduce");
+}
+
+template <typename TG, typename TY>
+int pool_reduce_t(const TG* gout, long gops, const TG* add, long aps, TG* gin, long gips, const TY* y, long yps, const float* coef, float slope,
+                  float* partial, int B, int D, int H, int W, int C, hipStream_t st) {
+    const long npix = (long)B * D * H * W;
+    const int nblk = pulpo_bn_bwd_blocks(npix, C);
+    const int RB = std::max(1, 256 / (C / 4));
+    const size_t lds = (size_t)RB * 2 * C * sizeof(float);
+    PoolGrad<TG> pg{gout, gops, add, aps, gin, gips, D, H, W, (D + 1) / 2, (H + 1) / 2, (W + 1) / 2};
+    hipLaunchKernelGGL((bn_lrelu_bwd_reduce_kernel<4, true, TG, TY>), dim3(nblk), dim3(256), lds, st, (const TG*)nullptr, 0L, y, yps, coef, npix, C, slope,
+                       partial, pg);
+    return pulpo::check_launch("avgpool2_bwd_bnred");
+}
+
+template <typename TG, typename TY>
+int bwd_apply_t(const TG* dz, long dzps, const TY* y, long yps, const float* coef, const double* totd, TY* dy, long dyps, long npix, int C, float slope,
+                float* partial2, hipStream_t st) {
+    pulpo::GroupProbe g(C);
+    g.add(dz, dzps, sizeof(TG)); g.add(y, yps, sizeof(TY)); g.add(dy, dyps, sizeof(TY)); g.add(coef, 8, 4);
+    const int vec = bwd_group(g, sizeof(TG) == 2 || sizeof(TY) == 2, C);
+    if (vec == -1) return pulpo::fail(-1, "bn_lrelu_bwd_apply: operands must be aligned to four elements when C %% 4 == 0");
+    if (vec == -2) return pulpo::fail(-1, "bn_lrelu_bwd_apply: too many channels (%d)", C);
+    const int nblk = pulpo_bn_bwd_blocks(npix, C);
+    const int RB = std::max(1, 256 / (C / vec));
+    const size_t lds = (size_t)(RB + 6) * C * sizeof(float);
+    if (vec == 8) hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<8, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2);
+    else if (vec == 4) hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<4, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2);
+    else hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<1, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2);
+    return pulpo::check_launch("bn_lrelu_bwd_apply");
+}
+}  // namespace
+
+PULPO_API int pulpo_bn_lrelu_bwd_reduce_t(const void* dz, int dz_dt, int64_t dzps, const void* y, int y_dt, int64_t yps, const float* coef, int64_t npix,
+                                          int C, float slope, float* partial, void* stream) {
+    PULPO_REQUIRE(dz && y && coef && partial && npix > 0 && C > 0, "bn_lrelu_bwd_reduce: bad arguments");
+    PULPO_REQUIRE_DT(dz_dt, "bn_lrelu_bwd_reduce"); PULPO_REQUIRE_DT(y_dt, "bn_lrelu_bwd_reduce");
+    PULPO_DISPATCH_DT(dz_dt, TG, PULPO_DISPATCH_DT(y_dt, TY,
+        return reduce_t((const TG*)dz, (long)dzps, (const TY*)y, (long)yps, coef, (long)npix, C, slope, partial, (hipStream_t)stream)));
+    return -1;
+}
+
 PULPO_API int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, int64_t npix, int C,
                                         float slope, float* partial, void* stream) {
-    PULPO_REQUIRE(dz && y && coef && partial && npix > 0 && C > 0, "bn_lrelu_bwd_reduce: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    const bool v4 = vec_ok(dz, dzps, y, yps, C) && (((uintptr_t)coef & 15) == 0);
-    PULPO_REQUIRE(C / (C % 4 == 0 ? 4 : 1) <= 256, "bn_lrelu_bwd_reduce: too many channels (%d)", C);
-    const int nblk = pulpo_bn_bwd_blocks(npix, C);
-    if (C % 4 == 0 && !v4) return pulpo::fail(-1, "bn_lrelu_bwd_reduce: operands must be 16-byte aligned when C %% 4 == 0");
-    const int RB = std::max(1, 256 / (C / (v4 ? 4 : 1)));
-    const size_t lds = (size_t)RB * 2 * C * sizeof(float);
-    if (v4) hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<4>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, npix, C, slope, partial);
-    else hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, npix, C, slope, partial);
-    return pulpo::check_launch("bn_lrelu_bwd_reduce");
+    return pulpo_bn_lrelu_bwd_reduce_t(dz, 0, dzps, y, 0, yps, coef, npix, C, slope, partial, stream);
 }
 
 // gin = (add +) avgpool2_bwd(gout) AND the first pass of the BatchNorm / LeakyReLU backward of the ConvUnit whose output was pooled (y, coef:
 // that unit's pre-norm tensor and coefficient block): partial rows as pulpo_bn_lrelu_bwd_reduce writes them (same voxel-to-row assignment,
 // same sums).  The last unit of every encoder level (components/pulpo.py:58): its gradient is read once instead of written, read, read.
-// Channels-last float4 operands only (C % 4 == 0, 16-byte aligned rows); add nullable.
+// Channels-last operands in groups of four channels only (C % 4 == 0, rows aligned to four elements); add nullable.  gout / add / gin share
+// one dtype (g_dt), y has its own.
+PULPO_API int pulpo_avgpool2_bwd_bnred_t(const void* gout, int64_t gops, const void* add, int64_t aps, void* gin, int64_t gips, int g_dt, const void* y,
+                                         int y_dt, int64_t yps, const float* coef, float slope, float* partial, int B, int D, int H, int W, int C,
+                                         void* stream) {
+    PULPO_REQUIRE(gout && gin && y && coef && partial && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "avgpool2_bwd_bnred: bad arguments");
+    PULPO_REQUIRE_DT(g_dt, "avgpool2_bwd_bnred"); PULPO_REQUIRE_DT(y_dt, "avgpool2_bwd_bnred");
+    const int eg = g_dt ? 8 : 16, ey = y_dt ? 8 : 16;
+    PULPO_REQUIRE(C % 4 == 0 && C / 4 <= 256 && gops % 4 == 0 && gips % 4 == 0 && yps % 4 == 0 && (add == nullptr || aps % 4 == 0) &&
+                      ((((uintptr_t)gout) | ((uintptr_t)gin) | ((uintptr_t)add)) % eg) == 0 && (((uintptr_t)y) % ey) == 0 && (((uintptr_t)coef) & 15) == 0,
+                  "avgpool2_bwd_bnred: operands must be channels-last, aligned to four elements, C %% 4 == 0");
+    PULPO_DISPATCH_DT(g_dt, TG, PULPO_DISPATCH_DT(y_dt, TY,
+        return pool_reduce_t((const TG*)gout, (long)gops, (const TG*)add, (long)aps, (TG*)gin, (long)gips, (const TY*)y, (long)yps, coef, slope, partial, B, D,
+                             H, W, C, (hipStream_t)stream)));
+    return -1;
+}
+
 PULPO_API int pulpo_avgpool2_bwd_bnred(const float* gout, int64_t gops, const float* add, int64_t aps, float* gin, int64_t gips, const float* y,
                                        int64_t yps, const float* coef, float slope, float* partial, int B, int D, int H, int W, int C, void* stream) {
-    PULPO_REQUIRE(gout && gin && y && coef && partial && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "avgpool2_bwd_bnred: bad arguments");
-    PULPO_REQUIRE(C % 4 == 0 && C / 4 <= 256 && gops % 4 == 0 && gips % 4 == 0 && yps % 4 == 0 && (add == nullptr || aps % 4 == 0) &&
-                      ((((uintptr_t)gout) | ((uintptr_t)gin) | ((uintptr_t)y) | ((uintptr_t)coef) | ((uintptr_t)add)) & 15) == 0,
-                  "avgpool2_bwd_bnred: operands must be channels-last, 16-byte aligned, C %% 4 == 0");
-    const long npix = (long)B * D * H * W;
-    const int nblk = pulpo_bn_bwd_blocks(npix, C);
-    const int RB = std::max(1, 256 / (C / 4));
-    const size_t lds = (size_t)RB * 2 * C * sizeof(float);
-    PoolGrad pg{gout, (long)gops, add, (long)aps, gin, (long)gips, D, H, W, (D + 1) / 2, (H + 1) / 2, (W + 1) / 2};
-    hipLaunchKernelGGL((bn_lrelu_bwd_reduce_kernel<4, true>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, nullptr, 0L, y, (long)yps, coef, npix, C, slope,
-                       partial, pg);
-    return pulpo::check_launch("avgpool2_bwd_bnred");
+    return pulpo_avgpool2_bwd_bnred_t(gout, gops, add, aps, gin, gips, 0, y, 0, yps, coef, slope, partial, B, D, H, W, C, stream);
 }
 
 // dbeta / dgamma: [C] each, written (accumulate = 0) or added to (accumulate = 1, e.g. the parameters' .grad storage).
@@ -556,18 +646,18 @@ PULPO_API int pulpo_bn_bwd_finalize(const float* tile_part, int ntile, int C, co
     return pulpo::check_launch("bn_bwd_finalize");
 }
 
+// dy has y's dtype (the unit's pre-norm tensor and its gradient are stored alike); dz has its own
+PULPO_API int pulpo_bn_lrelu_bwd_apply_t(const void* dz, int dz_dt, int64_t dzps, const void* y, int y_dt, int64_t yps, const float* coef,
+                                         const double* totd, void* dy, int64_t dyps, int64_t npix, int C, float slope, float* partial2, void* stream) {
+    PULPO_REQUIRE(dz && y && coef && totd && dy && partial2 && npix > 0 && C > 0, "bn_lrelu_bwd_apply: bad arguments");
+    PULPO_REQUIRE_DT(dz_dt, "bn_lrelu_bwd_apply"); PULPO_REQUIRE_DT(y_dt, "bn_lrelu_bwd_apply");
+    PULPO_DISPATCH_DT(dz_dt, TG, PULPO_DISPATCH_DT(y_dt, TY,
+        return bwd_apply_t((const TG*)dz, (long)dzps, (const TY*)y, (long)yps, coef, totd, (TY*)dy, (long)dyps, (long)npix, C, slope, partial2,
+                           (hipStream_t)stream)));
+    return -1;
+}
+
 PULPO_API int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd, float* dy,
                                        int64_t dyps, int64_t npix, int C, float slope, float* partial2, void* stream) {
-    PULPO_REQUIRE(dz && y && coef && totd && dy && partial2 && npix > 0 && C > 0, "bn_lrelu_bwd_apply: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    const bool v4 = vec_ok(dz, dzps, y, yps, C) && vec_ok(dy, dyps, coef, 4, C);
-    if (C % 4 == 0 && !v4) return pulpo::fail(-1, "bn_lrelu_bwd_apply: operands must be 16-byte aligned when C %% 4 == 0");
-    const int nblk = pulpo_bn_bwd_blocks(npix, C);
-    const int RB = std::max(1, 256 / (C / (v4 ? 4 : 1)));
-    const size_t lds = (size_t)(RB + 6) * C * sizeof(float);
-    if (v4)
-        hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel<4>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2);
-    else
-        hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel<1>, dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2);
-    return pulpo::check_launch("bn_lrelu_bwd_apply");
+    return pulpo_bn_lrelu_bwd_apply_t(dz, 0, dzps, y, 0, yps, coef, totd, dy, dyps, npix, C, slope, partial2, stream);
 }

@@ -4,13 +4,13 @@
 //                                                  (ResizeTransform), losses.py:313 (y_target)
 //   feedback gather: x2 trilinear up-sampling of the six planar level-(l+1) tensors fused with their channel
 //   concatenation into one channels-last 16-channel tensor (pulpo.py:195-206)
-#include "common.h"
+#include "act_io.h"
 
 namespace {
 
 // ------------------------------------------------------------------------------------------------ avg pool (channels-last)
-template <int VEC>
-__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ in, long ips, float* __restrict__ out, long ops, int B,
+template <int VEC, typename T = float>
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const T* __restrict__ in, long ips, T* __restrict__ out, long ops, int B,
                                                              int D, int H, int W, int Do, int Ho, int Wo, int C) {
     const int CV = C / VEC;
     const long total = (long)B * Do * Ho * Wo * CV;
@@ -28,26 +28,23 @@ __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restri
         for (int z = 2 * oz; z < z1; ++z)
             for (int y = 2 * oy; y < y1; ++y)
                 for (int x = 2 * ox; x < x1; ++x) {
-                    const float* s = in + ((((long)b * D + z) * H + y) * W + x) * ips + c;
-                    if constexpr (VEC == 4) {
-                        const float4 t = *reinterpret_cast<const float4*>(s);
-                        acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
-                    } else {
-                        acc[0] += s[0];
-                    }
+                    float t[VEC];
+                    pulpo::ldv<VEC>(in + ((((long)b * D + z) * H + y) * W + x) * ips + c, t);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += t[k];
                 }
         const float inv = 1.f / (float)((z1 - 2 * oz) * (y1 - 2 * oy) * (x1 - 2 * ox));   // ceil_mode: divisor = in-bounds taps
-        float* d = out + ((((long)b * Do + oz) * Ho + oy) * Wo + ox) * ops + c;
-        if constexpr (VEC == 4) *reinterpret_cast<float4*>(d) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
-        else d[0] = acc[0] * inv;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] *= inv;
+        pulpo::stv<VEC>(out + ((((long)b * Do + oz) * Ho + oy) * Wo + ox) * ops + c, acc);
     }
 }
 
 // (add, nullable: a second gradient of the same tensor - the pooled activation is also a skip connection - summed in the same pass:
 //  gin = add + up(gout) / count, the operand order of autograd's own accumulation)
-template <int VEC>
-__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ gout, long gops, float* __restrict__ gin, long gips, int B,
-                                                             int D, int H, int W, int Do, int Ho, int Wo, int C, const float* __restrict__ add, long aps) {
+template <int VEC, typename T = float>
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const T* __restrict__ gout, long gops, T* __restrict__ gin, long gips, int B,
+                                                             int D, int H, int W, int Do, int Ho, int Wo, int C, const T* __restrict__ add, long aps) {
     const int CV = C / VEC;
     const long total = (long)B * D * H * W * CV;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -60,17 +57,17 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
         const int oz = z >> 1, oy = y >> 1, ox = x >> 1;
         const int cnt = (min(2 * oz + 2, D) - 2 * oz) * (min(2 * oy + 2, H) - 2 * oy) * (min(2 * ox + 2, W) - 2 * ox);
         const float inv = 1.f / (float)cnt;
-        const float* s = gout + ((((long)b * Do + oz) * Ho + oy) * Wo + ox) * gops + c;
-        float* d = gin + ((((long)b * D + z) * H + y) * W + x) * gips + c;
-        const float* q = add != nullptr ? add + ((((long)b * D + z) * H + y) * W + x) * aps + c : nullptr;
-        if constexpr (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(s);
-            float4 r = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
-            if (q != nullptr) { const float4 u = *reinterpret_cast<const float4*>(q); r = make_float4(u.x + r.x, u.y + r.y, u.z + r.z, u.w + r.w); }
-            *reinterpret_cast<float4*>(d) = r;
-        } else {
-            d[0] = q != nullptr ? q[0] + s[0] * inv : s[0] * inv;
+        float r[VEC];
+        pulpo::ldv<VEC>(gout + ((((long)b * Do + oz) * Ho + oy) * Wo + ox) * gops + c, r);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) r[k] *= inv;
+        if (add != nullptr) {
+            float u[VEC];
+            pulpo::ldv<VEC>(add + ((((long)b * D + z) * H + y) * W + x) * aps + c, u);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) r[k] = u[k] + r[k];
         }
+        pulpo::stv<VEC>(gin + ((((long)b * D + z) * H + y) * W + x) * gips + c, r);
     }
 }
 
@@ -201,7 +198,8 @@ struct FeedbackArgs {
 };
 
 // out[b][fine voxel][ctot] (pixel stride ops) = concat_s up2(src_s)
-__global__ __launch_bounds__(256) void feedback_fwd_kernel(FeedbackArgs a, float* __restrict__ out, long ops) {
+template <typename T = float>
+__global__ __launch_bounds__(256) void feedback_fwd_kernel(FeedbackArgs a, T* __restrict__ out, long ops) {
     const int Do = 2 * a.Di, Ho = 2 * a.Hi, Wo = 2 * a.Wi;
     const long Vi = (long)a.Di * a.Hi * a.Wi;
     const long total = (long)a.B * Do * Ho * Wo;
@@ -219,13 +217,15 @@ __global__ __launch_bounds__(256) void feedback_fwd_kernel(FeedbackArgs a, float
         const long o00 = ((long)z0 * a.Hi + y0) * a.Wi, o01 = ((long)z0 * a.Hi + y1) * a.Wi;
         const long o10 = ((long)z1 * a.Hi + y0) * a.Wi, o11 = ((long)z1 * a.Hi + y1) * a.Wi;
         const float wz0 = 1.f - lz, wy0 = 1.f - ly, wx0 = 1.f - lx;
-        float* d = out + e * ops;
+        T* d = out + e * ops;
         int cc = 0;
         for (int s = 0; s < a.nsrc; ++s) {
             for (int c = 0; c < a.ch[s]; ++c, ++cc) {
                 const float* q = a.src[s] + ((long)b * a.ch[s] + c) * Vi;
-                d[cc] = wz0 * (wy0 * (wx0 * q[o00 + x0] + lx * q[o00 + x1]) + ly * (wx0 * q[o01 + x0] + lx * q[o01 + x1])) +
+                float val[1];
+                val[0] = wz0 * (wy0 * (wx0 * q[o00 + x0] + lx * q[o00 + x1]) + ly * (wx0 * q[o01 + x0] + lx * q[o01 + x1])) +
                         lz * (wy0 * (wx0 * q[o10 + x0] + lx * q[o10 + x1]) + ly * (wx0 * q[o11 + x0] + lx * q[o11 + x1]));
+                pulpo::stv<1>(d + cc, val);
             }
         }
     }
@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256) void feedback_fwd_kernel(FeedbackArgs a, float
 
 // gsrc_s[b][c][coarse voxel] = sum over the <= 4x4x4 fine contributors of w * gout[b][fine][choff_s + c]   (deterministic gather).
 // One thread per (coarse voxel, channel): 16 consecutive lanes read one 64-byte channel vector of a fine voxel.
-__global__ __launch_bounds__(256) void feedback_bwd_kernel(FeedbackArgs a, const float* __restrict__ gout, long gops) {
+template <typename T = float>
+__global__ __launch_bounds__(256) void feedback_bwd_kernel(FeedbackArgs a, const T* __restrict__ gout, long gops) {
     const int Do = 2 * a.Di, Ho = 2 * a.Hi, Wo = 2 * a.Wi;
     const long Vi = (long)a.Di * a.Hi * a.Wi;
     const int CT = a.ctot;
@@ -265,11 +266,15 @@ __global__ __launch_bounds__(256) void feedback_bwd_kernel(FeedbackArgs a, const
                 const int oy = 2 * y - 1 + ky;
                 if (oy < 0 || oy >= Ho) continue;
                 const float wzy = wz4[kz] * wy4[ky];
-                const float* row = gout + (((long)b * Do + oz) * Ho + oy) * Wo * gops + cc;
+                const T* row = gout + (((long)b * Do + oz) * Ho + oy) * Wo * gops + cc;
 #pragma unroll
                 for (int kx = 0; kx < 4; ++kx) {
                     const int ox = 2 * x - 1 + kx;
-                    if (ox >= 0 && ox < Wo) acc += wzy * wx4[kx] * row[(long)ox * gops];
+                    if (ox >= 0 && ox < Wo) {
+                        float g1[1];
+                        pulpo::ldv<1>(row + (long)ox * gops, g1);
+                        acc += wzy * wx4[kx] * g1[0];
+                    }
                 }
             }
         }
@@ -281,7 +286,8 @@ __global__ __launch_bounds__(256) void feedback_bwd_kernel(FeedbackArgs a, const
 
 // the same gather with four channels per thread (one 16-byte load per tap; ctot % 4 == 0, 16-byte aligned rows): a wave then covers 16
 // coarse voxels instead of 4 and issues a quarter of the loads (40^3 x 16 channels: 104 -> ~40 us)
-__global__ __launch_bounds__(256) void feedback_bwd4_kernel(FeedbackArgs a, const float* __restrict__ gout, long gops) {
+template <typename T = float>
+__global__ __launch_bounds__(256) void feedback_bwd4_kernel(FeedbackArgs a, const T* __restrict__ gout, long gops) {
     const int Do = 2 * a.Di, Ho = 2 * a.Hi, Wo = 2 * a.Wi;
     const long Vi = (long)a.Di * a.Hi * a.Wi;
     const int CQ = a.ctot / 4;
@@ -312,14 +318,15 @@ __global__ __launch_bounds__(256) void feedback_bwd4_kernel(FeedbackArgs a, cons
                 const int oy = 2 * y - 1 + ky;
                 if (oy < 0 || oy >= Ho) continue;
                 const float wzy = wz4[kz] * wy4[ky];
-                const float* row = gout + (((long)b * Do + oz) * Ho + oy) * Wo * gops + cc;
+                const T* row = gout + (((long)b * Do + oz) * Ho + oy) * Wo * gops + cc;
 #pragma unroll
                 for (int kx = 0; kx < 4; ++kx) {
                     const int ox = 2 * x - 1 + kx;
                     if (ox >= 0 && ox < Wo) {
                         const float w = wzy * wx4[kx];
-                        const float4 g = *reinterpret_cast<const float4*>(row + (long)ox * gops);
-                        acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+                        float g[4];
+                        pulpo::ldv<4>(row + (long)ox * gops, g);
+                        acc.x += w * g[0]; acc.y += w * g[1]; acc.z += w * g[2]; acc.w += w * g[3];
                     }
                 }
             }
@@ -338,38 +345,68 @@ inline int eblocks(long items) { return (int)std::max<long>(1, std::min<long>((i
 
 }  // namespace
 
-PULPO_API int pulpo_avgpool2_fwd(const float* in, int64_t ips, float* out, int64_t ops, int B, int D, int H, int W, int C, void* stream) {
-    PULPO_REQUIRE(in && out && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "avgpool2_fwd: bad arguments");
+// ---- typed forms: `dt` = dtype code of every activation operand of the call (0 fp32, 1 bf16), strides in elements
+namespace {
+template <typename T>
+int avgpool2_fwd_t(const T* in, long ips, T* out, long ops, int B, int D, int H, int W, int C, hipStream_t st) {
     const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    const bool v4 = C % 4 == 0 && ips % 4 == 0 && ops % 4 == 0 && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
-    const long items = (long)B * Do * Ho * Wo * (C / (v4 ? 4 : 1));
-    if (v4) hipLaunchKernelGGL(avgpool2_fwd_kernel<4>, dim3(eblocks(items)), dim3(256), 0, (hipStream_t)stream, in, ips, out, ops, B, D, H, W, Do, Ho, Wo, C);
-    else hipLaunchKernelGGL(avgpool2_fwd_kernel<1>, dim3(eblocks(items)), dim3(256), 0, (hipStream_t)stream, in, ips, out, ops, B, D, H, W, Do, Ho, Wo, C);
+    pulpo::GroupProbe g(C);
+    g.add(in, ips, sizeof(T)); g.add(out, ops, sizeof(T));
+    if (sizeof(T) == 2 && g.ok8) {
+        hipLaunchKernelGGL((avgpool2_fwd_kernel<8, T>), dim3(eblocks((long)B * Do * Ho * Wo * (C / 8))), dim3(256), 0, st, in, ips, out, ops, B, D, H, W, Do, Ho, Wo, C);
+    } else if (g.ok4) {
+        hipLaunchKernelGGL((avgpool2_fwd_kernel<4, T>), dim3(eblocks((long)B * Do * Ho * Wo * (C / 4))), dim3(256), 0, st, in, ips, out, ops, B, D, H, W, Do, Ho, Wo, C);
+    } else {
+        hipLaunchKernelGGL((avgpool2_fwd_kernel<1, T>), dim3(eblocks((long)B * Do * Ho * Wo * C)), dim3(256), 0, st, in, ips, out, ops, B, D, H, W, Do, Ho, Wo, C);
+    }
     return pulpo::check_launch("avgpool2_fwd");
 }
 
-static int avgpool2_bwd_impl(const float* gout, int64_t gops, const float* add, int64_t aps, float* gin, int64_t gips, int B, int D, int H, int W, int C,
-                             void* stream) {
-    PULPO_REQUIRE(gout && gin && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "avgpool2_bwd: bad arguments");
+template <typename T>
+int avgpool2_bwd_t(const T* gout, long gops, const T* add, long aps, T* gin, long gips, int B, int D, int H, int W, int C, hipStream_t st) {
     const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    const bool v4 = C % 4 == 0 && gips % 4 == 0 && gops % 4 == 0 && ((((uintptr_t)gin) | ((uintptr_t)gout)) & 15) == 0 &&
-                    (add == nullptr || (aps % 4 == 0 && (((uintptr_t)add) & 15) == 0));
-    const long items = (long)B * D * H * W * (C / (v4 ? 4 : 1));
-    if (v4) hipLaunchKernelGGL(avgpool2_bwd_kernel<4>, dim3(eblocks(items)), dim3(256), 0, (hipStream_t)stream, gout, gops, gin, gips, B, D, H, W, Do, Ho, Wo, C, add, (long)aps);
-    else hipLaunchKernelGGL(avgpool2_bwd_kernel<1>, dim3(eblocks(items)), dim3(256), 0, (hipStream_t)stream, gout, gops, gin, gips, B, D, H, W, Do, Ho, Wo, C, add, (long)aps);
+    pulpo::GroupProbe g(C);
+    g.add(gout, gops, sizeof(T)); g.add(gin, gips, sizeof(T)); g.add(add, aps, sizeof(T));
+    if (sizeof(T) == 2 && g.ok8) {
+        hipLaunchKernelGGL((avgpool2_bwd_kernel<8, T>), dim3(eblocks((long)B * D * H * W * (C / 8))), dim3(256), 0, st, gout, gops, gin, gips, B, D, H, W, Do, Ho, Wo, C, add, aps);
+    } else if (g.ok4) {
+        hipLaunchKernelGGL((avgpool2_bwd_kernel<4, T>), dim3(eblocks((long)B * D * H * W * (C / 4))), dim3(256), 0, st, gout, gops, gin, gips, B, D, H, W, Do, Ho, Wo, C, add, aps);
+    } else {
+        hipLaunchKernelGGL((avgpool2_bwd_kernel<1, T>), dim3(eblocks((long)B * D * H * W * C)), dim3(256), 0, st, gout, gops, gin, gips, B, D, H, W, Do, Ho, Wo, C, add, aps);
+    }
     return pulpo::check_launch("avgpool2_bwd");
+}
+}  // namespace
+
+PULPO_API int pulpo_avgpool2_fwd_t(const void* in, int64_t ips, void* out, int64_t ops, int dt, int B, int D, int H, int W, int C, void* stream) {
+    PULPO_REQUIRE(in && out && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "avgpool2_fwd: bad arguments");
+    PULPO_REQUIRE_DT(dt, "avgpool2_fwd");
+    PULPO_DISPATCH_DT(dt, T, return avgpool2_fwd_t((const T*)in, (long)ips, (T*)out, (long)ops, B, D, H, W, C, (hipStream_t)stream));
+    return -1;
+}
+
+PULPO_API int pulpo_avgpool2_fwd(const float* in, int64_t ips, float* out, int64_t ops, int B, int D, int H, int W, int C, void* stream) {
+    return pulpo_avgpool2_fwd_t(in, ips, out, ops, 0, B, D, H, W, C, stream);
+}
+
+// gin = (add +) avgpool2_bwd(gout); add (nullable) = the other gradient of a tensor that is pooled AND used as a skip connection
+// (channels-last, voxel stride aps: e.g. a channel slice of a concatenation's gradient), batch stride = D*H*W*aps
+PULPO_API int pulpo_avgpool2_bwd_t(const void* gout, int64_t gops, const void* add, int64_t aps, void* gin, int64_t gips, int dt, int B, int D, int H,
+                                   int W, int C, void* stream) {
+    PULPO_REQUIRE(gout && gin && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "avgpool2_bwd: bad arguments");
+    PULPO_REQUIRE_DT(dt, "avgpool2_bwd");
+    PULPO_DISPATCH_DT(dt, T, return avgpool2_bwd_t((const T*)gout, (long)gops, (const T*)add, (long)aps, (T*)gin, (long)gips, B, D, H, W, C, (hipStream_t)stream));
+    return -1;
 }
 
 PULPO_API int pulpo_avgpool2_bwd(const float* gout, int64_t gops, float* gin, int64_t gips, int B, int D, int H, int W, int C, void* stream) {
-    return avgpool2_bwd_impl(gout, gops, nullptr, 0, gin, gips, B, D, H, W, C, stream);
+    return pulpo_avgpool2_bwd_t(gout, gops, nullptr, 0, gin, gips, 0, B, D, H, W, C, stream);
 }
 
-// gin = add + avgpool2_bwd(gout): `add` = the other gradient of a tensor that is pooled AND used as a skip connection (channels-last, voxel
-// stride aps: e.g. a channel slice of a concatenation's gradient), batch stride = D*H*W*aps
 PULPO_API int pulpo_avgpool2_bwd_add(const float* gout, int64_t gops, const float* add, int64_t aps, float* gin, int64_t gips, int B, int D, int H, int W,
                                      int C, void* stream) {
     PULPO_REQUIRE(add != nullptr, "avgpool2_bwd_add: null pointer");
-    return avgpool2_bwd_impl(gout, gops, add, aps, gin, gips, B, D, H, W, C, stream);
+    return pulpo_avgpool2_bwd_t(gout, gops, add, aps, gin, gips, 0, B, D, H, W, C, stream);
 }
 
 // planar tensors: in (nplanes, Di, Hi, Wi) -> out (nplanes, Do, Ho, Wo); out = mult * interpolate(in) (+ add, nullable:
@@ -413,30 +450,44 @@ PULPO_API int pulpo_resize_trilinear_bwd(const float* gout, float* gin, int64_t 
     return pulpo_resize_trilinear_scaled_bwd(gout, gin, nplanes, Di, Hi, Wi, Do, Ho, Wo, 0.f, 0.f, 0.f, mult, stream);
 }
 
-// srcs[i]: planar (B, chans[i], Di, Hi, Wi); out: channels-last (B, 2Di, 2Hi, 2Wi, sum chans) with pixel stride ops
-PULPO_API int pulpo_feedback_up2_fwd(const float* const* srcs, const int* chans, int nsrc, float* out, int64_t ops, int B, int Di, int Hi, int Wi,
-                                     void* stream) {
+// srcs[i]: planar fp32 (B, chans[i], Di, Hi, Wi); out: channels-last (B, 2Di, 2Hi, 2Wi, sum chans) with pixel stride ops, dtype code dt
+PULPO_API int pulpo_feedback_up2_fwd_t(const float* const* srcs, const int* chans, int nsrc, void* out, int dt, int64_t ops, int B, int Di, int Hi,
+                                       int Wi, void* stream) {
     PULPO_REQUIRE(srcs && chans && out && nsrc > 0 && nsrc <= kMaxSrc && B > 0, "feedback_up2_fwd: bad arguments");
+    PULPO_REQUIRE_DT(dt, "feedback_up2_fwd");
     FeedbackArgs a;
     memset(&a, 0, sizeof(a));
     a.nsrc = nsrc; a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi;
     for (int i = 0; i < nsrc; ++i) { a.src[i] = srcs[i]; a.ch[i] = chans[i]; a.ctot += chans[i]; }
     PULPO_REQUIRE(a.ctot <= 16, "feedback_up2_fwd: more than 16 feedback channels");
-    hipLaunchKernelGGL(feedback_fwd_kernel, dim3(eblocks((long)B * 8 * Di * Hi * Wi)), dim3(256), 0, (hipStream_t)stream, a, out, (long)ops);
+    const int nb = eblocks((long)B * 8 * Di * Hi * Wi);
+    PULPO_DISPATCH_DT(dt, T, hipLaunchKernelGGL((feedback_fwd_kernel<T>), dim3(nb), dim3(256), 0, (hipStream_t)stream, a, (T*)out, (long)ops));
     return pulpo::check_launch("feedback_up2_fwd");
 }
 
-PULPO_API int pulpo_feedback_up2_bwd(const float* gout, int64_t gops, float* const* gsrcs, const int* chans, int nsrc, int B, int Di, int Hi, int Wi,
+PULPO_API int pulpo_feedback_up2_fwd(const float* const* srcs, const int* chans, int nsrc, float* out, int64_t ops, int B, int Di, int Hi, int Wi,
                                      void* stream) {
+    return pulpo_feedback_up2_fwd_t(srcs, chans, nsrc, out, 0, ops, B, Di, Hi, Wi, stream);
+}
+
+PULPO_API int pulpo_feedback_up2_bwd_t(const void* gout, int dt, int64_t gops, float* const* gsrcs, const int* chans, int nsrc, int B, int Di, int Hi,
+                                       int Wi, void* stream) {
     PULPO_REQUIRE(gout && gsrcs && chans && nsrc > 0 && nsrc <= kMaxSrc && B > 0, "feedback_up2_bwd: bad arguments");
+    PULPO_REQUIRE_DT(dt, "feedback_up2_bwd");
     FeedbackArgs a;
     memset(&a, 0, sizeof(a));
     a.nsrc = nsrc; a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi;
     for (int i = 0; i < nsrc; ++i) { a.gsrc[i] = gsrcs[i]; a.ch[i] = chans[i]; a.ctot += chans[i]; }
     PULPO_REQUIRE(a.ctot <= 16, "feedback_up2_bwd: more than 16 feedback channels");
-    if (a.ctot % 4 == 0 && gops % 4 == 0 && (((uintptr_t)gout) & 15) == 0)
-        hipLaunchKernelGGL(feedback_bwd4_kernel, dim3(eblocks((long)B * Di * Hi * Wi * (a.ctot / 4))), dim3(256), 0, (hipStream_t)stream, a, gout, (long)gops);
-    else
-        hipLaunchKernelGGL(feedback_bwd_kernel, dim3(eblocks((long)B * Di * Hi * Wi * a.ctot)), dim3(256), 0, (hipStream_t)stream, a, gout, (long)gops);
+    const bool four = a.ctot % 4 == 0 && gops % 4 == 0 && (((uintptr_t)gout) % (dt ? 8 : 16)) == 0;
+    PULPO_DISPATCH_DT(dt, T, {
+        if (four) hipLaunchKernelGGL((feedback_bwd4_kernel<T>), dim3(eblocks((long)B * Di * Hi * Wi * (a.ctot / 4))), dim3(256), 0, (hipStream_t)stream, a, (const T*)gout, (long)gops);
+        else hipLaunchKernelGGL((feedback_bwd_kernel<T>), dim3(eblocks((long)B * Di * Hi * Wi * a.ctot)), dim3(256), 0, (hipStream_t)stream, a, (const T*)gout, (long)gops);
+    });
     return pulpo::check_launch("feedback_up2_bwd");
+}
+
+PULPO_API int pulpo_feedback_up2_bwd(const float* gout, int64_t gops, float* const* gsrcs, const int* chans, int nsrc, int B, int Di, int Hi, int Wi,
+                                     void* stream) {
+    return pulpo_feedback_up2_bwd_t(gout, 0, gops, gsrcs, chans, nsrc, B, Di, Hi, Wi, stream);
 }

@@ -30,14 +30,24 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _require_gpu(*ts: Optional[torch.Tensor]):
+def _require_gpu(*ts: Optional[torch.Tensor], act: bool = False):
+    """act: the tensors are multi-channel activations, which may live in HBM as bf16 (ACT_BF16, BASELINE configs 4-5); everything else is fp32"""
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise PulpoHipError("pulpo_amd operators run on the GPU only (got a CPU tensor); there is no CPU fallback")
-        if t.dtype != torch.float32:
-            raise PulpoHipError(f"pulpo_amd operators are fp32 (got {t.dtype})")
+        if t.dtype != torch.float32 and not (act and t.dtype == torch.bfloat16):
+            raise PulpoHipError(f"pulpo_amd operators are fp32 (got {t.dtype})" + (" or bf16 activations" if act else ""))
+
+
+def _dt(t: torch.Tensor) -> int:
+    """dtype code of the typed C entry points (`*_t`): 0 fp32, 1 bf16"""
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def _esize(t: torch.Tensor) -> float:
+    return 2.0 if t.dtype == torch.bfloat16 else 4.0
 
 
 def _dense_grid(t: torch.Tensor) -> bool:
@@ -73,8 +83,8 @@ def to_cl(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous(memory_format=CL)
 
 
-def new_cl(B: int, C: int, D: int, H: int, W: int, device) -> torch.Tensor:
-    return torch.empty((B, C, D, H, W), device=device, dtype=torch.float32, memory_format=CL)
+def new_cl(B: int, C: int, D: int, H: int, W: int, device, dtype=torch.float32) -> torch.Tensor:
+    return torch.empty((B, C, D, H, W), device=device, dtype=dtype, memory_format=CL)
 
 
 def planar(t: torch.Tensor) -> torch.Tensor:
@@ -200,16 +210,31 @@ def _trace_end(start, name: str, flops: float, nbytes: float = 0.0):
 # 4-5: operands rounded to bf16 while staged, fp32 accumulation; activations, statistics, losses and gradients stay fp32).
 # Layers with <= 4 reduction channels (the 2-channel image input) always run the fp32 kernel.
 CONV_PRECISION = "fp32"
+# bf16 ACTIVATION STORAGE (BASELINE configs 4-5, on top of bf16 operands): the multi-channel activation tensors - a ConvUnit's pre-norm
+# output y and its output z, pooled / concatenated / up-sampled feature maps - and their gradients live in HBM as bf16; every kernel
+# computes in fp32 (BatchNorm statistics in double) and rounds on the store.  Images, latent samples, displacement fields, losses,
+# parameters, their gradients and the optimizer state stay fp32; so do the outputs of the layers with <= 4 reduction channels, which run
+# the exact-fp32 kernel.  Definition emulated by the oracle (oracle/pulpo_oracle.py ACT_PRECISION), "parity unpinned" against the reference.
+ACT_BF16 = False
 # None: the library's choice per shape (pulpo_conv3d_k3_algo); "direct" | "wino2": force that forward / data-gradient kernel
 # wherever a Winograd kernel would be eligible (A/B runs and the full-size consistency test)
 CONV_ALGO = None
 
 
-def set_conv_precision(precision: str) -> None:
-    global CONV_PRECISION
+def set_conv_precision(precision: str, activations: str = "fp32") -> None:
+    """precision: operand type of the 3x3x3 convolutions; activations: storage type of the multi-channel activation tensors ("bf16" only
+    together with bf16 operands)"""
+    global CONV_PRECISION, ACT_BF16
     if precision not in ("fp32", "bf16"):
         raise ValueError(f"conv precision is {precision}. Not a known option.")
+    if activations not in ("fp32", "bf16") or (activations == "bf16" and precision != "bf16"):
+        raise ValueError(f"activation storage is {activations} with {precision} operands. Not a known option.")
     CONV_PRECISION = precision
+    ACT_BF16 = activations == "bf16"
+
+
+def act_dtype():
+    return torch.bfloat16 if ACT_BF16 else torch.float32
 
 
 def _use_bf16(K: int) -> bool:
@@ -375,11 +400,21 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
     nscr = lib.query(f"pulpo_conv3d_k3_fwd{sfx}_scratch_floats", B, D, H, W, K, N)
     scratch = torch.empty(nscr, device=x.device, dtype=torch.float32) if nscr else None
     t0 = _trace_begin()
-    if coef is None:
-        lib.call(f"pulpo_conv3d_k3_fwd{sfx}", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc, _ptr(stats), _ptr(scratch), B, D, H,
+    if bf16:
+        # the typed entry points: operand and result share one storage type (fp32: rounded while staged; bf16: stored that way)
+        if x.dtype != out.dtype:
+            raise PulpoHipError(f"conv3d (bf16 operands): input {x.dtype} and output {out.dtype} must share one storage type")
+        if coef is None:
+            lib.call("pulpo_conv3d_k3_fwd_bf16_t", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc, _dt(x), _ptr(stats), _ptr(scratch),
+                     B, D, H, W, K, N, _stream())
+        else:
+            lib.call("pulpo_conv3d_k3_fwd_bn_lrelu_bf16_t", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc,
+                     _dt(x), _ptr(scratch), B, D, H, W, K, N, _stream())
+    elif coef is None:
+        lib.call("pulpo_conv3d_k3_fwd", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(out), ob, op, oc, _ptr(stats), _ptr(scratch), B, D, H,
                  W, K, N, _stream())
     else:
-        lib.call(f"pulpo_conv3d_k3_fwd_bn_lrelu{sfx}", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc,
+        lib.call("pulpo_conv3d_k3_fwd_bn_lrelu", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc,
                  _ptr(scratch), B, D, H, W, K, N, _stream())
     if t0 is not None:
         if bf16:
@@ -387,7 +422,7 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
         else:
             cfg = lib.query("pulpo_conv3d_k3_tile_config", K, N)
             name = f"conv3d_k3_mfma<{cfg // 1000},{cfg % 1000},{'true' if vec_ok and cfg // 1000 >= 16 else 'false'}>"
-        _trace_end(t0, name, 54.0 * K * N * B * D * H * W, 4.0 * (K + N) * B * D * H * W)
+        _trace_end(t0, name, 54.0 * K * N * B * D * H * W, (_esize(x) * K + _esize(out) * N) * B * D * H * W)
 
 
 # ---- deferred parameter-gradient epilogues (data-parallel stepper): inside a step the weight gradients stay in their packed scratch and
@@ -456,8 +491,20 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
     db, dp, dc = grid_strides(dy)
     t0 = _trace_begin()
     sfx = "_bf16" if _use_bf16(Cin) else ""
-    lib.call(f"pulpo_conv3d_k3_wgrad{sfx}", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), 2 if deferred else int(into is not None), _ptr(scratch),
-             B, D, H, W, Cin, Cout, _stream())
+    if sfx:
+        if x.dtype != dy.dtype:                      # (one storage type per launch; a mixed pair - a user's fp32 input to a bf16-storage unit - is rare)
+            x, dy = x.float(), dy.float()
+            xb, xp, xc = grid_strides(x)
+            db, dp, dc = grid_strides(dy)
+        lib.call("pulpo_conv3d_k3_wgrad_bf16_t", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _dt(x), _ptr(dw), 2 if deferred else int(into is not None),
+                 _ptr(scratch), B, D, H, W, Cin, Cout, _stream())
+    else:
+        if x.dtype != torch.float32 or dy.dtype != torch.float32:
+            x, dy = x.float(), dy.float()
+            xb, xp, xc = grid_strides(x)
+            db, dp, dc = grid_strides(dy)
+        lib.call("pulpo_conv3d_k3_wgrad", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), 2 if deferred else int(into is not None), _ptr(scratch),
+                 B, D, H, W, Cin, Cout, _stream())
     if deferred and not _pending_src(scratch):
         # (ONE finishing job per scratch: a unit applied twice in a step - shared weights, two forward passes - has accumulated both weight
         #  gradients into the same packed sums by the time the job runs)
@@ -469,7 +516,7 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
             vec = (xc == 1 and xp % 4 == 0 and xb % 4 == 0 and Cin % 4 == 0 and x.data_ptr() % 16 == 0 and dc == 1 and dp % 4 == 0 and db % 4 == 0
                    and Cout % 4 == 0 and dy.data_ptr() % 16 == 0)
             name = ("conv3d_k3_wgrad_mfma", "conv3d_k3_wgrad_wino", "conv3d_k3_wgrad_w2")[lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, Cin, Cout, int(vec))]
-        _trace_end(t0, name + ("" if deferred else "(+memset,unpack)"), 54.0 * Cin * Cout * B * D * H * W, 4.0 * (Cin + Cout) * B * D * H * W)
+        _trace_end(t0, name + ("" if deferred else "(+memset,unpack)"), 54.0 * Cin * Cout * B * D * H * W, (_esize(x) * Cin + _esize(dy) * Cout) * B * D * H * W)
     return None if into is not None else dw
 
 
@@ -555,14 +602,22 @@ class _ConvBNLReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool, momentum: float, eps: float,
                 bn_src=None, pool_after: bool = False):
-        _require_gpu(x, weight, bias, gamma, beta)
+        _require_gpu(x, act=True)
+        _require_gpu(weight, bias, gamma, beta)
         ctx.bn_src = bn_src
         x = as_grid(x)
         B, Cin, D, H, W = x.shape
         Cout = weight.shape[0]
         dev = x.device
         wp = _pack_weight(weight, dgrad=False, shape=(B, D, H, W), both=bool(training and ctx.needs_input_grad[0]))
-        y = new_cl(B, Cout, D, H, W, dev)
+        # storage types (ACT_BF16): z - what the next operator reads - is bf16; the pre-norm tensor y is bf16 when the bf16-operand kernel
+        # produces it and fp32 behind the exact-fp32 kernel of the <= 4-channel input layers; the kernels take operand and result in ONE type
+        half_conv = ACT_BF16 and wp._pulpo_algo == "bf16"
+        if x.dtype != (torch.bfloat16 if half_conv else torch.float32):
+            x = x.to(torch.bfloat16 if half_conv else torch.float32)
+        ydt = torch.bfloat16 if half_conv else torch.float32
+        zdt = act_dtype()
+        y = new_cl(B, Cout, D, H, W, dev, ydt)
         coef = torch.empty(8 * Cout, device=dev, dtype=torch.float32)      # [4][C] floats + [2][C] doubles
         if training:
             ntile = lib.query("pulpo_conv3d_k3_fwd_bf16_stat_tiles" if wp._pulpo_algo == "bf16" else "pulpo_conv3d_k3_stat_tiles", B, D, H, W)
@@ -574,24 +629,26 @@ class _ConvBNLReLU(torch.autograd.Function):
                      _ptr(running_var), _ptr(num_batches_tracked), momentum, eps, _ptr(coef), _ptr(scratch), _stream())
         else:
             lib.call("pulpo_bn_eval_coef", _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps, Cout, _ptr(coef), _stream())
-            if not any(ctx.needs_input_grad):
+            if not any(ctx.needs_input_grad) and ydt == zdt:
                 # inference: conv + folded BatchNorm + LeakyReLU in one kernel, the pre-norm tensor is never written
                 _conv_raw(x, wp, bias, y, Cin, Cout, None, coef=coef)
                 return y
             _conv_raw(x, wp, bias, y, Cin, Cout, None)
-        z = new_cl(B, Cout, D, H, W, dev)
+        z = new_cl(B, Cout, D, H, W, dev, zdt)
         pooled = None
+        nbytes = (_esize(y) + _esize(z)) * Cout * B * D * H * W             # read y, write z
         if pool_after and lib.query("pulpo_bn_lrelu_apply_pool2_ok", Cout, y.stride(4), z.stride(4), Cout):
             # the caller pools this output next (DownPath): z and AvgPool(z) from one read of y; avg_pool2_skip() picks the pooled tensor up
-            pooled = new_cl(B, Cout, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, dev)
+            pooled = new_cl(B, Cout, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, dev, zdt)
             t0 = _hbm_begin("bn_lrelu_apply")
-            lib.call("pulpo_bn_lrelu_apply_pool2", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(pooled), pooled.stride(4), _ptr(coef), B, D, H, W, Cout,
-                     LRELU_SLOPE, _stream())
-            _hbm_end(t0, "bn_lrelu_apply", 8.0 * Cout * B * D * H * W)
+            lib.call("pulpo_bn_lrelu_apply_pool2_t", _ptr(y), _dt(y), y.stride(4), _ptr(z), _dt(z), z.stride(4), _ptr(pooled), pooled.stride(4), _ptr(coef),
+                     B, D, H, W, Cout, LRELU_SLOPE, _stream())
+            _hbm_end(t0, "bn_lrelu_apply", nbytes)
         else:
             t0 = _hbm_begin("bn_lrelu_apply")
-            lib.call("pulpo_bn_lrelu_apply", _ptr(y), y.stride(4), _ptr(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
-            _hbm_end(t0, "bn_lrelu_apply", 8.0 * Cout * B * D * H * W)            # read y, write z
+            lib.call("pulpo_bn_lrelu_apply_t", _ptr(y), _dt(y), y.stride(4), _ptr(z), _dt(z), z.stride(4), _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE,
+                     _stream())
+            _hbm_end(t0, "bn_lrelu_apply", nbytes)
         ctx.save_for_backward(x, weight, y, coef)
         ctx.training = training
         ctx.params = (weight, bias, gamma, beta)      # for DIRECT_PARAM_GRADS (their .grad slots)
@@ -613,8 +670,9 @@ class _ConvBNLReLU(torch.autograd.Function):
         if tiles is None:
             part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
             t0 = _hbm_begin("bn_lrelu_bwd_reduce")
-            lib.call("pulpo_bn_lrelu_bwd_reduce", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE, _ptr(part), _stream())
-            _hbm_end(t0, "bn_lrelu_bwd_reduce", 8.0 * Cout * npix)                # read dz, y
+            lib.call("pulpo_bn_lrelu_bwd_reduce_t", _ptr(dz), _dt(dz), dz.stride(4), _ptr(y), _dt(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE,
+                     _ptr(part), _stream())
+            _hbm_end(t0, "bn_lrelu_bwd_reduce", (_esize(dz) + _esize(y)) * Cout * npix)                # read dz, y
         w_p, b_p, g_p, be_p = ctx.params
         slot_w, slot_b, slot_g, slot_be = (_grad_slot(t) if need else None
                                            for t, need in zip((w_p, b_p, g_p, be_p), ctx.needs_input_grad[1:5]))
@@ -627,7 +685,7 @@ class _ConvBNLReLU(torch.autograd.Function):
         nsd = lib.query("pulpo_bn_bwd_finalize_scratch_doubles", nrow, Cout)
         scratch = torch.empty(nsd, device=dev, dtype=torch.float64) if nsd else None
         lib.call("pulpo_bn_bwd_finalize", _ptr(rows), nrow, Cout, _ptr(coef), float(npix), int(ctx.training), *fin_out, _ptr(scratch), _stream())
-        dy = new_cl(B, Cout, D, H, W, dev)
+        dy = new_cl(B, Cout, D, H, W, dev, y.dtype)            # (the gradient of the pre-norm tensor is stored like the tensor)
         defer_b = DIRECT_PARAM_GRADS and ctx.needs_input_grad[2] and slot_b is not None
         part2 = _persistent_buffer(b_p, "_pulpo_dbias_part", nblk * Cout, zero=False) if defer_b else None
         if defer_b and _pending_src(part2):          # this unit has already run a backward pass in this step: its partials are still waiting
@@ -635,9 +693,9 @@ class _ConvBNLReLU(torch.autograd.Function):
         if not defer_b:
             part2 = torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
         t0 = _hbm_begin("bn_lrelu_bwd_apply")
-        lib.call("pulpo_bn_lrelu_bwd_apply", _ptr(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4), npix, Cout,
-                 LRELU_SLOPE, _ptr(part2), _stream())
-        _hbm_end(t0, "bn_lrelu_bwd_apply", 12.0 * Cout * npix)                # read dz, y; write dy
+        lib.call("pulpo_bn_lrelu_bwd_apply_t", _ptr(dz), _dt(dz), dz.stride(4), _ptr(y), _dt(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4),
+                 npix, Cout, LRELU_SLOPE, _ptr(part2), _stream())
+        _hbm_end(t0, "bn_lrelu_bwd_apply", (_esize(dz) + 2 * _esize(y)) * Cout * npix)                # read dz, y; write dy
         defer_w = ctx.needs_input_grad[1] and slot_w is not None and ASYNC_WGRAD_STREAM is not None
         if defer_b:
             _PENDING_GRAD_JOBS.append((part2.data_ptr(), slot_b.data_ptr(), 1, nblk, Cout, 0))
@@ -648,9 +706,11 @@ class _ConvBNLReLU(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             wpt = _pack_weight(weight, dgrad=True, shape=(B, D, H, W))
-            dx = torch.empty_like(x) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, dev)
-            if not _dgrad_with_bn_reduction(ctx.bn_src, x, dy, wpt, dx, Cout, Cin):
-                _conv_raw(dy, wpt, None, dx, Cout, Cin, None)
+            # (the bf16-operand kernel takes operand and result in one storage type; every other kernel is fp32)
+            dyc = dy if (wpt._pulpo_algo == "bf16" or dy.dtype == torch.float32) else dy.float()
+            dx = torch.empty_like(x, dtype=dyc.dtype) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, dev, dyc.dtype)
+            if not _dgrad_with_bn_reduction(ctx.bn_src, x, dyc, wpt, dx, Cout, Cin):
+                _conv_raw(dyc, wpt, None, dx, Cout, Cin, None)
         if defer_w:
             _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, w_p)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
@@ -682,8 +742,9 @@ class _Conv3dK3(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        _require_gpu(x, weight, bias)
-        x = as_grid(x)
+        _require_gpu(x, act=True)
+        _require_gpu(weight, bias)
+        x = as_grid(x.float())                        # (a bare convolution - VelocityField depth 1, tests - keeps fp32 storage)
         B, Cin, D, H, W = x.shape
         Cout = weight.shape[0]
         y = new_cl(B, Cout, D, H, W, x.device)
@@ -697,7 +758,7 @@ class _Conv3dK3(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         B, Cin, D, H, W = x.shape
         Cout = weight.shape[0]
-        dy = as_grid(dy)
+        dy = as_grid(dy.float())
         dw = _wgrad_raw(x, dy, Cin, Cout) if ctx.needs_input_grad[1] else None
         db = dy.sum(dim=(0, 2, 3, 4)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         dx = None
@@ -720,7 +781,8 @@ class _Heads(torch.autograd.Function):
         """params: the leaf parameters Wt / bias were assembled from, as ((tensor, first row of Wt, rows), ...) for the weights and
         ((tensor, first element of bias, elements), ...) for the biases: inside the data-parallel stepper their gradients are finished by
         flush_param_grads() straight from the backward kernel's partial rows (no column sum, no split, no AccumulateGrad add per parameter)"""
-        _require_gpu(h, Wt, bias, eps)
+        _require_gpu(h, act=True)
+        _require_gpu(Wt, bias, eps)
         ctx.params = params
         h = to_cl(h)
         B, C, D, H, W = h.shape
@@ -729,9 +791,9 @@ class _Heads(torch.autograd.Function):
         outs = [torch.empty((B, 3, D, H, W), device=dev, dtype=torch.float32) for _ in range(1 if nout == 3 else 3)]
         epsc = planar(eps) if eps is not None else None
         t0 = _hbm_begin("heads_fwd")
-        lib.call("pulpo_heads_fwd", _ptr(h), h.stride(4), _ptr(Wt), _ptr(bias), _ptr(epsc), _ptr(outs[0]), _ptr(outs[1]) if nout == 6 else None,
+        lib.call("pulpo_heads_fwd_t", _ptr(h), _dt(h), h.stride(4), _ptr(Wt), _ptr(bias), _ptr(epsc), _ptr(outs[0]), _ptr(outs[1]) if nout == 6 else None,
                  _ptr(outs[2]) if nout == 6 else None, nout, B, V, C, _stream())
-        _hbm_end(t0, "heads_fwd", 4.0 * B * V * (C + (12 if nout == 6 else 3)))       # read h (+ eps), write mu / sigma / z (or the field)
+        _hbm_end(t0, "heads_fwd", B * V * (_esize(h) * C + 4.0 * (12 if nout == 6 else 3)))       # read h (+ eps), write mu / sigma / z (or the field)
         ctx.nout = nout
         ctx.save_for_backward(h, Wt, epsc, outs[1] if nout == 6 else None)
         return outs[0] if nout == 3 else tuple(outs)
@@ -746,7 +808,7 @@ class _Heads(torch.autograd.Function):
         g = [planar(t) if t is not None else None for t in gs] + [None, None]
         if nout == 3 and g[0] is None:
             g[0] = torch.zeros((B, 3, D, H, W), device=dev)
-        dh = new_cl(B, C, D, H, W, dev)
+        dh = new_cl(B, C, D, H, W, dev, h.dtype)
         nblk = lib.query("pulpo_heads_bwd_blocks", B, V, C)
         rowlen = nout * C + nout
         # inside the stepper: the partial rows go to a persistent buffer (stable address: the finishing launch's job table is cached) and
@@ -762,9 +824,9 @@ class _Heads(torch.autograd.Function):
             slots = None
             part = torch.empty(nblk * rowlen, device=dev, dtype=torch.float32)
         t0 = _hbm_begin("heads_bwd")
-        lib.call("pulpo_heads_bwd", _ptr(h), h.stride(4), _ptr(Wt), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(eps), _ptr(sigma), _ptr(dh),
+        lib.call("pulpo_heads_bwd_t", _ptr(h), _dt(h), h.stride(4), _ptr(Wt), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(eps), _ptr(sigma), _ptr(dh),
                  dh.stride(4), _ptr(part), nout, B, V, C, _stream())
-        _hbm_end(t0, "heads_bwd", 4.0 * B * V * (2 * C + (15 if nout == 6 else 3)))   # read h, the output gradients (+ eps, sigma), write dh
+        _hbm_end(t0, "heads_bwd", B * V * (2 * _esize(h) * C + 4.0 * (15 if nout == 6 else 3)))   # read h, the output gradients (+ eps, sigma), write dh
         if slots is not None:
             nw = len(ctx.params[0])
             for k, (sl, off, n) in enumerate(slots):
@@ -827,14 +889,14 @@ def conv1x1_to3(h, w, b):
 class _AvgPool2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        _require_gpu(x)
+        _require_gpu(x, act=True)
         x = to_cl(x)
         B, C, D, H, W = x.shape
-        out = new_cl(B, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, x.device) if C > 1 else \
-            torch.empty((B, 1, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32)
+        out = new_cl(B, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, x.device, x.dtype) if C > 1 else \
+            torch.empty((B, 1, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=x.dtype)
         t0 = _hbm_begin("avgpool2_fwd")
-        lib.call("pulpo_avgpool2_fwd", _ptr(x), x.stride(4), _ptr(out), out.stride(4), B, D, H, W, C, _stream())
-        _hbm_end(t0, "avgpool2_fwd", 4.0 * C * (x.numel() // C + out.numel() // C))
+        lib.call("pulpo_avgpool2_fwd_t", _ptr(x), x.stride(4), _ptr(out), out.stride(4), _dt(x), B, D, H, W, C, _stream())
+        _hbm_end(t0, "avgpool2_fwd", _esize(x) * C * (x.numel() // C + out.numel() // C))
         ctx.shape = (B, C, D, H, W)
         return out
 
@@ -842,8 +904,8 @@ class _AvgPool2(torch.autograd.Function):
     def backward(ctx, g):
         B, C, D, H, W = ctx.shape
         g = to_cl(g)
-        gin = new_cl(B, C, D, H, W, g.device) if C > 1 else torch.empty((B, 1, D, H, W), device=g.device, dtype=torch.float32)
-        lib.call("pulpo_avgpool2_bwd", _ptr(g), g.stride(4), _ptr(gin), gin.stride(4), B, D, H, W, C, _stream())
+        gin = new_cl(B, C, D, H, W, g.device, g.dtype) if C > 1 else torch.empty((B, 1, D, H, W), device=g.device, dtype=g.dtype)
+        lib.call("pulpo_avgpool2_bwd_t", _ptr(g), g.stride(4), None, 0, _ptr(gin), gin.stride(4), _dt(g), B, D, H, W, C, _stream())
         return gin
 
 
@@ -863,7 +925,7 @@ class _AvgPool2Skip(torch.autograd.Function):
     def forward(ctx, x, ready=None, bn_y=None, bn_coef=None):
         """bn_y / bn_coef: x is the untouched output of a ConvUnit, these are its pre-norm tensor and coefficient block - the backward pass then
         also delivers that unit's BatchNorm-backward partial sums (see _BN_TILE_PARTS)"""
-        _require_gpu(x)
+        _require_gpu(x, act=True)
         ctx.set_materialize_grads(False)
         ctx.bn = (bn_y, bn_coef) if (bn_y is not None and BN_REDUCE_IN_DGRAD) else None
         xc = to_cl(x)
@@ -871,9 +933,9 @@ class _AvgPool2Skip(torch.autograd.Function):
         if ready is not None:                          # AvgPool(x) already written by the pass that wrote x (conv_bn_lrelu(pool_after=True))
             out = ready
         else:
-            out = new_cl(B, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, x.device) if C > 1 else \
-                torch.empty((B, 1, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32)
-            lib.call("pulpo_avgpool2_fwd", _ptr(xc), xc.stride(4), _ptr(out), out.stride(4), B, D, H, W, C, _stream())
+            out = new_cl(B, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, x.device, x.dtype) if C > 1 else \
+                torch.empty((B, 1, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=x.dtype)
+            lib.call("pulpo_avgpool2_fwd_t", _ptr(xc), xc.stride(4), _ptr(out), out.stride(4), _dt(xc), B, D, H, W, C, _stream())
         ctx.shape = (B, C, D, H, W)
         # (the alias keeps x's exact strides - view_as() would renumber the batch stride of a B = 1 tensor, and torch.cat then no longer
         #  recognises the channels-last layout of its inputs)
@@ -885,31 +947,33 @@ class _AvgPool2Skip(torch.autograd.Function):
         if gpool is None:
             return gskip, None, None, None
         g = to_cl(gpool)
-        gin = new_cl(B, C, D, H, W, g.device) if C > 1 else torch.empty((B, 1, D, H, W), device=g.device, dtype=torch.float32)
+        if gskip is not None and gskip.dtype != g.dtype:
+            gskip = gskip.to(g.dtype)
+        gin = new_cl(B, C, D, H, W, g.device, g.dtype) if C > 1 else torch.empty((B, 1, D, H, W), device=g.device, dtype=g.dtype)
+        grp = 4 * int(_esize(g))                      # bytes of a four-channel group
         skip_ok = False
         if gskip is not None:
             sb, sp, sc = grid_strides(gskip)
-            skip_ok = _dense_grid(gskip) and sc == 1 and sb == D * H * W * sp and C > 1 and gskip.dtype == torch.float32 and sp % 4 == 0 \
-                and gskip.data_ptr() % 16 == 0
-        if ctx.bn is not None and C % 4 == 0 and C // 4 <= 256 and (gskip is None or skip_ok) and g.stride(4) % 4 == 0 and g.data_ptr() % 16 == 0:
+            skip_ok = _dense_grid(gskip) and sc == 1 and sb == D * H * W * sp and C > 1 and sp % 4 == 0 and gskip.data_ptr() % grp == 0
+        if ctx.bn is not None and C % 4 == 0 and C // 4 <= 256 and (gskip is None or skip_ok) and g.stride(4) % 4 == 0 and g.data_ptr() % grp == 0:
             # the producing ConvUnit's first BatchNorm-backward pass rides along: this kernel has every element of its gradient in registers
             y, coef = ctx.bn
-            if tuple(y.shape) == (B, C, D, H, W) and y.stride(1) == 1 and y.stride(4) % 4 == 0 and y.data_ptr() % 16 == 0 and _dense_grid(y):
+            if tuple(y.shape) == (B, C, D, H, W) and y.stride(1) == 1 and y.stride(4) % 4 == 0 and y.data_ptr() % (4 * int(_esize(y))) == 0 and _dense_grid(y):
                 nblk = lib.query("pulpo_bn_bwd_blocks", B * D * H * W, C)
                 part = torch.empty(nblk * 2 * C, device=g.device, dtype=torch.float32)
                 t0 = _hbm_begin("avgpool2_bwd_bnred")
-                lib.call("pulpo_avgpool2_bwd_bnred", _ptr(g), g.stride(4), _ptr(gskip), grid_strides(gskip)[1] if gskip is not None else 0, _ptr(gin),
-                         gin.stride(4), _ptr(y), y.stride(4), _ptr(coef), LRELU_SLOPE, _ptr(part), B, D, H, W, C, _stream())
+                lib.call("pulpo_avgpool2_bwd_bnred_t", _ptr(g), g.stride(4), _ptr(gskip), grid_strides(gskip)[1] if gskip is not None else 0, _ptr(gin),
+                         gin.stride(4), _dt(g), _ptr(y), _dt(y), y.stride(4), _ptr(coef), LRELU_SLOPE, _ptr(part), B, D, H, W, C, _stream())
                 # read the pooled gradient, the skip gradient and y, write the summed gradient
-                _hbm_end(t0, "avgpool2_bwd_bnred", 4.0 * C * (g.numel() // C + (3 if gskip is not None else 2) * B * D * H * W))
+                _hbm_end(t0, "avgpool2_bwd_bnred", C * (_esize(g) * (g.numel() // C + (2 if gskip is not None else 1) * B * D * H * W) + _esize(y) * B * D * H * W))
                 _BN_TILE_PARTS[y.data_ptr()] = (part, nblk, coef.data_ptr(), gin.data_ptr(), gin._version, tuple(gin.shape), tuple(gin.stride()))
                 return gin, None, None, None
         if skip_ok:
             t0 = _hbm_begin("avgpool2_bwd_add")
-            lib.call("pulpo_avgpool2_bwd_add", _ptr(g), g.stride(4), _ptr(gskip), grid_strides(gskip)[1], _ptr(gin), gin.stride(4), B, D, H, W, C, _stream())
-            _hbm_end(t0, "avgpool2_bwd_add", 4.0 * C * (g.numel() // C + 2 * B * D * H * W))
+            lib.call("pulpo_avgpool2_bwd_t", _ptr(g), g.stride(4), _ptr(gskip), grid_strides(gskip)[1], _ptr(gin), gin.stride(4), _dt(g), B, D, H, W, C, _stream())
+            _hbm_end(t0, "avgpool2_bwd_add", _esize(g) * C * (g.numel() // C + 2 * B * D * H * W))
             return gin, None, None, None
-        lib.call("pulpo_avgpool2_bwd", _ptr(g), g.stride(4), _ptr(gin), gin.stride(4), B, D, H, W, C, _stream())
+        lib.call("pulpo_avgpool2_bwd_t", _ptr(g), g.stride(4), None, 0, _ptr(gin), gin.stride(4), _dt(g), B, D, H, W, C, _stream())
         return (gin if gskip is None else gskip + gin), None, None, None
 
 
@@ -973,13 +1037,13 @@ class _FeedbackUp2(torch.autograd.Function):
         B, _, Di, Hi, Wi = srcs[0].shape
         chans = [int(s.shape[1]) for s in srcs]
         ctot = sum(chans)
-        out = new_cl(B, ctot, 2 * Di, 2 * Hi, 2 * Wi, srcs[0].device)
+        out = new_cl(B, ctot, 2 * Di, 2 * Hi, 2 * Wi, srcs[0].device, act_dtype())
         n = len(srcs)
         ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
         ch = (ctypes.c_int * n)(*chans)
         t0 = _hbm_begin("feedback_up2_fwd")
-        lib.call("pulpo_feedback_up2_fwd", ptrs, ch, n, _ptr(out), out.stride(4), B, Di, Hi, Wi, _stream())
-        _hbm_end(t0, "feedback_up2_fwd", 4.0 * ctot * B * Di * Hi * Wi * 9)             # read the sources, write 8x as many voxels
+        lib.call("pulpo_feedback_up2_fwd_t", ptrs, ch, n, _ptr(out), _dt(out), out.stride(4), B, Di, Hi, Wi, _stream())
+        _hbm_end(t0, "feedback_up2_fwd", ctot * B * Di * Hi * Wi * (4.0 + 8 * _esize(out)))             # read the sources, write 8x as many voxels
         ctx.meta = (B, Di, Hi, Wi, chans)
         ctx.keep = srcs      # keep the sources alive until the kernel has been enqueued (same stream: safe afterwards)
         return out
@@ -994,8 +1058,8 @@ class _FeedbackUp2(torch.autograd.Function):
         ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in gs])
         ch = (ctypes.c_int * n)(*chans)
         t0 = _hbm_begin("feedback_up2_bwd")
-        lib.call("pulpo_feedback_up2_bwd", _ptr(g), g.stride(4), ptrs, ch, n, B, Di, Hi, Wi, _stream())
-        _hbm_end(t0, "feedback_up2_bwd", 4.0 * sum(chans) * B * Di * Hi * Wi * 9)
+        lib.call("pulpo_feedback_up2_bwd_t", _ptr(g), _dt(g), g.stride(4), ptrs, ch, n, B, Di, Hi, Wi, _stream())
+        _hbm_end(t0, "feedback_up2_bwd", sum(chans) * B * Di * Hi * Wi * (4.0 + 8 * _esize(g)))
         return tuple(gs)
 
 

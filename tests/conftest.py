@@ -42,14 +42,20 @@ def _clean_kernel_switches():
     if mod is not None:
         assert mod.CONV_ALGO is None, f"ops.CONV_ALGO leaked from an earlier test: {mod.CONV_ALGO!r}"
         assert mod.CONV_PRECISION == "fp32", f"ops.CONV_PRECISION leaked from an earlier test: {mod.CONV_PRECISION!r}"
+        assert mod.ACT_BF16 is False, "ops.ACT_BF16 leaked from an earlier test"
         fusion = mod.BN_REDUCE_IN_DGRAD
     yield
     mod = sys.modules.get("pulpo_amd.ops")
     if mod is not None:
-        leaked = (mod.CONV_ALGO, mod.CONV_PRECISION)
+        leaked = (mod.CONV_ALGO, mod.CONV_PRECISION, mod.ACT_BF16)
         mod.CONV_ALGO = None
         mod.set_conv_precision("fp32")
-        assert leaked == (None, "fp32"), f"test left ops.CONV_ALGO / CONV_PRECISION = {leaked!r}"
+        assert leaked == (None, "fp32", False), f"test left ops.CONV_ALGO / CONV_PRECISION / ACT_BF16 = {leaked!r}"
+    orc = sys.modules.get("oracle.pulpo_oracle")
+    if orc is not None:
+        left = (orc.CONV_PRECISION, orc.ACT_PRECISION)
+        orc.CONV_PRECISION, orc.ACT_PRECISION = "fp32", "fp32"
+        assert left == ("fp32", "fp32"), f"test left the oracle in {left!r}"
         if fusion is not None:
             now = mod.BN_REDUCE_IN_DGRAD
             mod.BN_REDUCE_IN_DGRAD = fusion

@@ -941,3 +941,137 @@ def test_mu_sigma_block_with_zdim_other_than_ndims_golden(ops, golden, zdim):
         vf = _load_block(nb.VelocityField([4, 5, 6], 5, 8, 3), g, "vf_z5").eval()
         with torch.no_grad():
             close(vf(dev(g["vf_z5.z"])), g["vf_z5.y"], atol=3e-6)
+
+
+# ================================================================================================ bf16 activation storage (configs 4-5)
+def _bf(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("Cin,Cout,size,pool", [(32, 32, (16, 16, 16), False), (16, 96, (8, 16, 16), True), (3, 32, (12, 8, 16), False), (40, 24, (9, 7, 10), True)])
+def test_bf16_storage_conv_unit_vs_definition(ops, Cin, Cout, size, pool):
+    """One ConvUnit with bf16 ACTIVATION STORAGE (ops.ACT_BF16, BASELINE configs 4-5) against the oracle's definition (O.ACT_PRECISION:
+    conv operands bf16, y / z and their gradients rounded to bf16 where they are stored, fp32 arithmetic, statistics of y as stored):
+    forward z, the pooled tensor, running statistics, and the input / parameter gradients.  A stored value sits on a different side of a
+    bf16 rounding boundary in the two evaluations with probability ~ fp32 error / bf16 spacing ~ 3e-4, so the tensors agree except for a
+    small fraction of one-ulp differences: relative L2 <= 1e-3 forward, 5e-3 for gradients (which carry the flips of y, dy and dz)."""
+    import src.network_blocks as nb
+    gen = torch.Generator().manual_seed(17)
+    torch.manual_seed(3)
+    unit = nb.ConvUnit(list(size), Cin, Cout)
+    with torch.no_grad():
+        unit._op[1].weight.copy_(torch.rand(Cout, generator=gen) * 0.5 + 0.75)
+        unit._op[1].bias.copy_(torch.randn(Cout, generator=gen) * 0.1)
+    sd = {"u." + k: v.detach().clone() for k, v in unit.state_dict().items()}
+    x = _bf(torch.randn(2, Cin, *size, generator=gen))
+    up = torch.randn(2, Cout, *size, generator=gen)
+    unit = unit.cuda().train()
+    O.CONV_PRECISION, O.ACT_PRECISION = "bf16", "bf16"
+    ops.set_conv_precision("bf16", activations="bf16")
+    try:
+        xr = x.clone().requires_grad_(True)
+        sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+        zr = O.conv_unit(xr, sdr, "u", training=True)
+        names = ["u._op.0.weight", "u._op.1.weight", "u._op.1.bias"]
+        gr = torch.autograd.grad((zr * up).sum(), [xr] + [sdr[n] for n in names])
+        xg = (x.cuda().contiguous(memory_format=torch.channels_last_3d) if Cin > 3 else x.cuda()).requires_grad_(True)
+        z = unit(xg, pool_after=pool)
+        assert z.dtype == torch.bfloat16
+        pooled = getattr(z, "_pulpo_pooled", None)
+        g = torch.autograd.grad((z.float() * up.cuda()).sum(), [xg, unit._op[0].weight, unit._op[1].weight, unit._op[1].bias])
+    finally:
+        O.CONV_PRECISION, O.ACT_PRECISION = "fp32", "fp32"
+        ops.set_conv_precision("fp32")
+    assert rel_l2(z.float(), zr) <= 1e-3, rel_l2(z.float(), zr)
+    diff = (z.float().cpu() - zr).abs()
+    # at most ~one bf16 ulp of the pre-norm value (through the BatchNorm scale), on few elements
+    assert float(diff.max()) <= 2.0 ** -6 * float(zr.abs().max()) and float((diff > 0).float().mean()) < 0.02, (float(diff.max()), float((diff > 0).float().mean()))
+    if pool and pooled is not None:
+        pr = _bf(F.avg_pool3d(zr.detach(), 2, 2, ceil_mode=True))
+        assert pooled[0].dtype == torch.bfloat16 and rel_l2(pooled[0].float(), pr) <= 1.5e-3
+    close(unit._op[1].running_mean, sdr["u._op.1.running_mean"], atol=2e-5, rtol=1e-4)
+    close(unit._op[1].running_var, sdr["u._op.1.running_var"], atol=2e-5, rtol=2e-4)
+    for got, want, nme in zip(g, gr, ["x"] + names):
+        assert rel_l2(got.float(), want) <= 5e-3, (nme, rel_l2(got.float(), want))
+
+
+def test_bf16_storage_elementwise_kernels_round_the_fp32_result(ops):
+    """the typed (bf16-storage) forms of the pooling, head, feedback and eval-mode kernels: on bf16-representable inputs each equals the fp32
+    operator's result rounded to bf16, up to one ulp on the elements whose fp32 value sits at a rounding boundary"""
+    import src.network_blocks as nb
+    gen = torch.Generator().manual_seed(23)
+
+    def ulp_close(a, b, frac=0.01):
+        a, b = a.float().cpu(), b.float().cpu()
+        d = (a - b).abs() / b.abs().clamp_min(1e-2)
+        assert float(d.max()) <= 2.0 ** -6, float(d.max())
+        assert float((d > 0).float().mean()) <= frac, float((d > 0).float().mean())
+
+    # ---- average pooling (ceil mode) forward / backward, odd sizes
+    x = _bf(torch.randn(2, 16, 9, 10, 7, generator=gen)).cuda().contiguous(memory_format=torch.channels_last_3d)
+    xb = x.bfloat16().requires_grad_(True)
+    p = ops.avg_pool2(xb)
+    assert p.dtype == torch.bfloat16
+    ulp_close(p, _bf(F.avg_pool3d(x, 2, 2, ceil_mode=True)))
+    up = _bf(torch.randn(p.shape, generator=gen)).cuda()
+    gx, = torch.autograd.grad(p, xb, up.bfloat16())
+    xr = x.clone().requires_grad_(True)
+    gr, = torch.autograd.grad(F.avg_pool3d(xr, 2, 2, ceil_mode=True), xr, up)
+    ulp_close(gx, _bf(gr))
+    # ---- 1x1x1 heads on a bf16 feature map: planar fp32 outputs, bf16 input gradient
+    ms = nb.MuSigmaBlock([6, 8, 8], 16, 3).cuda()
+    h = _bf(torch.randn(2, 16, 6, 8, 8, generator=gen)).cuda().contiguous(memory_format=torch.channels_last_3d)
+    eps = torch.randn(2, 3, 6, 8, 8, generator=gen).cuda()
+    hb = h.bfloat16().requires_grad_(True)
+    hf = h.clone().requires_grad_(True)
+    mu_b, sg_b, z_b = ms.sample(hb, eps)
+    mu_f, sg_f, z_f = ms.sample(hf, eps)
+    assert mu_b.dtype == torch.float32
+    close(mu_b, mu_f, atol=1e-6); close(sg_b, sg_f, atol=1e-6); close(z_b, z_f, atol=2e-6)
+    gb, = torch.autograd.grad((z_b * eps).sum() + sg_b.sum(), hb)
+    gf, = torch.autograd.grad((z_f * eps).sum() + sg_f.sum(), hf)
+    assert gb.dtype == torch.bfloat16
+    ulp_close(gb, _bf(gf))
+    # ---- feedback gather (x2 up-sampling + concatenation) written as bf16
+    srcs = [torch.randn(1, c, 4, 5, 6, generator=gen).cuda().requires_grad_(True) for c in (3, 3, 3, 3, 3, 1)]
+    ref = ops.feedback_up2(srcs)
+    ops.set_conv_precision("bf16", activations="bf16")
+    try:
+        fb = ops.feedback_up2(srcs)
+        assert fb.dtype == torch.bfloat16
+        ulp_close(fb, _bf(ref.detach()), frac=1.0)               # (every element is a fresh rounding here: one ulp at most, anywhere)
+        upf = _bf(torch.randn(fb.shape, generator=gen)).cuda().contiguous(memory_format=torch.channels_last_3d)
+        g_b = torch.autograd.grad(fb, srcs, upf.bfloat16())
+    finally:
+        ops.set_conv_precision("fp32")
+    g_f = torch.autograd.grad(ref, srcs, upf)
+    for a, b in zip(g_b, g_f):
+        close(a, b, atol=1e-5, rtol=1e-5)                        # (planar fp32 gradients of bf16-representable upstream values)
+
+
+@pytest.mark.parametrize("Cin,Cout,size", [(32, 64, (8, 16, 16)), (3, 32, (9, 8, 8))])
+def test_bf16_storage_eval_mode_unit(ops, Cin, Cout, size):
+    """eval-mode ConvUnit with bf16 activation storage: one fused kernel when operand and result share the storage type, convolution +
+    typed apply pass behind the exact-fp32 kernel of the narrow input layers - both equal the definition (oracle) to a bf16 rounding"""
+    import src.network_blocks as nb
+    gen = torch.Generator().manual_seed(29)
+    torch.manual_seed(5)
+    unit = nb.ConvUnit(list(size), Cin, Cout)
+    with torch.no_grad():
+        unit._op[1].running_mean.copy_(torch.randn(Cout, generator=gen) * 0.1)
+        unit._op[1].running_var.copy_(torch.rand(Cout, generator=gen) * 0.5 + 0.75)
+    sd = {"u." + k: v.detach().clone() for k, v in unit.state_dict().items()}
+    x = _bf(torch.randn(1, Cin, *size, generator=gen))
+    unit = unit.cuda().eval()
+    O.CONV_PRECISION, O.ACT_PRECISION = "bf16", "bf16"
+    ops.set_conv_precision("bf16", activations="bf16")
+    try:
+        with torch.no_grad():
+            zr = O.conv_unit(x, sd, "u", training=False)
+            z = unit(x.cuda().contiguous(memory_format=torch.channels_last_3d) if Cin > 3 else x.cuda())
+    finally:
+        O.CONV_PRECISION, O.ACT_PRECISION = "fp32", "fp32"
+        ops.set_conv_precision("fp32")
+    assert z.dtype == torch.bfloat16
+    # (the fused kernel never writes y, but rounds it as the unfused path would have stored it)
+    assert rel_l2(z.float(), zr) <= 1e-3, rel_l2(z.float(), zr)

@@ -425,7 +425,8 @@ def test_step_vs_oracle_at_baseline_width(api):
     assert checked > 60
 
 
-def test_bf16_operand_mode_step_vs_oracle_definition(api):
+@pytest.mark.parametrize("activations", ["fp32", "bf16"])
+def test_bf16_operand_mode_step_vs_oracle_definition(api, activations):
     """BASELINE configs 4-5 name bf16; the reference has no such mode, so the mode is DEFINED in oracle/pulpo_oracle.py
     (3x3x3 conv operands rounded to bf16, fp32 accumulation, all else fp32 - "parity unpinned" against the reference).
     Same case as the fp32 test above (n0 = 32, 32^3, T3/L2).
@@ -455,15 +456,20 @@ def test_bf16_operand_mode_step_vs_oracle_definition(api):
         model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(eps[l].cuda())
     sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     ls_true, g_true, outs_true = O.train_step(O.clone_sd(sd64, requires_grad=True), cfg, x.double(), y.double(), eps64)
-    O.CONV_PRECISION = "bf16"
-    ops.set_conv_precision("bf16")
+    # activations == "bf16": the mode of BASELINE configs 4-5 as benched - the multi-channel activation tensors and their gradients are
+    # additionally STORED as bf16 (ops.ACT_BF16; the oracle rounds value and gradient at the same tensors, O.ACT_PRECISION) - same criteria
+    O.CONV_PRECISION, O.ACT_PRECISION = "bf16", activations
+    ops.set_conv_precision("bf16", activations=activations)
     try:
         ls, g_def64, outs_o = O.train_step(O.clone_sd(sd64, requires_grad=True), cfg, x.double(), y.double(), eps64)
         _, g_def32, outs_o32 = O.train_step(O.clone_sd(sd, requires_grad=True), cfg, x, y, eps)
         outs, _, (total, kl, rec, reg), _ = model._forward_and_losses(x.cuda(), y.cuda())
         total.backward()
+        if activations == "bf16":       # the storage really is bf16 where the definition says so
+            acts = model.downpath(x.cuda(), y.cuda())
+            assert all(a.dtype == torch.bfloat16 for a in acts.values())
     finally:
-        O.CONV_PRECISION = "fp32"
+        O.CONV_PRECISION, O.ACT_PRECISION = "fp32", "fp32"
         ops.set_conv_precision("fp32")
 
     def maxerr(a, b):
@@ -484,7 +490,10 @@ def test_bf16_operand_mode_step_vs_oracle_definition(api):
             continue
         e_gpu, e_cpu, e_true = rel_l2(p.grad, g_def64[k]), rel_l2(g_def32[k], g_def64[k]), rel_l2(p.grad, g_true[k])
         worst, worst_true = max(worst, e_gpu), max(worst_true, e_true)
-        assert e_gpu <= 1.5 * e_cpu + 1e-2, (k, e_gpu, e_cpu)
+        # (bf16 storage: every stored tensor is one more discontinuous rounding - two fp32 evaluations of the definition drift further apart, and
+        #  the product path sums the bf16 gradients of a tensor with several consumers in bf16, which the definition's single rounding of the
+        #  fp32 sum does not model; the kernels themselves are held to the definition per operator, tests/test_gpu_ops.py::test_bf16_storage_*)
+        assert e_gpu <= (1.5 if activations == "fp32" else 2.5) * e_cpu + (1e-2 if activations == "fp32" else 2e-2), (k, e_gpu, e_cpu)
         assert e_true <= 0.5, (k, e_true)
         checked += 1
     assert checked > 60
@@ -493,7 +502,7 @@ def test_bf16_operand_mode_step_vs_oracle_definition(api):
     fin = OUT.index("final_dfs")
     dfe = maxerr(outs[fin][0], outs_true[fin][0]) * max(1.0, float(outs_true[fin][0].abs().max())) / float(outs_true[fin][0].abs().max())
     assert dfe < 5e-2, dfe
-    print(f"bf16-operand mode: worst output err vs definition {worst_out:.2e}, worst grad rel-L2 vs definition {worst:.2e}, vs fp32 arithmetic "
+    print(f"bf16-operand mode, {activations} activations: worst output err vs definition {worst_out:.2e}, worst grad rel-L2 vs definition {worst:.2e}, vs fp32 arithmetic "
           f"{worst_true:.2e}; final field vs fp32 {dfe:.2e}; total loss {float(total):.6f} vs fp32 {float(ls_true[0]):.6f}")
 
 
@@ -576,7 +585,7 @@ def test_config5_shape_bf16_train_step_and_mc_uncertainty(api):
     x, y = synthetic.oasis_like_pair(size, 1, 7, "cuda")
     assert 0.2 < float((y > 0).float().mean()) < 0.35            # ellipsoid with semi-axes 0.4: 4/3 pi 0.4^3 = 0.27 of the box
     empty = torch.empty((0,), device="cuda")
-    ops.set_conv_precision("bf16")
+    ops.set_conv_precision("bf16", activations="bf16")
     try:
         stepper = dp.DataParallelStepper(model)
         losses = [float(stepper.step((x, y, empty, empty, empty, empty, empty, empty))) for _ in range(3)]
@@ -626,7 +635,7 @@ def test_config4_160_bf16_oasis_step(api):
     outs32 = [{l: v.clone() for l, v in d.items()} for d in outs32]
     model.load_state_dict(state)
     empty = torch.empty((0,), device="cuda")
-    ops.set_conv_precision("bf16")
+    ops.set_conv_precision("bf16", activations="bf16")
     try:
         with torch.no_grad():
             outs, _, losses, _ = model._forward_and_losses(x, y)
