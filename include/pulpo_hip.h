@@ -291,6 +291,22 @@ int pulpo_mc_moments_std(const float* m2, const float* scale /*nullable (B,V)*/,
 int pulpo_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, float gscale,
                     void* stream);
 
+/* ------------------------------------------------------------------------- Winograd F(2x2x2,3x3x3): the deep layers (since ABI 3)
+ * The same convolution (src/network_blocks.py:23, forward and data gradient) with minimal filtering along z, y AND x: 64 products per 2x2x2
+ * output block instead of 216 (1.5x fewer matrix instructions than the (y, x) form above), all fp32, coefficients +-1 and 1/2 (results differ
+ * from the direct kernel by fp32 rounding only).  pulpo_conv3d_k3_algo() answers 3 for the shapes it takes: whole 4x8x8 tiles (D % 4 == 0,
+ * H % 8 == 0, W % 8 == 0), K % 8 == 0 and K >= 64, N % 32 == 0, at least 256 (tile, 32-channel) work items; operands channels-last and 16-byte
+ * aligned (the caller guarantees that; the entry point refuses anything else).  Own weight packing (kind 4 of PulpoPackJob); stats / coef / bias
+ * and the _bnred form as for the (y, x) kernel. */
+size_t pulpo_conv3d_k3_packed_wino3_floats(int K, int N);
+int pulpo_conv3d_k3_pack_weight_wino3(const float* w /*[Cout][Cin][3][3][3]*/, float* wp, int Cin, int Cout, int dgrad, void* stream);
+int pulpo_conv3d_k3_fwd_wino3(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,
+                              float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B, int D, int H, int W, int K,
+                              int N, void* stream);
+int pulpo_conv3d_k3_dgrad_wino3_bnred(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, float* out, int64_t out_bs,
+                                      int64_t out_ps, const float* bn_y, int64_t bn_y_bs, int64_t bn_y_ps, const float* bn_coef, float slope, float* part,
+                                      int B, int D, int H, int W, int K, int N, void* stream);
+
 /* ------------------------------------------------------------------------- bf16 ACTIVATION STORAGE (BASELINE configs 4-5; since ABI 3)
  * No counterpart in the reference (fp32 throughout).  On top of the bf16-operand convolutions the multi-channel activation
  * tensors of a ConvUnit - the pre-norm output y (src/network_blocks.py:23), the output z (:25), pooled / concatenated / up-sampled feature

@@ -513,11 +513,13 @@ PULPO_API int pulpo_conv3d_k3_stat_tiles(int B, int D, int H, int W) {
     return B * pulpo::cdiv(D, conv_tz(D, H, W)) * pulpo::cdiv(H, TY) * pulpo::cdiv(W, TX);
 }
 
-// forward / data-gradient kernel for a shape: 2 = Winograd F(2x2,3x3) in (y, x) (where it applies: 4x8x8-tiled volumes, > 4 reduction
+// forward / data-gradient kernel for a shape: 3 = Winograd F(2x2x2,3x3x3) in all three axes (conv3d_wino3.hip: whole 4x8x8 tiles, from 64
+// reduction channels up, channels-last operands), 2 = Winograd F(2x2,3x3) in (y, x) (where it applies: 4x8x8-tiled volumes, > 4 reduction
 // channels; the 10^3 level - depth not a multiple of 4 - where the pipelined kernel runs it with split-K work items), 0 = direct implicit GEMM.  (1, F(2,3) along x only, was retired in round 3.)
 PULPO_API int pulpo_conv3d_k3_algo(int B, int D, int H, int W, int K, int N) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("PULPO_CONV_WINOGRAD"); force = e ? atoi(e) + 1 : 0; }     // unset: policy; 0 / 1: force off / on
     if (force == 1) return 0;
+    if (pulpo_conv::wino3_shape_ok(B, D, H, W, K, N)) return 3;
     return (K > 4 && (conv_tz(D, H, W) == 4 || pulpo_conv::wino2_ragged_depth_ok(B, D, H, W, K, N))) ? 2 : 0;
 }

@@ -5,6 +5,7 @@
 // Same argument block, tile order, BatchNorm partial statistics and fused eval-mode epilogue as the direct kernel in conv3d.hip.
 #include "conv_shared.h"
 #include "../../include/pulpo_hip.h"
+#include "wino3_pack.h"
 #include <stdlib.h>
 
 
@@ -555,6 +556,10 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PulpoPack
     if (j.kind == 2) {
         const long total = (long)((K + WN_CH - 1) / WN_CH) * 3 * WN_CH * NPad;
         for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += step) pack_wino2_one(j.w, j.wp, j.Cin, j.Cout, NPad, j.dgrad, e);
+    } else if (j.kind == 4) {
+        // the F(2x2x2,3x3x3) kernel's layout (wino3_pack.h)
+        const long total = (long)((K + 7) / 8) * 8 * NPad;
+        for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += step) pulpo_conv::pack_wino3_one(j.w, j.wp, j.Cin, j.Cout, NPad, j.dgrad, e);
     } else if (j.kind == 3) {
         // the bf16-operand kernels' layout (conv3d_bf16.hip pack_weight_bf16_kernel): bf16 wp[k / 32][tap][n][k % 32]
         uint16_t* wp16 = reinterpret_cast<uint16_t*>(j.wp);
@@ -601,7 +606,8 @@ PULPO_API int pulpo_conv3d_k3_pack_weight_wino2(const float* w, float* wp, int C
     return pulpo::check_launch("pack_weight_wino2");
 }
 
-// jobs: DEVICE array; kind 0 = the layout of pulpo_conv3d_k3_pack_weight, 2 = of pulpo_conv3d_k3_pack_weight_wino2, 3 = of pulpo_conv3d_k3_pack_weight_bf16
+// jobs: DEVICE array; kind 0 = the layout of pulpo_conv3d_k3_pack_weight, 2 = of pulpo_conv3d_k3_pack_weight_wino2, 3 = of pulpo_conv3d_k3_pack_weight_bf16,
+// 4 = of pulpo_conv3d_k3_pack_weight_wino3
 PULPO_API int pulpo_conv3d_k3_pack_weights_multi(const PulpoPackJob* jobs, int njobs, void* stream) {
     PULPO_REQUIRE(jobs && njobs > 0, "conv3d_k3_pack_weights_multi: bad arguments");
     hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(160, njobs), dim3(256), 0, (hipStream_t)stream, jobs);

@@ -1,0 +1,484 @@
+// Winograd F(2x2x2, 3x3x3) - minimal filtering in ALL three axes - for the forward / data-gradient convolution of the deep layers: 64
+// transformed points per 2 x 2 x 2 output block instead of the 216 multiply-adds of the direct form (the (y, x) kernel of conv3d_wino2p.hip
+// issues 96): 1.5x fewer matrix instructions than that kernel, 3.375x fewer than the direct one, all fp32 (coefficients +-1 and 1/2; measured
+// error against fp64 2.8e-7 relative L2 at 32 channels, the (y, x) form 2.1e-7, the direct form 1.2e-7 - same 2e-6 test bound).
+//
+//   tile 4 x 8 x 8 voxels = 2 x 4 x 4 blocks = ONE 32-row MFMA tile per point; 32 output channels per work item; 8-channel chunks.
+//   512 threads = 8 waves, ONE workgroup per CU: wave (py, pzh) owns the eight points (pz in {2 pzh, 2 pzh + 1}, py, px 0..3) - eight
+//   32 x 32 accumulator tiles, the register budget of the (y, x) kernel's wave.
+//   LDS image of a chunk = the halo transformed along x AND z while it is staged (8 transformed planes per tile instead of 6 raw ones):
+//   the matrix loop then reads two rows per point step and forms the y combination in registers exactly like the (y, x) kernel - 0.5
+//   ds_read_b128 per MFMA - and the weights come global -> registers one chunk ahead.  Two images (the next chunk - or the next tile's first
+//   chunk - is staged underneath the MFMAs), one barrier per chunk.
+//   Epilogue: x inverse transform in registers, the z pair of a wave combined in registers, y (four waves) and the two z halves summed
+//   through a 64 KB exchange buffer, one output z-parity at a time; stores, bias, BatchNorm partials and the eval-mode store as in the
+//   (y, x) kernel's fast path.
+//
+// Whole tiles only (D % 4 == 0, H % 8 == 0, W % 8 == 0), channels-last 16-byte aligned operands, Cin % 8 == 0, Cout % 32 == 0: the deep
+// layers of the 80^3 / 40^3 levels.  pulpo_conv3d_k3_algo() selects it from 64 reduction channels up (below that the tile's epilogue - which no
+// second workgroup hides here - costs more than the matrix instructions saved).
+#include "conv_shared.h"
+#include "wino3_pack.h"
+#include <stdlib.h>
+
+namespace {
+
+using namespace pulpo_conv;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+constexpr int Q_CH = 8, Q_NT = 32;
+constexpr int Q_PX = HY * 4;                     // rows of one (zb, pz, px) slice: (hy, x-pair)
+constexpr int Q_PZ = 4 * Q_PX;                   // rows of one (zb, pz) plane: four px slices
+constexpr int Q_ZB = 4 * Q_PZ + 4;               // rows per z block (4 mod 16: the two z blocks of an MFMA row tile fall on different 16-byte slots)
+constexpr int Q_QROWS = 2 * Q_ZB + 4;            // rows per channel quad (x 4 dwords = 16 mod 32: the two quads of a ds_write_b128 group use different banks)
+constexpr int Q_IMG = 2 * Q_QROWS * 4;           // floats of one image
+constexpr int Q_NITEM = 2 * 4 * HY * 4 * 2;      // staging items of a chunk: (zb, px, hy, x-pair, channel quad) = 640: one per thread + a second for 128
+constexpr int Q_TAB = 3 * 512;                   // per-channel table [3][ncot * 32]: up to 512 output channels
+constexpr int Q_R = 8 * 2 * 16 * 64;             // floats of the exchange buffer of one output z parity: [wave][ox][r][lane]
+constexpr int Q_RED = 8 * 2 * Q_NT;              // statistics rows of the eight waves
+constexpr size_t Q_LDS = (size_t)(2 * Q_IMG + Q_TAB + Q_R + Q_RED) * sizeof(float);
+static_assert(Q_LDS <= 160 * 1024, "one workgroup per CU");
+
+template <bool BNR>
+__global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
+    constexpr int CH = Q_CH, NT = Q_NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const tab = smem + 2 * Q_IMG;                // [3][ctab]
+    float* const R = tab + Q_TAB;                       // exchange buffer
+    float* const red = R + Q_R;                         // [8 waves][2][NT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kk = lane >> 5;
+    const int py = wave & 3, pzh = wave >> 2;
+    const int nchunk = a.Cin / CH;
+    const int nwork = a.B * a.ntz * a.nty * a.ntx * a.ncot;
+    const int nwg = gridDim.x;
+    const unsigned ps_bytes = (unsigned)a.in_ps * 4u;
+    const unsigned plane_bytes = (unsigned)a.H * (unsigned)a.W * ps_bytes;
+
+    // ---- the two staging items of this thread: (zb, px, hy, x-pair xb, channel quad q); the second one exists for tid < 128 only
+    // x transform of tap pair (ta_, tb_): X = d[ta_] + sx * d[tb_];  z transform of planes 2 zb .. 2 zb + 3 likewise
+    unsigned roff[2];                                   // byte offset of (plane 2 zb, tap ta_) relative to the tile's halo origin
+    unsigned dtap[2];                                   // byte distance from tap ta_ to tap tb_ (modulo 2^32: px = 2 reads tb_ = ta_ - 1)
+    int lofs[2];                                        // float offset of the item's pz = 0 row in an image
+    float sx[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = tid + u * 512;
+        const int q = j & 1, rb = j >> 1;
+        const int xb = rb & 3, t = rb >> 2;
+        const int hy = t % HY, pp = (t / HY) & 7;
+        const int px = pp & 3, zb = pp >> 2;
+        const int tapa = px == 0 ? 0 : px == 2 ? 2 : 1, tapb = px == 2 ? 1 : px == 3 ? 3 : 2;
+        roff[u] = ((unsigned)((2 * zb * a.H + hy) * a.W + 2 * xb + tapa) * (unsigned)a.in_ps + 4u * q) * 4u;
+        dtap[u] = (unsigned)(tapb - tapa) * ps_bytes;
+        lofs[u] = (q * Q_QROWS + zb * Q_ZB + px * Q_PX + hy * 4 + xb) * 4;
+        sx[u] = px == 1 ? 1.f : -1.f;
+    }
+    const bool item1 = tid + 512 < Q_NITEM;
+    // y combination of this wave's point row: v = X[2 yb + ta] + sa * X[2 yb + tb]
+    const int ta = py == 0 ? 0 : py == 2 ? 2 : 1;
+    const int tb = py == 2 ? 1 : py == 3 ? 3 : 2;
+    const float sa = py == 1 ? 1.f : -1.f;
+    // MFMA row i = block (zb = i >> 4, yb = (i >> 2) & 3, xb = i & 3)
+    const int lrow = (i >> 4) * Q_ZB + ((i >> 2) & 3) * 8 + (i & 3);
+    const int pa_off = (kk * Q_QROWS + lrow + ta * 4 + 2 * pzh * Q_PZ) * 4;
+    const int pb_off = (kk * Q_QROWS + lrow + tb * 4 + 2 * pzh * Q_PZ) * 4;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, -1, 0x00020000);
+    const int in_bytes = (int)((long)a.D * a.H * a.W * a.in_ps * 4);
+    struct Tile {
+        int tile_lin, b, z0, y0, x0, co0;
+        unsigned wbase;              // byte offset of (chunk 0, point (2 pzh, py, 0), cout co0) in the packed weights
+    };
+    auto describe = [&](int work) {
+        Tile t;
+        const int cot = work % a.ncot;
+        int q = work / a.ncot;
+        int tx_, ty_, tz_;
+        if (a.tile_order == 1) {                        // blocks of 4 x 4 x 4 tiles, as in the (y, x) kernel
+            const int nt = a.ntx * a.nty * a.ntz;
+            t.b = q / nt;
+            q -= t.b * nt;
+            const int blk = q >> 6, w = q & 63;
+            const int nbx = a.ntx >> 2, nby = a.nty >> 2;
+            const int bx = blk % nbx, by = (blk / nbx) % nby, bz = blk / (nbx * nby);
+            tx_ = bx * 4 + (w & 3); ty_ = by * 4 + ((w >> 2) & 3); tz_ = bz * 4 + (w >> 4);
+        } else {
+            tx_ = q % a.ntx; q /= a.ntx;
+            ty_ = q % a.nty; q /= a.nty;
+            tz_ = q % a.ntz;
+            t.b = q / a.ntz;
+        }
+        t.tile_lin = ((t.b * a.ntz + tz_) * a.nty + ty_) * a.ntx + tx_;
+        t.z0 = tz_ * 4; t.y0 = ty_ * TY; t.x0 = tx_ * TX;
+        t.co0 = cot * NT;
+        t.wbase = (unsigned)(((2 * pzh) * 16 + py * 4) * a.NPad + t.co0) * (CH * 4u);
+        return t;
+    };
+    // per tile and item: the byte offset of (plane 2 zb, tap ta_) at chunk 0 relative to the batch element, and six validity bits - planes
+    // 0..3 inside the volume (and the item exists, and its row is inside), tap ta_ / tb_ inside.  A load outside the volume goes to an offset
+    // beyond num_records and returns zeros; the chunk's channel offset rides in the instruction's scalar offset.
+    unsigned hbase[2], hmask[2];
+    auto halo_offsets = [&](const Tile& t) {
+        const unsigned origin = (unsigned)(((t.z0 - 1) * a.H + (t.y0 - 1)) * a.W + (t.x0 - 1)) * ps_bytes;      // modulo 2^32: may be "negative"
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = tid + u * 512;
+            const int rb = j >> 1;
+            const int xb = rb & 3, tt = rb >> 2;
+            const int hy = tt % HY, pp = (tt / HY) & 7;
+            const int px = pp & 3, zb = pp >> 2;
+            const int tapa = px == 0 ? 0 : px == 2 ? 2 : 1, tapb = px == 2 ? 1 : px == 3 ? 3 : 2;
+            const bool yok = j < Q_NITEM && (unsigned)(t.y0 - 1 + hy) < (unsigned)a.H;
+            unsigned m = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) m |= (yok && (unsigned)(t.z0 - 1 + 2 * zb + p) < (unsigned)a.D) ? (1u << p) : 0u;
+            m |= (unsigned)(t.x0 - 1 + 2 * xb + tapa) < (unsigned)a.W ? 16u : 0u;
+            m |= (unsigned)(t.x0 - 1 + 2 * xb + tapb) < (unsigned)a.W ? 32u : 0u;
+            hbase[u] = origin + roff[u];
+            hmask[u] = m;
+        }
+    };
+    auto in_rsrc = [&](int b) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + (long)b * a.in_bs), 0, in_bytes, 0x00020000);
+    };
+    float4 xr[4];                                       // the x-transformed rows of the four planes of ONE staging item
+    auto load_x2 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned c0_bytes, int u, int p0) {
+        // planes p0, p0 + 1: two taps each, x combination
+#pragma unroll
+        for (int p = p0; p < p0 + 2; ++p) {
+            const unsigned m = hmask[u];
+            const unsigned oa = hbase[u] + p * plane_bytes;
+            const unsigned offa = ((m >> p) & 1u) && (m & 16u) ? oa : OOB;
+            const unsigned offb = ((m >> p) & 1u) && (m & 32u) ? oa + dtap[u] : OOB;
+            const float4 da = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)offa, (int)c0_bytes, 0));
+            const float4 db = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)offb, (int)c0_bytes, 0));
+            const float s_ = sx[u];
+            xr[p] = make_float4(fmaf(s_, db.x, da.x), fmaf(s_, db.y, da.y), fmaf(s_, db.z, da.z), fmaf(s_, db.w, da.w));
+        }
+    };
+    auto store_item = [&](float* img, int u) {
+        if (u == 0 || item1) {
+            float* o = img + lofs[u];
+            const float4 d0 = xr[0], d1 = xr[1], d2 = xr[2], d3 = xr[3];
+            *reinterpret_cast<float4*>(o) = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
+            *reinterpret_cast<float4*>(o + Q_PZ * 4) = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+            *reinterpret_cast<float4*>(o + 2 * Q_PZ * 4) = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+            *reinterpret_cast<float4*>(o + 3 * Q_PZ * 4) = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+        }
+    };
+    const unsigned w_chunk_stride = 64u * CH * a.NPad * 4u;     // bytes between consecutive chunks
+    const unsigned w_pt_stride = (unsigned)CH * a.NPad * 4u;    // bytes between consecutive points (px fastest, then py, then pz)
+    const int wl_off = (i * CH + 4 * kk) * 4;                   // this lane's 16 bytes inside a point's [32 n][8 k] piece
+    auto load_w = [&](unsigned wofs, int s) {                   // point step s = pz_local * 4 + px
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wl_off, (int)(wofs + ((s >> 2) * 16 + (s & 3)) * w_pt_stride), 0));
+    };
+
+    // ---- per-channel constants of the epilogue, once per workgroup
+    const int ctab = a.ncot * NT;
+    for (int c = tid; c < ctab; c += 512) {
+        const bool in = c < a.Cout;
+        float t0 = 0.f, t1 = 1.f, t2 = 0.f;
+        if (BNR) {
+            if (in) { t0 = a.bn_coef[c]; t1 = a.bn_coef[2 * a.Cout + c]; t2 = a.bn_coef[3 * a.Cout + c]; }
+        } else {
+            if (in && a.bias != nullptr) t0 = a.bias[c];
+            if (in && a.coef != nullptr) { t1 = a.coef[2 * a.Cout + c]; t2 = a.coef[3 * a.Cout + c]; }
+        }
+        tab[c] = t0; tab[ctab + c] = t1; tab[2 * ctab + c] = t2;
+    }
+    int work = pulpo::xcd_remap(blockIdx.x, nwg);
+    Tile cur = describe(work);
+    int cb = 0;                                         // image being read
+    // ---- prologue: chunk 0 of the first tile, the first weight rows
+    float4 wr[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) wr[s] = load_w(cur.wbase, s);
+    {
+        const __amdgpu_buffer_rsrc_t rs0 = in_rsrc(cur.b);
+        halo_offsets(cur);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            load_x2(rs0, 0u, u, 0);
+            load_x2(rs0, 0u, u, 2);
+            store_item(smem, u);
+        }
+    }
+    __syncthreads();
+
+    float4 ra[2], rb[2];                                // two register sets of the operand rows (ta, tb)
+
+    for (;;) {
+        int next_work = nwork;
+        bool has_next = false;
+        Tile nxt = cur;
+
+        f32x16 acc[2][4];                               // [pz local][px]
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][x][r] = 0.f;
+
+        unsigned wnext = cur.wbase + w_chunk_stride;    // weights of chunk + 1
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            const bool last_chunk = chunk + 1 == nchunk;
+            if (last_chunk) {
+                next_work = work + nwg;
+                has_next = next_work < nwork;
+                if (has_next) nxt = describe(next_work);
+                halo_offsets(has_next ? nxt : cur);     // (after the last tile: the tile's own chunk 0 again, into an image nobody reads)
+            }
+            const unsigned st_c0 = (unsigned)(last_chunk ? 0 : chunk + 1) * CH * 4u;
+            const __amdgpu_buffer_rsrc_t st_rs = in_rsrc(last_chunk ? nxt.b : cur.b);
+            const float* img_r = smem + cb * Q_IMG;
+            float* img_w = smem + (cb ^ 1) * Q_IMG;
+            const float* pa = img_r + pa_off;
+            const float* pb = img_r + pb_off;
+            auto fetch_a = [&](int s, int slot) {
+                const int off = ((s >> 2) * Q_PZ + (s & 3) * Q_PX) * 4;
+                ra[slot] = *reinterpret_cast<const float4*>(pa + off);
+                rb[slot] = *reinterpret_cast<const float4*>(pb + off);
+            };
+            const unsigned wsrc = last_chunk ? (has_next ? nxt.wbase : cur.wbase) : wnext;
+            fetch_a(0, 0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s + 1 < 8) fetch_a(s + 1, (s + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int sl = s & 1;
+                const float wv[4] = {wr[s].x, wr[s].y, wr[s].z, wr[s].w};
+                const f32x2 sav = {sa, sa};
+                const f32x2 lo = __builtin_elementwise_fma(sav, f32x2{rb[sl].x, rb[sl].y}, f32x2{ra[sl].x, ra[sl].y});
+                const f32x2 hi = __builtin_elementwise_fma(sav, f32x2{rb[sl].z, rb[sl].w}, f32x2{ra[sl].z, ra[sl].w});
+                const float av[4] = {lo.x, lo.y, hi.x, hi.y};
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    acc[s >> 2][s & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], wv[s2], acc[s >> 2][s & 3], 0, 0, 0);
+                    if (s2 == 0) {                      // behind the step's first MFMA: the side work of the step
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s == 0) load_x2(st_rs, st_c0, 0, 0);
+                        if (s == 1) load_x2(st_rs, st_c0, 0, 2);
+                        if (s == 3) store_item(img_w, 0);
+                        if (s == 4) load_x2(st_rs, st_c0, 1, 0);
+                        if (s == 5) load_x2(st_rs, st_c0, 1, 2);
+                        if (s == 7) store_item(img_w, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                wr[s] = load_w(wsrc, s);                // this point's weights are consumed: the same point of the next chunk
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wnext += w_chunk_stride;
+            __syncthreads();                            // image cb ^ 1 complete and visible; every wave has left image cb
+            cb ^= 1;
+        }
+
+        // ---- epilogue
+        float* out_b = a.out + (long)cur.b * a.out_bs;
+        const int z0 = cur.z0, y0 = cur.y0, x0 = cur.x0, co0 = cur.co0;
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
+        const int q = elane & 7, kh = (elane >> 3) & 1, g = elane >> 4;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 s4 = zero4, q4 = zero4;
+        const bool fuse = !BNR && a.coef != nullptr;
+        const float4 b4 = BNR ? zero4 : *reinterpret_cast<const float4*>(tab + co0 + 4 * q);
+        const float4 bm4 = *reinterpret_cast<const float4*>(tab + co0 + 4 * q);
+        const float4 sc4 = *reinterpret_cast<const float4*>(tab + ctab + co0 + 4 * q);
+        const float4 sh4 = *reinterpret_cast<const float4*>(tab + 2 * ctab + co0 + 4 * q);
+        const float* bn_b = BNR ? a.bn_y + (long)cur.b * a.bn_y_bs + co0 + 4 * q : nullptr;
+        // this lane finishes (ox, r) = combo of the exchange buffer, rows of half kh, channels 4 q .. 4 q + 3
+        const int combo = wave * 4 + g;
+        const int ox = combo >> 4, rr = combo & 15;
+        const int row = (rr & 3) + 8 * (rr >> 2) + 4 * kh;          // = MFMA row = block (zb, yb, xb)
+        const int vzb = row >> 4, vyb = (row >> 2) & 3, vxb = row & 3;
+#pragma unroll
+        for (int oz = 0; oz < 2; ++oz) {
+            if (oz > 0) __syncthreads();                // every wave has left the exchange buffer (previous parity)
+            // x inverse transform (4 px -> 2 ox) and this wave's share of the z inverse transform:
+            //   out z0 = q0 + q1 + q2, out z1 = q1 - q2 - q3;  wave pzh = 0 holds (q0, q1), pzh = 1 holds (q2, q3)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a0 = acc[0][0][r], a1 = acc[0][1][r], a2 = acc[0][2][r], a3 = acc[0][3][r];
+                const float c0 = acc[1][0][r], c1 = acc[1][1][r], c2 = acc[1][2][r], c3 = acc[1][3][r];
+                const float p0x0 = a0 + a1 + a2, p0x1 = a1 - a2 - a3;          // pz local 0
+                const float p1x0 = c0 + c1 + c2, p1x1 = c1 - c2 - c3;          // pz local 1
+                float e0, e1;
+                if (pzh == 0) {
+                    e0 = oz == 0 ? p0x0 + p1x0 : p1x0;
+                    e1 = oz == 0 ? p0x1 + p1x1 : p1x1;
+                } else {
+                    e0 = oz == 0 ? p0x0 : -p0x0 - p1x0;
+                    e1 = oz == 0 ? p0x1 : -p0x1 - p1x1;
+                }
+                R[((wave * 2 + 0) * 16 + r) * 64 + elane] = e0;
+                R[((wave * 2 + 1) * 16 + r) * 64 + elane] = e1;
+            }
+            const int gz = z0 + 2 * vzb + oz, gy = y0 + 2 * vyb, gx = x0 + 2 * vxb + ox;
+            const long vox = (long)(gz * a.H + gy) * a.W + gx;
+            float4 yv0 = zero4, yv1 = zero4;
+            if (BNR) {
+                yv0 = *reinterpret_cast<const float4*>(bn_b + vox * a.bn_y_ps);
+                yv1 = *reinterpret_cast<const float4*>(bn_b + (vox + a.W) * a.bn_y_ps);
+            }
+            __syncthreads();
+            float4 t[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {               // point row p: the two z halves summed
+                const float4 u0 = *reinterpret_cast<const float4*>(R + (((0 * 4 + p) * 2 + ox) * 16 + rr) * 64 + kh * 32 + 4 * q);
+                const float4 u1 = *reinterpret_cast<const float4*>(R + (((1 * 4 + p) * 2 + ox) * 16 + rr) * 64 + kh * 32 + 4 * q);
+                t[p] = make_float4(u0.x + u1.x, u0.y + u1.y, u0.z + u1.z, u0.w + u1.w);
+            }
+            float4 v0 = make_float4(t[0].x + t[1].x + t[2].x + b4.x, t[0].y + t[1].y + t[2].y + b4.y, t[0].z + t[1].z + t[2].z + b4.z, t[0].w + t[1].w + t[2].w + b4.w);
+            float4 v1 = make_float4(t[1].x - t[2].x - t[3].x + b4.x, t[1].y - t[2].y - t[3].y + b4.y, t[1].z - t[2].z - t[3].z + b4.z, t[1].w - t[2].w - t[3].w + b4.w);
+            if (BNR) {
+                auto red1 = [&](float dzv, float yy, float sc, float sh, float m32, float& s_, float& q_) {
+                    const float bn = yy * sc + sh;
+                    const float d = bn > 0.f ? dzv : dzv * a.slope;
+                    s_ += d;
+                    q_ = fmaf(d, yy - m32, q_);
+                };
+                red1(v0.x, yv0.x, sc4.x, sh4.x, bm4.x, s4.x, q4.x); red1(v0.y, yv0.y, sc4.y, sh4.y, bm4.y, s4.y, q4.y);
+                red1(v0.z, yv0.z, sc4.z, sh4.z, bm4.z, s4.z, q4.z); red1(v0.w, yv0.w, sc4.w, sh4.w, bm4.w, s4.w, q4.w);
+                red1(v1.x, yv1.x, sc4.x, sh4.x, bm4.x, s4.x, q4.x); red1(v1.y, yv1.y, sc4.y, sh4.y, bm4.y, s4.y, q4.y);
+                red1(v1.z, yv1.z, sc4.z, sh4.z, bm4.z, s4.z, q4.z); red1(v1.w, yv1.w, sc4.w, sh4.w, bm4.w, s4.w, q4.w);
+            } else {
+                s4.x += v0.x + v1.x; s4.y += v0.y + v1.y; s4.z += v0.z + v1.z; s4.w += v0.w + v1.w;
+                q4.x += v0.x * v0.x + v1.x * v1.x; q4.y += v0.y * v0.y + v1.y * v1.y; q4.z += v0.z * v0.z + v1.z * v1.z; q4.w += v0.w * v0.w + v1.w * v1.w;
+            }
+            if (fuse) {
+                auto act = [&](float v, float sc, float sh) { const float tt = v * sc + sh; return tt > 0.f ? tt : tt * a.slope; };
+                v0 = make_float4(act(v0.x, sc4.x, sh4.x), act(v0.y, sc4.y, sh4.y), act(v0.z, sc4.z, sh4.z), act(v0.w, sc4.w, sh4.w));
+                v1 = make_float4(act(v1.x, sc4.x, sh4.x), act(v1.y, sc4.y, sh4.y), act(v1.z, sc4.z, sh4.z), act(v1.w, sc4.w, sh4.w));
+            }
+            float* obase = out_b + co0 + 4 * q;
+            *reinterpret_cast<float4*>(obase + vox * a.out_ps) = v0;
+            *reinterpret_cast<float4*>(obase + (vox + a.W) * a.out_ps) = v1;
+        }
+        // per-tile BatchNorm partial sums: over the lanes that hold the same channels, then over the eight waves
+        if (a.stats != nullptr) {
+#pragma unroll
+            for (int o = 8; o <= 32; o <<= 1) {
+                s4.x += __shfl_xor(s4.x, o, 64); s4.y += __shfl_xor(s4.y, o, 64); s4.z += __shfl_xor(s4.z, o, 64); s4.w += __shfl_xor(s4.w, o, 64);
+                q4.x += __shfl_xor(q4.x, o, 64); q4.y += __shfl_xor(q4.y, o, 64); q4.z += __shfl_xor(q4.z, o, 64); q4.w += __shfl_xor(q4.w, o, 64);
+            }
+            if (elane < 8) {
+                *reinterpret_cast<float4*>(red + (wave * 2 + 0) * NT + 4 * q) = s4;
+                *reinterpret_cast<float4*>(red + (wave * 2 + 1) * NT + 4 * q) = q4;
+            }
+        }
+        __syncthreads();                                // (also: the exchange buffer's last reads are done before the next tile writes it)
+        if (a.stats != nullptr && tid < 2 * NT) {
+            const int which = tid / NT, c = tid - which * NT;
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) tot += red[(w * 2 + which) * NT + c];
+            a.stats[((long)cur.tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
+        }
+        if (!has_next) break;
+        cur = nxt;
+        work = next_work;
+    }
+}
+
+__global__ void pack_weight_wino3_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int NPad, int dgrad, long total) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+        pulpo_conv::pack_wino3_one(w, wp, Cin, Cout, NPad, dgrad, e);
+}
+
+int wino3_enabled() {                                   // PULPO_CONV_WINO3=0: the (y, x) kernel everywhere (A/B switch)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PULPO_CONV_WINO3"); on = e ? atoi(e) : 1; }
+    return on;
+}
+int wino3_min_k() {                                     // PULPO_CONV_WINO3_MINK: smallest reduction-channel count that takes this kernel
+    static int k = -1;
+    if (k < 0) { const char* e = getenv("PULPO_CONV_WINO3_MINK"); k = e ? atoi(e) : 64; }
+    return k;
+}
+
+}  // namespace
+
+namespace pulpo_conv {
+
+// shapes the F(2x2x2,3x3x3) kernel takes: whole 4 x 8 x 8 tiles, K % 8 == 0, N % 32 == 0, at least 256 work items (one per CU)
+int wino3_shape_ok(int B, int D, int H, int W, int K, int N) {
+    if (!wino3_enabled() || K < wino3_min_k() || K % Q_CH != 0 || N % Q_NT != 0 || 3 * N > Q_TAB) return 0;
+    if (D % 4 != 0 || H % TY != 0 || W % TX != 0) return 0;
+    const long items = (long)B * (D / 4) * (H / TY) * (W / TX) * (N / Q_NT);
+    return items >= 256;
+}
+
+}  // namespace pulpo_conv
+
+PULPO_API size_t pulpo_conv3d_k3_packed_wino3_floats(int K, int N) { return (size_t)((K + Q_CH - 1) / Q_CH) * 64 * Q_CH * npad(N); }
+
+PULPO_API int pulpo_conv3d_k3_pack_weight_wino3(const float* w, float* wp, int Cin, int Cout, int dgrad, void* stream) {
+    PULPO_REQUIRE(w && wp && Cin > 0 && Cout > 0, "conv3d_k3_pack_weight_wino3: bad arguments");
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    const long total = (long)((K + Q_CH - 1) / Q_CH) * Q_CH * npad(N);          // threads: one per (chunk, k, n)
+    const int nb = (int)std::min<long>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(pack_weight_wino3_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w, wp, Cin, Cout, npad(N), dgrad, total);
+    return pulpo::check_launch("pack_weight_wino3");
+}
+
+static int fwd_wino3_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef, float slope,
+                          float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, const float* bn_y, int64_t bn_y_bs, int64_t bn_y_ps,
+                          const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream) {
+    PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_wino3: null pointer");
+    PULPO_REQUIRE(B > 0 && K > 0 && N > 0 && D > 0 && D % 4 == 0 && H > 0 && H % TY == 0 && W > 0 && W % TX == 0 && K % Q_CH == 0 && N % Q_NT == 0 && 3 * N <= Q_TAB,
+                  "conv3d_k3_fwd_wino3: shape %dx%dx%d, %d -> %d channels is not whole 4x8x8 tiles of 8 / 32 channels (see pulpo_conv3d_k3_algo)", D, H, W, K, N);
+    PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd_wino3: batch statistics are not available from the fused eval-mode epilogue");
+    PULPO_REQUIRE(in_cs == 1 && in_ps % 4 == 0 && in_bs % 4 == 0 && (((uintptr_t)in) & 15) == 0 && (long)D * H * W * in_ps * 4 < (1L << 31),
+                  "conv3d_k3_fwd_wino3: the operand must be channels-last, 16-byte aligned and smaller than 2 GiB per batch element");
+    PULPO_REQUIRE(out_cs == 1 && out_ps % 4 == 0 && out_bs % 4 == 0 && (((uintptr_t)out) & 15) == 0, "conv3d_k3_fwd_wino3: the result must be channels-last, 16-byte aligned");
+    PULPO_REQUIRE((((uintptr_t)wp) & 15) == 0, "conv3d_k3_fwd_wino3: packed weights must be 16-byte aligned");
+    ConvArgs a{};
+    a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
+    a.wp = wp; a.bias = bias;
+    a.out = out; a.out_bs = out_bs; a.out_ps = out_ps; a.out_cs = out_cs;
+    a.stats = stats;
+    a.coef = coef; a.slope = slope;
+    a.bn_y = bn_y; a.bn_y_bs = bn_y_bs; a.bn_y_ps = bn_y_ps; a.bn_coef = bn_coef;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
+    a.ntz = D / 4; a.nty = H / TY; a.ntx = W / TX;
+    a.ncot = N / Q_NT;
+    a.ksplit = 1; a.part = nullptr;
+    a.tile_order = (a.ntx % 4 == 0 && a.nty % 4 == 0 && a.ntz % 4 == 0) ? 1 : 0;
+    const long nwork = (long)B * a.ntz * a.nty * a.ntx * a.ncot;
+    PULPO_REQUIRE(nwork < (1L << 31), "conv3d_k3_fwd_wino3: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    const bool bnr = bn_y != nullptr;
+    static bool attr_set[2] = {false, false};
+    const void* fn = bnr ? reinterpret_cast<const void*>(&conv3d_k3_wino3_mfma<true>) : reinterpret_cast<const void*>(&conv3d_k3_wino3_mfma<false>);
+    if (!attr_set[bnr]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q_LDS);
+        if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(conv3d wino3): %s", hipGetErrorString(e));
+        attr_set[bnr] = true;
+    }
+    const int nwg = (int)std::min<long>(nwork, 256);    // persistent workgroups: one per CU
+    if (bnr) hipLaunchKernelGGL((conv3d_k3_wino3_mfma<true>), dim3(nwg), dim3(512), Q_LDS, st, a);
+    else hipLaunchKernelGGL((conv3d_k3_wino3_mfma<false>), dim3(nwg), dim3(512), Q_LDS, st, a);
+    return pulpo::check_launch("conv3d_k3_wino3_mfma");
+}
+
+PULPO_API int pulpo_conv3d_k3_fwd_wino3(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias,
+                                        const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, int B,
+                                        int D, int H, int W, int K, int N, void* stream) {
+    return fwd_wino3_impl(in, in_bs, in_ps, in_cs, wp, bias, coef, slope, out, out_bs, out_ps, out_cs, stats, nullptr, 0, 0, nullptr, B, D, H, W, K, N, stream);
+}
+
+PULPO_API int pulpo_conv3d_k3_dgrad_wino3_bnred(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, float* out, int64_t out_bs,
+                                                int64_t out_ps, const float* bn_y, int64_t bn_y_bs, int64_t bn_y_ps, const float* bn_coef, float slope,
+                                                float* part, int B, int D, int H, int W, int K, int N, void* stream) {
+    PULPO_REQUIRE(bn_y && bn_coef && part, "conv3d_k3_dgrad_wino3_bnred: null pointer");
+    PULPO_REQUIRE(bn_y_ps % 4 == 0 && bn_y_bs % 4 == 0 && (((uintptr_t)bn_y) & 15) == 0 && (((uintptr_t)bn_coef) & 15) == 0,
+                  "conv3d_k3_dgrad_wino3_bnred: pre-norm tensor and coefficients must be channels-last and 16-byte aligned");
+    return fwd_wino3_impl(in, in_bs, in_ps, in_cs, wp, nullptr, nullptr, slope, out, out_bs, out_ps, 1, part, bn_y, bn_y_bs, bn_y_ps, bn_coef, B, D, H, W, K, N,
+                          stream);
+}

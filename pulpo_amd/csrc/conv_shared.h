@@ -17,6 +17,9 @@ __host__ __device__ inline int npad(int N) { return (N + 63) & ~63; }
 // Cin chunk of the direct kernel's weight packing (conv3d.hip pick_ch)
 __host__ __device__ inline int direct_ch(int K) { return K <= 2 ? 2 : K <= 4 ? 4 : 16; }
 
+// F(2x2x2,3x3x3) kernel (conv3d_wino3.hip): 1 when pulpo_conv3d_k3_algo may answer 3 for the shape
+int wino3_shape_ok(int B, int D, int H, int W, int K, int N);
+
 // out = sum over the ksplit partial slabs (fixed order) + per-row BatchNorm partials; see splitk_reduce_kernel in conv3d.hip
 // (coef != nullptr: eval-mode BatchNorm + LeakyReLU applied to the reduced value, see ConvArgs::coef)
 // (out_dt: dtype code of `out`, 0 fp32 / 1 bf16 - rounded on the store, the statistics describe the stored values)

@@ -350,7 +350,17 @@ def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None, register: bool = 
         return wp
     algo = lib.query("pulpo_conv3d_k3_algo", *shape, K, N) if shape is not None else 0
     if CONV_ALGO is not None and algo != 0:            # diagnostic override; only among the kernels valid for this shape
-        algo = {"direct": 0, "wino2": 2}[CONV_ALGO]
+        algo = {"direct": 0, "wino2": 2, "wino3": algo}[CONV_ALGO]          # ("wino3": wherever the library's own policy picks it)
+    if algo == 3:
+        wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_wino3_floats", K, N), device=w.device, dtype=torch.float32)
+        lib.call("pulpo_conv3d_k3_pack_weight_wino3", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
+        wp._pulpo_algo = "wino3"
+        if register:
+            if w.is_contiguous():
+                _register_pack(w, wp, Cin, Cout, dgrad, 4)
+            else:
+                _UNREFRESHABLE_PACKS = True
+        return wp
     if algo == 2:
         wp = torch.empty(lib.query("pulpo_conv3d_k3_packed_wino2_floats", K, N), device=w.device, dtype=torch.float32)
         lib.call("pulpo_conv3d_k3_pack_weight_wino2", _ptr(w.contiguous()), _ptr(wp), Cin, Cout, int(dgrad), _stream())
@@ -381,6 +391,18 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
     algo = getattr(wp, "_pulpo_algo", "bf16" if wp.dtype == torch.int16 else "direct")
     bf16 = algo == "bf16"
     vec_ok = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0
+    if algo == "wino3":
+        # F(2x2x2,3x3x3): channels-last, 16-byte aligned operand and result (the deep layers' tensors are; anything else is copied into that form)
+        if not vec_ok:
+            x = to_cl(x)
+            xb, xp, xc = grid_strides(x)
+        if oc != 1 or op % 4 or ob % 4 or out.data_ptr() % 16:
+            raise PulpoHipError("conv3d (F(2x2x2,3x3x3) kernel): the result must be channels-last and 16-byte aligned")
+        t0 = _trace_begin()
+        lib.call("pulpo_conv3d_k3_fwd_wino3", _ptr(x), xb, xp, xc, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(out), ob, op, oc, _ptr(stats),
+                 B, D, H, W, K, N, _stream())
+        _trace_end(t0, "conv3d_k3_wino3_mfma<false>", 54.0 * K * N * B * D * H * W, 4.0 * (K + N) * B * D * H * W)
+        return
     if algo == "wino2":
         if (D % 4 or D * H * W < 8000) and not vec_ok:     # (volumes below 20^3 - the 10^3 level - run on the pipelined kernel only: channels-last operand)
             x = to_cl(x)
@@ -557,7 +579,8 @@ _BN_TILE_PARTS: dict = {}
 
 
 def _dgrad_with_bn_reduction(bn_src, x, dy, wpt, dx, K: int, N: int) -> bool:
-    if bn_src is None or not BN_REDUCE_IN_DGRAD or getattr(wpt, "_pulpo_algo", "") != "wino2":
+    algo = getattr(wpt, "_pulpo_algo", "")
+    if bn_src is None or not BN_REDUCE_IN_DGRAD or algo not in ("wino2", "wino3"):
         return False
     y_prev, coef_prev = bn_src
     B, _, D, H, W = dy.shape
@@ -573,10 +596,10 @@ def _dgrad_with_bn_reduction(bn_src, x, dy, wpt, dx, K: int, N: int) -> bool:
     ntile = lib.query("pulpo_conv3d_k3_stat_tiles", B, D, H, W)
     part = torch.empty(ntile * 2 * N, device=dy.device, dtype=torch.float32)
     t0 = _trace_begin()
-    lib.call("pulpo_conv3d_k3_dgrad_wino2_bnred", _ptr(dy), db, dp, dc, _ptr(wpt), _ptr(dx), ob, op, _ptr(y_prev), yb, yp, _ptr(coef_prev), LRELU_SLOPE,
+    lib.call(f"pulpo_conv3d_k3_dgrad_{algo}_bnred", _ptr(dy), db, dp, dc, _ptr(wpt), _ptr(dx), ob, op, _ptr(y_prev), yb, yp, _ptr(coef_prev), LRELU_SLOPE,
              _ptr(part), B, D, H, W, K, N, _stream())
-    kname = "conv3d_k3_wino2_mfma<true>"
-    if t0 is not None and lib.query("pulpo_conv3d_k3_wino2_pipelined", D, H, W, K, dp):
+    kname = "conv3d_k3_wino3_mfma<true>" if algo == "wino3" else "conv3d_k3_wino2_mfma<true>"
+    if algo == "wino2" and t0 is not None and lib.query("pulpo_conv3d_k3_wino2_pipelined", D, H, W, K, dp):
         kname = "conv3d_k3_wino2p_mfma<true>"
     _trace_end(t0, kname, 54.0 * K * N * B * D * H * W, 4.0 * (K + 2 * N) * B * D * H * W)
     _BN_TILE_PARTS[y_prev.data_ptr()] = (part, ntile, coef_prev.data_ptr(), dx.data_ptr(), dx._version, tuple(dx.shape), tuple(dx.stride()))

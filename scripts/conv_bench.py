@@ -24,7 +24,7 @@ def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=10); ap.add_argument("--only", default="")
     ap.add_argument("--shapes", type=int, nargs="*", default=None)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="conv operand precision (bf16 = BASELINE configs 4-5)")
-    ap.add_argument("--algo", default=None, choices=["direct", "wino2"], help="force the forward / data-gradient kernel (default: the library's choice)")
+    ap.add_argument("--algo", default=None, choices=["direct", "wino2", "wino3"], help="force the forward / data-gradient kernel among those valid for a shape (default: the library's choice; PULPO_CONV_WINO3=0 / PULPO_CONV_WINO3_MINK=<k> move the F(2x2x2,3x3x3) policy)")
     a = ap.parse_args()
     lib.load()
     ops.set_conv_precision(a.precision)

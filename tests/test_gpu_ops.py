@@ -410,7 +410,8 @@ def test_eval_mode_fused_epilogue_equals_separate_passes(ops, precision, Cin, Co
 @pytest.mark.parametrize("B,Cin,Cout,size", [(1, 32, 32, (64, 64, 64)), (1, 64, 64, (64, 64, 64)), (2, 16, 96, (64, 56, 80)), (1, 20, 12, (64, 64, 70)),
                                             (1, 96, 32, (68, 61, 67)), (2, 192, 192, (20, 20, 20)), (1, 8, 40, (24, 20, 17)),
                                             (1, 288, 192, (20, 20, 20)), (1, 128, 192, (20, 20, 20)), (1, 192, 192, (10, 10, 10)),
-                                            (2, 96, 64, (10, 12, 9))])
+                                            (2, 96, 64, (10, 12, 9)), (1, 96, 96, (40, 40, 40)), (1, 160, 64, (32, 40, 48)), (2, 64, 128, (24, 32, 32)),
+                                            (1, 72, 32, (44, 64, 40))])
 def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size):
     """volumes of >= 20^3 voxels with depth % 4 == 0 take the F(2x2,3x3) Winograd kernels for forward and data gradient
     (pulpo_conv3d_k3_algo = 2: the pipelined conv3d_k3_wino2p_mfma for operands with a multiple of 8 channels, the round-2
@@ -419,7 +420,18 @@ def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size):
     channel layers (split-K work items where the tiles are few) included, and the 10^3 level, whose depth is not a multiple of 4
     (ragged depth tile: pipelined kernel with split-K only)"""
     from pulpo_amd._lib import lib
-    assert lib.query("pulpo_conv3d_k3_algo", B, *size, Cin, Cout) == 2
+    # F(2x2x2,3x3x3) (algo 3, conv3d_k3_wino3_mfma) where the volume is whole 4x8x8 tiles, the GEMM has >= 64 reduction channels (a
+    # multiple of 8) and a multiple of 32 output channels and there are >= 256 work items - forward and / or data gradient of the last
+    # five cases and of 64 -> 64 at 64^3; F(2x2,3x3) (algo 2) everywhere else
+    whole = size[0] % 4 == 0 and size[1] % 8 == 0 and size[2] % 8 == 0
+    items = B * (size[0] // 4) * (size[1] // 8) * (size[2] // 8)
+    expect = lambda K, N: 3 if (whole and K >= 64 and K % 8 == 0 and N % 32 == 0 and items * (N // 32) >= 256) else 2
+    assert lib.query("pulpo_conv3d_k3_algo", B, *size, Cin, Cout) == expect(Cin, Cout)
+    assert lib.query("pulpo_conv3d_k3_algo", B, *size, Cout, Cin) == expect(Cout, Cin)
+    if (Cin, Cout) in ((64, 64), (96, 96), (160, 64), (64, 128)):
+        assert expect(Cin, Cout) == 3 and expect(Cout, Cin) == 3
+    if (Cin, Cout) == (72, 32):
+        assert expect(Cin, Cout) == 3 and expect(Cout, Cin) == 2          # (72 reduction channels forward; 32 in the data gradient)
     assert lib.query("pulpo_conv3d_k3_wino2_pipelined", *size, Cin, Cin) == int(Cin % 8 == 0)
     if (B, Cin, size) == (1, 288, (20, 20, 20)):                     # few tiles, many reduction channels: three split-K work items per tile
         assert lib.query("pulpo_conv3d_k3_fwd_wino2_scratch_floats", B, *size, Cin, Cout) == 3 * B * 8000 * Cout
@@ -510,7 +522,8 @@ def test_every_live_weight_pack_follows_a_raw_pointer_update(ops):
     assert len(ops._PACK_REGISTRY) == n0
 
 
-@pytest.mark.parametrize("chans,size", [((16, 32, 64, 32), (24, 32, 40)), ((32, 32, 32), (32, 32, 32)), ((8, 96, 96), (20, 24, 24))])
+@pytest.mark.parametrize("chans,size", [((16, 32, 64, 32), (24, 32, 40)), ((32, 32, 32), (32, 32, 32)), ((8, 96, 96), (20, 24, 24)),
+                                        ((64, 64, 96, 64), (32, 32, 32))])
 def test_bn_backward_reduction_inside_the_data_gradient_kernel(ops, chans, size):
     """In a ConvSequence the data-gradient convolution of unit u also delivers the BatchNorm-backward sums of unit u-1 (one HBM pass over
     dz and y less per unit).  Checked: the fused path IS taken on every inner link of these shapes, its gradients equal those of the
