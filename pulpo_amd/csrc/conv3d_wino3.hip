@@ -1,25 +1,35 @@
-// Winograd F(2x2x2, 3x3x3) - minimal filtering in ALL three axes - for the forward / data-gradient convolution of the deep layers: 64
-// transformed points per 2 x 2 x 2 output block instead of the 216 multiply-adds of the direct form (the (y, x) kernel of conv3d_wino2p.hip
-// issues 96): 1.5x fewer matrix instructions than that kernel, 3.375x fewer than the direct one, all fp32 (coefficients +-1 and 1/2; measured
-// error against fp64 2.8e-7 relative L2 at 32 channels, the (y, x) form 2.1e-7, the direct form 1.2e-7 - same 2e-6 test bound).
+// Winograd F(2x2x2, 3x3x3) - minimal filtering in ALL three axes - for the forward / data-gradient convolution: 64 transformed points per
+// 2 x 2 x 2 output block instead of the 216 multiply-adds of the direct form (the (y, x) kernel of conv3d_wino2p.hip issues 96): 1.5x fewer
+// matrix instructions than that kernel, 3.375x fewer than the direct one, all fp32 (coefficients +-1 and 1/2; measured error against fp64
+// 2.8e-7 relative L2 at 32 channels, the (y, x) form 2.1e-7, the direct form 1.2e-7 - same 2e-6 test bound).
 //
 //   tile 4 x 8 x 8 voxels = 2 x 4 x 4 blocks = ONE 32-row MFMA tile per point; 32 output channels per work item; 8-channel chunks.
 //   512 threads = 8 waves, ONE workgroup per CU: wave (py, pzh) owns the eight points (pz in {2 pzh, 2 pzh + 1}, py, px 0..3) - eight
 //   32 x 32 accumulator tiles, the register budget of the (y, x) kernel's wave.
-//   LDS image of a chunk = the halo transformed along x AND z while it is staged (8 transformed planes per tile instead of 6 raw ones):
-//   the matrix loop then reads two rows per point step and forms the y combination in registers exactly like the (y, x) kernel - 0.5
-//   ds_read_b128 per MFMA - and the weights come global -> registers one chunk ahead.  Two images (the next chunk - or the next tile's first
-//   chunk - is staged underneath the MFMAs), one barrier per chunk.
+//   LDS image of a chunk = the (y, x) kernel's: the halo x-transformed while it is staged (one item per thread: four taps -> four px rows,
+//   six raw z planes).  The matrix loop reads four rows per point step - rows ta / tb of planes za / zb - and forms the y AND z
+//   combinations in registers (six two-wide fmas); point steps run in pairs whose MFMAs alternate between two accumulator tiles.
+//   Staging runs two chunks ahead: the taps a thread requests during chunk c stay in registers for a whole chunk (2000 matrix clocks, more
+//   than a trip to HBM) and are transformed into the image of chunk c + 2 at the start of chunk c + 1; two images, one barrier per chunk.
+//   Weights global -> registers through a ring of four point rows (a row is re-loaded for the point four steps on as soon as it is used).
 //   Epilogue: x inverse transform in registers, the z pair of a wave combined in registers, y (four waves) and the two z halves summed
-//   through a 64 KB exchange buffer, one output z-parity at a time; stores, bias, BatchNorm partials and the eval-mode store as in the
-//   (y, x) kernel's fast path.
+//   through a 64 KB exchange buffer, one output z parity at a time; stores, bias, BatchNorm partials, the eval-mode store and the fused
+//   BatchNorm-backward sums (BNR) as in the (y, x) kernel's fast path.
 //
-// Whole tiles only (D % 4 == 0, H % 8 == 0, W % 8 == 0), channels-last 16-byte aligned operands, Cin % 8 == 0, Cout % 32 == 0: the deep
-// layers of the 80^3 / 40^3 levels.  pulpo_conv3d_k3_algo() selects it from 64 reduction channels up (below that the tile's epilogue - which no
-// second workgroup hides here - costs more than the matrix instructions saved).
+// Whole tiles only (D % 4 == 0, H % 8 == 0, W % 8 == 0), channels-last 16-byte aligned operands, Cin % 8 == 0, Cout % 32 == 0, at least 256 work
+// items: every such layer from 32 reduction channels up (pulpo_conv3d_k3_algo = 3; PULPO_CONV_WINO3=0 / PULPO_CONV_WINO3_MINK=<k> move the policy).
+// What was measured while it was built: an image transformed along x AND z at staging time (two rows per step instead of
+// four) multiplies faster (bare loop 0.31 against 0.34 ms at 64 -> 64 / 80^3) but its staging - eight loads, 32 combinations and a second
+// item for a quarter of the threads - cost 20 - 24 % against 8 - 10 % here; wave-uniform branches around staging loads cost 15 % (every
+// vmcnt behind them becomes a worst-case guess); the plane offset must ride in the VECTOR offset of a buffer load (the bounds check that
+// zeroes out-of-volume planes ignores the scalar offset).
 #include "conv_shared.h"
 #include "wino3_pack.h"
 #include <stdlib.h>
+
+#ifndef PULPO_ABL
+#define PULPO_ABL 0          // diagnostic builds (scripts/ablate.py): timings only, results are garbage.  Bits: 1 no epilogue, 2 no halo staging,
+#endif                       // 4 no weight re-loads, 8 no chunk barrier, 32 no operand-row reads inside the loop
 
 namespace {
 
@@ -27,12 +37,12 @@ using namespace pulpo_conv;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int Q_CH = 8, Q_NT = 32;
-constexpr int Q_PX = HY * 4;                     // rows of one (zb, pz, px) slice: (hy, x-pair)
-constexpr int Q_PZ = 4 * Q_PX;                   // rows of one (zb, pz) plane: four px slices
-constexpr int Q_ZB = 4 * Q_PZ + 4;               // rows per z block (4 mod 16: the two z blocks of an MFMA row tile fall on different 16-byte slots)
-constexpr int Q_QROWS = 2 * Q_ZB + 4;            // rows per channel quad (x 4 dwords = 16 mod 32: the two quads of a ds_write_b128 group use different banks)
+constexpr int Q_PL = HY * 4;                     // rows of one px slice of a plane: (hy, x-pair)
+constexpr int Q_PLROWS = 4 * Q_PL + 2;           // rows per hz plane: the two z blocks of an MFMA row tile lie TWO planes apart = 4 rows mod 16
+constexpr int Q_QROWS = 6 * Q_PLROWS;            // rows per channel quad (x 4 dwords = 16 mod 32: the two quads of a ds_write_b128 group use different banks)
 constexpr int Q_IMG = 2 * Q_QROWS * 4;           // floats of one image
-constexpr int Q_NITEM = 2 * 4 * HY * 4 * 2;      // staging items of a chunk: (zb, px, hy, x-pair, channel quad) = 640: one per thread + a second for 128
+static_assert((2 * Q_PLROWS) % 16 == 4 && (Q_QROWS * 4) % 32 == 16, "bank layout");
+constexpr int Q_NITEM = 6 * HY * 4 * 2;          // staging items of a chunk: (hz, hy, x-pair, channel quad) = 480, one per thread
 constexpr int Q_TAB = 3 * 512;                   // per-channel table [3][ncot * 32]: up to 512 output channels
 constexpr int Q_R = 8 * 2 * 16 * 64;             // floats of the exchange buffer of one output z parity: [wave][ox][r][lane]
 constexpr int Q_RED = 8 * 2 * Q_NT;              // statistics rows of the eight waves
@@ -50,40 +60,36 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kk = lane >> 5;
     const int py = wave & 3, pzh = wave >> 2;
-    const int nchunk = a.Cin / CH;
+    const int nchunk = a.Cin / CH;                      // (host: >= 2)
     const int nwork = a.B * a.ntz * a.nty * a.ntx * a.ncot;
     const int nwg = gridDim.x;
     const unsigned ps_bytes = (unsigned)a.in_ps * 4u;
-    const unsigned plane_bytes = (unsigned)a.H * (unsigned)a.W * ps_bytes;
 
-    // ---- the two staging items of this thread: (zb, px, hy, x-pair xb, channel quad q); the second one exists for tid < 128 only
-    // x transform of tap pair (ta_, tb_): X = d[ta_] + sx * d[tb_];  z transform of planes 2 zb .. 2 zb + 3 likewise
-    unsigned roff[2];                                   // byte offset of (plane 2 zb, tap ta_) relative to the tile's halo origin
-    unsigned dtap[2];                                   // byte distance from tap ta_ to tap tb_ (modulo 2^32: px = 2 reads tb_ = ta_ - 1)
-    int lofs[2];                                        // float offset of the item's pz = 0 row in an image
-    float sx[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int j = tid + u * 512;
-        const int q = j & 1, rb = j >> 1;
-        const int xb = rb & 3, t = rb >> 2;
-        const int hy = t % HY, pp = (t / HY) & 7;
-        const int px = pp & 3, zb = pp >> 2;
-        const int tapa = px == 0 ? 0 : px == 2 ? 2 : 1, tapb = px == 2 ? 1 : px == 3 ? 3 : 2;
-        roff[u] = ((unsigned)((2 * zb * a.H + hy) * a.W + 2 * xb + tapa) * (unsigned)a.in_ps + 4u * q) * 4u;
-        dtap[u] = (unsigned)(tapb - tapa) * ps_bytes;
-        lofs[u] = (q * Q_QROWS + zb * Q_ZB + px * Q_PX + hy * 4 + xb) * 4;
-        sx[u] = px == 1 ? 1.f : -1.f;
+    // ---- the staging item of this thread (the (y, x) kernel's): (hz, hy, x-pair xb, channel quad q) -> the four x-transformed rows px = 0..3
+    unsigned roff;                                      // byte offset of tap 0 relative to the tile's halo origin
+    int lofs;                                           // float offset of the item's px = 0 row in an image
+    {
+        const int q = tid & 1, rb = tid >> 1;
+        const int xb = rb & 3, hrow = rb >> 2;
+        const int hz = hrow / HY, hy = hrow - hz * HY;
+        roff = ((unsigned)((hz * a.H + hy) * a.W + 2 * xb) * (unsigned)a.in_ps + 4u * q) * 4u;
+        lofs = (q * Q_QROWS + hz * Q_PLROWS + hy * 4 + xb) * 4;
     }
-    const bool item1 = tid + 512 < Q_NITEM;
-    // y combination of this wave's point row: v = X[2 yb + ta] + sa * X[2 yb + tb]
-    const int ta = py == 0 ? 0 : py == 2 ? 2 : 1;
-    const int tb = py == 2 ? 1 : py == 3 ? 3 : 2;
-    const float sa = py == 1 ? 1.f : -1.f;
-    // MFMA row i = block (zb = i >> 4, yb = (i >> 2) & 3, xb = i & 3)
-    const int lrow = (i >> 4) * Q_ZB + ((i >> 2) & 3) * 8 + (i & 3);
-    const int pa_off = (kk * Q_QROWS + lrow + ta * 4 + 2 * pzh * Q_PZ) * 4;
-    const int pb_off = (kk * Q_QROWS + lrow + tb * 4 + 2 * pzh * Q_PZ) * 4;
+    const bool item = tid < Q_NITEM;
+    // combination tables of B^T (rows t_a + s * t_b): point 0: (0, 2, -), 1: (1, 2, +), 2: (2, 1, -), 3: (1, 3, -)
+    auto tab_a = [](int p) { return p == 0 ? 0 : p == 2 ? 2 : 1; };
+    auto tab_b = [](int p) { return p == 2 ? 1 : p == 3 ? 3 : 2; };
+    auto tab_s = [](int p) { return p == 1 ? 1.f : -1.f; };
+    // y combination of this wave's point row, z combination of its two point planes pz = 2 pzh + (0, 1): per-wave scalars
+    const int ta = tab_a(py), tb = tab_b(py);
+    const float sa = tab_s(py);
+    const int za0 = tab_a(2 * pzh) * Q_PLROWS * 4, zb0 = tab_b(2 * pzh) * Q_PLROWS * 4;              // float offsets of the two planes, pz local 0
+    const int za1 = tab_a(2 * pzh + 1) * Q_PLROWS * 4, zb1 = tab_b(2 * pzh + 1) * Q_PLROWS * 4;      // ... pz local 1
+    const float sz0 = tab_s(2 * pzh), sz1 = tab_s(2 * pzh + 1);
+    // MFMA row i = block (zb = i >> 4, yb = (i >> 2) & 3, xb = i & 3): halo plane 2 zb + (0..3), halo row 2 yb + (0..3)
+    const int lrow = (i >> 4) * 2 * Q_PLROWS + ((i >> 2) & 3) * 8 + (i & 3);
+    const int pa_off = (kk * Q_QROWS + lrow + ta * 4) * 4;
+    const int pb_off = (kk * Q_QROWS + lrow + tb * 4) * 4;
 
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, -1, 0x00020000);
@@ -117,56 +123,34 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
         t.wbase = (unsigned)(((2 * pzh) * 16 + py * 4) * a.NPad + t.co0) * (CH * 4u);
         return t;
     };
-    // per tile and item: the byte offset of (plane 2 zb, tap ta_) at chunk 0 relative to the batch element, and six validity bits - planes
-    // 0..3 inside the volume (and the item exists, and its row is inside), tap ta_ / tb_ inside.  A load outside the volume goes to an offset
-    // beyond num_records and returns zeros; the chunk's channel offset rides in the instruction's scalar offset.
-    unsigned hbase[2], hmask[2];
+    // byte offsets of this thread's four tap loads of a tile's halo at chunk 0, relative to the batch element; OOB (beyond num_records: the load
+    // returns zeros) where the tap lies outside the volume or the item does not exist.  The chunk's channel offset rides in the scalar offset.
+    unsigned hoff[4];
     auto halo_offsets = [&](const Tile& t) {
         const unsigned origin = (unsigned)(((t.z0 - 1) * a.H + (t.y0 - 1)) * a.W + (t.x0 - 1)) * ps_bytes;      // modulo 2^32: may be "negative"
+        const int rb = tid >> 1;
+        const int xb = rb & 3, hrow = rb >> 2;
+        const int hz = hrow / HY, hy = hrow - hz * HY;
+        const bool rowok = item && (unsigned)(t.z0 - 1 + hz) < (unsigned)a.D && (unsigned)(t.y0 - 1 + hy) < (unsigned)a.H;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j = tid + u * 512;
-            const int rb = j >> 1;
-            const int xb = rb & 3, tt = rb >> 2;
-            const int hy = tt % HY, pp = (tt / HY) & 7;
-            const int px = pp & 3, zb = pp >> 2;
-            const int tapa = px == 0 ? 0 : px == 2 ? 2 : 1, tapb = px == 2 ? 1 : px == 3 ? 3 : 2;
-            const bool yok = j < Q_NITEM && (unsigned)(t.y0 - 1 + hy) < (unsigned)a.H;
-            unsigned m = 0;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) m |= (yok && (unsigned)(t.z0 - 1 + 2 * zb + p) < (unsigned)a.D) ? (1u << p) : 0u;
-            m |= (unsigned)(t.x0 - 1 + 2 * xb + tapa) < (unsigned)a.W ? 16u : 0u;
-            m |= (unsigned)(t.x0 - 1 + 2 * xb + tapb) < (unsigned)a.W ? 32u : 0u;
-            hbase[u] = origin + roff[u];
-            hmask[u] = m;
-        }
+        for (int tt = 0; tt < 4; ++tt)
+            hoff[tt] = (rowok && (unsigned)(t.x0 - 1 + 2 * xb + tt) < (unsigned)a.W) ? origin + roff + tt * ps_bytes : OOB;
     };
     auto in_rsrc = [&](int b) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + (long)b * a.in_bs), 0, in_bytes, 0x00020000);
     };
-    float4 xr[4];                                       // the x-transformed rows of the four planes of ONE staging item
-    auto load_x2 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned c0_bytes, int u, int p0) {
-        // planes p0, p0 + 1: two taps each, x combination
-#pragma unroll
-        for (int p = p0; p < p0 + 2; ++p) {
-            const unsigned m = hmask[u];
-            const unsigned oa = hbase[u] + p * plane_bytes;
-            const unsigned offa = ((m >> p) & 1u) && (m & 16u) ? oa : OOB;
-            const unsigned offb = ((m >> p) & 1u) && (m & 32u) ? oa + dtap[u] : OOB;
-            const float4 da = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)offa, (int)c0_bytes, 0));
-            const float4 db = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)offb, (int)c0_bytes, 0));
-            const float s_ = sx[u];
-            xr[p] = make_float4(fmaf(s_, db.x, da.x), fmaf(s_, db.y, da.y), fmaf(s_, db.z, da.z), fmaf(s_, db.w, da.w));
-        }
+    float4 raw[4];                                      // the four x taps of the staging item: loaded one chunk before they are transformed
+    auto load_raw = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned c0_bytes, int tt) {
+        raw[tt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)hoff[tt], (int)c0_bytes, 0));
     };
-    auto store_item = [&](float* img, int u) {
-        if (u == 0 || item1) {
-            float* o = img + lofs[u];
-            const float4 d0 = xr[0], d1 = xr[1], d2 = xr[2], d3 = xr[3];
+    auto store_item = [&](float* img) {
+        if (item) {
+            float* o = img + lofs;
+            const float4 d0 = raw[0], d1 = raw[1], d2 = raw[2], d3 = raw[3];
             *reinterpret_cast<float4*>(o) = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
-            *reinterpret_cast<float4*>(o + Q_PZ * 4) = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
-            *reinterpret_cast<float4*>(o + 2 * Q_PZ * 4) = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
-            *reinterpret_cast<float4*>(o + 3 * Q_PZ * 4) = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+            *reinterpret_cast<float4*>(o + Q_PL * 4) = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+            *reinterpret_cast<float4*>(o + 2 * Q_PL * 4) = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+            *reinterpret_cast<float4*>(o + 3 * Q_PL * 4) = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
         }
     };
     const unsigned w_chunk_stride = 64u * CH * a.NPad * 4u;     // bytes between consecutive chunks
@@ -192,23 +176,22 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
     int work = pulpo::xcd_remap(blockIdx.x, nwg);
     Tile cur = describe(work);
     int cb = 0;                                         // image being read
-    // ---- prologue: chunk 0 of the first tile, the first weight rows
-    float4 wr[8];
+    // ---- prologue: chunk 0 of the first tile staged, chunk 1 requested; the first weight rows
+    float4 wr[4];                                       // ring: point step s uses wr[s & 3], which is then re-loaded for step s + 4
 #pragma unroll
-    for (int s = 0; s < 8; ++s) wr[s] = load_w(cur.wbase, s);
+    for (int s = 0; s < 4; ++s) wr[s] = load_w(cur.wbase, s);
     {
         const __amdgpu_buffer_rsrc_t rs0 = in_rsrc(cur.b);
         halo_offsets(cur);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            load_x2(rs0, 0u, u, 0);
-            load_x2(rs0, 0u, u, 2);
-            store_item(smem, u);
-        }
+        for (int tt = 0; tt < 4; ++tt) load_raw(rs0, 0u, tt);
+        store_item(smem);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) load_raw(rs0, CH * 4u, tt);
     }
     __syncthreads();
 
-    float4 ra[2], rb[2];                                // two register sets of the operand rows (ta, tb)
+    float4 ra[2][2], rb[2][2];                          // the operand rows of a PAIR of point steps: [step of the pair][z plane a / b] of rows ta / tb
 
     for (;;) {
         int next_work = nwork;
@@ -223,58 +206,85 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[p][x][r] = 0.f;
 
-        unsigned wnext = cur.wbase + w_chunk_stride;    // weights of chunk + 1
+        unsigned wcur = cur.wbase;                      // weights of the chunk being multiplied
         for (int chunk = 0; chunk < nchunk; ++chunk) {
-            const bool last_chunk = chunk + 1 == nchunk;
-            if (last_chunk) {
+            // Staging runs TWO chunks ahead of the matrix loop: step 0 transforms the taps requested during the previous chunk into the image
+            // of chunk + 1 and steps 1 - 2 request those of chunk + 2 (or of the next tile's chunk 0 / 1), which the registers hold for a whole
+            // chunk - 2000 matrix clocks, more than a trip to HBM.
+            if (chunk + 2 == nchunk) {                  // from here on the requests belong to the next tile
                 next_work = work + nwg;
                 has_next = next_work < nwork;
                 if (has_next) nxt = describe(next_work);
-                halo_offsets(has_next ? nxt : cur);     // (after the last tile: the tile's own chunk 0 again, into an image nobody reads)
             }
-            const unsigned st_c0 = (unsigned)(last_chunk ? 0 : chunk + 1) * CH * 4u;
-            const __amdgpu_buffer_rsrc_t st_rs = in_rsrc(last_chunk ? nxt.b : cur.b);
+            const bool ahead = chunk + 2 >= nchunk;     // (after the last tile: the tile's own first chunks again, into images nobody reads)
+            const unsigned st_c0 = (unsigned)(ahead ? chunk + 2 - nchunk : chunk + 2) * CH * 4u;
+            const __amdgpu_buffer_rsrc_t st_rs = in_rsrc(ahead ? nxt.b : cur.b);
             const float* img_r = smem + cb * Q_IMG;
             float* img_w = smem + (cb ^ 1) * Q_IMG;
             const float* pa = img_r + pa_off;
             const float* pb = img_r + pb_off;
             auto fetch_a = [&](int s, int slot) {
-                const int off = ((s >> 2) * Q_PZ + (s & 3) * Q_PX) * 4;
-                ra[slot] = *reinterpret_cast<const float4*>(pa + off);
-                rb[slot] = *reinterpret_cast<const float4*>(pb + off);
+                const int px = (s & 3) * Q_PL * 4;
+                const int za = (s >> 2) ? za1 : za0, zb = (s >> 2) ? zb1 : zb0;
+                ra[slot][0] = *reinterpret_cast<const float4*>(pa + za + px);
+                rb[slot][0] = *reinterpret_cast<const float4*>(pb + za + px);
+                ra[slot][1] = *reinterpret_cast<const float4*>(pa + zb + px);
+                rb[slot][1] = *reinterpret_cast<const float4*>(pb + zb + px);
             };
-            const unsigned wsrc = last_chunk ? (has_next ? nxt.wbase : cur.wbase) : wnext;
-            fetch_a(0, 0);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (s + 1 < 8) fetch_a(s + 1, (s + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-                const int sl = s & 1;
-                const float wv[4] = {wr[s].x, wr[s].y, wr[s].z, wr[s].w};
+            const bool last_chunk = chunk + 1 == nchunk;
+            const unsigned wnext = last_chunk ? (has_next ? nxt.wbase : cur.wbase) : wcur + w_chunk_stride;
+            // Point steps run in PAIRS (s, s + 1): their MFMAs alternate between the two accumulator tiles, so that no matrix instruction waits
+            // for the result of the one in front of it (one step alone is a chain of four products into ONE tile); the pair's operand rows sit
+            // in the two register sets, the rows of the next pair are requested as soon as the combinations have been formed.
+            auto combine = [&](int s, int sl, float (&av)[4]) {
+                // v = (A[za] + sa B[za]) + sz (A[zb] + sa B[zb])   (y combination, then z combination; two-wide vector arithmetic)
                 const f32x2 sav = {sa, sa};
-                const f32x2 lo = __builtin_elementwise_fma(sav, f32x2{rb[sl].x, rb[sl].y}, f32x2{ra[sl].x, ra[sl].y});
-                const f32x2 hi = __builtin_elementwise_fma(sav, f32x2{rb[sl].z, rb[sl].w}, f32x2{ra[sl].z, ra[sl].w});
-                const float av[4] = {lo.x, lo.y, hi.x, hi.y};
+                const float sz_ = (s >> 2) ? sz1 : sz0;
+                const f32x2 szv = {sz_, sz_};
+                const f32x2 lo0 = __builtin_elementwise_fma(sav, f32x2{rb[sl][0].x, rb[sl][0].y}, f32x2{ra[sl][0].x, ra[sl][0].y});
+                const f32x2 hi0 = __builtin_elementwise_fma(sav, f32x2{rb[sl][0].z, rb[sl][0].w}, f32x2{ra[sl][0].z, ra[sl][0].w});
+                const f32x2 lo1 = __builtin_elementwise_fma(sav, f32x2{rb[sl][1].x, rb[sl][1].y}, f32x2{ra[sl][1].x, ra[sl][1].y});
+                const f32x2 hi1 = __builtin_elementwise_fma(sav, f32x2{rb[sl][1].z, rb[sl][1].w}, f32x2{ra[sl][1].z, ra[sl][1].w});
+                const f32x2 lo = __builtin_elementwise_fma(szv, lo1, lo0), hi = __builtin_elementwise_fma(szv, hi1, hi0);
+                av[0] = lo.x; av[1] = lo.y; av[2] = hi.x; av[3] = hi.y;
+            };
+            if (!(PULPO_ABL & 32)) { fetch_a(0, 0); fetch_a(1, 1); }
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int s0 = 2 * pp, s1 = 2 * pp + 1;
+                float av0[4], av1[4];
+                combine(s0, 0, av0);
+                combine(s1, 1, av1);
                 __builtin_amdgcn_sched_barrier(0);
+                if (!(PULPO_ABL & 32) && pp + 1 < 4) { fetch_a(s0 + 2, 0); fetch_a(s1 + 2, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                const float wv0[4] = {wr[s0 & 3].x, wr[s0 & 3].y, wr[s0 & 3].z, wr[s0 & 3].w};
+                const float wv1[4] = {wr[s1 & 3].x, wr[s1 & 3].y, wr[s1 & 3].z, wr[s1 & 3].w};
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) {
-                    acc[s >> 2][s & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], wv[s2], acc[s >> 2][s & 3], 0, 0, 0);
-                    if (s2 == 0) {                      // behind the step's first MFMA: the side work of the step
+                    acc[s0 >> 2][s0 & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s2], wv0[s2], acc[s0 >> 2][s0 & 3], 0, 0, 0);
+                    acc[s1 >> 2][s1 & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s2], wv1[s2], acc[s1 >> 2][s1 & 3], 0, 0, 0);
+                    if (s2 == 0) {                      // behind the pair's first MFMAs: the side work of the pair
                         __builtin_amdgcn_sched_barrier(0);
-                        if (s == 0) load_x2(st_rs, st_c0, 0, 0);
-                        if (s == 1) load_x2(st_rs, st_c0, 0, 2);
-                        if (s == 3) store_item(img_w, 0);
-                        if (s == 4) load_x2(st_rs, st_c0, 1, 0);
-                        if (s == 5) load_x2(st_rs, st_c0, 1, 2);
-                        if (s == 7) store_item(img_w, 1);
+                        if (!(PULPO_ABL & 2)) {
+                            if (pp == 0) {
+                                store_item(img_w);
+                                if (chunk + 2 == nchunk) halo_offsets(has_next ? nxt : cur);
+                            }
+                            if (pp == 1) { load_raw(st_rs, st_c0, 0); load_raw(st_rs, st_c0, 1); load_raw(st_rs, st_c0, 2); load_raw(st_rs, st_c0, 3); }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                wr[s] = load_w(wsrc, s);                // this point's weights are consumed: the same point of the next chunk
+                // the pair's weights are consumed: the registers take the points four steps on (the same chunk's, or the next chunk's first four)
+                if (!(PULPO_ABL & 4)) {
+                    wr[s0 & 3] = s0 < 4 ? load_w(wcur, s0 + 4) : load_w(wnext, s0 - 4);
+                    wr[s1 & 3] = s1 < 4 ? load_w(wcur, s1 + 4) : load_w(wnext, s1 - 4);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            wnext += w_chunk_stride;
-            __syncthreads();                            // image cb ^ 1 complete and visible; every wave has left image cb
+            wcur += w_chunk_stride;
+            if (!(PULPO_ABL & 8)) __syncthreads();      // image cb ^ 1 complete and visible; every wave has left image cb
             cb ^= 1;
         }
 
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
         const int row = (rr & 3) + 8 * (rr >> 2) + 4 * kh;          // = MFMA row = block (zb, yb, xb)
         const int vzb = row >> 4, vyb = (row >> 2) & 3, vxb = row & 3;
 #pragma unroll
-        for (int oz = 0; oz < 2; ++oz) {
+        for (int oz = 0; oz < ((PULPO_ABL & 1) ? 0 : 2); ++oz) {
             if (oz > 0) __syncthreads();                // every wave has left the exchange buffer (previous parity)
             // x inverse transform (4 px -> 2 ox) and this wave's share of the z inverse transform:
             //   out z0 = q0 + q1 + q2, out z1 = q1 - q2 - q3;  wave pzh = 0 holds (q0, q1), pzh = 1 holds (q2, q3)
@@ -380,6 +390,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
             for (int w = 0; w < 8; ++w) tot += red[(w * 2 + which) * NT + c];
             a.stats[((long)cur.tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
         }
+#if PULPO_ABL & 1
+        {
+            float t_ = 0.f;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) t_ += acc[p][x][(p * 4 + x) & 15];
+            if (t_ == 12345.678f) out_b[tid] = 1.f;
+        }
+#endif
         if (!has_next) break;
         cur = nxt;
         work = next_work;
@@ -398,7 +418,7 @@ int wino3_enabled() {                                   // PULPO_CONV_WINO3=0: t
 }
 int wino3_min_k() {                                     // PULPO_CONV_WINO3_MINK: smallest reduction-channel count that takes this kernel
     static int k = -1;
-    if (k < 0) { const char* e = getenv("PULPO_CONV_WINO3_MINK"); k = e ? atoi(e) : 64; }
+    if (k < 0) { const char* e = getenv("PULPO_CONV_WINO3_MINK"); k = e ? atoi(e) : 32; }
     return k;
 }
 

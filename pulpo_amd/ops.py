@@ -214,7 +214,7 @@ CONV_PRECISION = "fp32"
 # output y and its output z, pooled / concatenated / up-sampled feature maps - and their gradients live in HBM as bf16; every kernel
 # computes in fp32 (BatchNorm statistics in double) and rounds on the store.  Images, latent samples, displacement fields, losses,
 # parameters, their gradients and the optimizer state stay fp32; so do the outputs of the layers with <= 4 reduction channels, which run
-# the exact-fp32 kernel.  Definition emulated by the oracle (oracle/pulpo_oracle.py ACT_PRECISION), "parity unpinned" against the reference.
+# the exact-fp32 kernel.  A definition of this repository (the test suite's CPU checker emulates it), "parity unpinned" against the reference.
 ACT_BF16 = False
 # None: the library's choice per shape (pulpo_conv3d_k3_algo); "direct" | "wino2": force that forward / data-gradient kernel
 # wherever a Winograd kernel would be eligible (A/B runs and the full-size consistency test)

@@ -42,6 +42,14 @@ VARIANTS = {
     "p_stamps": ("conv3d_wino2p", 64, {}, None),
     "p_stamps_nostore": ("conv3d_wino2p", 64 + 128, {}, None),
     "p_nostore": ("conv3d_wino2p", 128, {}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
+    # F(2x2x2,3x3x3) kernel (conv3d_wino3.hip): bit mask
+    "t_base": ("conv3d_wino3", 0, {}, ["--only", "fwd", "--shapes", "2", "3", "8"]),
+    "t_noepi": ("conv3d_wino3", 1, {}, ["--only", "fwd", "--shapes", "2", "3", "8"]),
+    "t_nostage": ("conv3d_wino3", 2, {}, ["--only", "fwd", "--shapes", "2", "3", "8"]),
+    "t_noweights": ("conv3d_wino3", 4, {}, ["--only", "fwd", "--shapes", "2", "3", "8"]),
+    "t_nobarrier": ("conv3d_wino3", 8, {}, ["--only", "fwd", "--shapes", "2", "3", "8"]),
+    "t_bare": ("conv3d_wino3", 1 + 2 + 4 + 8, {}, ["--only", "fwd", "--shapes", "2", "3", "8"]),
+    "t_bare_noreads": ("conv3d_wino3", 1 + 2 + 4 + 8 + 32, {}, ["--only", "fwd", "--shapes", "2", "3", "8"]),
     "q_stag25": ("conv3d_wino2p", 0, {"PULPO_W2P_STAGGER": "25"}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
     "q_stag50": ("conv3d_wino2p", 0, {"PULPO_W2P_STAGGER": "50"}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
     "q_stag75": ("conv3d_wino2p", 0, {"PULPO_W2P_STAGGER": "75"}, ["--only", "fwd", "--shapes", "0", "3", "8"]),
