@@ -83,9 +83,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
     // y combination of this wave's point row, z combination of its two point planes pz = 2 pzh + (0, 1): per-wave scalars
     const int ta = tab_a(py), tb = tab_b(py);
     const float sa = tab_s(py);
-    const int za0 = tab_a(2 * pzh) * Q_PLROWS * 4, zb0 = tab_b(2 * pzh) * Q_PLROWS * 4;              // float offsets of the two planes, pz local 0
-    const int za1 = tab_a(2 * pzh + 1) * Q_PLROWS * 4, zb1 = tab_b(2 * pzh + 1) * Q_PLROWS * 4;      // ... pz local 1
-    const float sz0 = tab_s(2 * pzh), sz1 = tab_s(2 * pzh + 1);
+    // the wave's two z points share THREE planes U, V, W of a z block: pzh = 0: pz 0 = P0 - P2, pz 1 = P1 + P2 (U, V, W = P0, P1, P2);
+    // pzh = 1: pz 2 = P2 - P1, pz 3 = P1 - P3 = -(P3 - P1) (U, V, W = P2, P3, P1).  Both waves form  v0 = U - W  and  v1 = V + bw * W  (bw = +1 / -1):
+    // the second accumulator of a pzh = 1 wave therefore holds MINUS its point, which the epilogue's z inverse transform takes into account.
+    const int zu = (pzh == 0 ? 0 : 2) * Q_PLROWS * 4, zv = (pzh == 0 ? 1 : 3) * Q_PLROWS * 4, zw = (pzh == 0 ? 2 : 1) * Q_PLROWS * 4;
+    const float bw = pzh == 0 ? 1.f : -1.f;
     // MFMA row i = block (zb = i >> 4, yb = (i >> 2) & 3, xb = i & 3): halo plane 2 zb + (0..3), halo row 2 yb + (0..3)
     const int lrow = (i >> 4) * 2 * Q_PLROWS + ((i >> 2) & 3) * 8 + (i & 3);
     const int pa_off = (kk * Q_QROWS + lrow + ta * 4) * 4;
@@ -177,9 +179,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
     Tile cur = describe(work);
     int cb = 0;                                         // image being read
     // ---- prologue: chunk 0 of the first tile staged, chunk 1 requested; the first weight rows
-    float4 wr[4];                                       // ring: point step s uses wr[s & 3], which is then re-loaded for step s + 4
+    float4 wr[2][2];                                    // ring of two pairs of point rows: pair pp uses wr[pp & 1], which then takes pair pp + 2
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wr[s] = load_w(cur.wbase, s);
+    for (int pp = 0; pp < 2; ++pp) { wr[pp][0] = load_w(cur.wbase, pp); wr[pp][1] = load_w(cur.wbase, 4 + pp); }
     {
         const __amdgpu_buffer_rsrc_t rs0 = in_rsrc(cur.b);
         halo_offsets(cur);
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
     }
     __syncthreads();
 
-    float4 ra[2][2], rb[2][2];                          // the operand rows of a PAIR of point steps: [step of the pair][z plane a / b] of rows ta / tb
+    float4 ra[3], rb[3];                                // the operand rows of a PAIR of point steps (pz local 0 / 1 at one px): rows ta / tb of planes U, V, W
 
     for (;;) {
         int next_work = nwork;
@@ -223,43 +225,41 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
             float* img_w = smem + (cb ^ 1) * Q_IMG;
             const float* pa = img_r + pa_off;
             const float* pb = img_r + pb_off;
-            auto fetch_a = [&](int s, int slot) {
-                const int px = (s & 3) * Q_PL * 4;
-                const int za = (s >> 2) ? za1 : za0, zb = (s >> 2) ? zb1 : zb0;
-                ra[slot][0] = *reinterpret_cast<const float4*>(pa + za + px);
-                rb[slot][0] = *reinterpret_cast<const float4*>(pb + za + px);
-                ra[slot][1] = *reinterpret_cast<const float4*>(pa + zb + px);
-                rb[slot][1] = *reinterpret_cast<const float4*>(pb + zb + px);
+            auto fetch_a = [&](int px) {
+                const int o = px * Q_PL * 4;
+                ra[0] = *reinterpret_cast<const float4*>(pa + zu + o); rb[0] = *reinterpret_cast<const float4*>(pb + zu + o);
+                ra[1] = *reinterpret_cast<const float4*>(pa + zv + o); rb[1] = *reinterpret_cast<const float4*>(pb + zv + o);
+                ra[2] = *reinterpret_cast<const float4*>(pa + zw + o); rb[2] = *reinterpret_cast<const float4*>(pb + zw + o);
             };
             const bool last_chunk = chunk + 1 == nchunk;
             const unsigned wnext = last_chunk ? (has_next ? nxt.wbase : cur.wbase) : wcur + w_chunk_stride;
-            // Point steps run in PAIRS (s, s + 1): their MFMAs alternate between the two accumulator tiles, so that no matrix instruction waits
-            // for the result of the one in front of it (one step alone is a chain of four products into ONE tile); the pair's operand rows sit
-            // in the two register sets, the rows of the next pair are requested as soon as the combinations have been formed.
-            auto combine = [&](int s, int sl, float (&av)[4]) {
-                // v = (A[za] + sa B[za]) + sz (A[zb] + sa B[zb])   (y combination, then z combination; two-wide vector arithmetic)
-                const f32x2 sav = {sa, sa};
-                const float sz_ = (s >> 2) ? sz1 : sz0;
-                const f32x2 szv = {sz_, sz_};
-                const f32x2 lo0 = __builtin_elementwise_fma(sav, f32x2{rb[sl][0].x, rb[sl][0].y}, f32x2{ra[sl][0].x, ra[sl][0].y});
-                const f32x2 hi0 = __builtin_elementwise_fma(sav, f32x2{rb[sl][0].z, rb[sl][0].w}, f32x2{ra[sl][0].z, ra[sl][0].w});
-                const f32x2 lo1 = __builtin_elementwise_fma(sav, f32x2{rb[sl][1].x, rb[sl][1].y}, f32x2{ra[sl][1].x, ra[sl][1].y});
-                const f32x2 hi1 = __builtin_elementwise_fma(sav, f32x2{rb[sl][1].z, rb[sl][1].w}, f32x2{ra[sl][1].z, ra[sl][1].w});
-                const f32x2 lo = __builtin_elementwise_fma(szv, lo1, lo0), hi = __builtin_elementwise_fma(szv, hi1, hi0);
-                av[0] = lo.x; av[1] = lo.y; av[2] = hi.x; av[3] = hi.y;
-            };
-            if (!(PULPO_ABL & 32)) { fetch_a(0, 0); fetch_a(1, 1); }
+            // Point steps run in PAIRS - the wave's two z points at one px: they share the three planes U, V, W (six rows instead of eight), and
+            // their MFMAs alternate between two accumulator tiles, so that no matrix instruction waits for the result of the one in front of
+            // it.  The rows of the next pair are requested as soon as the combinations have been formed.
+            if (!(PULPO_ABL & 32)) fetch_a(0);
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
-                const int s0 = 2 * pp, s1 = 2 * pp + 1;
+                const int s0 = pp, s1 = 4 + pp;         // point steps (pz local 0, px = pp) and (pz local 1, px = pp)
                 float av0[4], av1[4];
-                combine(s0, 0, av0);
-                combine(s1, 1, av1);
+                {
+                    // y combination of each plane (Y = A + sa B), then the two z combinations; two-wide vector arithmetic
+                    const f32x2 sav = {sa, sa}, m1 = {-1.f, -1.f}, bwv = {bw, bw};
+                    f32x2 ylo[3], yhi[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        ylo[p] = __builtin_elementwise_fma(sav, f32x2{rb[p].x, rb[p].y}, f32x2{ra[p].x, ra[p].y});
+                        yhi[p] = __builtin_elementwise_fma(sav, f32x2{rb[p].z, rb[p].w}, f32x2{ra[p].z, ra[p].w});
+                    }
+                    const f32x2 lo0 = __builtin_elementwise_fma(m1, ylo[2], ylo[0]), hi0 = __builtin_elementwise_fma(m1, yhi[2], yhi[0]);
+                    const f32x2 lo1 = __builtin_elementwise_fma(bwv, ylo[2], ylo[1]), hi1 = __builtin_elementwise_fma(bwv, yhi[2], yhi[1]);
+                    av0[0] = lo0.x; av0[1] = lo0.y; av0[2] = hi0.x; av0[3] = hi0.y;
+                    av1[0] = lo1.x; av1[1] = lo1.y; av1[2] = hi1.x; av1[3] = hi1.y;
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(PULPO_ABL & 32) && pp + 1 < 4) { fetch_a(s0 + 2, 0); fetch_a(s1 + 2, 1); }
+                if (!(PULPO_ABL & 32) && pp + 1 < 4) fetch_a(pp + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                const float wv0[4] = {wr[s0 & 3].x, wr[s0 & 3].y, wr[s0 & 3].z, wr[s0 & 3].w};
-                const float wv1[4] = {wr[s1 & 3].x, wr[s1 & 3].y, wr[s1 & 3].z, wr[s1 & 3].w};
+                const float wv0[4] = {wr[pp & 1][0].x, wr[pp & 1][0].y, wr[pp & 1][0].z, wr[pp & 1][0].w};
+                const float wv1[4] = {wr[pp & 1][1].x, wr[pp & 1][1].y, wr[pp & 1][1].z, wr[pp & 1][1].w};
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) {
                     acc[s0 >> 2][s0 & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s2], wv0[s2], acc[s0 >> 2][s0 & 3], 0, 0, 0);
@@ -277,9 +277,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
                     }
                 }
                 // the pair's weights are consumed: the registers take the points four steps on (the same chunk's, or the next chunk's first four)
+                // (a ring of two pairs: the pair's rows take the points of the pair two on - the same chunk's, or the next chunk's first two)
                 if (!(PULPO_ABL & 4)) {
-                    wr[s0 & 3] = s0 < 4 ? load_w(wcur, s0 + 4) : load_w(wnext, s0 - 4);
-                    wr[s1 & 3] = s1 < 4 ? load_w(wcur, s1 + 4) : load_w(wnext, s1 - 4);
+                    wr[pp & 1][0] = pp < 2 ? load_w(wcur, s0 + 2) : load_w(wnext, s0 - 2);
+                    wr[pp & 1][1] = pp < 2 ? load_w(wcur, s1 + 2) : load_w(wnext, s1 - 2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -322,9 +323,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
                 if (pzh == 0) {
                     e0 = oz == 0 ? p0x0 + p1x0 : p1x0;
                     e1 = oz == 0 ? p0x1 + p1x1 : p1x1;
-                } else {
-                    e0 = oz == 0 ? p0x0 : -p0x0 - p1x0;
-                    e1 = oz == 0 ? p0x1 : -p0x1 - p1x1;
+                } else {                                // (the second accumulator of these waves holds MINUS its point, see the matrix loop)
+                    e0 = oz == 0 ? p0x0 : p1x0 - p0x0;
+                    e1 = oz == 0 ? p0x1 : p1x1 - p0x1;
                 }
                 R[((wave * 2 + 0) * 16 + r) * 64 + elane] = e0;
                 R[((wave * 2 + 1) * 16 + r) * 64 + elane] = e1;
