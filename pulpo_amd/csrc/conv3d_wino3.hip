@@ -236,35 +236,39 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
             // Point steps run in PAIRS - the wave's two z points at one px: they share the three planes U, V, W (six rows instead of eight), and
             // their MFMAs alternate between two accumulator tiles, so that no matrix instruction waits for the result of the one in front of
             // it.  The rows of the next pair are requested as soon as the combinations have been formed.
+            // y combination of each plane (Y = A + sa B), then the two z combinations; two-wide vector arithmetic
+            auto combine = [&](float (&av0)[4], float (&av1)[4]) {
+                const f32x2 sav = {sa, sa}, m1 = {-1.f, -1.f}, bwv = {bw, bw};
+                f32x2 ylo[3], yhi[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    ylo[p] = __builtin_elementwise_fma(sav, f32x2{rb[p].x, rb[p].y}, f32x2{ra[p].x, ra[p].y});
+                    yhi[p] = __builtin_elementwise_fma(sav, f32x2{rb[p].z, rb[p].w}, f32x2{ra[p].z, ra[p].w});
+                }
+                const f32x2 lo0 = __builtin_elementwise_fma(m1, ylo[2], ylo[0]), hi0 = __builtin_elementwise_fma(m1, yhi[2], yhi[0]);
+                const f32x2 lo1 = __builtin_elementwise_fma(bwv, ylo[2], ylo[1]), hi1 = __builtin_elementwise_fma(bwv, yhi[2], yhi[1]);
+                av0[0] = lo0.x; av0[1] = lo0.y; av0[2] = hi0.x; av0[3] = hi0.y;
+                av1[0] = lo1.x; av1[1] = lo1.y; av1[2] = hi1.x; av1[3] = hi1.y;
+            };
+            // Software pipeline over the chunk's four pairs: the operand rows of pair pp + 1 are requested in front of pair pp's MFMAs and
+            // COMBINED between them (behind the fourth of the eight), the rows of pair pp + 2 requested right after - a wave never stands in a
+            // vector-only phase while it has matrix instructions to issue, except in front of a chunk's first pair.
+            float avn0[4], avn1[4];                     // the operands of the pair in flight / of the next pair
             if (!(PULPO_ABL & 32)) fetch_a(0);
+            combine(avn0, avn1);
+            if (!(PULPO_ABL & 32)) fetch_a(1);
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
                 const int s0 = pp, s1 = 4 + pp;         // point steps (pz local 0, px = pp) and (pz local 1, px = pp)
-                float av0[4], av1[4];
-                {
-                    // y combination of each plane (Y = A + sa B), then the two z combinations; two-wide vector arithmetic
-                    const f32x2 sav = {sa, sa}, m1 = {-1.f, -1.f}, bwv = {bw, bw};
-                    f32x2 ylo[3], yhi[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        ylo[p] = __builtin_elementwise_fma(sav, f32x2{rb[p].x, rb[p].y}, f32x2{ra[p].x, ra[p].y});
-                        yhi[p] = __builtin_elementwise_fma(sav, f32x2{rb[p].z, rb[p].w}, f32x2{ra[p].z, ra[p].w});
-                    }
-                    const f32x2 lo0 = __builtin_elementwise_fma(m1, ylo[2], ylo[0]), hi0 = __builtin_elementwise_fma(m1, yhi[2], yhi[0]);
-                    const f32x2 lo1 = __builtin_elementwise_fma(bwv, ylo[2], ylo[1]), hi1 = __builtin_elementwise_fma(bwv, yhi[2], yhi[1]);
-                    av0[0] = lo0.x; av0[1] = lo0.y; av0[2] = hi0.x; av0[3] = hi0.y;
-                    av1[0] = lo1.x; av1[1] = lo1.y; av1[2] = hi1.x; av1[3] = hi1.y;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(PULPO_ABL & 32) && pp + 1 < 4) fetch_a(pp + 1);
-                __builtin_amdgcn_sched_barrier(0);
+                const float av0[4] = {avn0[0], avn0[1], avn0[2], avn0[3]}, av1[4] = {avn1[0], avn1[1], avn1[2], avn1[3]};
                 const float wv0[4] = {wr[pp & 1][0].x, wr[pp & 1][0].y, wr[pp & 1][0].z, wr[pp & 1][0].w};
                 const float wv1[4] = {wr[pp & 1][1].x, wr[pp & 1][1].y, wr[pp & 1][1].z, wr[pp & 1][1].w};
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) {
                     acc[s0 >> 2][s0 & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s2], wv0[s2], acc[s0 >> 2][s0 & 3], 0, 0, 0);
                     acc[s1 >> 2][s1 & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s2], wv1[s2], acc[s1 >> 2][s1 & 3], 0, 0, 0);
-                    if (s2 == 0) {                      // behind the pair's first MFMAs: the side work of the pair
+                    if (s2 == 0) {                      // behind the pair's first MFMAs: the staging work of the pair
                         __builtin_amdgcn_sched_barrier(0);
                         if (!(PULPO_ABL & 2)) {
                             if (pp == 0) {
@@ -275,9 +279,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    if (s2 == 1 && pp + 1 < 4) {        // behind the fourth MFMA: the next pair's combinations, then the request for the pair after it
+                        __builtin_amdgcn_sched_barrier(0);
+                        combine(avn0, avn1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!(PULPO_ABL & 32) && pp + 2 < 4) fetch_a(pp + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                // the pair's weights are consumed: the registers take the points four steps on (the same chunk's, or the next chunk's first four)
-                // (a ring of two pairs: the pair's rows take the points of the pair two on - the same chunk's, or the next chunk's first two)
+                // the pair's weights are consumed: a ring of two pairs - the rows take the points of the pair two on (the same chunk's, or the
+                // next chunk's first two)
                 if (!(PULPO_ABL & 4)) {
                     wr[pp & 1][0] = pp < 2 ? load_w(wcur, s0 + 2) : load_w(wnext, s0 - 2);
                     wr[pp & 1][1] = pp < 2 ? load_w(wcur, s1 + 2) : load_w(wnext, s1 - 2);
