@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16(ConvArgsH a) {
     constexpr int NN = NT / 32;
     constexpr int MT = TZv / 2;
     constexpr int HV = (TZv + 2) * HY * HX;
-    constexpr int TPB = (TZv == 4 && NT == 64) ? 3 : 1;  // taps (one dx row) per barrier: 3 on the big 64-cout tiles = 24 MFMAs per wave between
+#ifndef PULPO_BF16_TPB32
+#define PULPO_BF16_TPB32 1
+#endif
+    constexpr int TPB = (TZv == 4 && (NT == 64 || PULPO_BF16_TPB32 == 3)) ? 3 : 1;  // taps (one dx row) per barrier: 3 on the big 64-cout tiles = 24 MFMAs per wave between
                                                           // barriers (on the 32-cout tiles the extra registers cost the third wave per SIMD: measured slower)
     constexpr int WSLAB = TPB * NT * CP;                // bf16 elements of one LDS weight slab set [TPB][NT][CP]
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_h[];
@@ -428,7 +431,20 @@ __device__ __forceinline__ bf16x8 gather8(const uint16_t* p) {          // p[t *
     return __builtin_bit_cast(bf16x8, o);
 }
 
-template <int NTW, bool VEC, typename T = float>
+// TR: the fragments come out of the voxel-major images through gfx950's transposing LDS read (ds_read_b64_tr_b16: a group of 16 lanes reads
+// 4 voxel rows x 16 channel columns and each lane receives ONE column's four voxels): two reads per 8-voxel fragment instead of eight 2-byte
+// reads and four packing operations - the LDS instruction issue that bounded this kernel.  Needs every 16-lane group's 16 GEMM rows to be
+// 16 consecutive channels of one tap: Cin % 16 == 0 (every layer of the BASELINE configurations).
+typedef short tr_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* p, int hi_off) {
+    const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p));
+    const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p + hi_off));
+    typedef short tr_v8s __attribute__((ext_vector_type(8)));
+    const tr_v8s v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NTW, bool VEC, typename T = float, bool TR = false>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16(WgradArgsH a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_h[];
     uint16_t* xs = smem_h;                     // [WHV][CP]
@@ -446,12 +462,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16(WgradArgsH a) {
     const int i = lane & 31, kk = lane >> 5;
 
     int rowoff[NTW];
+    // (TR) lane 4 q + p of a 16-lane group supplies the address of voxel row q, channels 4 p .. 4 p + 3 of the group's 16 channel columns
+    const int tg = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
-        const int r = 32 * (wave + 4 * u) + i;
-        const int tap = r < rows ? r / Cc : 0, ci = r < rows ? r - tap * Cc : 0;      // spare rows read tap 0 / channel 0; never flushed
-        rowoff[u] = tap_halo_offset(tap) * CP + ci;
+        if constexpr (TR) {
+            const int r = 32 * (wave + 4 * u) + 16 * tg;                                  // first GEMM row of this lane's group
+            const int tap = r < rows ? r / Cc : 0, ci = r < rows ? r - tap * Cc : 0;      // spare groups read tap 0 / channel 0; never flushed
+            rowoff[u] = (tap_halo_offset(tap) + tq) * CP + ci + 4 * tp;
+        } else {
+            const int r = 32 * (wave + 4 * u) + i;
+            const int tap = r < rows ? r / Cc : 0, ci = r < rows ? r - tap * Cc : 0;      // spare rows read tap 0 / channel 0; never flushed
+            rowoff[u] = tap_halo_offset(tap) * CP + ci;
+        }
     }
+    const int bvoff = TR ? tq * CP + 16 * tg + 4 * tp : i;
     f32x16 acc[NTW];
 #pragma unroll
     for (int u = 0; u < NTW; ++u)
@@ -476,10 +501,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16(WgradArgsH a) {
         for (int ks = 0; ks < WMV / 16; ++ks) {
             const int vrow = 2 * ks + kk;                                   // x-row of the tile: z = vrow >> 3, y = vrow & 7
             const int hbase = ((vrow >> 3) * HY + (vrow & 7)) * HX * CP;
-            const bf16x8 bv = gather8(dys + vrow * 8 * CP + i);
+            const bf16x8 bv = TR ? tr_frag(dys + vrow * 8 * CP + bvoff, 4 * CP) : gather8(dys + vrow * 8 * CP + bvoff);
 #pragma unroll
             for (int u = 0; u < NTW; ++u) {
-                const bf16x8 av = gather8(xs + hbase + rowoff[u]);
+                const bf16x8 av = TR ? tr_frag(xs + hbase + rowoff[u], 4 * CP) : gather8(xs + hbase + rowoff[u]);
                 acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[u], 0, 0, 0);
             }
         }
@@ -514,7 +539,7 @@ int conv_ksplit_bf16(int B, int D, int H, int W, int K, int N) {
 
 template <int NT, bool VEC, int TZv, typename T>
 int launch_bf16(const ConvArgsH& a, int nblk, hipStream_t st) {
-    constexpr size_t lds = (size_t)((TZv + 2) * HY * HX * CP + 2 * ((TZv == 4 && NT == 64) ? 3 : 1) * NT * CP) * sizeof(uint16_t);
+    constexpr size_t lds = (size_t)((TZv + 2) * HY * HX * CP + 2 * ((TZv == 4 && (NT == 64 || PULPO_BF16_TPB32 == 3)) ? 3 : 1) * NT * CP) * sizeof(uint16_t);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma_bf16<NT, VEC, TZv, T>),
@@ -664,7 +689,15 @@ PULPO_API int pulpo_conv3d_k3_wgrad_bf16_t(const void* in, int64_t in_bs, int64_
     const int ntw = (nrt_max + 3) / 4;
     constexpr size_t lds = (size_t)(WHV + WMV) * CP * sizeof(uint16_t);
     const int nblk = npair * a.nsplit;
-#define PULPO_WGRAD_H(NTWV, VECV, TT) hipLaunchKernelGGL((conv3d_k3_wgrad_bf16<NTWV, VECV, TT>), dim3(nblk), dim3(256), lds, st, a)
+    // transposing LDS reads where every 16-lane group's rows are 16 channels of one tap (PULPO_WGRAD_BF16_TR=0: the 2-byte gathers, A/B switch)
+    static int tr_on = -1;
+    if (tr_on < 0) { const char* e = getenv("PULPO_WGRAD_BF16_TR"); tr_on = e ? atoi(e) : 1; }
+    const bool tr = tr_on && Cin % 16 == 0;
+#define PULPO_WGRAD_H(NTWV, VECV, TT)                                                                                             \
+    do {                                                                                                                            \
+        if (tr) hipLaunchKernelGGL((conv3d_k3_wgrad_bf16<NTWV, VECV, TT, true>), dim3(nblk), dim3(256), lds, st, a);                \
+        else hipLaunchKernelGGL((conv3d_k3_wgrad_bf16<NTWV, VECV, TT, false>), dim3(nblk), dim3(256), lds, st, a);                  \
+    } while (0)
 #define PULPO_WGRAD_T(TT)                                                                                                                           \
     do {                                                                                                                                            \
         if (vec) {                                                                                                                                  \
