@@ -27,6 +27,9 @@
 #include "wino3_pack.h"
 #include <stdlib.h>
 
+#ifndef PULPO_W3_PK
+#define PULPO_W3_PK 1        // the y / z combinations in two-wide vector arithmetic (v_pk_fma_f32); 0: scalar v_fma_f32 - measured 3-4 % slower here (64-clock fp32 MFMAs leave room)
+#endif
 #ifndef PULPO_ABL
 #define PULPO_ABL 0          // diagnostic builds (scripts/ablate.py): timings only, results are garbage.  Bits: 1 no epilogue, 2 no halo staging,
 #endif                       // 4 no weight re-loads, 8 no chunk barrier, 32 no operand-row reads inside the loop
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
             // it.  The rows of the next pair are requested as soon as the combinations have been formed.
             // y combination of each plane (Y = A + sa B), then the two z combinations; two-wide vector arithmetic
             auto combine = [&](float (&av0)[4], float (&av1)[4]) {
+#if PULPO_W3_PK
                 const f32x2 sav = {sa, sa}, m1 = {-1.f, -1.f}, bwv = {bw, bw};
                 f32x2 ylo[3], yhi[3];
 #pragma unroll
@@ -249,6 +253,20 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
                 const f32x2 lo1 = __builtin_elementwise_fma(bwv, ylo[2], ylo[1]), hi1 = __builtin_elementwise_fma(bwv, yhi[2], yhi[1]);
                 av0[0] = lo0.x; av0[1] = lo0.y; av0[2] = hi0.x; av0[3] = hi0.y;
                 av1[0] = lo1.x; av1[1] = lo1.y; av1[2] = hi1.x; av1[3] = hi1.y;
+#else
+                // scalar fmas (the guide prices v_pk_fma_f32 above two v_fma_f32 beside 32-clock bf16 MFMAs; beside these 64-clock fp32 MFMAs the packed form won)
+                float y[3][4];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    y[p][0] = fmaf(sa, rb[p].x, ra[p].x); y[p][1] = fmaf(sa, rb[p].y, ra[p].y);
+                    y[p][2] = fmaf(sa, rb[p].z, ra[p].z); y[p][3] = fmaf(sa, rb[p].w, ra[p].w);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    av0[k] = y[0][k] - y[2][k];
+                    av1[k] = fmaf(bw, y[2][k], y[1][k]);
+                }
+#endif
             };
             // Software pipeline over the chunk's four pairs: the operand rows of pair pp + 1 are requested in front of pair pp's MFMAs and
             // COMBINED between them (behind the fourth of the eight), the rows of pair pp + 2 requested right after - a wave never stands in a
