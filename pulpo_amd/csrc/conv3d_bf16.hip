@@ -11,6 +11,20 @@
 #include "conv_shared.h"
 #include "act_io.h"
 
+#ifndef PULPO_PW_ABL
+#define PULPO_PW_ABL 0                                  // diagnostic builds of the persistent kernel (scripts/build_variant.sh): 1 no output stores, 2 no halo
+#endif                                                  // loads, 4 no MFMAs, 8 no halo LDS stores, 16 no weight loads / stores, 64 phase stamps
+#if PULPO_PW_ABL & 64
+// g_pw_stamps[block][8 k + p]: clock at phase p of the block's k-th tile (0 start, 1 halo in LDS, 2.. end of each weight group, then stores issued, statistics done)
+__device__ unsigned long long g_pw_stamps[512 * 128];
+#define PW_STAMP(k, p) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && (k) < 10) g_pw_stamps[blockIdx.x * 128 + 12 * (k) + (p)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+PULPO_API int pulpo_debug_read_stamps_pw(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pw_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define PW_STAMP(k, p) do {} while (0)
+#endif
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
@@ -311,6 +325,336 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16(ConvArgsH a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ persistent forward / dgrad kernel
+// The kernel above takes ONE tile per workgroup and a barrier per tap (4 MFMAs per wave between barriers on the 32-cout tiles, the tap's
+// weights one L2 trip ahead): on the 32-channel 160^3 layers its matrix pipe was 23 % busy.  This variant, for bf16-stored activations with
+// whole 32-channel chunks on 4 x 8 x 8 tiles, keeps the tiling and the MFMA loop but
+//   * walks tiles with persistent workgroups (two per CU): the halo of the next chunk / tile travels to REGISTERS while this one is
+//     multiplied, requested in slices after each weight group's loads so that vmcnt (in order) never makes a weight store wait for a
+//     younger halo load, and only its LDS store stands between two tiles;
+//   * stages the weights in GROUPS of TPB taps (9 = one dz plane on 32-cout tiles: 36 MFMAs per wave between barriers; 3 on 64-cout
+//     tiles: 24), double-buffered, loaded a group ahead: 4 (10) barriers per chunk instead of 28;
+//   * drops the LDS row padding for XOR swizzles (64-byte rows; halo rows keyed by their y, weight rows by n / 4: every ds_read_b128
+//     lane group - 4 x 4 voxels of 4 consecutive y rows, or 16 rows n - lands on 16 distinct 16-byte slots), which is what lets two
+//     workgroups share the CU's 160 KB.
+constexpr int PW_HV = 6 * HY * HX;                      // halo voxels of a 4 x 8 x 8 tile
+constexpr int PW_HP = (PW_HV * 4 + 255) / 256;          // 16-byte halo pieces per thread (the last one on the low threads only)
+constexpr unsigned PW_OOB = 0x80000000u;
+
+template <int NN, int TPB>
+constexpr size_t pw_lds_bytes() { return (size_t)(PW_HV * CH + 2 * TPB * NN * 32 * CH) * sizeof(uint16_t) + 4 * 2 * NN * 32 * sizeof(float); }
+
+template <int NN, int TPB>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_bf16_pw(ConvArgsH a) {
+    using T = pulpo::bf16_t;
+    constexpr int NT = NN * 32, MT = 2, NG = 27 / TPB;
+    constexpr int WGE = TPB * NT * CH;                  // bf16 elements of one weight group
+    constexpr int WPC = TPB * NT * 4;                   // its 16-byte pieces
+    constexpr int WP = (WPC + 255) / 256;               // ... per thread
+    static_assert(NG * TPB == 27, "taps per group must divide 27");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem_h[];
+    uint16_t* xs = smem_h;                              // [PW_HV][32], slot s of row hv at s ^ (hy & 3)
+    uint16_t* ws = smem_h + PW_HV * CH;                 // [2][TPB][NT][32], slot s of row n at s ^ ((n >> 2) & 3)
+    float* red = reinterpret_cast<float*>(ws + 2 * WGE);// [4 waves][2][NT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int nwork = a.B * a.ntz * a.nty * a.ntx * a.ncot, nwg = gridDim.x;
+    const int nchunk = a.Cin / CH;
+
+    struct Tile { int tile_lin, b, z0, y0, x0, co0; };
+    auto describe = [&](int work) {
+        Tile t;
+        const int cot = work % a.ncot;
+        t.tile_lin = work / a.ncot;
+        int q = t.tile_lin;
+        const int tx_ = q % a.ntx; q /= a.ntx;
+        const int ty_ = q % a.nty; q /= a.nty;
+        const int tz_ = q % a.ntz;
+        t.b = q / a.ntz;
+        t.z0 = tz_ * 4; t.y0 = ty_ * TY; t.x0 = tx_ * TX;
+        t.co0 = cot * NT;
+        return t;
+    };
+
+    // ---- halo pieces of this thread: piece j = (halo voxel j / 4, 8-channel slot j % 4)
+    const unsigned ps_bytes = (unsigned)a.in_ps * 2u;
+    const int in_bytes = (int)((long)a.D * a.H * a.W * a.in_ps * 2);
+    unsigned hrel[PW_HP];                               // byte offset relative to the tile's halo origin
+    unsigned hbit[PW_HP];                               // 1 << hz | 1 << (6 + hy) | 1 << (16 + hx); bit 31 where the thread has no piece
+    int hlds[PW_HP];                                    // element offset in xs
+#pragma unroll
+    for (int u = 0; u < PW_HP; ++u) {
+        const int j = tid + u * 256;
+        const int hv = j >> 2, q = j & 3;
+        const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+        hrel[u] = (unsigned)((hz * a.H + hy) * a.W + hx) * ps_bytes + q * 16u;
+        hbit[u] = j < PW_HV * 4 ? (1u << hz) | (1u << (6 + hy)) | (1u << (16 + hx)) : 0x80000000u;
+        hlds[u] = hv * CH + ((q ^ (hy & 3)) << 3);
+    }
+    uint4 hreg[PW_HP];
+    if (PULPO_PW_ABL & 2) {
+#pragma unroll
+        for (int u = 0; u < PW_HP; ++u) hreg[u] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    }
+    // which halo planes / rows / columns of a tile lie inside the volume, as one mask in hbit's layout (a piece is inside when all three of
+    // its bits are set); outside pieces load from beyond num_records: zeros
+    auto inside_mask = [&](const Tile& t) {
+        auto run = [](int first, int extent, int n) {   // bits h in [0, n) with 0 <= first + h < extent
+            const int lo = first < 0 ? -first : 0, hi = extent - first < n ? extent - first : n;
+            return ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        };
+        return run(t.z0 - 1, a.D, 6) | (run(t.y0 - 1, a.H, HY) << 6) | (run(t.x0 - 1, a.W, HX) << 16);
+    };
+    auto load_halo = [&](const Tile& t, int chunk, int u0, int u1) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T*>(reinterpret_cast<const T*>(a.in) + (long)t.b * a.in_bs), 0, in_bytes, 0x00020000);
+        const unsigned origin = (unsigned)(((t.z0 - 1) * a.H + (t.y0 - 1)) * a.W + (t.x0 - 1)) * ps_bytes;        // modulo 2^32
+        const unsigned mask = inside_mask(t);
+        const int c0b = chunk * CH * 2;
+        if (PULPO_PW_ABL & 2) return;
+#pragma unroll
+        for (int u = u0; u < u1; ++u)
+            hreg[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((mask & hbit[u]) == hbit[u] ? origin + hrel[u] : PW_OOB), c0b, 0));
+    };
+    auto store_halo = [&]() {
+        if (PULPO_PW_ABL & 8) return;
+#pragma unroll
+        for (int u = 0; u < PW_HP; ++u)
+            if (u + 1 < PW_HP || tid < PW_HV * 4 - (PW_HP - 1) * 256) *reinterpret_cast<uint4*>(xs + hlds[u]) = hreg[u];
+    };
+
+    // ---- weight pieces of this thread: piece j of a group = (tap j / (4 NT), row n, slot j % 4).  (Named registers: an array indexed inside
+    //      the lambdas ends up in scratch.)
+    uint4 wr0, wr1, wr2, wr3, wr4;
+    wr0 = wr1 = wr2 = wr3 = wr4 = make_uint4(0, 0, 0, 0);
+    static_assert(WP <= 5, "weight pieces per thread");
+    auto w_has = [&](int u) { return u < WP && (u + 1 < WP || WPC % 256 == 0 || tid + u * 256 < WPC); };
+    // a group's pieces sit at fixed per-thread byte offsets from its first row ((chunk, first tap, co0): the scalar offset of a buffer load)
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.wp), 0, -1, 0x00020000);
+    auto w_voff = [&](int u) {
+        const int j = tid + u * 256;
+        const int tapl = j / (4 * NT), n = (j >> 2) % NT, q = j & 3;
+        return ((tapl * a.NPad + n) * CH + q * 8) * 2;
+    };
+    const int wv0 = w_voff(0), wv1 = w_voff(1), wv2 = w_voff(2), wv3 = w_voff(3), wv4 = w_voff(4);
+    auto w_dst = [&](int buf, int u) {
+        const int j = tid + u * 256;
+        const int tapl = j / (4 * NT), n = (j >> 2) % NT, q = j & 3;
+        return reinterpret_cast<uint4*>(ws + buf * WGE + (tapl * NT + n) * CH + ((q ^ ((n >> 2) & 3)) << 3));
+    };
+    auto load_wg = [&](int co0, int chunk, int g) {
+        if (PULPO_PW_ABL & 16) return;
+        const int soff = ((chunk * 27 + g * TPB) * a.NPad + co0) * CH * 2;
+        if (w_has(0)) wr0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv0, soff, 0));
+        if (w_has(1)) wr1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv1, soff, 0));
+        if (w_has(2)) wr2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv2, soff, 0));
+        if (w_has(3)) wr3 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv3, soff, 0));
+        if (w_has(4)) wr4 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv4, soff, 0));
+    };
+    auto store_wg = [&](int buf) {
+        if (PULPO_PW_ABL & 16) return;
+        if (w_has(0)) *w_dst(buf, 0) = wr0;
+        if (w_has(1)) *w_dst(buf, 1) = wr1;
+        if (w_has(2)) *w_dst(buf, 2) = wr2;
+        if (w_has(3)) *w_dst(buf, 3) = wr3;
+        if (w_has(4)) *w_dst(buf, 4) = wr4;
+    };
+
+    // ---- operand addresses (elements): A rows of the wave's two 32-voxel slabs per dy (the swizzle key is the halo row's y) and K half;
+    //      the tap's halo offset is an immediate
+    int xa[MT][3][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int v = (wave * MT + m) * 32 + i;
+        const int vz = v >> 6, vy = (v >> 3) & 7, vx = v & 7;
+        const int hb = (vz * HY + vy) * HX + vx;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xa[m][dy][ks] = hb * CH + (((ks * 2 + kk) ^ ((vy + dy) & 3)) << 3);
+    }
+    int wa[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wa[ks] = i * CH + (((ks * 2 + kk) ^ ((i >> 2) & 3)) << 3);
+
+    int work = pulpo::xcd_remap(blockIdx.x, nwg);
+    Tile cur = describe(work);
+    load_wg(cur.co0, 0, 0);
+    load_halo(cur, 0, 0, PW_HP);
+    store_wg(0);
+    store_halo();
+    int buf = 0;
+    [[maybe_unused]] int tile_no = 0;
+    int pend_tile = -1, pend_co0 = 0;                   // tile whose partial statistics wait in `red`
+    auto flush_stats = [&]() {                          // (behind a barrier that followed the writes of `red`; the next writes are four barriers away)
+        if (a.stats != nullptr && pend_tile >= 0 && tid < 2 * NT) {
+            const int which = tid / NT, c = tid - which * NT;
+            const float tot = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] + red[(2 * 2 + which) * NT + c] +
+                              red[(3 * 2 + which) * NT + c];
+            a.stats[((long)pend_tile * 2 + which) * a.Cout + pend_co0 + c] = tot;
+        }
+    };
+
+    for (;;) {
+        PW_STAMP(tile_no, 0);
+        const int next_work = work + nwg;
+        const bool has_next = next_work < nwork;
+        const Tile nxt = has_next ? describe(next_work) : cur;      // (after the last tile: its own halo again, into registers nobody stores)
+
+        // the epilogue's per-channel constants, requested before any of the tile's loads: consuming them later waits for nothing younger
+        // (a load at the epilogue would drain the halo slices still in flight)
+        const bool fused = a.coef != nullptr;
+        float ebias[NN], efsc[NN], efsh[NN];
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+            const int co = cur.co0 + n * 32 + i;
+            ebias[n] = a.bias != nullptr ? a.bias[co] : 0.f;
+            efsc[n] = fused ? a.coef[2 * a.Cout + co] : 1.f;
+            efsh[n] = fused ? a.coef[3 * a.Cout + co] : 0.f;
+        }
+        f32x16 acc[MT][NN];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NN; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+        int chunk = 0;
+        do {                                            // (at least one chunk: a zero-trip path would make the compiler's vmcnt bookkeeping drain
+                                                        //  every load in flight at the epilogue's first use of a constant loaded above)
+            __syncthreads();                            // the chunk's halo and its first weight group are in place
+            PW_STAMP(tile_no, 1);
+            if (chunk == 0) { flush_stats(); pend_tile = -1; }
+            const bool lastc = chunk + 1 == nchunk;
+            const Tile& ht = lastc ? nxt : cur;         // whose halo the registers take next
+            const int hchunk = lastc ? 0 : chunk + 1;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                // the next group's weights, then this group's slice of the next halo
+                {
+                    const bool same = g + 1 < NG;
+                    load_wg(same || !lastc ? cur.co0 : nxt.co0, same ? chunk : hchunk, same ? g + 1 : 0);
+                    const int u0 = (PW_HP * g) / NG, u1 = (PW_HP * (g + 1)) / NG;
+                    if (u1 > u0) load_halo(ht, hchunk, u0, u1);
+                }
+                const uint16_t* wb = ws + buf * WGE;
+                constexpr int STEPS = TPB * 2;
+                constexpr int SLOTS = 3;
+                bf16x8 av[SLOTS][MT], bv[SLOTS][NN];
+                auto fetch = [&](int st, int slot) {
+                    const int d = st >> 1, ks = st & 1;
+                    const int tap = g * TPB + d;
+                    const int off = tap_halo_offset(tap) * CH;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) av[slot][m] = *reinterpret_cast<const bf16x8*>(xs + xa[m][(tap / 3) % 3][ks] + off);
+#pragma unroll
+                    for (int n = 0; n < NN; ++n) bv[slot][n] = *reinterpret_cast<const bf16x8*>(wb + wa[ks] + (d * NT + n * 32) * CH);
+                };
+#pragma unroll
+                for (int st = 0; st < SLOTS - 1; ++st) fetch(st, st);
+#pragma unroll
+                for (int st = 0; st < STEPS; ++st) {
+                    if (st + SLOTS - 1 < STEPS) fetch(st + SLOTS - 1, (st + SLOTS - 1) % SLOTS);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int n = 0; n < NN; ++n)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            if (PULPO_PW_ABL & 4) { acc[m][n][0] += (float)av[st % SLOTS][m][0] * (float)bv[st % SLOTS][n][0]; continue; }
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[st % SLOTS][m], bv[st % SLOTS][n], acc[m][n], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                PW_STAMP(tile_no, 8 + g);
+                store_wg(buf ^ 1);                      // (the other buffer was last read a group ago: every wave has passed that barrier)
+                __syncthreads();
+                PW_STAMP(tile_no, 2 + g);
+                buf ^= 1;
+            }
+            // the registers' halo (the next chunk's, or the next tile's first) goes to LDS as soon as every wave has left this one: in front
+            // of the epilogue, whose arithmetic and stores then cover the writes and the wait for the last slice
+            store_halo();
+            PW_STAMP(tile_no, 7);
+        } while (++chunk < nchunk);
+
+        // ---- epilogue: bias, optional eval-mode BatchNorm + LeakyReLU, rounding, stores, partial statistics of the tensor as stored.
+        // A lane holds channel co of 16 voxels per 32-voxel slab (accumulator row r -> voxel x = (r & 3) + 4 kk, y = r >> 2); neighbouring lanes
+        // hold neighbouring channels.  Rows are taken in pairs (x, x + 1): a lane exchanges one packed pair with its neighbour (DPP) so that
+        // the even lane owns (co, co + 1) of voxel x and the odd lane (co - 1, co) of voxel x + 1 - one dword each.  The slab's dwords pass
+        // through a wave-private 2 KB image [32 voxels][32 channels] in the weight buffer that is idle until the next tile's second group
+        // (DS operations of one wave execute in order: no wait between its writes and reads), and leave as 16-byte pieces: two
+        // buffer_store_dwordx4 per slab (16 voxels x 64 bytes each) instead of sixteen dword stores.
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(a.out) + (long)cur.b * a.out_bs, 0,
+                                                                             (int)((long)a.D * a.H * a.W * a.out_ps * 2), 0x00020000);
+        const unsigned ops_b = (unsigned)a.out_ps * 2u;
+        const unsigned row_b = (unsigned)a.W * ops_b;
+        const unsigned obase = (unsigned)(((cur.z0 + wave) * a.H + cur.y0) * a.W + cur.x0) * ops_b + (unsigned)cur.co0 * 2u;
+        const bool odd = i & 1;
+        // v_perm_b32 selector of the owned dword from (neighbour's pair, own pair): even lane (own x, neighbour's x), odd lane (neighbour's
+        // x + 1, own x + 1) - bytes 0-3 of the operand pair are the own dword, 4-7 the neighbour's
+        const uint32_t psel = odd ? 0x03020706u : 0x05040100u;
+        uint16_t* xch = ws + (buf ^ 1) * WGE + wave * (32 * 32);                   // (after the toggle `buf` holds the next tile's first group)
+        uint32_t* xw = reinterpret_cast<uint32_t*>(xch + (4 * kk + (odd ? 1 : 0)) * 32 + (i - (odd ? 1 : 0)));
+        const uint4* xr = reinterpret_cast<const uint4*>(xch) + lane;              // piece `lane` (+ 64): voxel row lane / 4 (+ 16), channels 8 (lane % 4) ..
+        const unsigned st_off = obase + (unsigned)(lane >> 5) * row_b + (unsigned)((lane >> 2) & 7) * ops_b + (unsigned)(lane & 3) * 16u;
+        float ssum[NN], ssq[NN];
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+            const float bias = ebias[n], fsc = efsc[n], fsh = efsh[n];
+            using f32x2 = __attribute__((ext_vector_type(2))) float;
+            f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    float v0 = acc[m][n][r] + bias, v1 = acc[m][n][r + 1] + bias;
+                    if (fused) {
+                        const float t0 = pulpo::as_stored<T>(v0) * fsc + fsh, t1 = pulpo::as_stored<T>(v1) * fsc + fsh;
+                        v0 = t0 > 0.f ? t0 : t0 * a.slope;
+                        v1 = t1 > 0.f ? t1 : t1 * a.slope;
+                    }
+                    const uint32_t h = pulpo::pack_bf2(v0, v1);                    // (x, x + 1) of this lane's channel, rounded
+                    const f32x2 rr = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+                    s2 += rr;
+                    q2 = __builtin_elementwise_fma(rr, rr, q2);
+                    const uint32_t nbh = (uint32_t)__builtin_amdgcn_mov_dpp((int)h, 0xB1, 0xF, 0xF, true);         // quad_perm [1, 0, 3, 2]
+                    xw[((r & 3) + 8 * (r >> 2)) * 16] = __builtin_amdgcn_perm(nbh, h, psel);
+                }
+                const uint4 p0 = xr[0], p1 = xr[64];
+                if (!(PULPO_PW_ABL & 1) || p0.x == 0x12345678u) {
+                    const unsigned soff = (unsigned)(m * 4) * row_b + (unsigned)n * 64u;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, p0), ors, (int)st_off, (int)soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, p1), ors, (int)st_off, (int)(soff + 2 * row_b), 0);
+                }
+                if (n == 0 && m == 0) PW_STAMP(tile_no, 11);
+            }
+            const float s = s2.x + s2.y, q = q2.x + q2.y;
+            ssum[n] = s + __shfl_xor(s, 32, 64);
+            ssq[n] = q + __shfl_xor(q, 32, 64);
+        }
+        PW_STAMP(tile_no, 5);
+        // the waves' partial sums go to LDS; they are added and written behind the NEXT barrier every wave passes anyway (the next tile's
+        // "halo in place", or the one after the loop) - no barrier of their own
+        if (a.stats != nullptr && lane < 32) {
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                red[(wave * 2 + 0) * NT + n * 32 + i] = ssum[n];
+                red[(wave * 2 + 1) * NT + n * 32 + i] = ssq[n];
+            }
+        }
+        pend_tile = cur.tile_lin; pend_co0 = cur.co0;
+        PW_STAMP(tile_no, 6);
+        ++tile_no;
+        if (!has_next) break;
+        work = next_work;
+        cur = nxt;
+    }
+    __syncthreads();
+    flush_stats();
+}
+
 // w: PyTorch layout [Cout][Cin][27] fp32 -> bf16 wp[k/32][tap][n (NPad)][k%32]
 //   forward: K = Cin, N = Cout, value w[n][k][tap];  dgrad: K = Cout, N = Cin, value w[k][n][26 - tap]
 __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp, int Cin, int Cout, int NPad, int dgrad, long total) {
@@ -551,6 +895,30 @@ int launch_bf16(const ConvArgsH& a, int nblk, hipStream_t st) {
     return pulpo::check_launch("conv3d_k3_mfma_bf16");
 }
 
+template <int NN, int TPB>
+int launch_bf16_pw(const ConvArgsH& a, long nwork, hipStream_t st) {
+    constexpr size_t lds = pw_lds_bytes<NN, TPB>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma_bf16_pw<NN, TPB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(conv3d bf16 pw): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int nwg = (int)std::min<long>(nwork, 512);    // persistent workgroups: two per CU
+    hipLaunchKernelGGL((conv3d_k3_mfma_bf16_pw<NN, TPB>), dim3(nwg), dim3(256), lds, st, a);
+    return pulpo::check_launch("conv3d_k3_mfma_bf16_pw");
+}
+
+// PULPO_CONV_BF16_PW (A/B switch): 0 = never, 1 = the 32-cout tiles only, 2 (default) = the 64-cout tiles as well.
+// Measured on one MI355X (scripts/pw_ab.sh), modes 0 / 1 / 2: config 4 step 61.7 / 65.4 / 67.3 pairs/s, config 5 step 38.1 / 40.4 / 41.6,
+// config 4 inference 190 / 211 / 222.
+int bf16_pw_mode() {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("PULPO_CONV_BF16_PW"); mode = e ? atoi(e) : 2; }
+    return mode;
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -606,6 +974,12 @@ static int conv_fwd_bf16_impl(const void* in, int64_t in_bs, int64_t in_ps, int6
                           "conv3d_k3_fwd_bf16: bf16 channels-last output must be 4-byte aligned with even strides");
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    // the persistent kernel: bf16-stored activations in 16-byte pieces, whole 32-channel chunks, whole 4 x 8 x 8 tiles, whole cout tiles
+    const bool pw_ok = dt == 1 && vec && tz == 4 && a.ksplit == 1 && K % CH == 0 && N % NT == 0 && D % 4 == 0 && H % TY == 0 && W % TX == 0 &&
+                       (long)D * H * W * in_ps * 2 < (1L << 31) && out_cs == 1 && (long)D * H * W * out_ps * 2 < (1L << 31) &&
+                       out_ps % 8 == 0 && out_bs % 8 == 0 && (((uintptr_t)out & 15) == 0) &&
+                       bf16_pw_mode() >= (NT == 64 ? 2 : 1);
+    if (pw_ok) return NT == 64 ? launch_bf16_pw<2, 3>(a, nblk_l, st) : launch_bf16_pw<1, 9>(a, nblk_l, st);
 #define PULPO_BF16(NTV, VECV, TT) (tz == 4 ? launch_bf16<NTV, VECV, 4, TT>(a, nblk, st) : launch_bf16<NTV, VECV, 2, TT>(a, nblk, st))
 #define PULPO_BF16_T(TT)                                                                          \
     do {                                                                                          \

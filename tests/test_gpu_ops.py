@@ -961,7 +961,9 @@ def _bf(t):
     return t.bfloat16().float()
 
 
-@pytest.mark.parametrize("Cin,Cout,size,pool", [(32, 32, (16, 16, 16), False), (16, 96, (8, 16, 16), True), (3, 32, (12, 8, 16), False), (40, 24, (9, 7, 10), True)])
+@pytest.mark.parametrize("Cin,Cout,size,pool", [(32, 32, (16, 16, 16), False), (16, 96, (8, 16, 16), True), (3, 32, (12, 8, 16), False), (40, 24, (9, 7, 10), True),
+                                                # from 64^3 up with whole 32-channel chunks: the persistent kernel (one chunk; two / three chunks and three cout tiles)
+                                                (32, 32, (64, 72, 64), False), (64, 96, (64, 64, 64), True)])
 def test_bf16_storage_conv_unit_vs_definition(ops, Cin, Cout, size, pool):
     """One ConvUnit with bf16 ACTIVATION STORAGE (ops.ACT_BF16, BASELINE configs 4-5) against the oracle's definition (O.ACT_PRECISION:
     conv operands bf16, y / z and their gradients rounded to bf16 where they are stored, fp32 arithmetic, statistics of y as stored):
@@ -1062,7 +1064,7 @@ def test_bf16_storage_elementwise_kernels_round_the_fp32_result(ops):
         close(a, b, atol=1e-5, rtol=1e-5)                        # (planar fp32 gradients of bf16-representable upstream values)
 
 
-@pytest.mark.parametrize("Cin,Cout,size", [(32, 64, (8, 16, 16)), (3, 32, (9, 8, 8))])
+@pytest.mark.parametrize("Cin,Cout,size", [(32, 64, (8, 16, 16)), (3, 32, (9, 8, 8)), (32, 32, (64, 64, 72)), (64, 64, (64, 64, 64))])
 def test_bf16_storage_eval_mode_unit(ops, Cin, Cout, size):
     """eval-mode ConvUnit with bf16 activation storage: one fused kernel when operand and result share the storage type, convolution +
     typed apply pass behind the exact-fp32 kernel of the narrow input layers - both equal the definition (oracle) to a bf16 rounding"""
