@@ -25,6 +25,7 @@ PULPO_API int pulpo_debug_read_stamps_pw(void* dst, size_t bytes) {
 #define PW_STAMP(k, p) do {} while (0)
 #endif
 
+#include <stdlib.h>
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
@@ -35,7 +36,12 @@ using pulpo_conv::TY; using pulpo_conv::TX; using pulpo_conv::HY; using pulpo_co
 using pulpo_conv::npad;
 
 // z extent of this kernel's voxel tile (its own policy: the 4x8x8 tile pays from 64^3 up; pulpo_conv3d_k3_fwd_bf16_stat_tiles follows it)
-inline int conv_tz(int D, int H, int W) { return (D % 4 == 0 && (long)D * H * W >= 64L * 64 * 64) ? 4 : 2; }
+inline long conv_tz4_min_voxels() {
+    static long v = -1;
+    if (v < 0) { const char* e = getenv("PULPO_CONV_BF16_TZ4_MIN"); v = e ? atol(e) : 64L * 64 * 64; }
+    return v;
+}
+inline int conv_tz(int D, int H, int W) { return (D % 4 == 0 && (long)D * H * W >= conv_tz4_min_voxels()) ? 4 : 2; }
 
 constexpr int CH = 32;            // channels per staged chunk = two K=16 MFMA steps
 constexpr int CP = CH + 8;        // LDS row length in bf16 elements

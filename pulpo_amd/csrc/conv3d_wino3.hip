@@ -183,8 +183,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
     int cb = 0;                                         // image being read
     // ---- prologue: chunk 0 of the first tile staged, chunk 1 requested; the first weight rows
     float4 wr[2][2];                                    // ring of two pairs of point rows: pair pp uses wr[pp & 1], which then takes pair pp + 2
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) { wr[pp][0] = load_w(cur.wbase, pp); wr[pp][1] = load_w(cur.wbase, 4 + pp); }
     {
         const __amdgpu_buffer_rsrc_t rs0 = in_rsrc(cur.b);
         halo_offsets(cur);
@@ -194,6 +192,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) load_raw(rs0, CH * 4u, tt);
     }
+    // (the weight rows are requested AFTER the taps, as in the loop: the compiler's vmcnt bookkeeping merges this path with the loop's back
+    //  edge, and with the taps as the youngest loads here every chunk's transform waited for vmcnt(0) - the weight rows of the pair after next)
+    __builtin_amdgcn_sched_barrier(0);                  // (... and the scheduler would hoist them back in front)
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) { wr[pp][0] = load_w(cur.wbase, pp); wr[pp][1] = load_w(cur.wbase, 4 + pp); }
     __syncthreads();
 
     float4 ra[3], rb[3];                                // the operand rows of a PAIR of point steps (pz local 0 / 1 at one px): rows ta / tb of planes U, V, W
