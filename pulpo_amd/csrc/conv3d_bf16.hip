@@ -794,7 +794,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* p, int hi_off) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int NTW, bool VEC, typename T = float, bool TR = false>
+// PF (bf16-stored operands in 16-byte pieces, tensors below 2 GB): the NEXT tile's halo and dy pieces travel to registers (buffer loads; pieces
+// outside the volume or beyond the channel count read zeros from beyond num_records) while this tile is multiplied, so that only their LDS
+// stores and two barriers stand between the matrix loops of consecutive tiles - with one resident workgroup per CU nothing else hides a
+// staging phase.
+template <int NTW, bool VEC, typename T = float, bool TR = false, bool PF = false>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16(WgradArgsH a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_h[];
     uint16_t* xs = smem_h;                     // [WHV][CP]
@@ -836,7 +840,76 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16(WgradArgsH a) {
     const int ntile = a.B * a.ntz * a.nty * a.ntx;
     const int per = (ntile + a.nsplit - 1) / a.nsplit;
     const int t_begin = split * per, t_end = min(ntile, t_begin + per);
+
+    // ---- (PF) this thread's pieces: halo piece j = (halo voxel j / 4, 8-channel slot j % 4), dy piece likewise over the tile's voxels
+    constexpr int NHP = (WHV * 4 + 255) / 256, NDP = (WMV * 4) / 256;
+    constexpr unsigned OOB = 0x80000000u;
+    [[maybe_unused]] uint4 hr[NHP], dr[NDP];
+    [[maybe_unused]] unsigned hrel[NHP], hbit[NHP], drel[NDP];
+    [[maybe_unused]] const unsigned ips_b = (unsigned)a.in_ps * 2u, dps_b = (unsigned)a.dy_ps * 2u;
+    if constexpr (PF) {
+#pragma unroll
+        for (int u = 0; u < NHP; ++u) {
+            const int j = tid + u * 256;
+            const int hv = j >> 2, q = j & 3;
+            const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+            hrel[u] = (unsigned)((hz * a.H + hy) * a.W + hx) * ips_b + (unsigned)(ci0 + 8 * q) * 2u;
+            hbit[u] = (j < WHV * 4 && ci0 + 8 * q < a.Cin) ? (1u << hz) | (1u << (4 + hy)) | (1u << (14 + hx)) : 0x80000000u;
+        }
+#pragma unroll
+        for (int u = 0; u < NDP; ++u) {
+            const int j = tid + u * 256;
+            const int v = j >> 2, q = j & 3;
+            drel[u] = co0 + 8 * q < a.Cout ? (unsigned)(((v >> 6) * a.H + ((v >> 3) & 7)) * a.W + (v & 7)) * dps_b + (unsigned)(co0 + 8 * q) * 2u : OOB;
+        }
+    }
+    auto load_tile = [&](int tl) {
+        int t = tl;
+        const int tx_ = t % a.ntx; t /= a.ntx;
+        const int ty_ = t % a.nty; t /= a.nty;
+        const int tz_ = t % a.ntz;
+        const int b = t / a.ntz;
+        const int z0 = tz_ * WTZ, y0 = ty_ * TY, x0 = tx_ * TX;
+        const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T*>(reinterpret_cast<const T*>(a.in) + (long)b * a.in_bs), 0, (int)((long)a.D * a.H * a.W * a.in_ps * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T*>(reinterpret_cast<const T*>(a.dy) + (long)b * a.dy_bs), 0, (int)((long)a.D * a.H * a.W * a.dy_ps * 2), 0x00020000);
+        auto run = [](int first, int extent, int n) {   // bits h in [0, n) with 0 <= first + h < extent
+            const int lo = first < 0 ? -first : 0, hi = extent - first < n ? extent - first : n;
+            return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+        };
+        const unsigned mask = run(z0 - 1, a.D, WTZ + 2) | (run(y0 - 1, a.H, HY) << 4) | (run(x0 - 1, a.W, HX) << 14);
+        const unsigned origin = (unsigned)(((z0 - 1) * a.H + (y0 - 1)) * a.W + (x0 - 1)) * ips_b;            // modulo 2^32
+#pragma unroll
+        for (int u = 0; u < NHP; ++u)
+            hr[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(irs, (int)((mask & hbit[u]) == hbit[u] ? origin + hrel[u] : OOB), 0, 0));
+        // dy: the tile itself (whole in x and y by the host's condition; ragged only in z, where the rows lie beyond num_records)
+        const unsigned dorigin = (unsigned)((z0 * a.H + y0) * a.W + x0) * dps_b;
+#pragma unroll
+        for (int u = 0; u < NDP; ++u)
+            dr[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(drs, (int)(drel[u] == OOB ? OOB : dorigin + drel[u]), 0, 0));
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NHP; ++u) {
+            const int j = tid + u * 256;
+            if (u + 1 < NHP || j < WHV * 4) *reinterpret_cast<uint4*>(xs + (j >> 2) * CP + 8 * (j & 3)) = hr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NDP; ++u) {
+            const int j = tid + u * 256;
+            *reinterpret_cast<uint4*>(dys + (j >> 2) * CP + 8 * (j & 3)) = dr[u];
+        }
+    };
+    if constexpr (PF) { if (t_begin < t_end) load_tile(t_begin); }
+
     for (int tl = t_begin; tl < t_end; ++tl) {
+        if constexpr (PF) {
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+            load_tile(min(tl + 1, t_end - 1));          // (after the last tile: its own pieces again, into registers nobody stores)
+        } else {
         int t = tl;
         const int tx_ = t % a.ntx; t /= a.ntx;
         const int ty_ = t % a.nty; t /= a.nty;
@@ -847,6 +920,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16(WgradArgsH a) {
         stage_tile_bf16<VEC, WHV, true, T>(xs, reinterpret_cast<const T*>(a.in) + (long)b * a.in_bs, a.in_ps, a.in_cs, ci0, a.Cin, z0, y0, x0, a.D, a.H, a.W, tid);
         stage_tile_bf16<VEC, WMV, false, T>(dys, reinterpret_cast<const T*>(a.dy) + (long)b * a.dy_bs, a.dy_ps, a.dy_cs, co0, a.Cout, z0, y0, x0, a.D, a.H, a.W, tid);
         __syncthreads();
+        }
 #pragma unroll
         for (int ks = 0; ks < WMV / 16; ++ks) {
             const int vrow = 2 * ks + kk;                                   // x-row of the tile: z = vrow >> 3, y = vrow & 7
@@ -1073,8 +1147,16 @@ PULPO_API int pulpo_conv3d_k3_wgrad_bf16_t(const void* in, int64_t in_bs, int64_
     static int tr_on = -1;
     if (tr_on < 0) { const char* e = getenv("PULPO_WGRAD_BF16_TR"); tr_on = e ? atoi(e) : 1; }
     const bool tr = tr_on && Cin % 16 == 0;
+    // register-prefetched staging (PULPO_WGRAD_BF16_PF=0: the staged form, A/B switch): bf16 tensors in 16-byte pieces below 2 GB, tiles whole in x / y
+    static int pf_on = -1;
+    if (pf_on < 0) { const char* e = getenv("PULPO_WGRAD_BF16_PF"); pf_on = e ? atoi(e) : 1; }
+    const bool pf = pf_on && tr && dt == 1 && vec && H % TY == 0 && W % TX == 0 && (long)D * H * W * in_ps * 2 < (1L << 31) &&
+                    (long)D * H * W * dy_ps * 2 < (1L << 31);
 #define PULPO_WGRAD_H(NTWV, VECV, TT)                                                                                             \
     do {                                                                                                                            \
+        if constexpr (VECV && sizeof(TT) == 2) {                                                                                    \
+            if (pf) { hipLaunchKernelGGL((conv3d_k3_wgrad_bf16<NTWV, VECV, TT, true, true>), dim3(nblk), dim3(256), lds, st, a); break; } \
+        }                                                                                                                           \
         if (tr) hipLaunchKernelGGL((conv3d_k3_wgrad_bf16<NTWV, VECV, TT, true>), dim3(nblk), dim3(256), lds, st, a);                \
         else hipLaunchKernelGGL((conv3d_k3_wgrad_bf16<NTWV, VECV, TT, false>), dim3(nblk), dim3(256), lds, st, a);                  \
     } while (0)
