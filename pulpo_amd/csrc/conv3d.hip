@@ -251,6 +251,184 @@ __global__ __launch_bounds__(256, TZv == 4 ? 3 : 2) void conv3d_k3_mfma(ConvArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the 2- / 3-channel input layers, persistent
+// conv3d_k3_mfma<2 | 4, 32> above spends a tile's time around its matrix instructions (2 -> 32 at 160^3: 54 MFMAs per wave and tile = 90 us of
+// matrix time, 524 MB of output = 70 us of HBM, 258 us measured): one tile per workgroup, the halo's gather, the 27 weight slabs and 32 dword
+// stores per lane all exposed.  This variant (whole 4 x 8 x 8 tiles, a multiple of 32 output channels, channels-last fp32 output) keeps
+//   * the weights in REGISTERS for the workgroup's lifetime (a lane's B operand of tap t, k-step s is one float: 27 * CH / 2 registers),
+//   * persistent workgroups whose next halo (600 voxels x CH floats: 5 - 10 dword buffer loads per thread, zeros from beyond num_records
+//     outside the volume) travels to registers during the matrix loop and into the OTHER of two LDS images right behind the tile's barrier:
+//     one barrier per tile,
+//   * an epilogue that passes each wave's 64 x 32 slab through a wave-private LDS image and stores 16 bytes per lane (eight
+//     buffer_store_dwordx4 of 8 voxels x 128 bytes per wave instead of 32 dword stores); statistics' partial sums are added behind the next
+//     tile's barrier.
+template <int CH>
+constexpr size_t smallk_pw_lds_bytes() { return (size_t)(2 * (((TZ + 4) * HY * HX * (CH + 1) + 3) & ~3) + 4 * 64 * 32 + 4 * 2 * 32) * sizeof(float); }
+
+template <int CH>
+__global__ __launch_bounds__(256, CH == 2 ? 3 : 2) void conv3d_k3_smallk_pw(ConvArgs a) {
+    constexpr int CP = CH + 1, KS = CH / 2, MT = 2, NT = 32;
+    constexpr int PHV = 6 * HY * HX;                    // halo voxels of a 4 x 8 x 8 tile
+    constexpr int XS = (PHV * CP + 3) & ~3;
+    constexpr int NHP = (PHV * CH + 255) / 256;         // halo floats per thread
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                                   // [2][PHV][CP]
+    float* xch_all = smem + 2 * XS;                     // [4 waves][64 voxels][32 channels]: the epilogue's exchange images
+    float* red = xch_all + 4 * 64 * 32;                 // [4 waves][2][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int nwork = a.B * a.ntz * a.nty * a.ntx * a.ncot, nwg = gridDim.x;
+
+    struct Tile { int tile_lin, b, z0, y0, x0, co0; };
+    auto describe = [&](int work) {
+        Tile t;
+        const int cot = work % a.ncot;
+        t.tile_lin = work / a.ncot;
+        int q = t.tile_lin;
+        const int tx_ = q % a.ntx; q /= a.ntx;
+        const int ty_ = q % a.nty; q /= a.nty;
+        const int tz_ = q % a.ntz;
+        t.b = q / a.ntz;
+        t.z0 = tz_ * 4; t.y0 = ty_ * TY; t.x0 = tx_ * TX;
+        t.co0 = cot * NT;
+        return t;
+    };
+
+    // ---- this thread's halo floats: j = channel * PHV + halo voxel (voxel fastest: planar operands are read in runs along x)
+    const int in_bytes = (int)((((long)a.Cin - 1) * a.in_cs + ((long)a.D * a.H * a.W - 1) * a.in_ps + 1) * 4);
+    unsigned hrel[NHP], hbit[NHP];
+    int hlds[NHP];
+#pragma unroll
+    for (int u = 0; u < NHP; ++u) {
+        const int j = tid + u * 256;
+        const int c = j / PHV, hv = j - c * PHV;
+        const int hz = hv / (HY * HX), rem = hv - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+        hrel[u] = (unsigned)(((long)((hz * a.H + hy) * a.W + hx) * a.in_ps + (long)c * a.in_cs) * 4);
+        hbit[u] = (j < PHV * CH && c < a.Cin) ? (1u << hz) | (1u << (6 + hy)) | (1u << (16 + hx)) : 0x80000000u;
+        hlds[u] = hv * CP + c;
+    }
+    float hreg[NHP];
+    auto load_halo = [&](const Tile& t) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + (long)t.b * a.in_bs), 0, in_bytes, 0x00020000);
+        auto run = [](int first, int extent, int n) {   // bits h in [0, n) with 0 <= first + h < extent
+            const int lo = first < 0 ? -first : 0, hi = extent - first < n ? extent - first : n;
+            return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+        };
+        const unsigned mask = run(t.z0 - 1, a.D, 6) | (run(t.y0 - 1, a.H, HY) << 6) | (run(t.x0 - 1, a.W, HX) << 16);
+        const unsigned origin = (unsigned)((long)(((t.z0 - 1) * a.H + (t.y0 - 1)) * a.W + (t.x0 - 1)) * a.in_ps * 4);      // modulo 2^32
+#pragma unroll
+        for (int u = 0; u < NHP; ++u)
+            hreg[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)((mask & hbit[u]) == hbit[u] ? origin + hrel[u] : OOB), 0, 0));
+    };
+    auto store_halo = [&](float* img) {
+#pragma unroll
+        for (int u = 0; u < NHP; ++u)
+            if (u + 1 < NHP || tid + u * 256 < PHV * CH) img[hlds[u]] = hreg[u];
+    };
+
+    int xa[MT];                                         // this lane's A operand of slab m at tap (0, 0, 0), k-step 0: floats into an image
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int v = (wave * MT + m) * 32 + i;
+        xa[m] = (((v >> 6) * HY + ((v >> 3) & 7)) * HX + (v & 7)) * CP + kk;
+    }
+
+    int work = pulpo::xcd_remap(blockIdx.x, nwg);
+    Tile cur = describe(work);
+    float wreg[27][KS];
+    int wco0 = -1;
+    load_halo(cur);
+    store_halo(xs);
+    int buf = 0;
+    int pend_tile = -1, pend_co0 = 0;
+    auto flush_stats = [&]() {
+        if (a.stats != nullptr && pend_tile >= 0 && tid < 2 * NT) {
+            const int which = tid / NT, c = tid - which * NT;
+            const float tot = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] + red[(2 * 2 + which) * NT + c] + red[(3 * 2 + which) * NT + c];
+            a.stats[((long)pend_tile * 2 + which) * a.Cout + pend_co0 + c] = tot;
+        }
+    };
+    float* xch = xch_all + wave * (64 * 32);
+
+    for (;;) {
+        const int next_work = work + nwg;
+        const bool has_next = next_work < nwork;
+        const Tile nxt = has_next ? describe(next_work) : cur;
+        if (cur.co0 != wco0) {                          // (uniform; once per workgroup unless the layer has several cout tiles)
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) wreg[tap][s] = a.wp[(long)(tap * CH + 2 * s + kk) * a.NPad + cur.co0 + i];
+            wco0 = cur.co0;
+        }
+        const int co = cur.co0 + i;
+        const float bias = a.bias != nullptr ? a.bias[co] : 0.f;
+        const bool fused = a.coef != nullptr;
+        const float fsc = fused ? a.coef[2 * a.Cout + co] : 1.f, fsh = fused ? a.coef[3 * a.Cout + co] : 0.f;
+
+        __syncthreads();                                // this tile's image is in place; every wave has left the other one
+        flush_stats(); pend_tile = -1;
+        load_halo(nxt);                                 // (after the last tile: its own halo again, into an image nobody reads)
+        const float* img = xs + buf * XS;
+
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int off = tap_halo_offset(tap) * CP;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(img[xa[m] + off + 2 * s], wreg[tap][s], acc[m], 0, 0, 0);
+        }
+        store_halo(xs + (buf ^ 1) * XS);                // (the other image was last read before this tile's barrier)
+
+        // ---- epilogue.  Accumulator row r of slab m = voxel (x = (r & 3) + 4 kk, y = 4 m + (r >> 2)) of the wave's z plane, at channel i.
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)cur.b * a.out_bs, 0, (int)((long)a.D * a.H * a.W * a.out_ps * 4), 0x00020000);
+        const unsigned ops_b = (unsigned)a.out_ps * 4u, row_b = (unsigned)a.W * ops_b;
+        const unsigned obase = (unsigned)(((cur.z0 + wave) * a.H + cur.y0) * a.W + cur.x0) * ops_b + (unsigned)cur.co0 * 4u;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float val = acc[m][r] + bias;
+                if (fused) {
+                    const float t = val * fsc + fsh;
+                    val = t > 0.f ? t : t * a.slope;
+                }
+                s += val;
+                q += val * val;
+                xch[(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + i] = val;
+            }
+        }
+        // 16-byte pieces: piece p = lane + 64 t covers voxel row p / 8 of the slab pair (y = row / 8, x = row % 8), channels 4 (p % 8) ..
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(xch + (lane + 64 * t) * 4);
+            const unsigned voff = obase + (unsigned)(lane >> 3) * ops_b + (unsigned)(lane & 7) * 16u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ors, (int)voff, (int)((unsigned)t * row_b), 0);
+        }
+        if (a.stats != nullptr) {
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (lane < 32) { red[(wave * 2 + 0) * NT + i] = s; red[(wave * 2 + 1) * NT + i] = q; }
+            pend_tile = cur.tile_lin; pend_co0 = cur.co0;
+        }
+        buf ^= 1;
+        if (!has_next) break;
+        work = next_work;
+        cur = nxt;
+    }
+    __syncthreads();
+    flush_stats();
+}
+
 // split-K finish: out = sum_s part[s] in fixed order (deterministic), plus the per-row (sum, sum of squares) BatchNorm partials.
 // Row r of stats covers voxels [r*V/nrow, (r+1)*V/nrow): any partition is fine for the double-precision finalize.
 template <typename TO = float>
@@ -393,6 +571,20 @@ int launch_conv(const ConvArgs& a, int nblk, hipStream_t st, int tz) {
 
 // z extent of the forward voxel tile: 4 (the Winograd kernel's tile; in the direct kernel each wave = two 32-voxel MFMA row tiles)
 // when the volume's depth divides evenly and there are enough tiles (measured: the (y, x) Winograd kernel pays from 20^3 up)
+template <int CH>
+int launch_smallk_pw(const ConvArgs& a, long nwork, hipStream_t st) {
+    constexpr size_t lds = smallk_pw_lds_bytes<CH>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_smallk_pw<CH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(conv3d smallk pw): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int nwg = (int)std::min<long>(nwork, CH == 2 ? 768 : 512);       // persistent workgroups: three (two) per CU
+    hipLaunchKernelGGL((conv3d_k3_smallk_pw<CH>), dim3(nwg), dim3(256), lds, st, a);
+    return pulpo::check_launch("conv3d_k3_smallk_pw");
+}
+
 int pulpo_conv::conv_tz(int D, int H, int W) {
     return (D % 4 == 0 && (long)D * H * W >= 20L * 20 * 20) ? 4 : 2;
 }
@@ -484,6 +676,16 @@ static int conv_fwd_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t 
     const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (K % 4 == 0) && (((uintptr_t)in & 15) == 0) && CH >= 16;
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    // the persistent kernel of the 2- / 3-channel input layers (PULPO_CONV_SMALLK_PW=0: the one-tile-per-workgroup kernel, A/B switch)
+    static int spw = -1;
+    if (spw < 0) { const char* e = getenv("PULPO_CONV_SMALLK_PW"); spw = e ? atoi(e) : 1; }
+    const long in_span = (((long)K - 1) * in_cs + ((long)D * H * W - 1) * in_ps + 1) * 4;
+    if (spw && CH <= 4 && tz == 4 && N % 32 == 0 && D % 4 == 0 && H % TY == 0 && W % TX == 0 && out_cs == 1 && out_ps % 4 == 0 && out_bs % 4 == 0 &&
+        (((uintptr_t)out & 15) == 0) && in_span > 0 && in_span < (1L << 31) && in_cs >= 0 && in_ps >= 0 && (long)D * H * W * out_ps * 4 < (1L << 31)) {
+        a.ncot = N / 32;
+        const long nwork = (long)B * a.ntz * a.nty * a.ntx * a.ncot;
+        return CH == 2 ? launch_smallk_pw<2>(a, nwork, st) : launch_smallk_pw<4>(a, nwork, st);
+    }
     if (CH == 2) rc = NT == 64 ? launch_conv<2, 64, false>(a, nblk, st, tz) : launch_conv<2, 32, false>(a, nblk, st, tz);
     else if (CH == 4) rc = NT == 64 ? launch_conv<4, 64, false>(a, nblk, st, tz) : launch_conv<4, 32, false>(a, nblk, st, tz);
     else if (vec) rc = NT == 64 ? launch_conv<16, 64, true>(a, nblk, st, tz) : launch_conv<16, 32, true>(a, nblk, st, tz);

@@ -302,6 +302,10 @@ CONV_CASES = [
     (1, 20, 12, (7, 6, 5), True),       # odd channel counts (generic path)
     (1, 192, 192, (3, 5, 4), True),
     (1, 32, 3, (6, 7, 8), True),
+    # whole 4x8x8 tiles from 64^3 up with <= 4 input channels: the persistent kernel of the input layers (planar and channels-last operands, two / three cout tiles)
+    (1, 2, 32, (64, 64, 64), False),
+    (2, 3, 64, (64, 72, 64), False),
+    (1, 4, 96, (64, 64, 72), True),
 ]
 
 
@@ -327,6 +331,46 @@ def test_conv3d_vs_oracle(ops, B, Cin, Cout, size, cl):
     assert rel_l2(gx, gref[0]) < 2e-6
     assert rel_l2(gw, gref[1]) < 1e-5
     assert rel_l2(gb, gref[2]) < 1e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,size", [(2, 32, (64, 64, 64)), (3, 64, (64, 72, 64))])
+def test_narrow_input_unit_training_pass_vs_oracle(ops, Cin, Cout, size):
+    """a training-mode ConvUnit on a 2- / 3-channel image at a size the persistent input-layer kernel takes (whole 4x8x8 tiles from 64^3 up):
+    output, running statistics (the kernel's per-tile partial sums, flushed a tile late) and parameter gradients against the oracle in double"""
+    import src.network_blocks as nb
+    gen = torch.Generator().manual_seed(7 * Cin + Cout)
+    torch.manual_seed(11)
+    unit = nb.ConvUnit(list(size), Cin, Cout)
+    with torch.no_grad():
+        unit._op[1].weight.copy_(torch.rand(Cout, generator=gen) * 0.5 + 0.75)
+        unit._op[1].bias.copy_(torch.randn(Cout, generator=gen) * 0.1)
+    sd = {"u." + k: v.detach().clone() for k, v in unit.state_dict().items()}
+    x = torch.randn(2, Cin, *size, generator=gen)
+    up = torch.randn(2, Cout, *size, generator=gen)
+    unit = unit.cuda().train()
+    names = ["u._op.0.weight", "u._op.0.bias", "u._op.1.weight", "u._op.1.bias"]
+
+    def oracle(dtype):
+        sdr = {k: (v.to(dtype).requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.to(dtype) if v.is_floating_point() else v.clone()))
+               for k, v in sd.items()}
+        zr = O.conv_unit(x.to(dtype), sdr, "u", training=True)
+        return zr, torch.autograd.grad((zr * up.to(dtype)).sum(), [sdr[n] for n in names]), sdr
+
+    zr, gr, sdr = oracle(torch.float64)
+    z32, g32, _ = oracle(torch.float32)
+    z = unit(x.cuda())
+    g = torch.autograd.grad((z * up.cuda()).sum(), [unit._op[0].weight, unit._op[0].bias, unit._op[1].weight, unit._op[1].bias])
+    assert rel_l2(z, zr) < 3e-6
+    close(unit._op[1].running_mean, sdr["u._op.1.running_mean"].float(), atol=1e-6, rtol=1e-5)
+    close(unit._op[1].running_var, sdr["u._op.1.running_var"].float(), atol=1e-6, rtol=1e-5)
+    # gradients behind a training-mode BatchNorm cancel heavily (the conv's weight / bias gradients are sums of a zero-mean tensor): the bound is
+    # the fp32 oracle's own distance from the double evaluation
+    for got, want, o32, nme in zip(g, gr, g32, names):
+        if nme.endswith("0.bias"):
+            assert float(got.abs().max()) <= 1e-3 * float(g[2].abs().max()), nme      # (exactly zero in exact arithmetic)
+            continue
+        bound = 3.0 * rel_l2(o32, want) + 1e-5
+        assert rel_l2(got, want) <= bound, (nme, rel_l2(got, want), bound)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,size", [(1, 2, 32, (9, 11, 13)), (2, 3, 32, (20, 17, 33)), (1, 4, 48, (8, 24, 16)), (1, 1, 36, (13, 8, 9))])
@@ -375,7 +419,7 @@ def test_conv3d_bf16_operands_vs_oracle(ops, B, Cin, Cout, size, cl):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("Cin,Cout,size", [(32, 64, (8, 16, 16)), (192, 192, (5, 6, 4)), (3, 32, (9, 8, 8)), (16, 12, (7, 6, 5))])
+@pytest.mark.parametrize("Cin,Cout,size", [(32, 64, (8, 16, 16)), (192, 192, (5, 6, 4)), (3, 32, (9, 8, 8)), (16, 12, (7, 6, 5)), (2, 32, (64, 64, 64))])
 def test_eval_mode_fused_epilogue_equals_separate_passes(ops, precision, Cin, Cout, size):
     """inference runs conv + folded BatchNorm + LeakyReLU as one kernel (also through the split-K reduce of small volumes);
     with a gradient requested the pre-norm tensor is kept and the normalisation is a separate pass: same bits either way,
