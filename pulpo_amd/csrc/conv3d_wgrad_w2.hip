@@ -29,6 +29,7 @@
 #define PULPO_ABLX 0         // diagnostic builds of the eight-wave kernel (bit mask): 1 no barrier per plane step, 2 no staging writes, 4 no global loads,
 #endif                       // 8 no flush, 16 no operand combinations
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -599,6 +600,311 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2x(Wgrad2Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ F(2x2x2,3x3x3): Winograd along z as well
+// The eight-wave kernel with the z axis transformed too (round 4): output planes are taken in PAIRS (2 J, 2 J + 1), and with
+//     Vz = B^T over the input planes 2 J - 1 .. 2 J + 2,   Ez = (d0, d0 + d1, d0 - d1, -d1) over the pair's gradient planes
+// (the same B^T / A patterns the x axis uses at staging time), M[pz][py][px] = sum over 2x2x2 blocks of V^T E takes 64 matrix products per
+// block of eight outputs instead of 3 x 16 x 2 = 96 (and 216 in the direct form); dw = G^T M G along all three axes in the flush.
+// A pair step runs as TWO half steps h = 2 J, 2 J + 1, each reading the input planes h - 1, h, h + 1 - exactly the planes the (y, x) kernel's
+// plane step h reads, so ring, staging cadence (one input and one gradient plane staged per half step) and barrier count per plane are its own:
+//     h even:  acc[pz 0] += (P- - P+) x d0         acc[pz 1] += (P0 + P+) x (d0 + d1)
+//     h odd :  acc[pz 2] += (P0 - P-) x (d0 - d1)   acc[pz 3] += (P- - P+) x (-d1)              (P-, P0, P+ = planes h - 1, h, h + 1)
+// - 32 MFMAs per wave and plane instead of 48.  The z combinations are formed in registers behind the y combinations (ten ds_read_b128 per group
+// of eight MFMAs); both gradient planes of the pair stay resident, so the gradient ring has four slots: 90 + 72 KB = the CU's 160 KB exactly.
+// Accumulators: 2 px x 4 pz = eight tiles per wave.  Needs an even depth.
+constexpr int W3G_EX = 4 * 4 * W2G_ESLOT;                          // [px][4 slots][32 co][36]
+constexpr size_t W3G_LDS = (size_t)(W2G_VX + W3G_EX) * sizeof(float);     // 163,840 bytes
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* VX = smem;
+    float* EX = smem + W2G_VX;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kk = lane >> 5;
+    const int py = wave & 3, pxh = wave >> 2;             // this wave's points: (py, px = 2 pxh, 2 pxh + 1)
+    const int lid = pulpo::xcd_remap(blockIdx.x, gridDim.x);
+    const int npair = a.ncit * a.ncot;
+    const int pair = lid % npair, split = lid / npair;
+    const int cit = pair / a.ncot, cot = pair - cit * a.ncot;
+    const int ci0 = cit * 32, co0 = cot * 32;
+
+    // y combinations: V row = X[2 yb + ta] + sa * X[2 yb + tb];   E row = c0 * dY[2 yb] + c1 * dY[2 yb + 1]
+    const int ta = py == 0 ? 0 : py == 2 ? 2 : 1;
+    const int tb = py == 2 ? 1 : py == 3 ? 3 : 2;
+    const float sa = py == 1 ? 1.f : -1.f;
+    const float c0 = py == 3 ? 0.f : 1.f;
+    const float c1 = py == 0 ? 0.f : py == 1 ? 1.f : -1.f;
+
+    // ---- work: plane-PAIR steps [p_begin, p_end) of the linearised (column, z / 2) space of this pair's split
+    const int ncol = a.B * a.nty * a.ntx;
+    const int DP = a.D >> 1;
+    const long nstep = (long)ncol * DP;
+    const long p_begin = nstep * split / a.nsplit, p_end = nstep * (split + 1) / a.nsplit;
+
+    // ---- staging items of this thread (column-invariant geometry)
+    // X plane: items (hy 0..9, channel quad q 0..7, xb 0..3) = 320 of 512 threads; four x taps (gx = x0 - 1 + 2 xb + t) of four channels
+    const bool x_item = tid < 320;
+    const int x_q = tid & 7, x_xb = (tid >> 3) & 3, x_hy = tid >> 5;
+    // dY plane: items (y 0..7, channel quad q, xb) = 256 threads (the upper half: threads 256..511, so that the two kinds of item are spread)
+    const bool e_item = tid >= 256;
+    const int e_t = tid - 256;
+    const int e_q = e_t & 7, e_xb = (e_t >> 3) & 3, e_y = (e_t >> 5) & 7;
+    const bool x_cok = ci0 + 4 * x_q < a.Cin, e_cok = co0 + 4 * e_q < a.Cout;
+    float* const x_dst = VX + (4 * x_q) * W2G_VROW + x_hy * 4 + x_xb;          // + (px * 4 + slot) * VSLOT + c * VROW
+    float* const e_dst = EX + (4 * e_q) * W2G_EROW + e_y * 4 + e_xb;           // + (px * 4 + slot) * ESLOT + c * EROW
+
+    // Operand planes are read through buffer descriptors (as in conv3d_wino2p.hip): per column, every thread holds the byte offsets of its
+    // taps in plane 0 of the column's batch element - OOB (beyond num_records: the load returns zeros) where the tap lies outside the volume or
+    // the thread has no item - and a plane step adds the plane's offset as the instruction's scalar offset.  No branch, no zero-initialised
+    // destination, no 64-bit address arithmetic inside the loop.  (host: volume bytes < 2^31)
+    constexpr unsigned OOB = 0x80000000u;
+    const int x_bytes = (int)((long)a.D * a.H * a.W * a.in_ps * 4), e_bytes = (int)((long)a.D * a.H * a.W * a.go_ps * 4);
+    int cb = 0, y0 = 0, x0 = 0;                           // current column
+    unsigned x_off[4], e_off[2];
+    __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t e_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.go), 0, e_bytes, 0x00020000);
+    auto set_column = [&](int col) {
+        int t = col;
+        const int tx_ = t % a.ntx; t /= a.ntx;
+        const int ty_ = t % a.nty;
+        cb = t / a.nty;
+        y0 = ty_ * 8; x0 = tx_ * 8;
+        x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + (long)cb * a.in_bs), 0, x_bytes, 0x00020000);
+        e_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.go + (long)cb * a.go_bs), 0, e_bytes, 0x00020000);
+        const int gy = y0 - 1 + x_hy;
+        const bool xrow = x_item && x_cok && (unsigned)gy < (unsigned)a.H;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const int gx = x0 - 1 + 2 * x_xb + t4;
+            x_off[t4] = (xrow && (unsigned)gx < (unsigned)a.W) ? (unsigned)((gy * a.W + gx) * (int)a.in_ps + ci0 + 4 * x_q) * 4u : OOB;
+        }
+        const int ey = y0 + e_y;
+        const bool erow = e_item && e_cok && ey < a.H;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int gx = x0 + 2 * e_xb + t2;
+            e_off[t2] = (erow && gx < a.W) ? (unsigned)((ey * a.W + gx) * (int)a.go_ps + co0 + 4 * e_q) * 4u : OOB;
+        }
+    };
+    const unsigned x_plane = (unsigned)((long)a.H * a.W * a.in_ps * 4), e_plane = (unsigned)((long)a.H * a.W * a.go_ps * 4);
+
+    float4 xr[4], er[2];                                  // raw registers of the plane being fetched
+    auto issue_x = [&](int zp) {                          // input plane zp (zeros outside the volume)
+        const unsigned zmask = (unsigned)zp < (unsigned)a.D ? 0u : OOB;          // (wave-uniform)
+        const unsigned zo = zmask ? 0u : (unsigned)zp * x_plane;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+            xr[t4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)(x_off[t4] | zmask), (int)zo, 0));
+    };
+    auto issue_e = [&](int zp) {                          // output-gradient plane zp
+        const unsigned zmask = (unsigned)zp < (unsigned)a.D ? 0u : OOB;
+        const unsigned zo = zmask ? 0u : (unsigned)zp * e_plane;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+            er[t2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(e_rs, (int)(e_off[t2] | zmask), (int)zo, 0));
+    };
+    // point px of the x-transformed item -> LDS (transposed: one ds_write_b32 per channel)
+    auto write_x = [&](int px, int slot) {
+        if (x_item) {
+            // (two-wide vector arithmetic: v_pk_add_f32)
+            const float4 pa_ = px == 0 ? xr[0] : px == 2 ? xr[2] : xr[1], pb_ = px == 0 ? xr[2] : px == 1 ? xr[2] : px == 2 ? xr[1] : xr[3];
+            const f32x2 sg = px == 1 ? f32x2{1.f, 1.f} : f32x2{-1.f, -1.f};
+            const f32x2 lo = f32x2{pa_.x, pa_.y} + sg * f32x2{pb_.x, pb_.y}, hi = f32x2{pa_.z, pa_.w} + sg * f32x2{pb_.z, pb_.w};
+            const float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
+            float* o = x_dst + (px * 4 + slot) * W2G_VSLOT;
+            o[0] = v.x; o[W2G_VROW] = v.y; o[2 * W2G_VROW] = v.z; o[3 * W2G_VROW] = v.w;
+        }
+    };
+    auto write_e = [&](int px, int slot) {
+        if (e_item) {
+            const float4 d0 = er[0], d1 = er[1];
+            float4 v;
+            if (px == 0) v = d0;
+            else if (px == 3) v = make_float4(-d1.x, -d1.y, -d1.z, -d1.w);
+            else {
+                const f32x2 sg = px == 1 ? f32x2{1.f, 1.f} : f32x2{-1.f, -1.f};
+                const f32x2 lo = f32x2{d0.x, d0.y} + sg * f32x2{d1.x, d1.y}, hi = f32x2{d0.z, d0.w} + sg * f32x2{d1.z, d1.w};
+                v = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+            float* o = e_dst + (px * 4 + slot) * W2G_ESLOT;
+            o[0] = v.x; o[W2G_EROW] = v.y; o[2 * W2G_EROW] = v.z; o[3 * W2G_EROW] = v.w;
+        }
+    };
+    // every thread "uses" its raw registers unconditionally (see conv3d_wino.hip): the compiler's wait for the loads sits in straight-line code
+    auto touch_raw = [&]() {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) asm volatile("" : : "v"(xr[t4].x), "v"(xr[t4].y), "v"(xr[t4].z), "v"(xr[t4].w));
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) asm volatile("" : : "v"(er[t2].x), "v"(er[t2].y), "v"(er[t2].z), "v"(er[t2].w));
+    };
+
+    f32x16 acc[2][4];                                     // [px of this wave][pz]
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int pz = 0; pz < 4; ++pz)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][pz][r] = 0.f;
+
+    // operand row addresses of this lane (floats): + (px * 4 + slot) * VSLOT + g * 16 for V, + (px * 4 + slot) * ESLOT + g * 16 for E (gradient plane q in slot q & 3)
+    // (block row yb = 2 g + kk: V rows hy = 2 yb + ta / tb, E rows y = 2 yb, 2 yb + 1; four floats per row; input plane p sits in slot (p + 1) & 3)
+    const float* va = VX + i * W2G_VROW + (2 * kk + ta) * 4;
+    const float* vb = VX + i * W2G_VROW + (2 * kk + tb) * 4;
+    const float* ea = EX + i * W2G_EROW + (2 * kk) * 4;
+
+    // ---- main loop: column segments of pair steps [Js, Je) of this split's range, i.e. half steps h = 2 Js .. 2 Je - 1, each segment entered
+    // through three warm-up half steps (stage only).  Half step h: barrier; its 32 MFMAs; the registers (input plane h + 2, gradient plane
+    // h + 2) are transformed and written into the free slots; the loads of planes h + 3 are issued.
+    long p = p_begin;
+    while (p < p_end) {
+        const int pc = (int)(p / DP);
+        const int Js = (int)(p - (long)pc * DP);
+        const int Je = (int)min((long)DP, (long)Js + (p_end - p));
+        set_column(pc);
+        const int hs = 2 * Js;
+        issue_x(hs - 1);
+        issue_e(hs);
+#pragma unroll 1
+        for (int h = hs - 3; h < hs; ++h) {               // warm-up: input planes hs - 1, hs, hs + 1 and gradient planes hs, hs + 1 (the first e write is a dummy)
+            __syncthreads();
+            touch_raw();
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                write_x(gi, (h + 3) & 3);
+                write_e(gi, (h + 2) & 3);
+            }
+            issue_x(h + 3);
+            issue_e(h + 3 < hs ? hs : h + 3);             // (h = hs - 3: plane hs again, h = hs - 2: hs + 1, h = hs - 1: hs + 2)
+        }
+        // one half step; HB = false: h even (pz 0, 1), true: h odd (pz 2, 3)
+        auto half_step = [&](int h, auto hb_tag) {
+            constexpr bool HB = decltype(hb_tag)::value;
+#if !(PULPO_ABLX & 1)
+            __syncthreads();                              // staged planes visible; everybody has finished the previous half step's reads
+#endif
+            const int xs_slot = (h + 3) & 3, ew_slot = (h + 2) & 3;
+            const int d0s = (HB ? h - 1 : h) & 3, d1s = (HB ? h : h + 1) & 3;      // slots of the pair's gradient planes 2 J, 2 J + 1
+            float4 av[3], bv[3], e0[2], e1[2];
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                const int g = gi >> 1, px = 2 * pxh + (gi & 1), pl = gi & 1;
+                const float* eb0 = ea + (px * 4 + d0s) * W2G_ESLOT + g * 16;
+                const float* eb1 = ea + (px * 4 + d1s) * W2G_ESLOT + g * 16;
+                if (!HB) { e0[0] = *reinterpret_cast<const float4*>(eb0); e1[0] = *reinterpret_cast<const float4*>(eb0 + 4); }
+                e0[1] = *reinterpret_cast<const float4*>(eb1); e1[1] = *reinterpret_cast<const float4*>(eb1 + 4);
+                if (HB) { e0[0] = *reinterpret_cast<const float4*>(eb0); e1[0] = *reinterpret_cast<const float4*>(eb0 + 4); }
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    const int off = (px * 4 + ((h + dz) & 3)) * W2G_VSLOT + g * 16;
+                    av[dz] = *reinterpret_cast<const float4*>(va + off);
+                    bv[dz] = *reinterpret_cast<const float4*>(vb + off);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // y combinations of the three input planes and the two gradient planes, then the z combinations (two-wide vector arithmetic)
+                const f32x2 c0v = {c0, c0}, c1v = {c1, c1}, sav = {sa, sa};
+                f32x2 P[3][2], E[2][2];
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    const float4 pa_ = av[dz], pb_ = bv[dz];
+                    P[dz][0] = __builtin_elementwise_fma(sav, f32x2{pb_.x, pb_.y}, f32x2{pa_.x, pa_.y});
+                    P[dz][1] = __builtin_elementwise_fma(sav, f32x2{pb_.z, pb_.w}, f32x2{pa_.z, pa_.w});
+                }
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    E[d][0] = __builtin_elementwise_fma(c1v, f32x2{e1[d].x, e1[d].y}, c0v * f32x2{e0[d].x, e0[d].y});
+                    E[d][1] = __builtin_elementwise_fma(c1v, f32x2{e1[d].z, e1[d].w}, c0v * f32x2{e0[d].z, e0[d].w});
+                }
+                f32x2 VA[2], VB[2], EA[2], EB[2];         // operands of the half step's two z points
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (!HB) { VA[q] = P[0][q] - P[2][q]; VB[q] = P[1][q] + P[2][q]; EA[q] = E[0][q]; EB[q] = E[0][q] + E[1][q]; }
+                    else { VA[q] = P[1][q] - P[0][q]; VB[q] = P[0][q] - P[2][q]; EA[q] = E[0][q] - E[1][q]; EB[q] = -E[1][q]; }
+                }
+                const float va4[4] = {VA[0].x, VA[0].y, VA[1].x, VA[1].y}, vb4[4] = {VB[0].x, VB[0].y, VB[1].x, VB[1].y};
+                const float ea4[4] = {EA[0].x, EA[0].y, EA[1].x, EA[1].y}, eb4[4] = {EB[0].x, EB[0].y, EB[1].x, EB[1].y};
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int PZA = HB ? 2 : 0, PZB = HB ? 3 : 1;
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    acc[pl][PZA] = __builtin_amdgcn_mfma_f32_32x32x2f32(va4[s_], ea4[s_], acc[pl][PZA], 0, 0, 0);
+                    acc[pl][PZB] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb4[s_], eb4[s_], acc[pl][PZB], 0, 0, 0);
+                    if (s_ == 0 && gi < 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (gi == 0) touch_raw();
+#if !(PULPO_ABLX & 2)
+                        write_x(2 * gi, xs_slot);
+                        write_x(2 * gi + 1, xs_slot);
+                        write_e(2 * gi, ew_slot);
+                        write_e(2 * gi + 1, ew_slot);
+#endif
+#if !(PULPO_ABLX & 4)
+                        if (gi == 1) {
+                            issue_x(h + 3);
+                            issue_e(h + 3);
+                        }
+#endif
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+#pragma unroll 1
+        for (int J = Js; J < Je; ++J) {
+            half_step(2 * J, std::false_type{});
+            half_step(2 * J + 1, std::true_type{});
+        }
+        p += Je - Js;
+        __syncthreads();                                  // (the next segment's warm-up overwrites the rings)
+    }
+
+#if PULPO_ABLX & 8
+    if (acc[0][0][0] + acc[1][1][3] + acc[0][2][7] + acc[1][0][9] + acc[0][1][11] + acc[1][2][15] != 12345.678f) return;      // (no flush)
+#endif
+    // ---- flush: first the z axis in-lane, M[dz] = sum_pz G[pz][dz] acc[pz] (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]); then, as in the
+    // (y, x) kernel, dw[dz][ky][kx] = sum_py sum_px G[py][ky] G[px][kx] M[py][px][dz]: the px sum in-lane (this wave's two px), the (py, px-half)
+    // sum through LDS, one dz at a time: X[wave][kx][r][lane] (8 x 3 x 1024 floats = 96 KB)
+    __syncthreads();
+    float* X = smem;
+    const int Cc = min(32, a.Cin - ci0);
+#pragma unroll 1
+    for (int dz = 0; dz < 3; ++dz) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float h0 = 0.5f * (acc[0][1][r] + acc[0][2][r]), h1 = 0.5f * (acc[1][1][r] + acc[1][2][r]);
+            const float m0 = dz == 0 ? acc[0][0][r] + h0 : dz == 1 ? 0.5f * (acc[0][1][r] - acc[0][2][r]) : h0 + acc[0][3][r];
+            const float m1 = dz == 0 ? acc[1][0][r] + h1 : dz == 1 ? 0.5f * (acc[1][1][r] - acc[1][2][r]) : h1 + acc[1][3][r];
+            float t0, t1, t2;                             // kx = 0, 1, 2 from px = 2 pxh (m0), 2 pxh + 1 (m1)
+            if (pxh == 0) { t0 = m0 + 0.5f * m1; t1 = 0.5f * m1; t2 = 0.5f * m1; }               // px 0: G = (1,0,0); px 1: (.5,.5,.5)
+            else { t0 = 0.5f * m0; t1 = -0.5f * m0; t2 = 0.5f * m0 + m1; }                          // px 2: (.5,-.5,.5); px 3: (0,0,1)
+            X[((wave * 3 + 0) * 16 + r) * 64 + lane] = t0;
+            X[((wave * 3 + 1) * 16 + r) * 64 + lane] = t1;
+            X[((wave * 3 + 2) * 16 + r) * 64 + lane] = t2;
+        }
+        __syncthreads();
+        // 3 kx x 16 r x 64 lanes = 3072 entries, 6 per thread; each yields the three ky taps
+        for (int e = tid; e < 3 * 16 * 64; e += 512) {
+            const int l = e & 63, r = (e >> 6) & 15, kx = e >> 10;
+            float s[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)                   // py = q: waves q (px half 0) and q + 4 (px half 1)
+                s[q] = X[((q * 3 + kx) * 16 + r) * 64 + l] + X[(((q + 4) * 3 + kx) * 16 + r) * 64 + l];
+            const int ci = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), co = co0 + (l & 31);
+            if (ci < Cc && co < a.Cout) {
+                const float hs = 0.5f * (s[1] + s[2]);
+                float* d = a.dwp + ((long)((dz * 3 + 0) * 3 + kx) * a.Cin + ci0 + ci) * a.NPad + co;
+                const long kystride = 3L * a.Cin * a.NPad;
+                atomicAdd(d, s[0] + hs);
+                atomicAdd(d + kystride, 0.5f * (s[1] - s[2]));
+                atomicAdd(d + 2 * kystride, hs + s[3]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 namespace pulpo_conv {
@@ -623,6 +929,22 @@ int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, lo
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_w2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2G_LDS);
         if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(wgrad w2): %s", hipGetErrorString(e));
         attr = true;
+    }
+    const bool small32 = (long)D * H * W * in_ps * 4 < (1L << 31) && (long)D * H * W * go_ps * 4 < (1L << 31);
+    // PULPO_WGRAD_W3=0: the (y, x) kernel for every shape (A/B switch).  Default: the F(2x2x2,3x3x3) kernel where the depth is even
+    static int w3 = -1;
+    if (w3 < 0) { const char* e = getenv("PULPO_WGRAD_W3"); w3 = e ? atoi(e) : 1; }
+    if (w3 && small32 && D % 2 == 0 && D >= 4) {
+        static bool attr3 = false;
+        if (!attr3) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_w3x<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3G_LDS);
+            if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(wgrad w3x): %s", hipGetErrorString(e));
+            attr3 = true;
+        }
+        const long nstep3 = (long)B * a.nty * a.ntx * (D / 2);
+        a.nsplit = (int)std::min<long>(std::max(1, 256 / npair), nstep3);
+        hipLaunchKernelGGL((conv3d_k3_wgrad_w3x<0>), dim3(npair * a.nsplit), dim3(512), W3G_LDS, st, a);
+        return pulpo::check_launch("conv3d_k3_wgrad_w3x");
     }
     // PULPO_WGRAD_WAVES8=0: the four-wave build (one wave per SIMD, 405 registers).  Default: eight waves, two per SIMD at 2 x 198 registers -
     // 11 % faster alone (step-weighted 9.24 against 10.26 ms) and 0.6 ms per 160^3 training step (37.5 -> 36.9 ms)
