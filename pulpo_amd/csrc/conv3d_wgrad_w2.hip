@@ -830,17 +830,29 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
                 for (int s_ = 0; s_ < 4; ++s_) {
                     acc[pl][PZA] = __builtin_amdgcn_mfma_f32_32x32x2f32(va4[s_], ea4[s_], acc[pl][PZA], 0, 0, 0);
                     acc[pl][PZB] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb4[s_], eb4[s_], acc[pl][PZB], 0, 0, 0);
-                    if (s_ == 0 && gi < 2) {
+#ifndef PULPO_W3_STAGE
+#define PULPO_W3_STAGE 0                                  // 0: two points behind the first MFMAs of groups 0 and 1 (the (y, x) kernel's placement), 1: all four in group 0
+#endif
+                    if (s_ == 0 && gi < (PULPO_W3_STAGE ? 1 : 2)) {
+                        // the planes fetched during the previous half step are transformed and written behind the group's first MFMAs; their
+                        // registers are then free and the next planes are requested.  (All four points in ONE group - 30 instead of 24 of the half
+                        // step's 32 MFMAs for the loads to land - measured 1.5 - 2 % SLOWER although a build without any loads is 14 - 18 % faster:
+                        // what the loads cost is not their latency.)
                         __builtin_amdgcn_sched_barrier(0);
                         if (gi == 0) touch_raw();
 #if !(PULPO_ABLX & 2)
-                        write_x(2 * gi, xs_slot);
-                        write_x(2 * gi + 1, xs_slot);
-                        write_e(2 * gi, ew_slot);
-                        write_e(2 * gi + 1, ew_slot);
+                        if (PULPO_W3_STAGE) {
+                            write_x(0, xs_slot); write_x(1, xs_slot); write_x(2, xs_slot); write_x(3, xs_slot);
+                            write_e(0, ew_slot); write_e(1, ew_slot); write_e(2, ew_slot); write_e(3, ew_slot);
+                        } else {
+                            write_x(2 * gi, xs_slot);
+                            write_x(2 * gi + 1, xs_slot);
+                            write_e(2 * gi, ew_slot);
+                            write_e(2 * gi + 1, ew_slot);
+                        }
 #endif
 #if !(PULPO_ABLX & 4)
-                        if (gi == 1) {
+                        if (gi == (PULPO_W3_STAGE ? 0 : 1)) {
                             issue_x(h + 3);
                             issue_e(h + 3);
                         }
