@@ -41,7 +41,7 @@ BYTES_ALG_PER_PAIR_160 = 41.98e9       # fused-kernel compulso
 
 def ISSUED_FRACTION(kernel_name: str) -> float:
     """matrix-pipe FLOP issued per direct-convolution FLOP for a traced kernel name"""
-    if "wino3" in kernel_name:
+    if "wino3" in kernel_name or "wgrad_w3" in kernel_name:
         return 8.0 / 27.0
     if "wgrad_w2" in kernel_name or "wino2" in kernel_name:
         return 4.0 / 9.0

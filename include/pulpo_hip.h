@@ -97,8 +97,8 @@ typedef struct PulpoPackJob {
 int pulpo_conv3d_k3_pack_weights_multi(const PulpoPackJob* jobs, int njobs, void* stream);
 /* weight gradient: dw[Cout][Cin][27] = sum_voxels in[v + tap - 1][ci] * dy[v][co]; scratch is overwritten */
 size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
-/* which weight-gradient kernel pulpo_conv3d_k3_wgrad runs for a shape: 2 = Winograd F(2x2,3x3) in (y, x), 1 = Winograd F(2,3) along x,
- * 0 = direct.  vec != 0: both operands channels-last, 16-byte aligned, channel counts multiples of 4 (diagnostics / roofline accounting) */
+/* which weight-gradient kernel pulpo_conv3d_k3_wgrad runs for a shape: 3 = Winograd F(2x2x2,3x3x3) (even depths), 2 = Winograd F(2x2,3x3) in
+ * (y, x), 1 = Winograd F(2,3) along x, 0 = direct.  vec != 0: both operands channels-last, 16-byte aligned, channel counts multiples of 4 (diagnostics / roofline accounting) */
 int pulpo_conv3d_k3_wgrad_algo(int B, int D, int H, int W, int Cin, int Cout, int vec);
 /* accumulate: 0 dw = result, 1 dw += result, 2 DEFERRED - `scratch` must arrive all zero, keeps the packed sums [27][Cin][NPad] and dw (may
  * be NULL) is not touched: the caller finishes every deferred gradient of a backward pass with one pulpo_grad_finish_multi launch (which

@@ -667,15 +667,17 @@ int pulpo_conv::launch_unpack_wgrad(const float* packed, float* dw, int Cin, int
 // ================================================================================================ C ABI
 PULPO_API size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout) { return (size_t)27 * Cin * npad(Cout); }
 
-// weight-gradient kernel for a shape with 16-byte-vectorisable channels-last operands (vec != 0) or not: 2 = Winograd F(2x2,3x3) in (y, x)
-// (conv3d_wgrad_w2.hip), 1 = Winograd F(2,3) along x, 0 = direct; PULPO_WGRAD_WINOGRAD = 0 / 1 caps the choice (A/B runs)
+// weight-gradient kernel for a shape with 16-byte-vectorisable channels-last operands (vec != 0) or not: 3 = Winograd F(2x2x2,3x3x3) (even depths),
+// 2 = Winograd F(2x2,3x3) in (y, x) (both conv3d_wgrad_w2.hip), 1 = Winograd F(2,3) along x, 0 = direct; PULPO_WGRAD_WINOGRAD = 0 / 1 caps
+// the choice, PULPO_WGRAD_W3=0 keeps the (y, x) kernel (A/B runs)
 PULPO_API int pulpo_conv3d_k3_wgrad_algo(int B, int D, int H, int W, int Cin, int Cout, int vec) {
     static int cap = -1;
     if (cap < 0) { const char* e = getenv("PULPO_WGRAD_WINOGRAD"); cap = e ? atoi(e) : 2; }
     static long minvox = -1;                                                   // PULPO_WGRAD_MIN_VOXELS: smallest volume for the Winograd forms (A/B runs)
     if (minvox < 0) { const char* e = getenv("PULPO_WGRAD_MIN_VOXELS"); minvox = e ? atol(e) : 1000; }
     const bool big = vec && Cin >= 8 && (long)D * H * W >= minvox;             // (measured: the (y, x) form also wins on the 20^3 and 10^3 pyramid levels)
-    return big ? std::min(cap, 2) : 0;
+    const int algo = big ? std::min(cap, 2) : 0;
+    return algo == 2 && pulpo_conv::wgrad_w3_depth_ok(D) ? 3 : algo;           // (operands of 2 GiB and more still take the (y, x) kernel)
 }
 
 // dw[Cout][Cin][27] (+)= sum_vox in[vox+tap-1][ci] * dy[vox][co]  (accumulate != 0 adds to dw, e.g. a parameter's .grad storage).
@@ -726,8 +728,8 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
         hipLaunchKernelGGL((conv3d_k3_wgrad_mfma<VECV, NTWV>), dim3(nblk), dim3(256), bytes, st, a);                              \
     }
     const int algo = pulpo_conv3d_k3_wgrad_algo(B, D, H, W, Cin, Cout, (int)vec);
-    if (algo == 2) {
-        // F(2x2,3x3) in (y, x), register-staged transposed operand images, z-streaming workgroups (conv3d_wgrad_w2.hip)
+    if (algo >= 2) {
+        // F(2x2,3x3) in (y, x) / F(2x2x2,3x3x3), register-staged transposed operand images, z-streaming workgroups (conv3d_wgrad_w2.hip)
         rc = pulpo_conv::launch_wgrad_w2(in, in_bs, in_ps, dy, dy_bs, dy_ps, scratch, B, D, H, W, Cin, Cout, st);
         if (rc || deferred) return rc;
         return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);

@@ -921,6 +921,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
 
 namespace pulpo_conv {
 
+// PULPO_WGRAD_W3=0: the (y, x) kernel for every shape (A/B switch).  Default: the F(2x2x2,3x3x3) kernel where the depth is even
+bool wgrad_w3_depth_ok(int D) {
+    static int w3 = -1;
+    if (w3 < 0) { const char* e = getenv("PULPO_WGRAD_W3"); w3 = e ? atoi(e) : 1; }
+    return w3 && D % 2 == 0 && D >= 4;
+}
+
 // launched by pulpo_conv3d_k3_wgrad (conv3d_wgrad.hip) for channels-last operands on large volumes; scratch must be zeroed by the caller
 int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, long go_bs, long go_ps, float* scratch, int B, int D, int H, int W,
                     int Cin, int Cout, hipStream_t st) {
@@ -943,18 +950,20 @@ int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, lo
         attr = true;
     }
     const bool small32 = (long)D * H * W * in_ps * 4 < (1L << 31) && (long)D * H * W * go_ps * 4 < (1L << 31);
-    // PULPO_WGRAD_W3=0: the (y, x) kernel for every shape (A/B switch).  Default: the F(2x2x2,3x3x3) kernel where the depth is even
-    static int w3 = -1;
-    if (w3 < 0) { const char* e = getenv("PULPO_WGRAD_W3"); w3 = e ? atoi(e) : 1; }
-    if (w3 && small32 && D % 2 == 0 && D >= 4) {
+    if (wgrad_w3_depth_ok(D) && small32) {
         static bool attr3 = false;
         if (!attr3) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_w3x<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3G_LDS);
             if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(wgrad w3x): %s", hipGetErrorString(e));
             attr3 = true;
         }
+        // workgroups: one per CU, each with the CU's whole LDS and 2 x 234 of a SIMD's 512 registers - on a CU it holds, no kernel of the main
+        // stream that needs LDS (the BatchNorm finalize / column-sum kernels between two data-gradient launches) starts until it retires.
+        // PULPO_WGRAD_W3_WGS (default 256) leaves CUs free for them.
+        static int wgs3 = -1;
+        if (wgs3 < 0) { const char* e = getenv("PULPO_WGRAD_W3_WGS"); wgs3 = e ? atoi(e) : 256; }
         const long nstep3 = (long)B * a.nty * a.ntx * (D / 2);
-        a.nsplit = (int)std::min<long>(std::max(1, 256 / npair), nstep3);
+        a.nsplit = (int)std::min<long>(std::max(1, wgs3 / npair), nstep3);
         hipLaunchKernelGGL((conv3d_k3_wgrad_w3x<0>), dim3(npair * a.nsplit), dim3(512), W3G_LDS, st, a);
         return pulpo::check_launch("conv3d_k3_wgrad_w3x");
     }

@@ -32,6 +32,7 @@ int launch_unpack_wgrad(const float* packed, float* dw, int Cin, int Cout, int a
 // weight gradient, Winograd F(2x2,3x3) form (conv3d_wgrad_w2.hip): channels-last operands, accumulates into the zeroed packed scratch
 int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, long go_bs, long go_ps, float* scratch, int B, int D, int H, int W,
                     int Cin, int Cout, hipStream_t st);
+bool wgrad_w3_depth_ok(int D);                      // the F(2x2x2,3x3x3) weight-gradient kernel takes this depth (even, PULPO_WGRAD_W3 != 0)
 
 // forward / data gradient, pipelined F(2x2,3x3) kernel (conv3d_wino2p.hip): channels-last 16-byte-aligned operands, K % 4 == 0; bnr = with the
 // BatchNorm-backward sums of the unit in front in the epilogue (ConvArgs::bn_y)

@@ -537,7 +537,7 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
         if not sfx:
             vec = (xc == 1 and xp % 4 == 0 and xb % 4 == 0 and Cin % 4 == 0 and x.data_ptr() % 16 == 0 and dc == 1 and dp % 4 == 0 and db % 4 == 0
                    and Cout % 4 == 0 and dy.data_ptr() % 16 == 0)
-            name = ("conv3d_k3_wgrad_mfma", "conv3d_k3_wgrad_wino", "conv3d_k3_wgrad_w2")[lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, Cin, Cout, int(vec))]
+            name = ("conv3d_k3_wgrad_mfma", "conv3d_k3_wgrad_wino", "conv3d_k3_wgrad_w2", "conv3d_k3_wgrad_w3x")[lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, Cin, Cout, int(vec))]
         _trace_end(t0, name + ("" if deferred else "(+memset,unpack)"), 54.0 * Cin * Cout * B * D * H * W, (_esize(x) * Cin + _esize(dy) * Cout) * B * D * H * W)
     return None if into is not None else dw
 

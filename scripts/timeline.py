@@ -48,7 +48,7 @@ g = sorted(queues[main]); gaps = [g[i + 1][0] - max(x[1] for x in g[: i + 1][-3:
 pos = [x for x in gaps if x > 0]
 print(f"main-queue gaps: {sum(pos)/1e6:.2f} ms in {len(pos)} gaps (median {sorted(pos)[len(pos)//2]/1e3:.1f} us)")
 # ---- exposed time: the parts of the window in which NO matrix-bound convolution kernel runs on either queue, by what the main queue runs then
-MATRIX = ("conv3d_k3_wino3", "conv3d_k3_wino2p", "conv3d_k3_wino2_", "conv3d_k3_wgrad", "conv3d_k3_mfma")
+MATRIX = ("conv3d_k3_wino3", "conv3d_k3_wino2p", "conv3d_k3_wino2_", "conv3d_k3_wgrad", "conv3d_k3_mfma", "conv3d_k3_smallk")
 mat = sorted((s, e) for s, e, q, n in ev if n.startswith(MATRIX))
 merged = []
 for s, e in mat:

@@ -373,6 +373,26 @@ def test_narrow_input_unit_training_pass_vs_oracle(ops, Cin, Cout, size):
         assert rel_l2(got, want) <= bound, (nme, rel_l2(got, want), bound)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,size", [(1, 32, 32, (64, 64, 64)), (2, 16, 96, (10, 20, 28)), (1, 64, 32, (6, 12, 17)), (1, 8, 8, (4, 16, 16)), (1, 40, 24, (12, 10, 9)),
+                                             (1, 32, 64, (9, 16, 16)), (3, 96, 32, (2, 24, 24))])
+def test_weight_gradient_winograd_in_all_three_axes_vs_oracle(ops, B, Cin, Cout, size):
+    """the weight gradient of channels-last operands: F(2x2x2,3x3x3) (conv3d_k3_wgrad_w3x: plane pairs, even depths - ragged rows and columns, depths
+    that are not multiples of four, several batch elements and column segments per workgroup) and, for the odd and the two-plane depths, the (y, x)
+    kernel it falls back to; against the double-precision gradient"""
+    gen = torch.Generator().manual_seed(B * 100 + Cin + Cout)
+    x = torch.randn(B, Cin, *size, generator=gen)
+    dy = torch.randn(B, Cout, *size, generator=gen)
+    w = torch.zeros(Cout, Cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad((F.conv3d(x.double(), w, padding=1) * dy.double()).sum(), [w])
+    xd = x.cuda().contiguous(memory_format=torch.channels_last_3d)
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last_3d)
+    D, H, W = size
+    algo = ops.lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, Cin, Cout, 1)
+    assert D * H * W >= 1000 and algo == (3 if D % 2 == 0 and D >= 4 else 2), algo
+    got = ops._wgrad_raw(xd, dyd, Cin, Cout)
+    assert rel_l2(got, ref) < 3e-6, rel_l2(got, ref)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,size", [(1, 2, 32, (9, 11, 13)), (2, 3, 32, (20, 17, 33)), (1, 4, 48, (8, 24, 16)), (1, 1, 36, (13, 8, 9))])
 def test_weight_gradient_of_the_narrow_input_layers(ops, B, Cin, Cout, size):
     """<= 4 input channels with a channels-last output gradient (what a ConvUnit's backward hands over) take their own kernel
