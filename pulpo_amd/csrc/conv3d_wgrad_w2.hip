@@ -754,6 +754,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
     const float* vb = VX + i * W2G_VROW + (2 * kk + tb) * 4;
     const float* ea = EX + i * W2G_EROW + (2 * kk) * 4;
 
+#ifndef PULPO_W3_SETPRIO
+#define PULPO_W3_SETPRIO 0
+#endif
+    if (PULPO_W3_SETPRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);       // (the second-dispatched half loses every issue arbitration otherwise: MI355X_MICROARCH.md)
     // ---- main loop: column segments of pair steps [Js, Je) of this split's range, i.e. half steps h = 2 Js .. 2 Je - 1, each segment entered
     // through three warm-up half steps (stage only).  Half step h: barrier; its 32 MFMAs; the registers (input plane h + 2, gradient plane
     // h + 2) are transformed and written into the free slots; the loads of planes h + 3 are issued.

@@ -199,8 +199,26 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
     for (int pp = 0; pp < 2; ++pp) { wr[pp][0] = load_w(cur.wbase, pp); wr[pp][1] = load_w(cur.wbase, 4 + pp); }
     __syncthreads();
 
+#ifndef PULPO_W3_SETPRIO
+#define PULPO_W3_SETPRIO 0
+#endif
+    if (PULPO_W3_SETPRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);       // (the second-dispatched half loses every issue arbitration otherwise: MI355X_MICROARCH.md)
     float4 ra[3], rb[3];                                // the operand rows of a PAIR of point steps (pz local 0 / 1 at one px): rows ta / tb of planes U, V, W
 
+    // The tile's statistics: the waves' partial sums wait in `red` and are added behind the NEXT barrier every wave passes anyway (the end of the
+    // next tile's first chunk, or the one after the loop): the epilogue needs no barrier of its own at its end - the exchange buffer and `red`
+    // are not written again before the next tile's epilogue, nchunk barriers away.
+    int pend_tile = -1, pend_co0 = 0;
+    auto flush_stats = [&]() {
+        if (a.stats != nullptr && pend_tile >= 0 && tid < 2 * NT) {
+            const int which = tid / NT, c = tid - which * NT;
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) tot += red[(w * 2 + which) * NT + c];
+            a.stats[((long)pend_tile * 2 + which) * a.Cout + pend_co0 + c] = tot;
+        }
+        pend_tile = -1;
+    };
     for (;;) {
         int next_work = nwork;
         bool has_next = false;
@@ -319,6 +337,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
             wcur += w_chunk_stride;
             if (!(PULPO_ABL & 8)) __syncthreads();      // image cb ^ 1 complete and visible; every wave has left image cb
             cb ^= 1;
+            if (chunk == 0) flush_stats();              // (the previous tile's, see above)
         }
 
         // ---- epilogue
@@ -415,14 +434,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
                 *reinterpret_cast<float4*>(red + (wave * 2 + 1) * NT + 4 * q) = q4;
             }
         }
-        __syncthreads();                                // (also: the exchange buffer's last reads are done before the next tile writes it)
-        if (a.stats != nullptr && tid < 2 * NT) {
-            const int which = tid / NT, c = tid - which * NT;
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) tot += red[(w * 2 + which) * NT + c];
-            a.stats[((long)cur.tile_lin * 2 + which) * a.Cout + co0 + c] = tot;
-        }
+        pend_tile = cur.tile_lin; pend_co0 = co0;
 #if PULPO_ABL & 1
         {
             float t_ = 0.f;
@@ -437,6 +449,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
         cur = nxt;
         work = next_work;
     }
+    __syncthreads();
+    flush_stats();
 }
 
 __global__ void pack_weight_wino3_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int NPad, int dgrad, long total) {
@@ -452,7 +466,7 @@ int wino3_enabled() {                                   // PULPO_CONV_WINO3=0: t
 int wino3_min_k() {                                     // PULPO_CONV_WINO3_MINK: smallest reduction-channel count that takes this kernel
     static int k = -1;
     if (k < 0) { const char* e = getenv("PULPO_CONV_WINO3_MINK"); k = e ? atoi(e) : 32; }
-    return k;
+    return k < 16 ? 16 : k;                             // (at least two chunks per tile: the statistics' deferred flush counts on a second chunk barrier)
 }
 
 }  // namespace
