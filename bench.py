@@ -190,7 +190,7 @@ def plumbing_only(args) -> None:
         names = ["cpu (rank 0)"]
     if rank == 0:
         print(json.dumps({"metric": "plumbing only (no kernels run; not a measurement)", "valid": False, "value": None, "unit": "volume-pairs/s",
-                          "loop": "none", "stepper": {"overlap": False, "async_wgrad": False,
+                          "loop": "none", "stepper": {"overlap": False, "async_wgrad": False, "wgrad_side_stream": False,
                                                       "fallback": "relaunched" if os.environ.get("PULPO_BENCH_RELAUNCHED") == "1" else "none"},
                           "dist": {"backend": dist.get_backend() if world > 1 else None, "world": world, "devices": names},
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(1, args.steps) * 1e3,
@@ -572,6 +572,7 @@ def main():
             "loop": loop_name,
             "loops_ms_per_step": loops_ms,
             "stepper": None if stepper is None else {"overlap": bool(stepper.overlap and world > 1), "async_wgrad": bool(stepper.async_wgrad),
+                                                     "wgrad_side_stream": bool(stepper.wgrad_on_side_stream()),
                                                      "buckets": len(stepper.buckets) if (stepper.overlap and world > 1) else 1, "fallback": fallback,
                                                      "exposed_exchange_ms_per_step": exchange_ms},
             "dist": {"backend": dist.get_backend() if world > 1 else None, "world": dist.get_world_size() if world > 1 else 1, "devices": devices},

@@ -284,7 +284,7 @@ class DataParallelStepper:
         self._works, self._launched = [], 0
         ops._BN_TILE_PARTS.clear()                 # (BatchNorm-backward sums a data-gradient kernel left for a unit whose backward never ran)
         ops.DIRECT_PARAM_GRADS = bool(direct)      # conv / BN backward kernels add straight into the arena's .grad views
-        ops.ASYNC_WGRAD_STREAM = self._side if (self.async_wgrad and direct) else None
+        ops.ASYNC_WGRAD_STREAM = self._side if (self.wgrad_on_side_stream() and direct) else None
         self._in_backward = True
         try:
             if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype:
@@ -339,8 +339,22 @@ class DataParallelStepper:
         self.reduce_and_update()
         return loss.detach()
 
+    def wgrad_on_side_stream(self) -> bool:
+        """whether this step's weight gradients go to the side stream.  With async_wgrad enabled (the default) the choice follows what was
+        measured: the bf16 weight gradient leaves room on its CUs and hides the BatchNorm backward passes (config 4: 14.3 against 14.9 ms per
+        step), the fp32 F(2x2x2,3x3x3) weight gradient holds its CUs whole - all of the LDS, 2 x 234 registers - so that on a second stream it
+        only delays the main stream's small kernels (160^3 step 29.0 against 28.7 ms in line).  PULPO_WGRAD_SIDE_STREAM=1 / 0 forces it."""
+        if not self.async_wgrad:
+            return False
+        force = os.environ.get("PULPO_WGRAD_SIDE_STREAM", "auto")
+        if force in ("0", "1"):
+            return force == "1"
+        from . import ops
+        return ops.CONV_PRECISION == "bf16"
+
     def describe(self) -> dict:
-        return {"overlap": bool(self.overlap and world() > 1), "async_wgrad": bool(self.async_wgrad), "buckets": len(self.buckets)}
+        return {"overlap": bool(self.overlap and world() > 1), "async_wgrad": bool(self.async_wgrad), "wgrad_side_stream": self.wgrad_on_side_stream(),
+                "buckets": len(self.buckets)}
 
 
 class ArenaAdam(torch.optim.Adam):

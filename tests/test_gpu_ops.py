@@ -917,7 +917,7 @@ class _TwiceNet(torch.nn.Module):
 
 @pytest.mark.parametrize("pooled_second", [False, True])
 @pytest.mark.parametrize("mode", ["async", "inline", "flush-between"])
-def test_unit_and_head_applied_twice_in_one_stepper_step(ops, pooled_second, mode):
+def test_unit_and_head_applied_twice_in_one_stepper_step(ops, pooled_second, mode, monkeypatch):
     """advisor (round 3): `_pending_src` - a ConvUnit / 1x1x1 head applied twice inside one DataParallelStepper step accumulates both weight
     gradients into ONE persistent scratch with ONE finishing job, the second bias / head backward takes the immediate path while the first
     is still deferred, and a mid-backward flush (the bucket hook of a multi-rank run) clears the pending list in between.  All three must
@@ -936,8 +936,9 @@ def test_unit_and_head_applied_twice_in_one_stepper_step(ops, pooled_second, mod
     ref.training_step((x, z), 0).backward()
     want = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
     net = make()
+    monkeypatch.setenv("PULPO_WGRAD_SIDE_STREAM", "1")   # (fp32 steps keep the weight gradients in line by default: this test is about the side stream)
     stepper = dp.DataParallelStepper(net, lr=0.0, async_wgrad=(mode != "inline"))
-    assert stepper.async_wgrad == (mode != "inline")
+    assert stepper.async_wgrad == (mode != "inline") and stepper.wgrad_on_side_stream() == (mode != "inline")
     if mode == "flush-between":
         net.mid_hook = lambda g: (ops.join_async_wgrad(), None)[1]
     stepper.opt.step = lambda scale: None                # keep the weights: the gradients are what is compared

@@ -506,10 +506,13 @@ def test_bf16_operand_mode_step_vs_oracle_definition(api, activations):
           f"{worst_true:.2e}; final field vs fp32 {dfe:.2e}; total loss {float(total):.6f} vs fp32 {float(ls_true[0]):.6f}")
 
 
-def test_fused_adam_arena_step_matches_torch_adam(api):
-    """DataParallelStepper (flat arenas + fused Adam, world size 1) vs torch.optim.Adam on the same model"""
+@pytest.mark.parametrize("side_stream", ["auto", "1"])
+def test_fused_adam_arena_step_matches_torch_adam(api, side_stream, monkeypatch):
+    """DataParallelStepper (flat arenas + fused Adam, world size 1) vs torch.optim.Adam on the same model; with the weight gradients in line
+    (the fp32 default) and forced onto the side stream (PULPO_WGRAD_SIDE_STREAM=1: the bf16 configurations' path, here in fp32)"""
     models, nb = api
     from pulpo_amd.dp import DataParallelStepper
+    monkeypatch.setenv("PULPO_WGRAD_SIDE_STREAM", side_stream)
     torch.manual_seed(0)
     gen = torch.Generator().manual_seed(4)
     x, y = torch.rand(1, 1, 16, 16, 16, generator=gen).cuda(), torch.rand(1, 1, 16, 16, 16, generator=gen).cuda()
@@ -526,6 +529,7 @@ def test_fused_adam_arena_step_matches_torch_adam(api):
 
     a, b = make(), make()
     stepper = DataParallelStepper(a)
+    assert stepper.wgrad_on_side_stream() == (side_stream == "1")
     opt = b.configure_optimizers()
     for _ in range(2):
         stepper.step(batch)
@@ -898,6 +902,7 @@ def test_headline_160_stepper_and_lightning_hooks_equal_autograd(api):
     model = make()
     stepper = dp.DataParallelStepper(model, lr=1e-4)
     assert stepper.async_wgrad and ops.BN_REDUCE_IN_DGRAD, "default switches"
+    assert stepper.wgrad_on_side_stream() is False, "fp32: the weight gradient holds its CUs whole and runs in line (dp.DataParallelStepper.wgrad_on_side_stream)"
     l_b = float(stepper.step(batch))
     first_b = snapshot(model)
     l_b2 = float(stepper.step(batch))
