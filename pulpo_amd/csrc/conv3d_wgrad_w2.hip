@@ -652,8 +652,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
     const int e_t = tid - 256;
     const int e_q = e_t & 7, e_xb = (e_t >> 3) & 3, e_y = (e_t >> 5) & 7;
     const bool x_cok = ci0 + 4 * x_q < a.Cin, e_cok = co0 + 4 * e_q < a.Cout;
-    float* const x_dst = VX + (4 * x_q) * W2G_VROW + x_hy * 4 + x_xb;          // + (px * 4 + slot) * VSLOT + c * VROW
-    float* const e_dst = EX + (4 * e_q) * W2G_EROW + e_y * 4 + e_xb;           // + (px * 4 + slot) * ESLOT + c * EROW
+    // Channel rows sit in PERMUTED order: channel c = 4 q + k lives in row perm(c) = 8 k + (q ^ 4 (k >> 1)).  In channel order the rows of the
+    // eight quads q a staging instruction writes (channel k of each quad: rows 4 q + k, 176 floats apart) fall on TWO of the 32 ds_write_b32
+    // banks groups - a 4-way conflict on every staging write (SQ_LDS_BANK_CONFLICT: 36 % of the LDS cycles).  Permuted, the eight rows of
+    // an instruction are 8 consecutive rows (all residues mod 8: conflict-free) and every ds_read_b128 lane group still covers all 16 residues
+    // of its sixteen-byte slots.
+    float* const x_dst = VX + x_q * W2G_VROW + x_hy * 4 + x_xb;                // + (px * 4 + slot) * VSLOT + perm-row offsets below
+    float* const e_dst = EX + e_q * W2G_EROW + e_y * 4 + e_xb;                 // + (px * 4 + slot) * ESLOT + ...
+    const int x_d4 = ((x_q ^ 4) - x_q) * W2G_VROW, e_d4 = ((e_q ^ 4) - e_q) * W2G_EROW;    // rows of channels 4 q + 2, 4 q + 3: 16 / 24 + (q ^ 4)
 
     // Operand planes are read through buffer descriptors (as in conv3d_wino2p.hip): per column, every thread holds the byte offsets of its
     // taps in plane 0 of the column's batch element - OOB (beyond num_records: the load returns zeros) where the tap lies outside the volume or
@@ -714,7 +720,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
             const f32x2 lo = f32x2{pa_.x, pa_.y} + sg * f32x2{pb_.x, pb_.y}, hi = f32x2{pa_.z, pa_.w} + sg * f32x2{pb_.z, pb_.w};
             const float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
             float* o = x_dst + (px * 4 + slot) * W2G_VSLOT;
-            o[0] = v.x; o[W2G_VROW] = v.y; o[2 * W2G_VROW] = v.z; o[3 * W2G_VROW] = v.w;
+            o[0] = v.x; o[8 * W2G_VROW] = v.y; o[16 * W2G_VROW + x_d4] = v.z; o[24 * W2G_VROW + x_d4] = v.w;
         }
     };
     auto write_e = [&](int px, int slot) {
@@ -729,7 +735,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
                 v = make_float4(lo.x, lo.y, hi.x, hi.y);
             }
             float* o = e_dst + (px * 4 + slot) * W2G_ESLOT;
-            o[0] = v.x; o[W2G_EROW] = v.y; o[2 * W2G_EROW] = v.z; o[3 * W2G_EROW] = v.w;
+            o[0] = v.x; o[8 * W2G_EROW] = v.y; o[16 * W2G_EROW + e_d4] = v.z; o[24 * W2G_EROW + e_d4] = v.w;
         }
     };
     // every thread "uses" its raw registers unconditionally (see conv3d_wino.hip): the compiler's wait for the loads sits in straight-line code
@@ -750,9 +756,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
 
     // operand row addresses of this lane (floats): + (px * 4 + slot) * VSLOT + g * 16 for V, + (px * 4 + slot) * ESLOT + g * 16 for E (gradient plane q in slot q & 3)
     // (block row yb = 2 g + kk: V rows hy = 2 yb + ta / tb, E rows y = 2 yb, 2 yb + 1; four floats per row; input plane p sits in slot (p + 1) & 3)
-    const float* va = VX + i * W2G_VROW + (2 * kk + ta) * 4;
-    const float* vb = VX + i * W2G_VROW + (2 * kk + tb) * 4;
-    const float* ea = EX + i * W2G_EROW + (2 * kk) * 4;
+    const int irow = 8 * (i & 3) + ((i >> 2) ^ (4 * ((i >> 1) & 1)));            // perm(i): the row of this lane's channel
+    const float* va = VX + irow * W2G_VROW + (2 * kk + ta) * 4;
+    const float* vb = VX + irow * W2G_VROW + (2 * kk + tb) * 4;
+    const float* ea = EX + irow * W2G_EROW + (2 * kk) * 4;
 
 #ifndef PULPO_W3_SETPRIO
 #define PULPO_W3_SETPRIO 0
