@@ -220,9 +220,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
         pend_tile = -1;
     };
     for (;;) {
-        int next_work = nwork;
-        bool has_next = false;
-        Tile nxt = cur;
+        // the next tile is known from the start (its description inside the chunk loop, under `chunk + 2 == nchunk`, was if-converted by the
+        // compiler: five integer divisions' worth of scalar instructions and a dozen spilled-register reloads in EVERY chunk)
+        const int next_work = work + nwg;
+        const bool has_next = next_work < nwork;
+        const Tile nxt = has_next ? describe(next_work) : cur;
 
         f32x16 acc[2][4];                               // [pz local][px]
 #pragma unroll
@@ -237,11 +239,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
             // Staging runs TWO chunks ahead of the matrix loop: step 0 transforms the taps requested during the previous chunk into the image
             // of chunk + 1 and steps 1 - 2 request those of chunk + 2 (or of the next tile's chunk 0 / 1), which the registers hold for a whole
             // chunk - 2000 matrix clocks, more than a trip to HBM.
-            if (chunk + 2 == nchunk) {                  // from here on the requests belong to the next tile
-                next_work = work + nwg;
-                has_next = next_work < nwork;
-                if (has_next) nxt = describe(next_work);
-            }
             const bool ahead = chunk + 2 >= nchunk;     // (after the last tile: the tile's own first chunks again, into images nobody reads)
             const unsigned st_c0 = (unsigned)(ahead ? chunk + 2 - nchunk : chunk + 2) * CH * 4u;
             const __amdgpu_buffer_rsrc_t st_rs = in_rsrc(ahead ? nxt.b : cur.b);
@@ -359,27 +356,37 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
         const int ox = combo >> 4, rr = combo & 15;
         const int row = (rr & 3) + 8 * (rr >> 2) + 4 * kh;          // = MFMA row = block (zb, yb, xb)
         const int vzb = row >> 4, vyb = (row >> 2) & 3, vxb = row & 3;
+        // x inverse transform (4 px -> 2 ox), once and in place: acc[p][0] <- out x0 = q0 + q1 + q2, acc[p][1] <- out x1 = q1 - q2 - q3
+        if (!(PULPO_ABL & 1)) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float a0 = acc[p][0][r], a1 = acc[p][1][r], a2 = acc[p][2][r], a3 = acc[p][3][r];
+                    acc[p][0][r] = a0 + a1 + a2;
+                    acc[p][1][r] = a1 - a2 - a3;
+                }
+        }
 #pragma unroll
         for (int oz = 0; oz < ((PULPO_ABL & 1) ? 0 : 2); ++oz) {
             if (oz > 0) __syncthreads();                // every wave has left the exchange buffer (previous parity)
-            // x inverse transform (4 px -> 2 ox) and this wave's share of the z inverse transform:
-            //   out z0 = q0 + q1 + q2, out z1 = q1 - q2 - q3;  wave pzh = 0 holds (q0, q1), pzh = 1 holds (q2, q3)
+            // this wave's share of the z inverse transform: out z0 = q0 + q1 + q2, out z1 = q1 - q2 - q3; wave pzh = 0 holds (q0, q1), pzh = 1
+            // holds (q2, -q3) (the second accumulator of those waves holds MINUS its point, see the matrix loop).  A branch per wave (pzh is
+            // wave-uniform) instead of two selects per value.
+            float* const r0 = R + ((wave * 2 + 0) * 16) * 64 + elane;
+            float* const r1 = R + ((wave * 2 + 1) * 16) * 64 + elane;
+            if (pzh == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float a0 = acc[0][0][r], a1 = acc[0][1][r], a2 = acc[0][2][r], a3 = acc[0][3][r];
-                const float c0 = acc[1][0][r], c1 = acc[1][1][r], c2 = acc[1][2][r], c3 = acc[1][3][r];
-                const float p0x0 = a0 + a1 + a2, p0x1 = a1 - a2 - a3;          // pz local 0
-                const float p1x0 = c0 + c1 + c2, p1x1 = c1 - c2 - c3;          // pz local 1
-                float e0, e1;
-                if (pzh == 0) {
-                    e0 = oz == 0 ? p0x0 + p1x0 : p1x0;
-                    e1 = oz == 0 ? p0x1 + p1x1 : p1x1;
-                } else {                                // (the second accumulator of these waves holds MINUS its point, see the matrix loop)
-                    e0 = oz == 0 ? p0x0 : p1x0 - p0x0;
-                    e1 = oz == 0 ? p0x1 : p1x1 - p0x1;
+                for (int r = 0; r < 16; ++r) {
+                    r0[r * 64] = oz == 0 ? acc[0][0][r] + acc[1][0][r] : acc[1][0][r];
+                    r1[r * 64] = oz == 0 ? acc[0][1][r] + acc[1][1][r] : acc[1][1][r];
                 }
-                R[((wave * 2 + 0) * 16 + r) * 64 + elane] = e0;
-                R[((wave * 2 + 1) * 16 + r) * 64 + elane] = e1;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    r0[r * 64] = oz == 0 ? acc[0][0][r] : acc[1][0][r] - acc[0][0][r];
+                    r1[r * 64] = oz == 0 ? acc[0][1][r] : acc[1][1][r] - acc[0][1][r];
+                }
             }
             const int gz = z0 + 2 * vzb + oz, gy = y0 + 2 * vyb, gx = x0 + 2 * vxb + ox;
             const long vox = (long)(gz * a.H + gy) * a.W + gx;
