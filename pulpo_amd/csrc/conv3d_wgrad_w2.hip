@@ -634,8 +634,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
     const int ta = py == 0 ? 0 : py == 2 ? 2 : 1;
     const int tb = py == 2 ? 1 : py == 3 ? 3 : 2;
     const float sa = py == 1 ? 1.f : -1.f;
-    const float c0 = py == 3 ? 0.f : 1.f;
-    const float c1 = py == 0 ? 0.f : py == 1 ? 1.f : -1.f;
+    // E row = dY[2 yb + ea_] + se * dY[2 yb + eb_] - ONE fused multiply-add per value: py 0: d0 (+ 0 d0), 1: d0 + d1, 2: d0 - d1, 3: -d1 = d1 - 2 d1
+    const int ea_ = py == 3 ? 1 : 0, eb_ = py == 0 ? 0 : 1;
+    const float se = py == 0 ? 0.f : py == 1 ? 1.f : py == 2 ? -1.f : -2.f;
 
     // ---- work: plane-PAIR steps [p_begin, p_end) of the linearised (column, z / 2) space of this pair's split
     const int ncol = a.B * a.nty * a.ntx;
@@ -789,32 +790,33 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
             issue_x(h + 3);
             issue_e(h + 3 < hs ? hs : h + 3);             // (h = hs - 3: plane hs again, h = hs - 2: hs + 1, h = hs - 1: hs + 2)
         }
-        // one half step; HB = false: h even (pz 0, 1), true: h odd (pz 2, 3)
-        auto half_step = [&](int h, auto hb_tag) {
-            constexpr bool HB = decltype(hb_tag)::value;
+        // one half step; HM = h mod 4 as a compile-time constant (every ring slot is then an immediate offset of the operand reads - computed at
+        // run time they cost a dozen address additions per group of eight MFMAs); HB = h odd (pz 2, 3), else pz 0, 1
+        auto half_step = [&](int h, auto hm_tag) {
+            constexpr int HM = decltype(hm_tag)::value;
+            constexpr bool HB = (HM & 1) != 0;
 #if !(PULPO_ABLX & 1)
             __syncthreads();                              // staged planes visible; everybody has finished the previous half step's reads
 #endif
-            const int xs_slot = (h + 3) & 3, ew_slot = (h + 2) & 3;
-            const int d0s = (HB ? h - 1 : h) & 3, d1s = (HB ? h : h + 1) & 3;      // slots of the pair's gradient planes 2 J, 2 J + 1
+            constexpr int xs_slot = (HM + 3) & 3, ew_slot = (HM + 2) & 3;
+            constexpr int d0s = (HB ? HM - 1 : HM) & 3, d1s = (HB ? HM : HM + 1) & 3;      // slots of the pair's gradient planes 2 J, 2 J + 1
             float4 av[3], bv[3], e0[2], e1[2];
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi) {
                 const int g = gi >> 1, px = 2 * pxh + (gi & 1), pl = gi & 1;
                 const float* eb0 = ea + (px * 4 + d0s) * W2G_ESLOT + g * 16;
                 const float* eb1 = ea + (px * 4 + d1s) * W2G_ESLOT + g * 16;
-                if (!HB) { e0[0] = *reinterpret_cast<const float4*>(eb0); e1[0] = *reinterpret_cast<const float4*>(eb0 + 4); }
-                e0[1] = *reinterpret_cast<const float4*>(eb1); e1[1] = *reinterpret_cast<const float4*>(eb1 + 4);
-                if (HB) { e0[0] = *reinterpret_cast<const float4*>(eb0); e1[0] = *reinterpret_cast<const float4*>(eb0 + 4); }
+                e0[0] = *reinterpret_cast<const float4*>(eb0 + 4 * ea_); e1[0] = *reinterpret_cast<const float4*>(eb0 + 4 * eb_);
+                e0[1] = *reinterpret_cast<const float4*>(eb1 + 4 * ea_); e1[1] = *reinterpret_cast<const float4*>(eb1 + 4 * eb_);
 #pragma unroll
                 for (int dz = 0; dz < 3; ++dz) {
-                    const int off = (px * 4 + ((h + dz) & 3)) * W2G_VSLOT + g * 16;
+                    const int off = (px * 4 + ((HM + dz) & 3)) * W2G_VSLOT + g * 16;
                     av[dz] = *reinterpret_cast<const float4*>(va + off);
                     bv[dz] = *reinterpret_cast<const float4*>(vb + off);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // y combinations of the three input planes and the two gradient planes, then the z combinations (two-wide vector arithmetic)
-                const f32x2 c0v = {c0, c0}, c1v = {c1, c1}, sav = {sa, sa};
+                const f32x2 sev = {se, se}, sav = {sa, sa};
                 f32x2 P[3][2], E[2][2];
 #pragma unroll
                 for (int dz = 0; dz < 3; ++dz) {
@@ -824,14 +826,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
                 }
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
-                    E[d][0] = __builtin_elementwise_fma(c1v, f32x2{e1[d].x, e1[d].y}, c0v * f32x2{e0[d].x, e0[d].y});
-                    E[d][1] = __builtin_elementwise_fma(c1v, f32x2{e1[d].z, e1[d].w}, c0v * f32x2{e0[d].z, e0[d].w});
+                    E[d][0] = __builtin_elementwise_fma(sev, f32x2{e1[d].x, e1[d].y}, f32x2{e0[d].x, e0[d].y});
+                    E[d][1] = __builtin_elementwise_fma(sev, f32x2{e1[d].z, e1[d].w}, f32x2{e0[d].z, e0[d].w});
                 }
                 f32x2 VA[2], VB[2], EA[2], EB[2];         // operands of the half step's two z points
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     if (!HB) { VA[q] = P[0][q] - P[2][q]; VB[q] = P[1][q] + P[2][q]; EA[q] = E[0][q]; EB[q] = E[0][q] + E[1][q]; }
-                    else { VA[q] = P[1][q] - P[0][q]; VB[q] = P[0][q] - P[2][q]; EA[q] = E[0][q] - E[1][q]; EB[q] = -E[1][q]; }
+                    else { VA[q] = P[1][q] - P[0][q]; VB[q] = P[2][q] - P[0][q]; EA[q] = E[0][q] - E[1][q]; EB[q] = E[1][q]; }       // (pz 3: (P- - P+)(-d1) = (P+ - P-) d1)
                 }
                 const float va4[4] = {VA[0].x, VA[0].y, VA[1].x, VA[1].y}, vb4[4] = {VB[0].x, VB[0].y, VB[1].x, VB[1].y};
                 const float ea4[4] = {EA[0].x, EA[0].y, EA[1].x, EA[1].y}, eb4[4] = {EB[0].x, EB[0].y, EB[1].x, EB[1].y};
@@ -874,10 +876,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        {
+            using H0 = std::integral_constant<int, 0>; using H1 = std::integral_constant<int, 1>;
+            using H2 = std::integral_constant<int, 2>; using H3 = std::integral_constant<int, 3>;
+            int J = Js;
+            if (J < Je && (J & 1)) { half_step(2 * J, H2{}); half_step(2 * J + 1, H3{}); ++J; }
 #pragma unroll 1
-        for (int J = Js; J < Je; ++J) {
-            half_step(2 * J, std::false_type{});
-            half_step(2 * J + 1, std::true_type{});
+            for (; J + 1 < Je; J += 2) {
+                half_step(2 * J, H0{}); half_step(2 * J + 1, H1{});
+                half_step(2 * J + 2, H2{}); half_step(2 * J + 3, H3{});
+            }
+            if (J < Je) { half_step(2 * J, H0{}); half_step(2 * J + 1, H1{}); }
         }
         p += Je - Js;
         __syncthreads();                                  // (the next segment's warm-up overwrites the rings)
