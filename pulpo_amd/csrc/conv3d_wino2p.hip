@@ -222,9 +222,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
     float4 ra[2][2], rb[2][2];                          // two register sets of operand rows ((ta, tb) x two row tiles)
 
     for (;;) {
-        int next_work = nwork;
-        bool has_next = false;
-        Tile nxt = cur;
+        // (the next tile is described once, here: inside the chunk loop - under `last_chunk` - the compiler if-converted the description into
+        //  every chunk's instruction stream, scalar divisions and spilled-register reloads included; conv3d_wino3.hip, same finding)
+        const int next_work = work + nwg;
+        const bool has_next = next_work < nwork;
+        const Tile nxt = has_next ? describe(next_work) : cur;
 
         f32x16 acc[2][4];
 #pragma unroll
@@ -238,11 +240,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wino2p_mfma(ConvArgs a) {
         int it = 0;
         for (int chunk = cur.c0; chunk < cur.c1; ++chunk) {
             const bool last_chunk = chunk + 1 == cur.c1;
-            if (last_chunk) {
-                next_work = work + nwg;
-                has_next = next_work < nwork;
-                if (has_next) nxt = describe(next_work);
-            }
             constexpr bool stage = !(PULPO_ABL & 2);
             // what is staged underneath this chunk's MFMAs: the tile's next chunk, or chunk 0 of the next tile (after the last tile: the
             // tile's own chunk 0 again, into an image nobody reads - cheaper than a branch around every piece of the side work)
