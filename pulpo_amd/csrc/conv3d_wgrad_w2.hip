@@ -763,9 +763,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
     const float* ea = EX + irow * W2G_EROW + (2 * kk) * 4;
 
 #ifndef PULPO_W3_SETPRIO
-#define PULPO_W3_SETPRIO 0
+#define PULPO_W3_SETPRIO 0       // 1: waves 4-7 raised for good, 2: the partners of a SIMD (w, w + 4) alternate per group (conv3d_wino3.hip)
 #endif
-    if (PULPO_W3_SETPRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);       // (the second-dispatched half loses every issue arbitration otherwise: MI355X_MICROARCH.md)
+    if (PULPO_W3_SETPRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);       // (the second-dispatched half loses every issue arbitration otherwise: MI355X_MICROARCH.md)
     // ---- main loop: column segments of pair steps [Js, Je) of this split's range, i.e. half steps h = 2 Js .. 2 Je - 1, each segment entered
     // through three warm-up half steps (stage only).  Half step h: barrier; its 32 MFMAs; the registers (input plane h + 2, gradient plane
     // h + 2) are transformed and written into the free slots; the loads of planes h + 3 are issued.
@@ -804,6 +804,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi) {
                 const int g = gi >> 1, px = 2 * pxh + (gi & 1), pl = gi & 1;
+                if (PULPO_W3_SETPRIO == 2) { if (((gi + pxh) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
                 const float* eb0 = ea + (px * 4 + d0s) * W2G_ESLOT + g * 16;
                 const float* eb1 = ea + (px * 4 + d1s) * W2G_ESLOT + g * 16;
                 e0[0] = *reinterpret_cast<const float4*>(eb0 + 4 * ea_); e1[0] = *reinterpret_cast<const float4*>(eb0 + 4 * eb_);

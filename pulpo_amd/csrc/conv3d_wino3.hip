@@ -27,6 +27,22 @@
 #include "wino3_pack.h"
 #include <stdlib.h>
 
+#ifndef PULPO_W3_STAMPS
+#define PULPO_W3_STAMPS 0        // diagnostic build (scripts/stamps_w3.py): s_memtime stamps of one tile's phases per wave, kept in registers until the tile's end
+#endif
+#if PULPO_W3_STAMPS
+__device__ unsigned g_w3_stamps[256 * 8 * 32];
+PULPO_API int pulpo_debug_read_stamps_w3(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_w3_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#define W3_CLK() ((unsigned)__builtin_amdgcn_s_memtime())                        // (waits for lgkmcnt(0) where it is consumed: the stamps sit where that wait is due anyway)
+// scalar stamps (SGPRs): T = now; the phase accumulators of the tile are wave-uniform sums
+#define W3_NOW(var) do { __builtin_amdgcn_sched_barrier(0); var = W3_CLK(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W3_STAMP(i) do {} while (0)
+#else
+#define W3_STAMP(i) do {} while (0)
+#endif
+
 #ifndef PULPO_W3_PK
 #define PULPO_W3_PK 1        // the y / z combinations in two-wide vector arithmetic (v_pk_fma_f32); 0: scalar v_fma_f32 - measured 3-4 % slower here (64-clock fp32 MFMAs leave room)
 #endif
@@ -200,9 +216,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
     __syncthreads();
 
 #ifndef PULPO_W3_SETPRIO
-#define PULPO_W3_SETPRIO 0
+#define PULPO_W3_SETPRIO 2       // 0: equal priorities, 1: waves 4-7 raised for good (no gain), 2: the partners of a SIMD alternate per pair (+1.5 %)
 #endif
-    if (PULPO_W3_SETPRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);       // (the second-dispatched half loses every issue arbitration otherwise: MI355X_MICROARCH.md)
+    if (PULPO_W3_SETPRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);       // (the second-dispatched half loses every issue arbitration otherwise: MI355X_MICROARCH.md)
     float4 ra[3], rb[3];                                // the operand rows of a PAIR of point steps (pz local 0 / 1 at one px): rows ta / tb of planes U, V, W
 
     // The tile's statistics: the waves' partial sums wait in `red` and are added behind the NEXT barrier every wave passes anyway (the end of the
@@ -219,6 +235,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
         }
         pend_tile = -1;
     };
+#if PULPO_W3_STAMPS
+    int tile_no = 0;
+    unsigned w3_tile0 = 0, w3_rows = 0, w3_mfma = 0, w3_bar = 0;
+#endif
     for (;;) {
         // the next tile is known from the start (its description inside the chunk loop, under `chunk + 2 == nchunk`, was if-converted by the
         // compiler: five integer divisions' worth of scalar instructions and a dozen spilled-register reloads in EVERY chunk)
@@ -290,12 +310,24 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
             // COMBINED between them (behind the fourth of the eight), the rows of pair pp + 2 requested right after - a wave never stands in a
             // vector-only phase while it has matrix instructions to issue, except in front of a chunk's first pair.
             float avn0[4], avn1[4];                     // the operands of the pair in flight / of the next pair
+#if PULPO_W3_STAMPS
+            unsigned t_a, t_b, t_c, t_d;
+            W3_NOW(t_a);
+            if (chunk == 0) { w3_tile0 = t_a; w3_rows = 0; w3_mfma = 0; w3_bar = 0; }
+#endif
             if (!(PULPO_ABL & 32)) fetch_a(0);
             combine(avn0, avn1);
+#if PULPO_W3_STAMPS
+            W3_NOW(t_b);
+#endif
             if (!(PULPO_ABL & 32)) fetch_a(1);
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
                 const int s0 = pp, s1 = 4 + pp;         // point steps (pz local 0, px = pp) and (pz local 1, px = pp)
+                // PULPO_W3_SETPRIO = 2: the two waves of a SIMD (w and w + 4: pzh 0 / 1) take the higher issue priority in ALTERNATING pairs.  At
+                // equal priority the older wave wins every arbitration: it runs its 32 MFMAs of a chunk in 3 350 clocks, the younger one gets
+                // the leftover slots and finishes alone 1 300 clocks later (scripts/stamps_w3.py), with the pipe idle in its gaps.
+                if (PULPO_W3_SETPRIO == 2) { if (((pp + pzh) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
                 const float av0[4] = {avn0[0], avn0[1], avn0[2], avn0[3]}, av1[4] = {avn1[0], avn1[1], avn1[2], avn1[3]};
                 const float wv0[4] = {wr[pp & 1][0].x, wr[pp & 1][0].y, wr[pp & 1][0].z, wr[pp & 1][0].w};
                 const float wv1[4] = {wr[pp & 1][1].x, wr[pp & 1][1].y, wr[pp & 1][1].z, wr[pp & 1][1].w};
@@ -332,7 +364,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             wcur += w_chunk_stride;
+#if PULPO_W3_STAMPS
+            W3_NOW(t_c);
+#endif
             if (!(PULPO_ABL & 8)) __syncthreads();      // image cb ^ 1 complete and visible; every wave has left image cb
+#if PULPO_W3_STAMPS
+            W3_NOW(t_d);
+            w3_rows += t_b - t_a; w3_mfma += t_c - t_b; w3_bar += t_d - t_c;
+#endif
             cb ^= 1;
             if (chunk == 0) flush_stats();              // (the previous tile's, see above)
         }
@@ -356,6 +395,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
         const int ox = combo >> 4, rr = combo & 15;
         const int row = (rr & 3) + 8 * (rr >> 2) + 4 * kh;          // = MFMA row = block (zb, yb, xb)
         const int vzb = row >> 4, vyb = (row >> 2) & 3, vxb = row & 3;
+#if PULPO_W3_STAMPS
+        unsigned t_e0, t_e1 = 0, t_e2 = 0, t_e3;
+        W3_NOW(t_e0);
+#endif
         // x inverse transform (4 px -> 2 ox), once and in place: acc[p][0] <- out x0 = q0 + q1 + q2, acc[p][1] <- out x1 = q1 - q2 - q3
         if (!(PULPO_ABL & 1)) {
 #pragma unroll
@@ -396,6 +439,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
                 yv1 = *reinterpret_cast<const float4*>(bn_b + (vox + a.W) * a.bn_y_ps);
             }
             __syncthreads();
+#if PULPO_W3_STAMPS
+            if (oz == 0) W3_NOW(t_e1);
+#endif
             float4 t[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {               // point row p: the two z halves summed
@@ -428,6 +474,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
             float* obase = out_b + co0 + 4 * q;
             *reinterpret_cast<float4*>(obase + vox * a.out_ps) = v0;
             *reinterpret_cast<float4*>(obase + (vox + a.W) * a.out_ps) = v1;
+#if PULPO_W3_STAMPS
+            if (oz == 0) W3_NOW(t_e2);
+#endif
         }
         // per-tile BatchNorm partial sums: over the lanes that hold the same channels, then over the eight waves
         if (a.stats != nullptr) {
@@ -442,6 +491,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
             }
         }
         pend_tile = cur.tile_lin; pend_co0 = co0;
+#if PULPO_W3_STAMPS
+        W3_NOW(t_e3);
+        if (tile_no == 1 && lane == 0) {
+            unsigned* o_ = g_w3_stamps + (blockIdx.x * 8 + wave) * 32;
+            o_[0] = w3_rows; o_[1] = w3_mfma; o_[2] = w3_bar; o_[3] = t_e0 - w3_tile0; o_[4] = t_e1 - t_e0; o_[5] = t_e2 - t_e1; o_[6] = t_e3 - t_e2;
+            o_[7] = t_e3 - w3_tile0;
+        }
+        ++tile_no;
+#endif
 #if PULPO_ABL & 1
         {
             float t_ = 0.f;
