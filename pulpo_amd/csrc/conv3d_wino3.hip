@@ -306,6 +306,22 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
                 }
 #endif
             };
+#ifndef PULPO_W3_SPREAD
+#define PULPO_W3_SPREAD 0        // 1: the next pair's combinations spread over the gaps behind the fourth, sixth and eighth MFMA instead of one block behind the fourth
+#endif
+            f32x2 sy_lo[3], sy_hi[3];
+            auto comb_y = [&](int p) {
+                const f32x2 sav = {sa, sa};
+                sy_lo[p] = __builtin_elementwise_fma(sav, f32x2{rb[p].x, rb[p].y}, f32x2{ra[p].x, ra[p].y});
+                sy_hi[p] = __builtin_elementwise_fma(sav, f32x2{rb[p].z, rb[p].w}, f32x2{ra[p].z, ra[p].w});
+            };
+            auto comb_z = [&](float (&av0)[4], float (&av1)[4]) {
+                const f32x2 m1 = {-1.f, -1.f}, bwv = {bw, bw};
+                const f32x2 lo0 = __builtin_elementwise_fma(m1, sy_lo[2], sy_lo[0]), hi0 = __builtin_elementwise_fma(m1, sy_hi[2], sy_hi[0]);
+                const f32x2 lo1 = __builtin_elementwise_fma(bwv, sy_lo[2], sy_lo[1]), hi1 = __builtin_elementwise_fma(bwv, sy_hi[2], sy_hi[1]);
+                av0[0] = lo0.x; av0[1] = lo0.y; av0[2] = hi0.x; av0[3] = hi0.y;
+                av1[0] = lo1.x; av1[1] = lo1.y; av1[2] = hi1.x; av1[3] = hi1.y;
+            };
             // Software pipeline over the chunk's four pairs: the operand rows of pair pp + 1 are requested in front of pair pp's MFMAs and
             // COMBINED between them (behind the fourth of the eight), the rows of pair pp + 2 requested right after - a wave never stands in a
             // vector-only phase while it has matrix instructions to issue, except in front of a chunk's first pair.
@@ -347,11 +363,18 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (s2 == 1 && pp + 1 < 4) {        // behind the fourth MFMA: the next pair's combinations, then the request for the pair after it
+                    if (!PULPO_W3_SPREAD && s2 == 1 && pp + 1 < 4) {        // behind the fourth MFMA: the next pair's combinations, then the request for the pair after it
                         __builtin_amdgcn_sched_barrier(0);
                         combine(avn0, avn1);
                         __builtin_amdgcn_sched_barrier(0);
                         if (!(PULPO_ABL & 32) && pp + 2 < 4) fetch_a(pp + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (PULPO_W3_SPREAD && pp + 1 < 4 && s2 >= 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s2 == 1) { comb_y(0); comb_y(1); }
+                        if (s2 == 2) { comb_y(2); comb_z(avn0, avn1); }
+                        if (s2 == 3 && !(PULPO_ABL & 32) && pp + 2 < 4) fetch_a(pp + 2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
