@@ -65,7 +65,8 @@ constexpr int Q_NITEM = 6 * HY * 4 * 2;          // staging items of a chunk: (h
 constexpr int Q_TAB = 3 * 512;                   // per-channel table [3][ncot * 32]: up to 512 output channels
 constexpr int Q_R = 8 * 2 * 16 * 64;             // floats of the exchange buffer of one output z parity: [wave][ox][r][lane]
 constexpr int Q_RED = 8 * 2 * Q_NT;              // statistics rows of the eight waves
-constexpr size_t Q_LDS = (size_t)(2 * Q_IMG + Q_TAB + Q_R + Q_RED) * sizeof(float);
+constexpr int Q_PART = 8 * 64 * 8;               // a wave's per-lane statistics before its own (in-order, barrier-free) reduction: [wave][lane][8]
+constexpr size_t Q_LDS = (size_t)(2 * Q_IMG + Q_TAB + Q_R + Q_RED + Q_PART) * sizeof(float);
 static_assert(Q_LDS <= 160 * 1024, "one workgroup per CU");
 
 template <bool BNR>
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
     float* const tab = smem + 2 * Q_IMG;                // [3][ctab]
     float* const R = tab + Q_TAB;                       // exchange buffer
     float* const red = R + Q_R;                         // [8 waves][2][NT]
+    float* const part = red + Q_RED;                    // [8 waves][64 lanes][8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kk = lane >> 5;
@@ -502,16 +504,18 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
 #endif
         }
         // per-tile BatchNorm partial sums: over the lanes that hold the same channels, then over the eight waves
+        // (through the wave's own LDS rows - DS operations of one wave execute in order, no barrier - instead of three rounds of cross-lane
+        //  shuffles: lane l then owns ONE of the wave's 64 sums (which = l / 32, channel l % 32) and adds the eight lanes that hold its channel quad)
         if (a.stats != nullptr) {
+            float* pw_ = part + (wave * 64 + elane) * 8;
+            *reinterpret_cast<float4*>(pw_) = s4;
+            *reinterpret_cast<float4*>(pw_ + 4) = q4;
+            const int c_ = elane & 31, wh_ = elane >> 5;
+            const float* pr_ = part + (wave * 64 + (c_ >> 2)) * 8 + wh_ * 4 + (c_ & 3);
+            float t_ = 0.f;
 #pragma unroll
-            for (int o = 8; o <= 32; o <<= 1) {
-                s4.x += __shfl_xor(s4.x, o, 64); s4.y += __shfl_xor(s4.y, o, 64); s4.z += __shfl_xor(s4.z, o, 64); s4.w += __shfl_xor(s4.w, o, 64);
-                q4.x += __shfl_xor(q4.x, o, 64); q4.y += __shfl_xor(q4.y, o, 64); q4.z += __shfl_xor(q4.z, o, 64); q4.w += __shfl_xor(q4.w, o, 64);
-            }
-            if (elane < 8) {
-                *reinterpret_cast<float4*>(red + (wave * 2 + 0) * NT + 4 * q) = s4;
-                *reinterpret_cast<float4*>(red + (wave * 2 + 1) * NT + 4 * q) = q4;
-            }
+            for (int j = 0; j < 8; ++j) t_ += pr_[j * 64];          // lanes q + 8 j
+            red[(wave * 2 + wh_) * NT + c_] = t_;
         }
         pend_tile = cur.tile_lin; pend_co0 = co0;
 #if PULPO_W3_STAMPS
