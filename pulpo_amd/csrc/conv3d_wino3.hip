@@ -17,7 +17,8 @@
 //   BatchNorm-backward sums (BNR) as in the (y, x) kernel's fast path.
 //
 // Whole tiles only (D % 4 == 0, H % 8 == 0, W % 8 == 0), channels-last 16-byte aligned operands, Cin % 8 == 0, Cout % 32 == 0, at least 256 work
-// items: every such layer from 32 reduction channels up (pulpo_conv3d_k3_algo = 3; PULPO_CONV_WINO3=0 / PULPO_CONV_WINO3_MINK=<k> move the policy).
+// items: every such layer from 16 reduction channels up (pulpo_conv3d_k3_algo = 3; 32 until the end of round 4 - with the leaner tile head and epilogue
+// two chunks per tile pay too: 16 -> 96 at 80^3 0.242 -> 0.213 ms; PULPO_CONV_WINO3=0 / PULPO_CONV_WINO3_MINK=<k> move the policy).
 // What was measured while it was built: an image transformed along x AND z at staging time (two rows per step instead of
 // four) multiplies faster (bare loop 0.31 against 0.34 ms at 64 -> 64 / 80^3) but its staging - eight loads, 32 combinations and a second
 // item for a quarter of the threads - cost 20 - 24 % against 8 - 10 % here; wave-uniform branches around staging loads cost 15 % (every
@@ -557,7 +558,7 @@ int wino3_enabled() {                                   // PULPO_CONV_WINO3=0: t
 }
 int wino3_min_k() {                                     // PULPO_CONV_WINO3_MINK: smallest reduction-channel count that takes this kernel
     static int k = -1;
-    if (k < 0) { const char* e = getenv("PULPO_CONV_WINO3_MINK"); k = e ? atoi(e) : 32; }
+    if (k < 0) { const char* e = getenv("PULPO_CONV_WINO3_MINK"); k = e ? atoi(e) : 16; }
     return k < 16 ? 16 : k;                             // (at least two chunks per tile: the statistics' deferred flush counts on a second chunk barrier)
 }
 

@@ -45,9 +45,11 @@ def test_library_exports_every_declared_symbol():
     assert lib.query("pulpo_conv3d_k3_stat_tiles", 2, 32, 32, 32) == 2 * 8 * 4 * 4
     assert lib.query("pulpo_conv3d_k3_stat_tiles", 1, 10, 10, 10) == 5 * 2 * 2             # 2x8x8 otherwise
     assert lib.query("pulpo_conv3d_k3_packed_bf16_elems", 48, 32) == 2 * 27 * 64 * 32
-    assert lib.query("pulpo_conv3d_k3_algo", 1, 40, 40, 40, 24, 128) == 2 and lib.query("pulpo_conv3d_k3_algo", 1, 10, 10, 10, 192, 192) == 2      # (10^3: split-K pipelined kernel)
-    # F(2x2x2,3x3x3): whole 4x8x8 tiles, >= 32 reduction channels (multiple of 8), couts a multiple of 32, >= 256 work items
-    assert lib.query("pulpo_conv3d_k3_algo", 1, 160, 160, 160, 32, 32) == 3 and lib.query("pulpo_conv3d_k3_algo", 1, 80, 80, 80, 16, 96) == 2
+    assert lib.query("pulpo_conv3d_k3_algo", 1, 40, 40, 40, 12, 128) == 2 and lib.query("pulpo_conv3d_k3_algo", 1, 10, 10, 10, 192, 192) == 2      # (10^3: split-K pipelined kernel)
+    assert lib.query("pulpo_conv3d_k3_algo", 1, 40, 40, 40, 24, 128) == 3
+    # F(2x2x2,3x3x3): whole 4x8x8 tiles, >= 16 reduction channels (multiple of 8), couts a multiple of 32, >= 256 work items
+    assert lib.query("pulpo_conv3d_k3_algo", 1, 160, 160, 160, 32, 32) == 3 and lib.query("pulpo_conv3d_k3_algo", 1, 80, 80, 80, 16, 96) == 3
+    assert lib.query("pulpo_conv3d_k3_algo", 1, 80, 80, 80, 8, 96) == 2
     assert lib.query("pulpo_conv3d_k3_algo", 1, 40, 40, 40, 64, 128) == 3 and lib.query("pulpo_conv3d_k3_algo", 1, 80, 80, 80, 96, 96) == 3
     assert lib.query("pulpo_conv3d_k3_algo", 1, 80, 80, 80, 96, 16) == 2 and lib.query("pulpo_conv3d_k3_algo", 1, 20, 20, 20, 192, 192) == 2
     assert lib.query("pulpo_conv3d_k3_algo", 1, 44, 40, 40, 64, 64) == 3 and lib.query("pulpo_conv3d_k3_algo", 1, 40, 44, 40, 64, 64) == 2
