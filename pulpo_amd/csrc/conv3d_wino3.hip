@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) tot += red[(w * 2 + which) * NT + c];
-            a.stats[((long)pend_tile * 2 + which) * a.Cout + pend_co0 + c] = tot;
+            if (pend_co0 + c < a.Cout) a.stats[((long)pend_tile * 2 + which) * a.Cout + pend_co0 + c] = tot;
         }
         pend_tile = -1;
     };
@@ -460,7 +460,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
             const int gz = z0 + 2 * vzb + oz, gy = y0 + 2 * vyb, gx = x0 + 2 * vxb + ox;
             const long vox = (long)(gz * a.H + gy) * a.W + gx;
             float4 yv0 = zero4, yv1 = zero4;
-            if (BNR) {
+            const bool qok = co0 + 4 * q < a.Cout;     // (a partly empty cout tile: channel quads beyond the tensor are neither read nor stored)
+            if (BNR && qok) {
                 yv0 = *reinterpret_cast<const float4*>(bn_b + vox * a.bn_y_ps);
                 yv1 = *reinterpret_cast<const float4*>(bn_b + (vox + a.W) * a.bn_y_ps);
             }
@@ -498,8 +499,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
                 v1 = make_float4(act(v1.x, sc4.x, sh4.x), act(v1.y, sc4.y, sh4.y), act(v1.z, sc4.z, sh4.z), act(v1.w, sc4.w, sh4.w));
             }
             float* obase = out_b + co0 + 4 * q;
-            *reinterpret_cast<float4*>(obase + vox * a.out_ps) = v0;
-            *reinterpret_cast<float4*>(obase + (vox + a.W) * a.out_ps) = v1;
+            if (qok) {
+                *reinterpret_cast<float4*>(obase + vox * a.out_ps) = v0;
+                *reinterpret_cast<float4*>(obase + (vox + a.W) * a.out_ps) = v1;
+            }
 #if PULPO_W3_STAMPS
             if (oz == 0) W3_NOW(t_e2);
 #endif
@@ -568,9 +571,12 @@ namespace pulpo_conv {
 
 // shapes the F(2x2x2,3x3x3) kernel takes: whole 4 x 8 x 8 tiles, K % 8 == 0, N % 32 == 0, at least 256 work items (one per CU)
 int wino3_shape_ok(int B, int D, int H, int W, int K, int N) {
-    if (!wino3_enabled() || K < wino3_min_k() || K % Q_CH != 0 || N % Q_NT != 0 || 3 * N > Q_TAB) return 0;
+    // (output channels: a multiple of 4; a cout tile of 32 may be partly empty - the 16-channel data gradient of the feedback layer runs at half
+    //  the tile's columns here as it did in the (y, x) kernel, on 1.5x fewer matrix instructions)
+    const int ncot = (N + Q_NT - 1) / Q_NT;
+    if (!wino3_enabled() || K < wino3_min_k() || K % Q_CH != 0 || N % 4 != 0 || (N % Q_NT != 0 && N < 16) || 3 * ncot * Q_NT > Q_TAB) return 0;
     if (D % 4 != 0 || H % TY != 0 || W % TX != 0) return 0;
-    const long items = (long)B * (D / 4) * (H / TY) * (W / TX) * (N / Q_NT);
+    const long items = (long)B * (D / 4) * (H / TY) * (W / TX) * ncot;
     return items >= 256;
 }
 
@@ -591,7 +597,7 @@ static int fwd_wino3_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t
                           float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, const float* bn_y, int64_t bn_y_bs, int64_t bn_y_ps,
                           const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream) {
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_wino3: null pointer");
-    PULPO_REQUIRE(B > 0 && K > 0 && N > 0 && D > 0 && D % 4 == 0 && H > 0 && H % TY == 0 && W > 0 && W % TX == 0 && K % Q_CH == 0 && N % Q_NT == 0 && 3 * N <= Q_TAB,
+    PULPO_REQUIRE(B > 0 && K > 0 && N > 0 && D > 0 && D % 4 == 0 && H > 0 && H % TY == 0 && W > 0 && W % TX == 0 && K % Q_CH == 0 && N % 4 == 0 && 3 * ((N + Q_NT - 1) / Q_NT) * Q_NT <= Q_TAB,
                   "conv3d_k3_fwd_wino3: shape %dx%dx%d, %d -> %d channels is not whole 4x8x8 tiles of 8 / 32 channels (see pulpo_conv3d_k3_algo)", D, H, W, K, N);
     PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd_wino3: batch statistics are not available from the fused eval-mode epilogue");
     PULPO_REQUIRE(in_cs == 1 && in_ps % 4 == 0 && in_bs % 4 == 0 && (((uintptr_t)in) & 15) == 0 && (long)D * H * W * in_ps * 4 < (1L << 31),
@@ -607,7 +613,7 @@ static int fwd_wino3_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t
     a.bn_y = bn_y; a.bn_y_bs = bn_y_bs; a.bn_y_ps = bn_y_ps; a.bn_coef = bn_coef;
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = K; a.Cout = N; a.NPad = npad(N);
     a.ntz = D / 4; a.nty = H / TY; a.ntx = W / TX;
-    a.ncot = N / Q_NT;
+    a.ncot = (N + Q_NT - 1) / Q_NT;
     a.ksplit = 1; a.part = nullptr;
     a.tile_order = (a.ntx % 4 == 0 && a.nty % 4 == 0 && a.ntz % 4 == 0) ? 1 : 0;
     const long nwork = (long)B * a.ntz * a.nty * a.ntx * a.ncot;

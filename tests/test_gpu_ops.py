@@ -333,10 +333,13 @@ def test_conv3d_vs_oracle(ops, B, Cin, Cout, size, cl):
     assert rel_l2(gb, gref[2]) < 1e-5
 
 
-@pytest.mark.parametrize("Cin,Cout,size", [(2, 32, (64, 64, 64)), (3, 64, (64, 72, 64))])
+@pytest.mark.parametrize("Cin,Cout,size", [(2, 32, (64, 64, 64)), (3, 64, (64, 72, 64)), (32, 48, (32, 32, 32)), (48, 16, (32, 32, 64))])
 def test_narrow_input_unit_training_pass_vs_oracle(ops, Cin, Cout, size):
     """a training-mode ConvUnit on a 2- / 3-channel image at a size the persistent input-layer kernel takes (whole 4x8x8 tiles from 64^3 up):
-    output, running statistics (the kernel's per-tile partial sums, flushed a tile late) and parameter gradients against the oracle in double"""
+    output, running statistics (the kernel's per-tile partial sums, flushed a tile late) and parameter gradients against the oracle in double.
+    Also: 48 and 16 output channels through the F(2x2x2,3x3x3) kernel - cout tiles of 32 that are half empty (statistics and stores masked)."""
+    if Cin > 4:
+        assert ops.lib.query("pulpo_conv3d_k3_algo", 2, *size, Cin, Cout) == 3
     import src.network_blocks as nb
     gen = torch.Generator().manual_seed(7 * Cin + Cout)
     torch.manual_seed(11)
@@ -485,17 +488,19 @@ def test_conv3d_winograd_kernel_vs_oracle(ops, B, Cin, Cout, size):
     (ragged depth tile: pipelined kernel with split-K only)"""
     from pulpo_amd._lib import lib
     # F(2x2x2,3x3x3) (algo 3, conv3d_k3_wino3_mfma) where the volume is whole 4x8x8 tiles, the GEMM has >= 16 reduction channels (a
-    # multiple of 8) and a multiple of 32 output channels and there are >= 256 work items - forward and / or data gradient of the last
+    # multiple of 8) and a multiple of 4 (>= 16) output channels - cout tiles of 32, the last one possibly partly empty - and there are >= 256 work items - forward and / or data gradient of the last
     # five cases, of the two 64^3 cases and the data gradient of 16 -> 96; F(2x2,3x3) (algo 2) everywhere else
     whole = size[0] % 4 == 0 and size[1] % 8 == 0 and size[2] % 8 == 0
     items = B * (size[0] // 4) * (size[1] // 8) * (size[2] // 8)
-    expect = lambda K, N: 3 if (whole and K >= 16 and K % 8 == 0 and N % 32 == 0 and items * (N // 32) >= 256) else 2
+    expect = lambda K, N: 3 if (whole and K >= 16 and K % 8 == 0 and N % 4 == 0 and (N % 32 == 0 or N >= 16) and items * ((N + 31) // 32) >= 256) else 2
     assert lib.query("pulpo_conv3d_k3_algo", B, *size, Cin, Cout) == expect(Cin, Cout)
     assert lib.query("pulpo_conv3d_k3_algo", B, *size, Cout, Cin) == expect(Cout, Cin)
     if (Cin, Cout) in ((64, 64), (96, 96), (160, 64), (64, 128)):
         assert expect(Cin, Cout) == 3 and expect(Cout, Cin) == 3
     if (Cin, Cout) == (72, 32):
-        assert expect(Cin, Cout) == 3 and expect(Cout, Cin) == 2          # (72 reduction channels forward; 32 in the data gradient)
+        assert expect(Cin, Cout) == 3 and expect(Cout, Cin) == 3          # (data gradient: 72 output channels = three cout tiles, the last a quarter full)
+    if (Cin, Cout) == (16, 96):
+        assert expect(Cin, Cout) == 3 and expect(Cout, Cin) == 3          # (16 reduction channels = two chunks; 16 output channels = half a cout tile)
     assert lib.query("pulpo_conv3d_k3_wino2_pipelined", *size, Cin, Cin) == int(Cin % 8 == 0)
     if (B, Cin, size) == (1, 288, (20, 20, 20)):                     # few tiles, many reduction channels: three split-K work items per tile
         assert lib.query("pulpo_conv3d_k3_fwd_wino2_scratch_floats", B, *size, Cin, Cout) == 3 * B * 8000 * Cout

@@ -51,7 +51,8 @@ def test_library_exports_every_declared_symbol():
     assert lib.query("pulpo_conv3d_k3_algo", 1, 160, 160, 160, 32, 32) == 3 and lib.query("pulpo_conv3d_k3_algo", 1, 80, 80, 80, 16, 96) == 3
     assert lib.query("pulpo_conv3d_k3_algo", 1, 80, 80, 80, 8, 96) == 2
     assert lib.query("pulpo_conv3d_k3_algo", 1, 40, 40, 40, 64, 128) == 3 and lib.query("pulpo_conv3d_k3_algo", 1, 80, 80, 80, 96, 96) == 3
-    assert lib.query("pulpo_conv3d_k3_algo", 1, 80, 80, 80, 96, 16) == 2 and lib.query("pulpo_conv3d_k3_algo", 1, 20, 20, 20, 192, 192) == 2
+    assert lib.query("pulpo_conv3d_k3_algo", 1, 80, 80, 80, 96, 16) == 3 and lib.query("pulpo_conv3d_k3_algo", 1, 20, 20, 20, 192, 192) == 2     # (a half-empty cout tile)
+    assert lib.query("pulpo_conv3d_k3_algo", 1, 80, 80, 80, 96, 12) == 2 and lib.query("pulpo_conv3d_k3_algo", 1, 80, 80, 80, 96, 18) == 2
     assert lib.query("pulpo_conv3d_k3_algo", 1, 44, 40, 40, 64, 64) == 3 and lib.query("pulpo_conv3d_k3_algo", 1, 40, 44, 40, 64, 64) == 2
     assert lib.query("pulpo_conv3d_k3_packed_wino3_floats", 64, 32) == 8 * 64 * 8 * 64
     assert lib.query("pulpo_conv3d_k3_algo", 1, 10, 10, 10, 20, 12) == 0 and lib.query("pulpo_conv3d_k3_algo", 1, 6, 6, 6, 192, 192) == 0
