@@ -318,6 +318,9 @@ def main():
         raise SystemExit(launch_ranks(args))           # (nothing has touched the GPU in this process)
     if args.plumbing_only:
         return plumbing_only(args)
+    # (a full Python garbage collection costs 60 - 100 ms of host time every few steps - a sixth of the short bf16 steps: the stepper moves
+    #  what is alive after its second step to the collector's permanent generation.  Opt-in; this process is nothing but the benchmark.)
+    os.environ.setdefault("PULPO_GC_FREEZE", "1")
     from pulpo_amd import dp, ops
     from pulpo_amd._lib import lib
     local = dp.init_from_env(os.environ.get("PULPO_DIST_BACKEND", "nccl"))     # (gloo: rehearsal of the multi-rank path on a one-GPU box)
@@ -431,9 +434,12 @@ def main():
     ops.CONV_TRACE_STRIDE_USED = ops.CONV_TRACE_STRIDE
     if stepper is not None and world > 1:
         stepper.exchange_events = []        # HIP events around the waits for the gradient exchange: what of it is NOT hidden under the backward pass
+    host_enq = []                           # host time spent inside each step's enqueue (no synchronisation inside a step: the host runs ahead)
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        th = time.perf_counter()
         loss = one_step()
+        host_enq.append(time.perf_counter() - th)
     barrier()
     dt = time.perf_counter() - t0
     trace, ops.CONV_TRACE = ops.CONV_TRACE, None
@@ -519,6 +525,7 @@ def main():
                 k[2] += s_.elapsed_time(e_) * 1e-3
                 k[3] += nb
             dom = max(per_kernel.items(), key=lambda kv: kv[1][2])
+            side_stream = bool(stepper is not None and stepper.wgrad_on_side_stream())
             n, fl, sec, nbytes = dom[1]
             peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom[0] else PEAK_FP32_MFMA_TFLOPS
             # FLOP the kernel ISSUES on the matrix pipe per algorithmic (direct-convolution) FLOP: the Winograd forms evaluate the
@@ -541,8 +548,13 @@ def main():
                     fls, secs = sum(a_ for a_, _ in ts), sum(b_ for _, b_ in ts)
                     roof["serialized"] = {"achieved": fls * issued / secs / 1e12, "frac": fls * issued / secs / 1e12 / peak,
                                           "effective_TFLOPs": fls / secs / 1e12, "avg_launch_ms": secs / len(ts) * 1e3, "launches": len(ts),
-                                          "note": "same kernel, weight-gradient stream overlap switched off (2 untimed steps)"}
-                roof["overlap_note"] = "timed-region brackets include CU sharing with the weight-gradient kernels on the second stream"
+                                          "note": ("same kernel with the weight gradients queued in line instead of on the second stream (2 untimed steps)"
+                                                   if side_stream else
+                                                   "the same brackets repeated in 2 untimed steps with every launch bracketed; the weight gradients already run in "
+                                                   "line in the timed region (stepper.wgrad_side_stream = false), so this is a repeat measurement, not a different schedule")}
+            roof["overlap_note"] = ("timed-region brackets include CU sharing with the weight-gradient kernels on the second stream" if side_stream else
+                                    "nothing overlaps in this step: weight gradients run in line on the main stream (stepper.wgrad_side_stream = false), "
+                                    "every bracket is the kernel alone on the machine")
             if is160_cfg and not bf16:
                 roof.update(pmc_traffic(dom[0]))
                 if roof.get("traffic"):
@@ -559,6 +571,24 @@ def main():
             hbm_roof = {name: {"bound": "hbm", "achieved": v[1] / v[2] / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": v[1] / v[2] / 8.0e12,
                                "launches_sampled": v[0], "avg_launch_ms": v[2] / v[0] * 1e3} for name, v in fam.items()}
         is160 = is160_cfg
+        # ---- where the step's time goes, from this run's own HIP events: matrix kernels (sampled brackets of the timed region, scaled by the
+        # sampling stride), the bracketed memory-bound classes (every launch of the two extra untimed steps), the host's enqueue time
+        time_split = None
+        if trace and not infer:
+            ms_step = dt / args.steps * 1e3
+            matrix_ms = sum(v[2] for v in per_kernel.values()) * ops.CONV_TRACE_STRIDE_USED / args.steps * 1e3
+            hbm_ms = (sum(s_.elapsed_time(e_) for _, _, s_, e_ in hbm_trace) / 2.0) if hbm_trace else None
+            enq = sorted(host_enq)
+            overlapped = bool(stepper is not None and stepper.wgrad_on_side_stream())
+            time_split = {"ms_per_step": ms_step, "matrix_ms_per_step": matrix_ms,
+                          "non_matrix_ms_per_step": None if overlapped else ms_step - matrix_ms,
+                          "hbm_classes_ms_per_step": hbm_ms,
+                          "host_enqueue_ms_per_step": enq[len(enq) // 2] * 1e3 if enq else None,
+                          "note": "matrix = every 3x3x3 convolution / weight-gradient launch (1-in-%d sampled HIP-event brackets of the timed region, scaled); "
+                                  "non_matrix = step - matrix (%s); hbm_classes = sum of the brackets of the memory-bound kernel classes listed under "
+                                  "hbm_rooflines in two extra untimed steps (finalize / column-sum / torch glue launches and kernel boundaries are in "
+                                  "non_matrix but not in hbm_classes); host_enqueue = median host time inside one step's enqueue (timed region)"
+                                  % (ops.CONV_TRACE_STRIDE_USED, "weight gradients on a second stream: not defined" if overlapped else "nothing overlaps: weight gradients in line")}
         out = {
             "metric": ("volume-pairs/sec, 8-sample MC uncertainty maps per pair, " if args.mode == "mc8" else "volume-pairs/sec inference (predict_deterministic), " if infer
                        else "volume-pairs/sec fwd+bwd, ") + ("160^3 " if size == [160, 160, 160] else f"{size[0]}x{size[1]}x{size[2]} ") + prec_name,
@@ -579,6 +609,7 @@ def main():
             "parity_note": "outputs / losses within 1e-4 of the CPU oracle at this size; whole-step parameter gradients on the statistical criterion of "
                            "DESIGN.md section 4 (6e-3 per parameter at 160^3 against SURVEY 8(c)'s suggested 5e-3, 1e-2 on the 32^3 reference golden against 1e-3)",
             "roofline": roof,
+            "time_split": time_split,
             "hbm_rooflines": hbm_roof,
             "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
             "conv_kernels": {k: {"launches_sampled": v[0], "effective_TFLOPs": v[1] / v[2] / 1e12, "matrix_pipe_TFLOPs": v[1] * ISSUED_FRACTION(k) / v[2] / 1e12,

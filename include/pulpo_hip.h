@@ -295,9 +295,11 @@ int pulpo_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
  * The same convolution (src/network_blocks.py:23, forward and data gradient) with minimal filtering along z, y AND x: 64 products per 2x2x2
  * output block instead of 216 (1.5x fewer matrix instructions than the (y, x) form above), all fp32, coefficients +-1 and 1/2 (results differ
  * from the direct kernel by fp32 rounding only).  pulpo_conv3d_k3_algo() answers 3 for the shapes it takes: whole 4x8x8 tiles (D % 4 == 0,
- * H % 8 == 0, W % 8 == 0), K % 8 == 0 and K >= 64, N % 32 == 0, at least 256 (tile, 32-channel) work items; operands channels-last and 16-byte
- * aligned (the caller guarantees that; the entry point refuses anything else).  Own weight packing (kind 4 of PulpoPackJob); stats / coef / bias
- * and the _bnred form as for the (y, x) kernel. */
+ * H % 8 == 0, W % 8 == 0) of a volume of at least 20^3 voxels (where pulpo_conv3d_k3_stat_tiles() counts 4-deep tiles too), K % 8 == 0 and
+ * K >= 16 (two 8-channel chunks: the entry point refuses fewer), N % 4 == 0 and N >= 16 (cout tiles of 32, the last one may be partly empty), at
+ * least 256 (tile, cout tile) work items; operands channels-last and 16-byte aligned (the caller guarantees that; the entry point refuses
+ * anything else).  stats / part: pulpo_conv3d_k3_stat_tiles(B, D, H, W) rows of 2 * N floats, one row per 4x8x8 tile.  Own weight packing
+ * (kind 4 of PulpoPackJob); stats / coef / bias and the _bnred form as for the (y, x) kernel. */
 size_t pulpo_conv3d_k3_packed_wino3_floats(int K, int N);
 int pulpo_conv3d_k3_pack_weight_wino3(const float* w /*[Cout][Cin][3][3][3]*/, float* wp, int Cin, int Cout, int dgrad, void* stream);
 int pulpo_conv3d_k3_fwd_wino3(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef,

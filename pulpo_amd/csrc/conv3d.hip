@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, TZv == 4 ? 3 : 2) void conv3d_k3_mfma(ConvArgs
 //     buffer_store_dwordx4 of 8 voxels x 128 bytes per wave instead of 32 dword stores); statistics' partial sums are added behind the next
 //     tile's barrier.
 template <int CH>
-constexpr size_t smallk_pw_lds_bytes() { return (size_t)(2 * (((TZ + 4) * HY * HX * (CH + 1) + 3) & ~3) + 4 * 64 * 32 + 4 * 2 * 32) * sizeof(float); }
+constexpr size_t smallk_pw_lds_bytes() { return (size_t)(2 * (((TZ + 4) * HY * HX * (CH + 1) + 3) & ~3) + 4 * 64 * 32 + 2 * 4 * 2 * 32) * sizeof(float); }
 
 template <int CH>
 __global__ __launch_bounds__(256, CH == 2 ? 3 : 2) void conv3d_k3_smallk_pw(ConvArgs a) {
@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256, CH == 2 ? 3 : 2) void conv3d_k3_smallk_pw(Conv
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                                   // [2][PHV][CP]
     float* xch_all = smem + 2 * XS;                     // [4 waves][64 voxels][32 channels]: the epilogue's exchange images
-    float* red = xch_all + 4 * 64 * 32;                 // [4 waves][2][32]
+    float* red_all = xch_all + 4 * 64 * 32;             // [tile parity][4 waves][2][32]: wave 0 reads a tile's sums behind the NEXT tile's barrier while the
+                                                        // other waves may already be writing that tile's - into the other half
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kk = lane >> 5;
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(256, CH == 2 ? 3 : 2) void conv3d_k3_smallk_pw(Conv
     auto flush_stats = [&]() {
         if (a.stats != nullptr && pend_tile >= 0 && tid < 2 * NT) {
             const int which = tid / NT, c = tid - which * NT;
+            const float* red = red_all + (buf ^ 1) * (4 * 2 * NT);      // (buf has been flipped since the pending tile wrote its sums)
             const float tot = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] + red[(2 * 2 + which) * NT + c] + red[(3 * 2 + which) * NT + c];
             a.stats[((long)pend_tile * 2 + which) * a.Cout + pend_co0 + c] = tot;
         }
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(256, CH == 2 ? 3 : 2) void conv3d_k3_smallk_pw(Conv
         if (a.stats != nullptr) {
             s += __shfl_xor(s, 32, 64);
             q += __shfl_xor(q, 32, 64);
+            float* red = red_all + buf * (4 * 2 * NT);
             if (lane < 32) { red[(wave * 2 + 0) * NT + i] = s; red[(wave * 2 + 1) * NT + i] = q; }
             pend_tile = cur.tile_lin; pend_co0 = cur.co0;
         }

@@ -576,6 +576,8 @@ int wino3_shape_ok(int B, int D, int H, int W, int K, int N) {
     const int ncot = (N + Q_NT - 1) / Q_NT;
     if (!wino3_enabled() || K < wino3_min_k() || K % Q_CH != 0 || N % 4 != 0 || (N % Q_NT != 0 && N < 16) || 3 * ncot * Q_NT > Q_TAB) return 0;
     if (D % 4 != 0 || H % TY != 0 || W % TX != 0) return 0;
+    // the BatchNorm statistics rows are counted by pulpo_conv3d_k3_stat_tiles(), i.e. with conv_tz(): this kernel writes one row per 4-deep tile
+    if (conv_tz(D, H, W) != 4) return 0;
     const long items = (long)B * (D / 4) * (H / TY) * (W / TX) * ncot;
     return items >= 256;
 }
@@ -599,6 +601,8 @@ static int fwd_wino3_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_wino3: null pointer");
     PULPO_REQUIRE(B > 0 && K > 0 && N > 0 && D > 0 && D % 4 == 0 && H > 0 && H % TY == 0 && W > 0 && W % TX == 0 && K % Q_CH == 0 && N % 4 == 0 && 3 * ((N + Q_NT - 1) / Q_NT) * Q_NT <= Q_TAB,
                   "conv3d_k3_fwd_wino3: shape %dx%dx%d, %d -> %d channels is not whole 4x8x8 tiles of 8 / 32 channels (see pulpo_conv3d_k3_algo)", D, H, W, K, N);
+    PULPO_REQUIRE(K >= 2 * Q_CH, "conv3d_k3_fwd_wino3: at least two 8-channel chunks per tile (%d reduction channels given): the staging runs two chunks ahead", K);
+    PULPO_REQUIRE(!stats || conv_tz(D, H, W) == 4, "conv3d_k3_fwd_wino3: %dx%dx%d is tiled 2-deep by pulpo_conv3d_k3_stat_tiles(); this kernel writes 4-deep statistics rows", D, H, W);
     PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd_wino3: batch statistics are not available from the fused eval-mode epilogue");
     PULPO_REQUIRE(in_cs == 1 && in_ps % 4 == 0 && in_bs % 4 == 0 && (((uintptr_t)in) & 15) == 0 && (long)D * H * W * in_ps * 4 < (1L << 31),
                   "conv3d_k3_fwd_wino3: the operand must be channels-last, 16-byte aligned and smaller than 2 GiB per batch element");

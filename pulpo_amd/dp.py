@@ -163,9 +163,11 @@ def _freeze_garbage_collector() -> None:
     moved to the collector's permanent generation (gc.freeze()), so that a full collection only walks what later steps allocate.  A step
     creates enough container objects for a full collection every few steps, and one over the whole heap takes 60 - 100 ms of HOST time:
     invisible while the GPU is 20 ms per step behind the host (160^3 fp32), a third of the step time in the bf16 modes, whose steps the host
-    barely stays ahead of (measured at 192x224x160 / T6 / L5: 31.8 -> 28.0 ms per step).  PULPO_GC_FREEZE=0 leaves the collector alone."""
+    barely stays ahead of (measured at 192x224x160 / T6 / L5: 31.8 -> 28.0 ms per step).
+    OPT-IN (a process-wide side effect a library call should not have by default: reference cycles through the frozen objects are never
+    collected afterwards): PULPO_GC_FREEZE=1 in the environment (bench.py sets it) or DataParallelStepper(freeze_gc=True)."""
     global _GC_FROZEN
-    if _GC_FROZEN or os.environ.get("PULPO_GC_FREEZE", "1") == "0":
+    if _GC_FROZEN:
         return
     import gc
     gc.collect()
@@ -215,8 +217,12 @@ class DataParallelStepper:
     remaining, parameter-poor part of the backward pass.  RCCL orders the collective after the kernels already enqueued on
     the compute stream, and the Adam step waits for all buckets."""
 
-    def __init__(self, model: nn.Module, lr: Optional[float] = None, overlap: bool = True, async_wgrad: bool = True):
+    def __init__(self, model: nn.Module, lr: Optional[float] = None, overlap: bool = True, async_wgrad: bool = True,
+                 freeze_gc: Optional[bool] = None):
         self.model = model
+        # freeze_gc: after the second step move everything alive to the garbage collector's permanent generation (see
+        # _freeze_garbage_collector); None = the environment's PULPO_GC_FREEZE == "1" (off unless asked for)
+        self.freeze_gc = (os.environ.get("PULPO_GC_FREEZE", "0") == "1") if freeze_gc is None else bool(freeze_gc)
         # weight gradients on a second stream (ops.ASYNC_WGRAD_STREAM): overlaps them with the BatchNorm backward passes
         dev0 = next(model.parameters()).device
         self.async_wgrad = bool(async_wgrad) and dev0.type == "cuda" and os.environ.get("PULPO_ASYNC_WGRAD", "1") != "0"
@@ -306,7 +312,7 @@ class DataParallelStepper:
         if reduced_elsewhere:
             self.opt.step(1.0)
             self._steps_done += 1
-            if self._steps_done == 2:
+            if self._steps_done == 2 and self.freeze_gc:
                 _freeze_garbage_collector()
             return
         ev = None
@@ -325,7 +331,7 @@ class DataParallelStepper:
             self.exchange_events.append(ev)
         self.opt.step(1.0 / world())
         self._steps_done += 1
-        if self._steps_done == 2:
+        if self._steps_done == 2 and self.freeze_gc:
             _freeze_garbage_collector()
 
     def step(self, batch) -> torch.Tensor:

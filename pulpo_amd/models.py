@@ -271,7 +271,14 @@ class PULPo(ABC, LightningModule):
         first = next(self.parameters())
         if not first.is_cuda or os.environ.get("PULPO_LIGHTNING_FAST", "1") == "0":
             self._pulpo_optimizer = None
-            return torch.optim.Adam(self.parameters(), lr=self.hparams.lr)     # (a model that is not on the GPU cannot step anyway: construction only)
+            if not first.is_cuda:
+                # a strategy that builds its optimizers BEFORE it moves the model to the device would end up here for good: say so instead of
+                # silently handing it the slow loop (plain autograd + torch.optim.Adam, every operator still a HIP kernel)
+                import warnings
+                warnings.warn("pulpo_amd: configure_optimizers() was called while the parameters are not on a GPU - returning plain torch.optim.Adam "
+                              "(no flat arena, no fused update, no direct-to-arena gradients).  Move the model to the device first and call "
+                              "configure_optimizers() again for the fast step.", RuntimeWarning, stacklevel=2)
+            return torch.optim.Adam(self.parameters(), lr=self.hparams.lr)
         from .dp import ArenaAdam
         opt = ArenaAdam(self, lr=float(self.hparams.lr))
         self._pulpo_optimizer = opt                # (a plain attribute: neither a sub-module nor part of the state dict)
@@ -284,7 +291,12 @@ class PULPo(ABC, LightningModule):
     def _ddp_wrapped(self) -> bool:
         """is a DistributedDataParallel wrapper (Lightning's ddp strategies) reducing the gradients?  It needs them from autograd's
         AccumulateGrad nodes, so the direct-to-arena path is off and the optimizer neither exchanges nor rescales them."""
-        tr = getattr(self, "_trainer", None) or getattr(self, "trainer", None)
+        tr = getattr(self, "_trainer", None)           # (pytorch_lightning >= 1.8: `trainer` is a property that RAISES while no Trainer is attached)
+        if tr is None:
+            try:
+                tr = getattr(self, "trainer", None)
+            except RuntimeError:
+                tr = None                              # no Trainer: nothing wraps the module
         wrapped = getattr(getattr(tr, "strategy", None), "model", None)
         return isinstance(wrapped, torch.nn.parallel.DistributedDataParallel)
 

@@ -376,6 +376,36 @@ def test_narrow_input_unit_training_pass_vs_oracle(ops, Cin, Cout, size):
         assert rel_l2(got, want) <= bound, (nme, rel_l2(got, want), bound)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,size", [(4, 64, 128, (16, 16, 16)), (3, 32, 192, (16, 16, 16)), (2, 32, 256, (16, 16, 16))])
+def test_training_statistics_on_small_volumes_with_many_work_items(ops, B, Cin, Cout, size):
+    """whole 4x8x8 tiles, >= 256 (tile, cout tile) work items, but fewer than 20^3 voxels: pulpo_conv3d_k3_stat_tiles() counts 2-deep tiles there
+    while the F(2x2x2,3x3x3) kernel writes one statistics row per 4-deep tile (round-4 advisor finding: half of the statistics buffer stayed
+    uninitialised and bn_fwd_finalize summed it).  The policy must not pick that kernel for such a volume, its entry point must refuse the call,
+    and the training-mode unit's output and running statistics must match the oracle in double."""
+    assert ops.lib.query("pulpo_conv3d_k3_algo", B, *size, Cin, Cout) != 3
+    import src.network_blocks as nb
+    gen = torch.Generator().manual_seed(3 * Cin + Cout + B)
+    torch.manual_seed(5)
+    unit = nb.ConvUnit(list(size), Cin, Cout)
+    sd = {"u." + k: v.detach().clone().double() if v.is_floating_point() else v.clone() for k, v in unit.state_dict().items()}
+    x = torch.randn(B, Cin, *size, generator=gen)
+    zr = O.conv_unit(x.double(), sd, "u", training=True)
+    unit = unit.cuda().train()
+    z = unit(x.cuda())
+    assert rel_l2(z, zr) < 3e-6
+    close(unit._op[1].running_mean, sd["u._op.1.running_mean"].float(), atol=1e-6, rtol=1e-5)
+    close(unit._op[1].running_var, sd["u._op.1.running_var"].float(), atol=1e-6, rtol=1e-5)
+    # the entry point itself refuses statistics rows it cannot count
+    import ctypes
+    xc = x.cuda().contiguous(memory_format=torch.channels_last_3d)
+    y = ops.new_cl(B, Cout, *size, "cuda")
+    wp = torch.empty(ops.lib.query("pulpo_conv3d_k3_packed_wino3_floats", Cin, Cout), device="cuda")
+    stats = torch.empty(ops.lib.query("pulpo_conv3d_k3_stat_tiles", B, *size) * 2 * Cout, device="cuda")
+    with pytest.raises(Exception, match="statistics rows"):
+        ops.lib.call("pulpo_conv3d_k3_fwd_wino3", ctypes.c_void_p(xc.data_ptr()), *ops.grid_strides(xc), ctypes.c_void_p(wp.data_ptr()), None, None, 0.2,
+                     ctypes.c_void_p(y.data_ptr()), *ops.grid_strides(y), ctypes.c_void_p(stats.data_ptr()), B, *size, Cin, Cout, ops._stream())
+
+
 @pytest.mark.parametrize("B,Cin,Cout,size", [(1, 32, 32, (64, 64, 64)), (2, 16, 96, (10, 20, 28)), (1, 64, 32, (6, 12, 17)), (1, 8, 8, (4, 16, 16)), (1, 40, 24, (12, 10, 9)),
                                              (1, 32, 64, (9, 16, 16)), (3, 96, 32, (2, 24, 24))])
 def test_weight_gradient_winograd_in_all_three_axes_vs_oracle(ops, B, Cin, Cout, size):

@@ -75,8 +75,8 @@ def check_outputs(outs, g, prefix, atol=1e-4):
 STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16", "step_fullres_T3L2_n2_16", "step_T3L2_n8_32", "step_cp0_T3L2_n2_16"]
 
 
-# (case, forward / data-gradient kernel): None = the library's per-shape default (F(2x2,3x3) Winograd where eligible, which on these
-# fixtures is the 32^3 case only); that case is also pinned with the direct kernels forced
+# (case, forward / data-gradient kernel): None = the library's per-shape default (the Winograd kernels - F(2x2x2,3x3x3) on whole 4x8x8 tiles,
+# F(2x2,3x3) elsewhere - where eligible, which on these fixtures is the 32^3 case only); that case is also pinned with the direct kernels forced
 STEP_ALGO_CASES = [(c, None) for c in STEP_CASES] + [("step_T3L2_n8_32", "direct")]
 
 
@@ -691,8 +691,8 @@ def _write_parity_report(vs32, e_gpu, e_ref):
 
 
 def test_headline_160_step_vs_cpu_oracle(api):
-    """The metric's workload at FULL size (160^3, T5/L4, n0 = 32, B = 1), default kernel selection (F(2x2,3x3) Winograd forward / data
-    gradient, F(2x2,3x3) weight gradient), against ONE step of the CPU oracle in fp32 (the reference's arithmetic; ~11 s) and in fp64
+    """The metric's workload at FULL size (160^3, T5/L4, n0 = 32, B = 1), default kernel selection (F(2x2x2,3x3x3) Winograd forward / data
+    gradient / weight gradient on the 160^3 - 40^3 levels, the (y, x) form F(2x2,3x3) on the 20^3 / 10^3 levels), against ONE step of the CPU oracle in fp32 (the reference's arithmetic; ~11 s) and in fp64
     (the ground truth for gradients; ~30 s): every output dictionary atol 1e-4 (scaled by the tensor's magnitude), loss terms rtol 1e-4.
     Gradients: at this size every fp32 evaluation flips LeakyReLU slopes against any other (~6e8 activations) and carries the
     summation noise of 4e6-voxel reductions (the reference's own fp32-vs-fp64 envelope grows with the volume), so the
