@@ -34,7 +34,7 @@ extern "C" {
  * PULPO_ABI_VERSION is bumped whenever a prototype below changes its argument list or a buffer contract, or an entry point is removed
  * (history: INTEGRATION.md "ABI history").  pulpo_abi_version() returns the value the library was built with: a client compares it with
  * the header it was compiled against before the first call (pulpo_amd/_lib.py does). */
-#define PULPO_ABI_VERSION 3
+#define PULPO_ABI_VERSION 4
 int pulpo_abi_version(void);
 const char* pulpo_last_error(void);
 
@@ -349,6 +349,34 @@ int pulpo_feedback_up2_fwd_t(const float* const* srcs /*host array of device ptr
 int pulpo_feedback_up2_bwd_t(const void* gout, int dt, int64_t gops, float* const* gsrcs /*host array, entries may be NULL*/, const int* chans,
                              int nsrc, int B, int Di, int Hi, int Wi, void* stream);
 
+/* ------------------------------------------------------------------------- DETERMINISTIC forms of the backward kernels that add with float atomics (since ABI 4)
+ * The reference's CPU backward is run-to-run deterministic; the plain entry points above add the weight-gradient partial sums
+ * of concurrent workgroups (aten::convolution_backward, src/network_blocks.py:23) and the image-gradient scatter of grid_sampler_3d_backward
+ * (src/network_blocks.py:120, :175) with float atomics, i.e. in arrival order: gradients differ in their last bits from run to run.  These forms
+ * give bit-identical results on every run of the same build (pulpo_amd.ops.set_deterministic / PULPO_DETERMINISTIC=1 routes the operators here):
+ *  - weight gradient: the same kernels, but workgroups that share a (ci tile, co tile) accumulate into separate zeroed copies ("slabs") of the
+ *    packed scratch, which an ordered pass adds up.  slabs: nslab * pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout) floats, 16-byte aligned, any
+ *    content; nslab = pulpo_conv3d_k3_wgrad_det_slabs(Cin, Cout) (a smaller count is accepted and caps the spatial splits of the grid).
+ *  - warp / VecInt backward: every scattered contribution enters a 64-bit fixed-point accumulator (integer adds commute) scaled by the largest
+ *    |upstream gradient| of the pass (2^46 units per that maximum), a second pass converts back.  ws: caller-owned workspace of the queried
+ *    size, any content.
+ *  - F.interpolate backward at ratios other than the exact x2 (src/network_blocks.py:146-150 with other factors, losses.py:313): a gather in fixed
+ *    order instead of the scatter. */
+int pulpo_conv3d_k3_wgrad_det_slabs(int Cin, int Cout);
+int pulpo_conv3d_k3_wgrad_det(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs, int64_t dy_ps,
+                              int64_t dy_cs, float* dw, int accumulate, float* scratch, float* slabs, int nslab, int B, int D, int H, int W,
+                              int Cin, int Cout, void* stream);
+int pulpo_conv3d_k3_wgrad_bf16_det_t(const void* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const void* dy, int64_t dy_bs, int64_t dy_ps,
+                                     int64_t dy_cs, int dt, float* dw, int accumulate, float* scratch, float* slabs, int nslab, int B, int D,
+                                     int H, int W, int Cin, int Cout, void* stream);
+int pulpo_resize_trilinear_scaled_bwd_det(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                          float scale_d, float scale_h, float scale_w, float mult, void* stream);
+size_t pulpo_warp3d_bwd_det_ws_bytes(int B, int C, int Di, int Hi, int Wi);
+int pulpo_warp3d_bwd_det(const float* df, const float* img, const float* gout, float* gdf /*nullable*/, float* gimg /*nullable*/,
+                         void* ws /*nullable when gimg is*/, int B, int C, int Dg, int Hg, int Wg, int Di, int Hi, int Wi, void* stream);
+size_t pulpo_vecint_bwd_det_ws_bytes(int B, int D, int H, int W, int nsteps);
+int pulpo_vecint_bwd_det(const float* work, const float* gout, float* gin, void* ws /*nullable if the query is 0*/, int B, int D, int H, int W,
+                         int nsteps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,8 @@ def _stale(target: str, deps) -> bool:
 def build_library(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h")))
+    # (runtime.hip takes PULPO_ABI_VERSION from the public header: a version bump must rebuild it)
+    hdrs.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "pulpo_hip.h"))
     if not srcs:
         raise RuntimeError("no HIP sources under " + CSRC)
     os.makedirs(OBJ, exist_ok=True)

@@ -687,6 +687,7 @@ struct WgradArgsH {
     float* dwp;                   // zero-initialised fp32 scratch [27][Cin][NPad], accumulated with float atomics
     int B, D, H, W, Cin, Cout, NPad;
     int ntz, nty, ntx, ncit, ncot, nsplit;
+    long split_stride;            // 0, or (deterministic mode) floats between the per-split copies of dwp (see WgradArgs in conv3d_wgrad.hip)
 };
 
 constexpr int WTZ = 2, WMV = WTZ * TY * TX, WHV = (WTZ + 2) * HY * HX;     // 2x8x8 voxel tiles: 8 K=16 steps (one x-row of voxels per half-wave)
@@ -944,7 +945,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16(WgradArgsH a) {
                     const int rg = 32 * (wave + 4 * u) + (r & 3) + 8 * (r >> 2) + 4 * kk;
                     if (rg < rows) {
                         const int tap = rg / Cc, ci = rg - tap * Cc;
-                        atomicAdd(a.dwp + ((long)tap * a.Cin + ci0 + ci) * a.NPad + co, acc[u][r]);
+                        atomicAdd(a.dwp + (long)split * a.split_stride + ((long)tap * a.Cin + ci0 + ci) * a.NPad + co, acc[u][r]);
                     }
                 }
             }
@@ -1107,9 +1108,9 @@ PULPO_API int pulpo_conv3d_k3_fwd_bn_lrelu_bf16(const float* in, int64_t in_bs, 
 /* weight gradient with bf16 operands: dw[Cout][Cin][27] (+)= sum_voxels bf16(in[v + tap - 1][ci]) * bf16(dy[v][co]), fp32 accumulation */
 PULPO_API size_t pulpo_conv3d_k3_wgrad_scratch_floats(int Cin, int Cout);
 
-PULPO_API int pulpo_conv3d_k3_wgrad_bf16_t(const void* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const void* dy, int64_t dy_bs, int64_t dy_ps,
-                                           int64_t dy_cs, int dt, float* dw, int accumulate, float* scratch, int B, int D, int H, int W, int Cin,
-                                           int Cout, void* stream) {
+static int wgrad_bf16_impl(const void* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const void* dy, int64_t dy_bs, int64_t dy_ps,
+                           int64_t dy_cs, int dt, float* dw, int accumulate, float* scratch, float* slabs, int nslab, int B, int D, int H, int W, int Cin,
+                           int Cout, void* stream) {
     PULPO_REQUIRE(in && dy && scratch && (dw || accumulate == 2), "conv3d_k3_wgrad_bf16: null pointer");
     PULPO_REQUIRE_DT(dt, "conv3d_k3_wgrad_bf16");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3d_k3_wgrad_bf16: bad dims");
@@ -1131,10 +1132,18 @@ PULPO_API int pulpo_conv3d_k3_wgrad_bf16_t(const void* in, int64_t in_bs, int64_
     static int wgs = -1;
     if (wgs < 0) { const char* e = getenv("PULPO_WGRAD_BF16_WGS"); wgs = e ? atoi(e) : 256; }
     a.nsplit = std::min(std::max(1, wgs / npair), ntile);
+    if (slabs) a.nsplit = std::min(a.nsplit, nslab);
     const bool deferred = accumulate == 2;                 // see pulpo_conv3d_k3_wgrad
     if (!deferred) {
         hipError_t e = hipMemsetAsync(scratch, 0, pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout) * sizeof(float), st);
         if (e != hipSuccess) return pulpo::fail((int)e, "wgrad_bf16 memset: %s", hipGetErrorString(e));
+    }
+    const size_t base = pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout);
+    a.split_stride = 0;
+    if (slabs) {                                           // deterministic mode, see pulpo_conv3d_k3_wgrad_det
+        a.dwp = slabs; a.split_stride = (long)base;
+        hipError_t e = hipMemsetAsync(slabs, 0, (size_t)a.nsplit * base * sizeof(float), st);
+        if (e != hipSuccess) return pulpo::fail((int)e, "wgrad_bf16 slab memset: %s", hipGetErrorString(e));
     }
     const int g = dt ? 8 : 4;             // channels per 16-byte piece
     const bool vec = (in_cs == 1) && (in_ps % g == 0) && (in_bs % g == 0) && (Cin % g == 0) && (((uintptr_t)in & 15) == 0) &&
@@ -1174,8 +1183,23 @@ PULPO_API int pulpo_conv3d_k3_wgrad_bf16_t(const void* in, int64_t in_bs, int64_
 #undef PULPO_WGRAD_T
 #undef PULPO_WGRAD_H
     int rc = pulpo::check_launch("conv3d_k3_wgrad_bf16");
+    if (rc == 0 && slabs) rc = pulpo_conv::launch_wgrad_slab_reduce(scratch, slabs, a.nsplit, (long)base, st);
     if (rc || deferred) return rc;
     return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
+}
+
+PULPO_API int pulpo_conv3d_k3_wgrad_bf16_t(const void* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const void* dy, int64_t dy_bs, int64_t dy_ps,
+                                           int64_t dy_cs, int dt, float* dw, int accumulate, float* scratch, int B, int D, int H, int W, int Cin,
+                                           int Cout, void* stream) {
+    return wgrad_bf16_impl(in, in_bs, in_ps, in_cs, dy, dy_bs, dy_ps, dy_cs, dt, dw, accumulate, scratch, nullptr, 0, B, D, H, W, Cin, Cout, stream);
+}
+
+// deterministic form of the bf16-operand weight gradient (see pulpo_conv3d_k3_wgrad_det; same slab count query)
+PULPO_API int pulpo_conv3d_k3_wgrad_bf16_det_t(const void* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const void* dy, int64_t dy_bs,
+                                               int64_t dy_ps, int64_t dy_cs, int dt, float* dw, int accumulate, float* scratch, float* slabs,
+                                               int nslab, int B, int D, int H, int W, int Cin, int Cout, void* stream) {
+    PULPO_REQUIRE(slabs && nslab >= 1, "conv3d_k3_wgrad_bf16_det: slabs of nslab >= 1 copies of the packed scratch required");
+    return wgrad_bf16_impl(in, in_bs, in_ps, in_cs, dy, dy_bs, dy_ps, dy_cs, dt, dw, accumulate, scratch, slabs, nslab, B, D, H, W, Cin, Cout, stream);
 }
 
 PULPO_API int pulpo_conv3d_k3_wgrad_bf16(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,

@@ -30,6 +30,8 @@ struct WgradArgs {
     float* dwp;                   // zero-initialised scratch [27][Cin][NPad], accumulated with float atomics
     int B, D, H, W, Cin, Cout, NPad;
     int ntz, nty, ntx, ncit, ncot, nsplit;
+    long split_stride;            // 0, or (deterministic mode) floats between the per-split copies of dwp: split s adds into dwp + s * split_stride,
+                                  // which no other workgroup of the same (ci tile, co tile) touches - every element receives ONE add
 };
 
 constexpr int WG_CH = 32, WG_NT = 32, WG_CP = WG_CH + 1;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256, VEC ? 1 : 2) void conv3d_k3_wgrad_mfma(WgradAr
                     const int rg = 32 * (wave + 4 * u) + (r & 3) + 8 * (r >> 2) + 4 * kk;
                     if (rg < rows) {
                         const int tap = rg / Cc, ci = rg - tap * Cc;
-                        atomicAdd(a.dwp + ((long)tap * a.Cin + ci0 + ci) * a.NPad + co, acc[u][r]);
+                        atomicAdd(a.dwp + (long)split * a.split_stride + ((long)tap * a.Cin + ci0 + ci) * a.NPad + co, acc[u][r]);
                     }
                 }
             }
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_smallc(WgradArgs a) {
         const int row = j >> 5, co = co0 + (j & 31);
         if (co < a.Cout) {
             const int tap = row / a.Cin, ci = row - tap * a.Cin;
-            atomicAdd(a.dwp + ((long)tap * a.Cin + ci) * a.NPad + co, red[j]);
+            atomicAdd(a.dwp + (long)split * a.split_stride + ((long)tap * a.Cin + ci) * a.NPad + co, red[j]);
         }
     }
 }
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino(WgradArgs a) {
             const int rg = 32 * (g0 + tl) + (r & 3) + 8 * (r >> 2) + 4 * kk;
             if (rg < rows && co < a.Cout) {
                 const int zy = rg / Cc, ci = rg - zy * Cc;
-                float* d = a.dwp + ((long)(zy * 3) * a.Cin + ci0 + ci) * a.NPad + co;
+                float* d = a.dwp + (long)split * a.split_stride + ((long)(zy * 3) * a.Cin + ci0 + ci) * a.NPad + co;
                 const float hs = 0.5f * (m1 + m2);
                 atomicAdd(d, m0 + hs);
                 atomicAdd(d + (long)a.Cin * a.NPad, 0.5f * (m1 - m2));
@@ -682,9 +684,9 @@ PULPO_API int pulpo_conv3d_k3_wgrad_algo(int B, int D, int H, int W, int Cin, in
 
 // dw[Cout][Cin][27] (+)= sum_vox in[vox+tap-1][ci] * dy[vox][co]  (accumulate != 0 adds to dw, e.g. a parameter's .grad storage).
 // scratch: pulpo_conv3d_k3_wgrad_scratch_floats floats.
-PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
-                                    int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, int B, int D, int H, int W,
-                                    int Cin, int Cout, void* stream) {
+static int wgrad_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
+                      int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, float* slabs, int nslab, int B, int D, int H, int W,
+                      int Cin, int Cout, void* stream) {
     PULPO_REQUIRE(in && dy && scratch && (dw || accumulate == 2), "conv3d_k3_wgrad: null pointer");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3d_k3_wgrad: bad dims");
     hipStream_t st = (hipStream_t)stream;
@@ -703,12 +705,33 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
     // scalar variant: two per CU
     int nsplit = std::max(1, (vec ? 256 : 512) / npair);
     nsplit = std::min(nsplit, ntile);
+    if (slabs) nsplit = std::min(nsplit, nslab);
     a.nsplit = nsplit;
     const bool deferred = accumulate == 2;                 // scratch arrives zeroed and keeps the packed sums: the caller unpacks later
     if (!deferred) {
         hipError_t e = hipMemsetAsync(scratch, 0, pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout) * sizeof(float), st);
         if (e != hipSuccess) return pulpo::fail((int)e, "wgrad memset: %s", hipGetErrorString(e));
     }
+    // Deterministic mode: the kernels' float atomics land in per-split copies of the packed sums (one add per element and copy: order-free),
+    // which finish() adds to `scratch` in fixed order.
+    const long base = (long)pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout);
+    a.split_stride = 0;
+    if (slabs) { a.dwp = slabs; a.split_stride = base; }
+    int used = nsplit;                                     // copies the launch below writes (the other TU's launcher reports its own count)
+    auto prepare = [&](int n) -> int {
+        if (!slabs) return 0;
+        hipError_t e = hipMemsetAsync(slabs, 0, (size_t)n * base * sizeof(float), st);
+        return e == hipSuccess ? 0 : pulpo::fail((int)e, "wgrad slab memset: %s", hipGetErrorString(e));
+    };
+    auto finish = [&](int rc0) -> int {
+        if (rc0) return rc0;
+        if (slabs) {
+            const int r = pulpo_conv::launch_wgrad_slab_reduce(scratch, slabs, used, base, st);
+            if (r) return r;
+        }
+        if (deferred) return 0;
+        return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
+    };
     const int nrt_max = (27 * std::min(Cin, WG_CH) + 31) / 32;
     const int ntw = (nrt_max + 3) / 4;                 // 1..7
     constexpr size_t lds = (size_t)(((HV * WG_CP + 3) & ~3) + MV * WG_NT) * sizeof(float);
@@ -730,10 +753,16 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
     const int algo = pulpo_conv3d_k3_wgrad_algo(B, D, H, W, Cin, Cout, (int)vec);
     if (algo >= 2) {
         // F(2x2,3x3) in (y, x) / F(2x2x2,3x3x3), register-staged transposed operand images, z-streaming workgroups (conv3d_wgrad_w2.hip)
-        rc = pulpo_conv::launch_wgrad_w2(in, in_bs, in_ps, dy, dy_bs, dy_ps, scratch, B, D, H, W, Cin, Cout, st);
-        if (rc || deferred) return rc;
-        return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
+        // (its launcher picks its own split count: it zeroes the copies it will use and reports how many)
+        rc = pulpo_conv::launch_wgrad_w2(in, in_bs, in_ps, dy, dy_bs, dy_ps, scratch, B, D, H, W, Cin, Cout, st, slabs, nslab, &used);
+        return finish(rc);
     }
+    if (Cin <= 4 && (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0) && algo != 1) {
+        const int ntile4 = B * pulpo::cdiv(D, 4) * a.nty * a.ntx;
+        used = std::min(std::max(1, 512 / a.ncot), ntile4);
+        if (slabs) used = std::min(used, nslab);
+    }
+    if ((rc = prepare(used))) return rc;
     if (algo == 1) {
         // Winograd-x variant: wave = transformed point, nine (dz, dy) row tiles of <= 32 channels
         const int nrt9 = (9 * std::min(Cin, WG_CH) + 31) / 32;
@@ -757,6 +786,7 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
         const int ntile4 = B * b.ntz * b.nty * b.ntx;
         b.ncit = 1;
         b.nsplit = std::min(std::max(1, 512 / b.ncot), ntile4);
+        if (slabs) b.nsplit = std::min(b.nsplit, nslab);
         const int nrt = (27 * Cin + 31) / 32;
         constexpr size_t lds_s = (size_t)(4 * (6 * HY * HX + 4) + 256 * WG_NT) * sizeof(float);
         static_assert(4 * 32 * WG_NT <= 256 * WG_NT, "the partial sums of four row tiles fit the gradient image");
@@ -779,7 +809,48 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
         if (ntw <= 1) PULPO_WGRAD(false, 1) else if (ntw <= 2) PULPO_WGRAD(false, 2) else if (ntw <= 4) PULPO_WGRAD(false, 4) else PULPO_WGRAD(false, 7)
     }
 #undef PULPO_WGRAD
-    rc = pulpo::check_launch("conv3d_k3_wgrad_mfma");
-    if (rc || deferred) return rc;
-    return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
+    return finish(pulpo::check_launch("conv3d_k3_wgrad_mfma"));
+}
+
+PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
+                                    int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, int B, int D, int H, int W,
+                                    int Cin, int Cout, void* stream) {
+    return wgrad_impl(in, in_bs, in_ps, in_cs, dy, dy_bs, dy_ps, dy_cs, dw, accumulate, scratch, nullptr, 0, B, D, H, W, Cin, Cout, stream);
+}
+
+// ---- deterministic form (PULPO_DETERMINISTIC): the same kernels, but workgroups that share a (ci tile, co tile) add their partial sums into
+// separate zeroed copies ("slabs") of the packed scratch, and an ordered pass adds the copies up: results are bit-identical run to run (the plain
+// form's float atomics add the workgroups' sums in arrival order).  slabs: nslab * pulpo_conv3d_k3_wgrad_scratch_floats(Cin, Cout) floats with
+// nslab = pulpo_conv3d_k3_wgrad_det_slabs(Cin, Cout) (fewer are accepted: the spatial splits are capped at nslab).
+PULPO_API int pulpo_conv3d_k3_wgrad_det_slabs(int Cin, int Cout) {
+    const int npair = pulpo::cdiv(Cin, WG_CH) * pulpo::cdiv(Cout, WG_NT);
+    return std::max(1, 512 / std::max(1, Cin <= 4 ? pulpo::cdiv(Cout, WG_NT) : npair));
+}
+
+PULPO_API int pulpo_conv3d_k3_wgrad_det(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
+                                        int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, float* slabs, int nslab, int B,
+                                        int D, int H, int W, int Cin, int Cout, void* stream) {
+    PULPO_REQUIRE(slabs && nslab >= 1, "conv3d_k3_wgrad_det: slabs of nslab >= 1 copies of the packed scratch required");
+    return wgrad_impl(in, in_bs, in_ps, in_cs, dy, dy_bs, dy_ps, dy_cs, dw, accumulate, scratch, slabs, nslab, B, D, H, W, Cin, Cout, stream);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(float* __restrict__ scratch, const float* __restrict__ slabs, int nslab, long n) {
+    for (long e = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4; e < n; e += (long)gridDim.x * blockDim.x * 4) {
+        float4 t = *reinterpret_cast<const float4*>(scratch + e);
+        for (int s_ = 0; s_ < nslab; ++s_) {
+            const float4 u = *reinterpret_cast<const float4*>(slabs + (long)s_ * n + e);
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        *reinterpret_cast<float4*>(scratch + e) = t;
+    }
+}
+}  // namespace
+
+int pulpo_conv::launch_wgrad_slab_reduce(float* scratch, const float* slabs, int nslab, long n, hipStream_t st) {
+    // (n = 27 * Cin * npad(Cout) is a multiple of 64 floats; scratch and slabs come from the caller's allocator: 16-byte aligned)
+    if ((n & 3) || (((uintptr_t)scratch | (uintptr_t)slabs) & 15)) return pulpo::fail(1, "wgrad slab reduce: operands must be 16-byte aligned");
+    const int nb = (int)std::min<long>((n / 4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(nb), dim3(256), 0, st, scratch, slabs, nslab, n);
+    return pulpo::check_launch("wgrad_slab_reduce");
 }

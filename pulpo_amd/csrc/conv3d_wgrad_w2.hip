@@ -50,6 +50,7 @@ struct Wgrad2Args {
     float* dwp;                   // zero-initialised scratch [27][Cin][NPad], accumulated with float atomics
     int B, D, H, W, Cin, Cout, NPad;
     int nty, ntx, ncit, ncot, nsplit;
+    long split_stride;            // 0, or (deterministic mode) floats between the per-split copies of dwp (see WgradArgs in conv3d_wgrad.hip)
 };
 
 template <int DUMMY>
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_w2(Wgrad2Args a) {
             const int ci = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), co = co0 + (l & 31);
             if (ci < Cc && co < a.Cout) {
                 const float hs = 0.5f * (s4[1] + s4[2]);
-                float* d = a.dwp + ((long)((dz * 3 + 0) * 3 + kx) * a.Cin + ci0 + ci) * a.NPad + co;
+                float* d = a.dwp + (long)split * a.split_stride + ((long)((dz * 3 + 0) * 3 + kx) * a.Cin + ci0 + ci) * a.NPad + co;
                 const long kystride = 3L * a.Cin * a.NPad;
                 atomicAdd(d, s4[0] + hs);
                 atomicAdd(d + kystride, 0.5f * (s4[1] - s4[2]));
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2x(Wgrad2Args a) {
             const int ci = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), co = co0 + (l & 31);
             if (ci < Cc && co < a.Cout) {
                 const float hs = 0.5f * (s[1] + s[2]);
-                float* d = a.dwp + ((long)((dz * 3 + 0) * 3 + kx) * a.Cin + ci0 + ci) * a.NPad + co;
+                float* d = a.dwp + (long)split * a.split_stride + ((long)((dz * 3 + 0) * 3 + kx) * a.Cin + ci0 + ci) * a.NPad + co;
                 const long kystride = 3L * a.Cin * a.NPad;
                 atomicAdd(d, s[0] + hs);
                 atomicAdd(d + kystride, 0.5f * (s[1] - s[2]));
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
             const int ci = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), co = co0 + (l & 31);
             if (ci < Cc && co < a.Cout) {
                 const float hs = 0.5f * (s[1] + s[2]);
-                float* d = a.dwp + ((long)((dz * 3 + 0) * 3 + kx) * a.Cin + ci0 + ci) * a.NPad + co;
+                float* d = a.dwp + (long)split * a.split_stride + ((long)((dz * 3 + 0) * 3 + kx) * a.Cin + ci0 + ci) * a.NPad + co;
                 const long kystride = 3L * a.Cin * a.NPad;
                 atomicAdd(d, s[0] + hs);
                 atomicAdd(d + kystride, 0.5f * (s[1] - s[2]));
@@ -951,8 +952,18 @@ bool wgrad_w3_depth_ok(int D) {
 
 // launched by pulpo_conv3d_k3_wgrad (conv3d_wgrad.hip) for channels-last operands on large volumes; scratch must be zeroed by the caller
 int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, long go_bs, long go_ps, float* scratch, int B, int D, int H, int W,
-                    int Cin, int Cout, hipStream_t st) {
+                    int Cin, int Cout, hipStream_t st, float* slabs, int nslab, int* used_slabs) {
     Wgrad2Args a;
+    a.split_stride = 0;
+    // deterministic mode: the splits of the grid add into their own zeroed copies of the packed sums (zeroed here, once the split count is known)
+    auto use_slabs = [&](int nsplit_) -> int {
+        if (!slabs) return 0;
+        const size_t base = (size_t)27 * Cin * npad(Cout);
+        a.dwp = slabs; a.split_stride = (long)base;
+        if (used_slabs) *used_slabs = nsplit_;
+        hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nsplit_ * base * sizeof(float), st);
+        return e == hipSuccess ? 0 : pulpo::fail((int)e, "wgrad slab memset: %s", hipGetErrorString(e));
+    };
     a.in = in; a.in_bs = in_bs; a.in_ps = in_ps;
     a.go = go; a.go_bs = go_bs; a.go_ps = go_ps;
     a.dwp = scratch;
@@ -963,6 +974,7 @@ int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, lo
     const long nstep = (long)B * a.nty * a.ntx * D;
     int nsplit = std::max(1, 256 / npair);                 // one workgroup per CU
     nsplit = (int)std::min<long>(nsplit, nstep);
+    if (slabs) nsplit = std::min(nsplit, nslab);
     a.nsplit = nsplit;
     static bool attr = false;
     if (!attr) {
@@ -985,6 +997,8 @@ int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, lo
         if (wgs3 < 0) { const char* e = getenv("PULPO_WGRAD_W3_WGS"); wgs3 = e ? atoi(e) : 256; }
         const long nstep3 = (long)B * a.nty * a.ntx * (D / 2);
         a.nsplit = (int)std::min<long>(std::max(1, wgs3 / npair), nstep3);
+        if (slabs) a.nsplit = std::min(a.nsplit, nslab);
+        if (int rc = use_slabs(a.nsplit)) return rc;
         hipLaunchKernelGGL((conv3d_k3_wgrad_w3x<0>), dim3(npair * a.nsplit), dim3(512), W3G_LDS, st, a);
         return pulpo::check_launch("conv3d_k3_wgrad_w3x");
     }
@@ -1001,9 +1015,11 @@ int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, lo
             if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(wgrad w2x): %s", hipGetErrorString(e));
             attr8 = true;
         }
+        if (int rc = use_slabs(nsplit)) return rc;
         hipLaunchKernelGGL((conv3d_k3_wgrad_w2x<0>), dim3(npair * nsplit), dim3(512), W2G_LDS, st, a);
         return pulpo::check_launch("conv3d_k3_wgrad_w2x");
     }
+    if (int rc = use_slabs(nsplit)) return rc;
     hipLaunchKernelGGL((conv3d_k3_wgrad_w2<0>), dim3(npair * nsplit), dim3(256), W2G_LDS, st, a);
     return pulpo::check_launch("conv3d_k3_wgrad_w2");
 }

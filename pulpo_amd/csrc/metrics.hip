@@ -64,10 +64,12 @@ __global__ void dice_finalize_kernel(const float* __restrict__ partial, int npla
         }
         const double num = 2.0 * s0 + 1e-6, den = s1 + s2 + 1e-6;
         numden[2 * p] = num; numden[2 * p + 1] = den;
-        atomicAdd(&acc, 1.0 - num / den);
     }
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] = (float)(acc / nplanes * V / dice_factor);
+    if (threadIdx.x == 0) {                       // (the planes' terms in plane order: a shared double atomic summed them in arrival order)
+        for (int p = 0; p < nplanes; ++p) acc += 1.0 - numden[2 * p] / numden[2 * p + 1];
+        loss[0] = (float)(acc / nplanes * V / dice_factor);
+    }
 }
 
 // d loss / d inp = -(V / (dice_factor * nplanes)) * (2 t den - 2 i num) / den^2

@@ -135,6 +135,56 @@ __global__ __launch_bounds__(256) void resize_bwd_atomic_kernel(const float* __r
     }
 }
 
+// generic transpose as a GATHER (deterministic form, PULPO_DETERMINISTIC): input voxel m collects, in ascending output order, every output voxel
+// whose two taps along each axis include it - the same products as resize_bwd_atomic_kernel, summed in a fixed order instead of arrival order.
+// Candidates along an axis: the source coordinate is monotone in the output index, so the outputs with i0 in {m - 1, m} lie in a window of
+// about 2 / scale indices around (m + 0.5) / scale.
+__device__ __forceinline__ void gather_window(int m, float scale, int out_size, int& lo, int& hi) {
+    const float inv = 1.f / scale;
+    lo = (int)floorf(((float)m - 0.5f) * inv - 0.5f) - 1;
+    hi = (int)ceilf(((float)m + 1.5f) * inv - 0.5f) + 1;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > out_size - 1 ? out_size - 1 : hi;
+}
+__device__ __forceinline__ float gather_weight(int o, int m, float scale, int in_size) {
+    int i0, i1;
+    float lam;
+    src_index(o, scale, in_size, i0, i1, lam);
+    return (i0 == m ? 1.f - lam : 0.f) + (i1 == m ? lam : 0.f);
+}
+__global__ __launch_bounds__(256) void resize_bwd_gather_kernel(const float* __restrict__ gout, float* __restrict__ gin, long nplanes, int Di, int Hi,
+                                                                  int Wi, int Do, int Ho, int Wo, float sd, float sh, float sw, float mult) {
+    const long total = nplanes * Di * Hi * Wi;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long p = e;
+        const int x = (int)(p % Wi); p /= Wi;
+        const int y = (int)(p % Hi); p /= Hi;
+        const int z = (int)(p % Di);
+        const long pl = p / Di;
+        int zl, zh, yl, yh, xl, xh;
+        gather_window(z, sd, Do, zl, zh);
+        gather_window(y, sh, Ho, yl, yh);
+        gather_window(x, sw, Wo, xl, xh);
+        const float* g = gout + pl * (long)Do * Ho * Wo;
+        float acc = 0.f;
+        for (int oz = zl; oz <= zh; ++oz) {
+            const float wz = gather_weight(oz, z, sd, Di);
+            if (wz == 0.f) continue;
+            for (int oy = yl; oy <= yh; ++oy) {
+                const float wy = gather_weight(oy, y, sh, Hi);
+                if (wy == 0.f) continue;
+                float row = 0.f;
+                for (int ox = xl; ox <= xh; ++ox) {
+                    const float wx = gather_weight(ox, x, sw, Wi);
+                    if (wx != 0.f) row += g[((long)oz * Ho + oy) * Wo + ox] * mult * wx;
+                }
+                acc += row * (wz * wy);
+            }
+        }
+        gin[e] = acc;
+    }
+}
+
 // weight with which coarse index m contributes to fine index o (exact x2 up-sampling), 0 if none
 __device__ __forceinline__ float up2_weight(int o, int m, int in_size) {
     int i0, i1;
@@ -428,8 +478,8 @@ PULPO_API int pulpo_resize_trilinear_fwd(const float* in, const float* add, floa
     return pulpo_resize_trilinear_scaled_fwd(in, add, out, nplanes, Di, Hi, Wi, Do, Ho, Wo, 0.f, 0.f, 0.f, mult, stream);
 }
 
-PULPO_API int pulpo_resize_trilinear_scaled_bwd(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-                                                float scale_d, float scale_h, float scale_w, float mult, void* stream) {
+static int resize_bwd_impl(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                           float scale_d, float scale_h, float scale_w, float mult, bool det, void* stream) {
     PULPO_REQUIRE(gout && gin && nplanes > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, "resize_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const float sd = scale_d > 0.f ? scale_d : (float)Di / (float)Do, sh = scale_h > 0.f ? scale_h : (float)Hi / (float)Ho,
@@ -438,11 +488,27 @@ PULPO_API int pulpo_resize_trilinear_scaled_bwd(const float* gout, float* gin, i
         hipLaunchKernelGGL(resize_up2_bwd_kernel, dim3(eblocks(nplanes * Di * Hi * Wi)), dim3(256), 0, st, gout, gin, (long)nplanes, Di, Hi, Wi, mult);
         return pulpo::check_launch("resize_up2_bwd");
     }
+    if (det) {
+        hipLaunchKernelGGL(resize_bwd_gather_kernel, dim3(eblocks(nplanes * Di * Hi * Wi)), dim3(256), 0, st, gout, gin, (long)nplanes, Di, Hi, Wi, Do,
+                           Ho, Wo, sd, sh, sw, mult);
+        return pulpo::check_launch("resize_bwd_gather");
+    }
     hipError_t e = hipMemsetAsync(gin, 0, sizeof(float) * nplanes * Di * Hi * Wi, st);
     if (e != hipSuccess) return pulpo::fail((int)e, "resize_bwd memset: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(resize_bwd_atomic_kernel, dim3(eblocks(nplanes * Do * Ho * Wo)), dim3(256), 0, st, gout, gin, (long)nplanes, Di, Hi, Wi, Do,
                        Ho, Wo, sd, sh, sw, mult);
     return pulpo::check_launch("resize_bwd_atomic");
+}
+
+PULPO_API int pulpo_resize_trilinear_scaled_bwd(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                                float scale_d, float scale_h, float scale_w, float mult, void* stream) {
+    return resize_bwd_impl(gout, gin, nplanes, Di, Hi, Wi, Do, Ho, Wo, scale_d, scale_h, scale_w, mult, false, stream);
+}
+
+// deterministic form (since ABI 4): ratios other than the exact x2 are transposed by a gather in fixed order instead of float atomics
+PULPO_API int pulpo_resize_trilinear_scaled_bwd_det(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                                    float scale_d, float scale_h, float scale_w, float mult, void* stream) {
+    return resize_bwd_impl(gout, gin, nplanes, Di, Hi, Wi, Do, Ho, Wo, scale_d, scale_h, scale_w, mult, true, stream);
 }
 
 PULPO_API int pulpo_resize_trilinear_bwd(const float* gout, float* gin, int64_t nplanes, int Di, int Hi, int Wi, int Do, int Ho, int Wo, float mult,

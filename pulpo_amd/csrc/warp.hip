@@ -314,6 +314,105 @@ __global__ __launch_bounds__(VI_THREADS) void vecint_fwd_lds_kernel(const float*
 
 inline int eblocks(long items) { return (int)std::max<long>(1, std::min<long>((items + 255) / 256, 8192)); }
 
+// ------------------------------------------------------------------------------------------------ deterministic backward (PULPO_DETERMINISTIC)
+// The scatter of the image gradient (grid_sampler_3d_backward's atomics; network_blocks.py:120, :175) is what makes these backward passes differ
+// in the last bits from run to run: float atomics add in arrival order.  Here every contribution enters a 64-bit FIXED-POINT accumulator
+// - integer adds commute, so the sum does not depend on the order - as llrint(v * 2^S) with S taken from the largest |gradient| of the pass
+// (2^46 units per that maximum: 22 bits below fp32's last place of the largest value, 17 bits of head-room for the sums); a second pass turns the
+// accumulators back into floats (and returns them to zero).  Same contributions as the plain kernels, summed exactly instead of in fp32.
+__device__ __forceinline__ double fx_unit(const unsigned* maxbits) {          // 2^S for the pass whose largest |gradient| has these bits
+    const float m = __uint_as_float(*maxbits);
+    if (!(m > 0.f) || !(m < INFINITY)) return 1.0;                           // all zero (or not finite: the result is not finite either way)
+    int ex;
+    frexpf(m, &ex);                                                           // m = f * 2^ex, f in [0.5, 1)
+    return ldexp(1.0, 46 - ex);
+}
+__device__ __forceinline__ void fx_add(long long* p, float v, double unit) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * unit));
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(g[e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));          // (bit patterns of non-negative floats order like the values)
+}
+
+// SELF = a VecInt squaring step (v' = v + warp(v, v): image and displacement are the same 3-channel field; the identity path and the
+// displacement gradient join the voxel's own accumulator).  !SELF = SpatialTransformer: acc collects the image gradient, gdf is written plainly.
+template <bool SELF>
+__global__ __launch_bounds__(256) void warp_bwd_fx_kernel(const float* __restrict__ df, const float* __restrict__ img, const float* __restrict__ gout,
+                                                            float* __restrict__ gdf, long long* __restrict__ acc, const unsigned* __restrict__ maxbits,
+                                                            int B, int Dg, int Hg, int Wg, int Di, int Hi, int Wi, int nch) {
+    const long Vg = (long)Dg * Hg * Wg, Vi = (long)Di * Hi * Wi;
+    const long total = (long)B * Vg;
+    const double unit = fx_unit(maxbits);
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long b = e / Vg, v = e - b * Vg;
+        const int x = (int)(v % Wg), y = (int)((v / Wg) % Hg), z = (int)(v / ((long)Wg * Hg));
+        const float* d = df + b * 3 * Vg + v;
+        const Corner cz = sample_coord((float)z, d[0], Dg, Di);
+        const Corner cy = sample_coord((float)y, d[Vg], Hg, Hi);
+        const Corner cx = sample_coord((float)x, d[2 * Vg], Wg, Wi);
+        const long o00 = ((long)cz.i0 * Hi + cy.i0) * Wi, o01 = ((long)cz.i0 * Hi + cy.i1) * Wi;
+        const long o10 = ((long)cz.i1 * Hi + cy.i0) * Wi, o11 = ((long)cz.i1 * Hi + cy.i1) * Wi;
+        const float wz0 = 1.f - cz.f, wy0 = 1.f - cy.f, wx0 = 1.f - cx.f;
+        float gz = 0.f, gy = 0.f, gx = 0.f;
+        float gid[3] = {0.f, 0.f, 0.f};
+        for (int c = 0; c < nch; ++c) {
+            const float g = gout[(b * nch + c) * Vg + v];
+            if (SELF && c < 3) gid[c] = g;
+            const float* s = img + (b * nch + c) * Vi;
+            const float s000 = s[o00 + cx.i0], s001 = s[o00 + cx.i1], s010 = s[o01 + cx.i0], s011 = s[o01 + cx.i1];
+            const float s100 = s[o10 + cx.i0], s101 = s[o10 + cx.i1], s110 = s[o11 + cx.i0], s111 = s[o11 + cx.i1];
+            gz += g * (wy0 * wx0 * (s100 - s000) + wy0 * cx.f * (s101 - s001) + cy.f * wx0 * (s110 - s010) + cy.f * cx.f * (s111 - s011));
+            gy += g * (wz0 * wx0 * (s010 - s000) + wz0 * cx.f * (s011 - s001) + cz.f * wx0 * (s110 - s100) + cz.f * cx.f * (s111 - s101));
+            gx += g * (wz0 * wy0 * (s001 - s000) + wz0 * cy.f * (s011 - s010) + cz.f * wy0 * (s101 - s100) + cz.f * cy.f * (s111 - s110));
+            if (acc != nullptr) {
+                long long* q = acc + (b * nch + c) * Vi;
+                fx_add(q + o00 + cx.i0, g * wz0 * wy0 * wx0, unit);
+                fx_add(q + o00 + cx.i1, g * wz0 * wy0 * cx.f, unit);
+                fx_add(q + o01 + cx.i0, g * wz0 * cy.f * wx0, unit);
+                fx_add(q + o01 + cx.i1, g * wz0 * cy.f * cx.f, unit);
+                fx_add(q + o10 + cx.i0, g * cz.f * wy0 * wx0, unit);
+                fx_add(q + o10 + cx.i1, g * cz.f * wy0 * cx.f, unit);
+                fx_add(q + o11 + cx.i0, g * cz.f * cy.f * wx0, unit);
+                fx_add(q + o11 + cx.i1, g * cz.f * cy.f * cx.f, unit);
+            }
+        }
+        if (SELF) {
+            long long* q = acc + b * 3 * Vg + v;
+            fx_add(q, gid[0] + gz * cz.dscale, unit);
+            fx_add(q + Vg, gid[1] + gy * cy.dscale, unit);
+            fx_add(q + 2 * Vg, gid[2] + gx * cx.dscale, unit);
+        } else if (gdf != nullptr) {
+            float* q = gdf + b * 3 * Vg + v;
+            q[0] = gz * cz.dscale;
+            q[Vg] = gy * cy.dscale;
+            q[2 * Vg] = gx * cx.dscale;
+        }
+    }
+}
+
+// out = float(acc / 2^S) * post, acc <- 0; next_max (nullable) receives the largest |out| (the next pass's scale)
+__global__ __launch_bounds__(256) void fx_to_float_kernel(long long* __restrict__ acc, float* __restrict__ out, long n, const unsigned* __restrict__ maxbits,
+                                                            float post, unsigned* __restrict__ next_max) {
+    const double inv = 1.0 / fx_unit(maxbits);
+    float m = 0.f;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const float val = (float)((double)acc[e] * inv) * post;
+        acc[e] = 0;
+        out[e] = val;
+        m = fmaxf(m, fabsf(val));
+    }
+    if (next_max != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(next_max, __float_as_uint(m));
+    }
+}
+
 }  // namespace
 
 // df: (B,3,Dg,Hg,Wg) planar; img: (B,C,Di,Hi,Wi) planar; out: (B,C,Dg,Hg,Wg)
@@ -415,4 +514,63 @@ PULPO_API int pulpo_vecint_bwd(const float* work, const float* gout, float* gin,
     }
     hipLaunchKernelGGL(scale_kernel, dim3(eblocks(n)), dim3(256), 0, st, g, gin, scale, n);
     return pulpo::check_launch("vecint_bwd scale");
+}
+
+// ------------------------------------------------------------------------------------------------ deterministic forms (since ABI 4)
+// Workspaces (caller-owned, any content on entry): see the kernels above.  Layout: [256 bytes of scale slots][int64 accumulators][float buffers].
+PULPO_API size_t pulpo_warp3d_bwd_det_ws_bytes(int B, int C, int Di, int Hi, int Wi) {
+    if (B <= 0 || C <= 0 || Di < 1 || Hi < 1 || Wi < 1) return 0;
+    return 256 + sizeof(long long) * (size_t)B * C * Di * Hi * Wi;
+}
+
+PULPO_API int pulpo_warp3d_bwd_det(const float* df, const float* img, const float* gout, float* gdf, float* gimg, void* ws, int B, int C, int Dg, int Hg,
+                                   int Wg, int Di, int Hi, int Wi, void* stream) {
+    PULPO_REQUIRE(df && img && gout && B > 0 && C > 0, "warp3d_bwd_det: bad arguments");
+    PULPO_REQUIRE(Dg >= 1 && Hg > 1 && Wg > 1, "warp3d_bwd_det: grid H, W must be > 1");
+    PULPO_REQUIRE(ws != nullptr || gimg == nullptr, "warp3d_bwd_det: workspace of pulpo_warp3d_bwd_det_ws_bytes() bytes required for the image gradient");
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)B * Dg * Hg * Wg, ni = (long)B * C * Di * Hi * Wi;
+    unsigned* slots = (unsigned*)ws;
+    long long* acc = gimg ? (long long*)((char*)ws + 256) : nullptr;
+    if (gimg != nullptr) {
+        hipError_t e = hipMemsetAsync(ws, 0, 256 + sizeof(long long) * (size_t)ni, st);
+        if (e != hipSuccess) return pulpo::fail((int)e, "warp3d_bwd_det memset: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(absmax_kernel, dim3(eblocks((long)B * C * Dg * Hg * Wg)), dim3(256), 0, st, gout, (long)B * C * Dg * Hg * Wg, slots);
+    }
+    hipLaunchKernelGGL(warp_bwd_fx_kernel<false>, dim3(eblocks(total)), dim3(256), 0, st, df, img, gout, gdf, acc, slots, B, Dg, Hg, Wg, Di, Hi, Wi, C);
+    if (gimg != nullptr) hipLaunchKernelGGL(fx_to_float_kernel, dim3(eblocks(ni)), dim3(256), 0, st, acc, gimg, ni, slots, 1.0f, (unsigned*)nullptr);
+    return pulpo::check_launch("warp3d_bwd_det");
+}
+
+PULPO_API size_t pulpo_vecint_bwd_det_ws_bytes(int B, int D, int H, int W, int nsteps) {
+    if (B <= 0 || D < 1 || H < 1 || W < 1 || nsteps <= 0) return 0;
+    const size_t n = (size_t)B * 3 * D * H * W;
+    return 256 + sizeof(long long) * n + 2 * sizeof(float) * n;
+}
+
+PULPO_API int pulpo_vecint_bwd_det(const float* work, const float* gout, float* gin, void* ws, int B, int D, int H, int W, int nsteps, void* stream) {
+    PULPO_REQUIRE(work && gout && gin && B > 0 && D >= 1 && H > 1 && W > 1 && nsteps >= 0 && nsteps < 60, "vecint_bwd_det: bad arguments");
+    PULPO_REQUIRE(ws || nsteps == 0, "vecint_bwd_det: workspace of pulpo_vecint_bwd_det_ws_bytes() bytes required");
+    hipStream_t st = (hipStream_t)stream;
+    const long n = (long)B * 3 * D * H * W, total = (long)B * D * H * W;
+    const float scale = 1.0f / (float)(1 << nsteps);
+    if (nsteps == 0) {
+        hipLaunchKernelGGL(scale_kernel, dim3(eblocks(n)), dim3(256), 0, st, gout, gin, scale, n);
+        return pulpo::check_launch("vecint_bwd_det scale");
+    }
+    unsigned* slots = (unsigned*)ws;                       // slot k: largest |gradient| entering step k's scatter
+    long long* acc = (long long*)((char*)ws + 256);
+    float* buf[2] = {(float*)(acc + n), (float*)(acc + n) + n};
+    hipError_t e = hipMemsetAsync(ws, 0, 256 + sizeof(long long) * (size_t)n, st);
+    if (e != hipSuccess) return pulpo::fail((int)e, "vecint_bwd_det memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(absmax_kernel, dim3(eblocks(n)), dim3(256), 0, st, gout, n, slots + (nsteps - 1));
+    const float* g = gout;
+    for (int k = nsteps - 1; k >= 0; --k) {
+        const float* cur = work + (long)k * n;
+        hipLaunchKernelGGL(warp_bwd_fx_kernel<true>, dim3(eblocks(total)), dim3(256), 0, st, cur, cur, g, (float*)nullptr, acc, slots + k, B, D, H, W, D, H, W, 3);
+        float* out = k == 0 ? gin : buf[k & 1];
+        hipLaunchKernelGGL(fx_to_float_kernel, dim3(eblocks(n)), dim3(256), 0, st, acc, out, n, slots + k, k == 0 ? scale : 1.0f, k == 0 ? (unsigned*)nullptr : slots + (k - 1));
+        g = out;
+    }
+    return pulpo::check_launch("vecint_bwd_det");
 }

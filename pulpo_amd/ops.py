@@ -237,6 +237,19 @@ def act_dtype():
     return torch.bfloat16 if ACT_BF16 else torch.float32
 
 
+# Deterministic mode (PULPO_DETERMINISTIC=1 / set_deterministic(True)): the backward kernels that add with float atomics - the weight-gradient
+# flush of concurrent workgroups, the image-gradient scatter of the warp / VecInt backward, the generic trilinear-resize backward - are replaced
+# by their ordered forms (`*_det` entry points: per-split slabs + an ordered sum; 64-bit fixed-point accumulation; a gather): two runs of the same
+# build on the same inputs give bit-identical gradients, as the reference's CPU backward does.  Everything else in a step is
+# deterministic already (two-stage reductions in fixed order).  Not covered: the `jdet` regulariser's backward (raises in this mode).
+DETERMINISTIC = os.environ.get("PULPO_DETERMINISTIC", "0") == "1"
+
+
+def set_deterministic(on: bool = True) -> None:
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+
+
 def _use_bf16(K: int) -> bool:
     return CONV_PRECISION == "bf16" and K > 4
 
@@ -513,20 +526,26 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
     db, dp, dc = grid_strides(dy)
     t0 = _trace_begin()
     sfx = "_bf16" if _use_bf16(Cin) else ""
+    det = ()
+    if DETERMINISTIC:
+        # one zero-initialised copy of the packed sums per spatial split of the grid (<= ~110 MB, transient), added up in fixed order
+        nslab = lib.query("pulpo_conv3d_k3_wgrad_det_slabs", Cin, Cout)
+        slabs = torch.empty(nslab * nscr, device=x.device, dtype=torch.float32)
+        det = (_ptr(slabs), nslab)
     if sfx:
         if x.dtype != dy.dtype:                      # (one storage type per launch; a mixed pair - a user's fp32 input to a bf16-storage unit - is rare)
             x, dy = x.float(), dy.float()
             xb, xp, xc = grid_strides(x)
             db, dp, dc = grid_strides(dy)
-        lib.call("pulpo_conv3d_k3_wgrad_bf16_t", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _dt(x), _ptr(dw), 2 if deferred else int(into is not None),
-                 _ptr(scratch), B, D, H, W, Cin, Cout, _stream())
+        lib.call("pulpo_conv3d_k3_wgrad_bf16_det_t" if det else "pulpo_conv3d_k3_wgrad_bf16_t", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _dt(x), _ptr(dw),
+                 2 if deferred else int(into is not None), _ptr(scratch), *det, B, D, H, W, Cin, Cout, _stream())
     else:
         if x.dtype != torch.float32 or dy.dtype != torch.float32:
             x, dy = x.float(), dy.float()
             xb, xp, xc = grid_strides(x)
             db, dp, dc = grid_strides(dy)
-        lib.call("pulpo_conv3d_k3_wgrad", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw), 2 if deferred else int(into is not None), _ptr(scratch),
-                 B, D, H, W, Cin, Cout, _stream())
+        lib.call("pulpo_conv3d_k3_wgrad_det" if det else "pulpo_conv3d_k3_wgrad", _ptr(x), xb, xp, xc, _ptr(dy), db, dp, dc, _ptr(dw),
+                 2 if deferred else int(into is not None), _ptr(scratch), *det, B, D, H, W, Cin, Cout, _stream())
     if deferred and not _pending_src(scratch):
         # (ONE finishing job per scratch: a unit applied twice in a step - shared weights, two forward passes - has accumulated both weight
         #  gradients into the same packed sums by the time the job runs)
@@ -1036,7 +1055,8 @@ class _Resize(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gin = torch.empty((B, C, Di, Hi, Wi), device=g.device, dtype=torch.float32)
             t0 = _hbm_begin("resize_trilinear_bwd")
-            lib.call("pulpo_resize_trilinear_scaled_bwd", _ptr(g), _ptr(gin), B * C, Di, Hi, Wi, Do, Ho, Wo, *ctx.scale, ctx.mult, _stream())
+            lib.call("pulpo_resize_trilinear_scaled_bwd_det" if DETERMINISTIC else "pulpo_resize_trilinear_scaled_bwd", _ptr(g), _ptr(gin), B * C, Di, Hi, Wi,
+                     Do, Ho, Wo, *ctx.scale, ctx.mult, _stream())
             _hbm_end(t0, "resize_trilinear_bwd", 4.0 * (g.numel() + gin.numel()))
         return gin, None, None, (g if ctx.has_add and ctx.needs_input_grad[3] else None), None
 
@@ -1115,7 +1135,11 @@ class _Warp(torch.autograd.Function):
         gdf = torch.empty_like(df) if ctx.needs_input_grad[0] else None
         gimg = torch.empty_like(img) if ctx.needs_input_grad[1] else None
         t0 = _hbm_begin("warp3d_bwd")
-        lib.call("pulpo_warp3d_bwd", _ptr(df), _ptr(img), _ptr(g), _ptr(gdf), _ptr(gimg), B, C, Dg, Hg, Wg, Di, Hi, Wi, _stream())
+        if DETERMINISTIC and gimg is not None:          # (the displacement gradient alone is a gather: nothing to order)
+            ws = torch.empty(lib.query("pulpo_warp3d_bwd_det_ws_bytes", B, C, Di, Hi, Wi), device=df.device, dtype=torch.uint8)
+            lib.call("pulpo_warp3d_bwd_det", _ptr(df), _ptr(img), _ptr(g), _ptr(gdf), _ptr(gimg), _ptr(ws), B, C, Dg, Hg, Wg, Di, Hi, Wi, _stream())
+        else:
+            lib.call("pulpo_warp3d_bwd", _ptr(df), _ptr(img), _ptr(g), _ptr(gdf), _ptr(gimg), B, C, Dg, Hg, Wg, Di, Hi, Wi, _stream())
         _hbm_end(t0, "warp3d_bwd", 4.0 * (df.numel() + img.numel() + g.numel() + (gdf.numel() if gdf is not None else 0)
                                           + (2 * gimg.numel() if gimg is not None else 0)))      # (image gradient: zero fill + scatter)
         return gdf, gimg
@@ -1148,10 +1172,15 @@ class _VecInt(torch.autograd.Function):
         g = planar(g)
         _, B, _, D, H, W = work.shape
         gin = torch.empty((B, 3, D, H, W), device=g.device, dtype=torch.float32)
-        ntmp = lib.query("pulpo_vecint_bwd_tmp_floats", B, D, H, W, ctx.nsteps)
-        tmp = torch.empty(ntmp, device=g.device, dtype=torch.float32) if ntmp else None
         t0 = _hbm_begin("vecint_bwd")
-        lib.call("pulpo_vecint_bwd", _ptr(work), _ptr(g), _ptr(gin), _ptr(tmp), B, D, H, W, ctx.nsteps, _stream())
+        if DETERMINISTIC:
+            nws = lib.query("pulpo_vecint_bwd_det_ws_bytes", B, D, H, W, ctx.nsteps)
+            ws = torch.empty(nws, device=g.device, dtype=torch.uint8) if nws else None
+            lib.call("pulpo_vecint_bwd_det", _ptr(work), _ptr(g), _ptr(gin), _ptr(ws), B, D, H, W, ctx.nsteps, _stream())
+        else:
+            ntmp = lib.query("pulpo_vecint_bwd_tmp_floats", B, D, H, W, ctx.nsteps)
+            tmp = torch.empty(ntmp, device=g.device, dtype=torch.float32) if ntmp else None
+            lib.call("pulpo_vecint_bwd", _ptr(work), _ptr(g), _ptr(gin), _ptr(tmp), B, D, H, W, ctx.nsteps, _stream())
         _hbm_end(t0, "vecint_bwd", 4.0 * gin.numel() * (3 * ctx.nsteps + 2))                 # every step: read the field and the gradient, write a gradient
         return gin, None
 
@@ -1423,6 +1452,9 @@ class _JDetStd(torch.autograd.Function):
         df, jd, stat = ctx.saved_tensors
         lamb, normalize = ctx.meta
         B, _, D, H, W = df.shape
+        if DETERMINISTIC:
+            raise PulpoHipError("the `jdet` regulariser's backward scatters with float atomics and has no deterministic form (PULPO_DETERMINISTIC covers "
+                                "the default training path: ncc / mse / dice + L2 regulariser)")
         gdf = torch.empty_like(df)
         lib.call("pulpo_jdetstd_bwd", _ptr(df), _ptr(jd), _ptr(stat), _ptr(g.contiguous()), lamb, _ptr(gdf), B, D, H, W, int(normalize), _stream())
         return gdf, None, None

@@ -44,6 +44,8 @@ def _clean_kernel_switches():
         assert mod.CONV_PRECISION == "fp32", f"ops.CONV_PRECISION leaked from an earlier test: {mod.CONV_PRECISION!r}"
         assert mod.ACT_BF16 is False, "ops.ACT_BF16 leaked from an earlier test"
         fusion = mod.BN_REDUCE_IN_DGRAD
+        want_det = os.environ.get("PULPO_DETERMINISTIC", "0") == "1"
+        assert mod.DETERMINISTIC == want_det, "ops.DETERMINISTIC leaked from an earlier test"
     yield
     mod = sys.modules.get("pulpo_amd.ops")
     if mod is not None:
@@ -51,6 +53,9 @@ def _clean_kernel_switches():
         mod.CONV_ALGO = None
         mod.set_conv_precision("fp32")
         assert leaked == (None, "fp32", False), f"test left ops.CONV_ALGO / CONV_PRECISION / ACT_BF16 = {leaked!r}"
+        det_left = mod.DETERMINISTIC
+        mod.set_deterministic(os.environ.get("PULPO_DETERMINISTIC", "0") == "1")
+        assert det_left == mod.DETERMINISTIC, "test left ops.DETERMINISTIC switched"
     orc = sys.modules.get("oracle.pulpo_oracle")
     if orc is not None:
         left = (orc.CONV_PRECISION, orc.ACT_PRECISION)

@@ -1190,3 +1190,99 @@ def test_bf16_storage_eval_mode_unit(ops, Cin, Cout, size):
     assert z.dtype == torch.bfloat16
     # (the fused kernel never writes y, but rounds it as the unfused path would have stored it)
     assert rel_l2(z.float(), zr) <= 1e-3, rel_l2(z.float(), zr)
+
+
+# ================================================================================================ deterministic mode (PULPO_DETERMINISTIC)
+@pytest.fixture
+def deterministic(ops):
+    import os
+    ops.set_deterministic(True)
+    yield
+    ops.set_deterministic(os.environ.get("PULPO_DETERMINISTIC", "0") == "1")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,size,precision", [(1, 32, 32, (64, 64, 64), "fp32"), (1, 96, 64, (32, 32, 32), "fp32"), (2, 16, 96, (10, 20, 28), "fp32"),
+                                                       (1, 64, 32, (7, 12, 17), "fp32"), (1, 2, 32, (64, 64, 64), "fp32"), (2, 3, 32, (20, 17, 33), "fp32"),
+                                                       (1, 40, 24, (12, 10, 9), "fp32"), (1, 192, 192, (20, 20, 20), "fp32"), (1, 32, 64, (32, 32, 32), "bf16")])
+def test_deterministic_weight_gradient_is_bit_reproducible(ops, deterministic, B, Cin, Cout, size, precision):
+    """ordered per-split slabs instead of float atomics between the workgroups of a (ci tile, co tile): every weight-gradient kernel (F(2x2x2) and
+    F(2x2) Winograd, direct, narrow-input, bf16 operands) gives the same bits on every run, and the same value as the atomic form up to the
+    order of the sums (1e-6) and as the double-precision gradient (the kernels' own test bound)"""
+    gen = torch.Generator().manual_seed(Cin + 3 * Cout)
+    x = torch.randn(B, Cin, *size, generator=gen).cuda()
+    dy = torch.randn(B, Cout, *size, generator=gen).cuda()
+    if Cin > 4:
+        x = x.contiguous(memory_format=torch.channels_last_3d)
+    dy = dy.contiguous(memory_format=torch.channels_last_3d)
+    ops.set_conv_precision(precision)
+    try:
+        a = ops._wgrad_raw(x, dy, Cin, Cout)
+        for _ in range(3):
+            assert torch.equal(ops._wgrad_raw(x, dy, Cin, Cout), a)
+        acc = torch.full_like(a, 0.5)
+        ops._wgrad_raw(x, dy, Cin, Cout, into=acc)            # (accumulating form: dw += ...)
+        assert rel_l2(acc - 0.5, a) < 1e-5
+        ops.set_deterministic(False)
+        plain = ops._wgrad_raw(x, dy, Cin, Cout)
+    finally:
+        ops.set_conv_precision("fp32")
+    assert rel_l2(a, plain) < 2e-6
+    if precision == "fp32":
+        ref = torch.nn.grad.conv3d_weight(x.double().cpu().contiguous(), (Cout, Cin, 3, 3, 3), dy.double().cpu().contiguous(), padding=1)
+        assert rel_l2(a, ref) < 1e-5
+
+
+@pytest.mark.parametrize("size,amp", [((24, 20, 28), 1.0), ((16, 32, 18), 12.0), ((10, 10, 10), 2.0), ((40, 40, 40), 3.0)])
+def test_deterministic_vecint_backward_fixed_point_vs_oracle(ops, deterministic, size, amp):
+    """VecInt backward with the scatter accumulated in 64-bit fixed point (2^46 units per the largest upstream gradient of a squaring step):
+    bit-identical on every run, and against autograd through the oracle's VecInt in double at the plain kernel's bound"""
+    gen = torch.Generator().manual_seed(int(amp * 10) + size[0])
+    v = torch.randn(2, 3, *size, generator=gen) * amp
+    up = torch.randn(2, 3, *size, generator=gen)
+    vg = v.cuda().requires_grad_(True)
+
+    def grad():
+        out = ops.vecint(vg, 7)
+        return torch.autograd.grad((out * up.cuda()).sum(), [vg])[0]
+
+    g0 = grad()
+    for _ in range(3):
+        assert torch.equal(grad(), g0)
+    vr = v.double().requires_grad_(True)
+    gr, = torch.autograd.grad((O.vecint(vr, 7) * up.double()).sum(), [vr])
+    v32 = v.clone().requires_grad_(True)
+    g32, = torch.autograd.grad((O.vecint(v32, 7) * up).sum(), [v32])
+    assert rel_l2(g0, gr) < max(1e-4, 3.0 * rel_l2(g32, gr))
+    ops.set_deterministic(False)
+    assert rel_l2(grad(), g0) < max(1e-5, 0.5 * rel_l2(g32, gr))       # (floor() of a sample coordinate at a cell boundary: both forms compute it alike)
+
+
+def test_deterministic_warp_and_resize_backward(ops, deterministic):
+    """SpatialTransformer backward with an image that requires a gradient (fixed-point scatter) and the trilinear resize backward at ratios other
+    than the exact x2 (gather): reproducible bits, autograd's values"""
+    gen = torch.Generator().manual_seed(4)
+    df = (torch.randn(2, 3, 12, 14, 10, generator=gen) * 2.0)
+    img = torch.rand(2, 2, 9, 11, 13, generator=gen)
+    up = torch.randn(2, 2, 12, 14, 10, generator=gen)
+    dfg, imgg = df.cuda().requires_grad_(True), img.cuda().requires_grad_(True)
+
+    def grads():
+        return torch.autograd.grad((ops.warp3d(dfg, imgg) * up.cuda()).sum(), [dfg, imgg])
+
+    a = grads()
+    for _ in range(3):
+        b = grads()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    dfr, imgr = df.double().requires_grad_(True), img.double().requires_grad_(True)
+    r = torch.autograd.grad((O.warp(dfr, imgr) * up.double()).sum(), [dfr, imgr])
+    assert rel_l2(a[0], r[0]) < 1e-5 and rel_l2(a[1], r[1]) < 1e-5
+    for in_size, out_size in (((5, 6, 7), (9, 8, 16)), ((8, 8, 8), (32, 32, 32)), ((12, 9, 10), (6, 5, 4)), ((4, 5, 6), (4, 5, 6))):
+        xg = torch.randn(2, 3, *in_size, generator=gen)
+        u = torch.randn(2, 3, *out_size, generator=gen)
+        xc = xg.cuda().requires_grad_(True)
+        g0, = torch.autograd.grad((ops.resize_trilinear(xc, out_size, mult=1.5) * u.cuda()).sum(), [xc])
+        g1, = torch.autograd.grad((ops.resize_trilinear(xc, out_size, mult=1.5) * u.cuda()).sum(), [xc])
+        assert torch.equal(g0, g1)
+        xr = xg.double().requires_grad_(True)
+        gr, = torch.autograd.grad((1.5 * F.interpolate(xr, size=out_size, mode="trilinear", align_corners=False) * u.double()).sum(), [xr])
+        assert rel_l2(g0, gr) < 1e-6, (in_size, out_size, rel_l2(g0, gr))

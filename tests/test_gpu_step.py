@@ -77,7 +77,13 @@ STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16", "step_fullres_T3L2_n2_
 
 # (case, forward / data-gradient kernel): None = the library's per-shape default (the Winograd kernels - F(2x2x2,3x3x3) on whole 4x8x8 tiles,
 # F(2x2,3x3) elsewhere - where eligible, which on these fixtures is the 32^3 case only); that case is also pinned with the direct kernels forced
-STEP_ALGO_CASES = [(c, None) for c in STEP_CASES] + [("step_T3L2_n8_32", "direct")]
+STEP_ALGO_CASES = [(c, None) for c in STEP_CASES] + [("step_T3L2_n8_32", "direct"), ("step_T3L2_n8_32", "deterministic"), ("step_fullres_T3L2_n2_16", "deterministic")]
+
+# the 32^3 golden step in DETERMINISTIC mode: the GPU's gradients are then one fixed set of numbers (bit-identical run to run), so the bound
+# against the reference's fp32 gradients is set on what that evaluation measures (profiles/r5_deterministic.md) instead of leaving room for the
+# spread of the float-atomic sums.  It cannot reach SURVEY 8(c)'s 1e-3: the reference's own fp32 gradients sit up to 2e-3 from an fp64
+# evaluation on this case (windowed-variance cancellation at 9^3 NCC windows), and a LeakyReLU slope that differs moves a gradient by more.
+GRAD_BOUND_32_DETERMINISTIC = 5e-3          # measured 4.24e-3 (0 slope flips), a fixed number in this mode
 
 
 @pytest.mark.parametrize("case,algo", STEP_ALGO_CASES)
@@ -86,14 +92,17 @@ def test_training_step_matches_reference_golden(api, golden, case, algo):
     from pulpo_amd._lib import lib
     if case == "step_T3L2_n8_32":           # the shipped default really is the (y, x) Winograd kernel on this case's full-resolution layers
         assert lib.query("pulpo_conv3d_k3_algo", 1, 32, 32, 32, 8, 8) == 2
-    ops.CONV_ALGO = algo
+    det = algo == "deterministic"
+    ops.CONV_ALGO = None if det else algo
+    ops.set_deterministic(det or ops.DETERMINISTIC)
     try:
-        _training_step_vs_golden(api, golden, case)
+        _training_step_vs_golden(api, golden, case, det)
     finally:
         ops.CONV_ALGO = None
+        ops.set_deterministic(__import__("os").environ.get("PULPO_DETERMINISTIC", "0") == "1")
 
 
-def _training_step_vs_golden(api, golden, case):
+def _training_step_vs_golden(api, golden, case, det=False):
     models, nb = api
     g = golden(case)
     model, (Tl, L, n0, B, size) = build_from_golden(models, nb, g, case=case)
@@ -138,7 +147,7 @@ def _training_step_vs_golden(api, golden, case):
         sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
         _, g64, _ = O.train_step(O.clone_sd(sd64, requires_grad=True), cfg, T(g["x"]).double(), T(g["y"]).double(),
                                  {l: T(g[f"eps.{l}"]).double() for l in range(L)})
-        grad_bound = 1e-2
+        grad_bound = GRAD_BOUND_32_DETERMINISTIC if det else 1e-2
     for key, val in zip(("total", "kl", "rec", "reg"), (total, kl, rec, reg)):
         np.testing.assert_allclose(float(val), float(g["train." + key]), rtol=1e-4)
     for nm, d in zip(("kl_l", "rec_l", "reg_l"), levels):
@@ -168,6 +177,7 @@ def _training_step_vs_golden(api, golden, case):
             assert "nograd." + k in g, k
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k     # encoders[L-1].sample_merge_block is never used
     assert n_checked > 40
+    print(f"{case} (deterministic {det}): {flips} slope flips, largest gradient distance from the reference {worst:.3e} (bound {grad_bound:g})")
     if vs64:        # noise-dominated quantities (they move run to run with the atomic order): compare the distributions, not parameter by parameter
         e_gpu, e_ref = np.array(vs64).T
         # (measured medians: reference 5.6e-4, Winograd kernels 5.4e-4, direct kernels - one sequential 216-term fmaf chain per output
@@ -666,9 +676,12 @@ def test_config4_160_bf16_oasis_step(api):
 # distribution it rests on: maximum 3.5e-3 over 129 parameters (the fp32 oracle itself sits 3.9e-3 from fp64) - SURVEY 8(c) suggested
 # 5e-3 at >= 64^3; 6e-3 leaves the run-to-run spread of the float-atomic sums (~1.7x the measured maximum) inside the bound
 GRAD_BOUND_160 = 6e-3
+# ... and in DETERMINISTIC mode (ops.set_deterministic: ordered sums instead of float atomics) the gradients are one fixed set of numbers: the
+# bound is SURVEY 8(c)'s 5e-3 itself (measured maximum: profiles/r5_parity_160.md)
+GRAD_BOUND_160_DETERMINISTIC = 5e-3
 
 
-def _write_parity_report(vs32, e_gpu, e_ref):
+def _write_parity_report(vs32, e_gpu, e_ref, mode="atomic", bound=None):
     """the measured gradient distances of the 160^3 step, kept as a file (gpurun_out/parity_160.md; a builder run's copy is committed as
     profiles/r3_parity_160.md): the evidence the bound above is set from"""
     import os
@@ -677,15 +690,15 @@ def _write_parity_report(vs32, e_gpu, e_ref):
         os.makedirs(out, exist_ok=True)
         d = np.array([v for v, _ in vs32])
         worst = sorted(vs32, reverse=True)[:8]
-        with open(os.path.join(out, "parity_160.md"), "w") as f:
-            f.write("# 160^3 / T5 / L4 / n0 32 training step: parameter gradients, GPU vs CPU oracle (test_headline_160_step_vs_cpu_oracle)\n\n")
+        with open(os.path.join(out, "parity_160.md"), "w" if mode == "atomic" else "a") as f:
+            f.write(f"# 160^3 / T5 / L4 / n0 32 training step: parameter gradients, GPU ({mode} mode) vs CPU oracle (test_headline_160_step_vs_cpu_oracle)\n\n")
             f.write(f"{len(d)} parameters compared (conv biases in front of a BatchNorm excluded: true gradient zero).\n\n")
             f.write("| relative L2 distance | median | p90 | p99 | max |\n|---|---|---|---|---|\n")
             f.write(f"| GPU vs fp32 CPU oracle | {np.median(d):.2e} | {np.percentile(d, 90):.2e} | {np.percentile(d, 99):.2e} | {d.max():.2e} |\n")
             f.write(f"| GPU vs fp64 oracle | {np.median(e_gpu):.2e} | {np.percentile(e_gpu, 90):.2e} | {np.percentile(e_gpu, 99):.2e} | {e_gpu.max():.2e} |\n")
             f.write(f"| fp32 CPU oracle vs fp64 oracle | {np.median(e_ref):.2e} | {np.percentile(e_ref, 90):.2e} | {np.percentile(e_ref, 99):.2e} | {e_ref.max():.2e} |\n\n")
             f.write("Largest GPU-vs-fp32 distances:\n\n" + "".join(f"* `{k}` {v:.2e}\n" for v, k in worst))
-            f.write(f"\nBound applied by the test: every parameter < {GRAD_BOUND_160:g} of the fp32 oracle; distance from fp64 distributed like the fp32 oracle's own.\n")
+            f.write(f"\nBound applied by the test: every parameter < {bound if bound else GRAD_BOUND_160:g} of the fp32 oracle; distance from fp64 distributed like the fp32 oracle's own.\n\n")
     except OSError:
         pass
 
@@ -705,19 +718,33 @@ def test_headline_160_step_vs_cpu_oracle(api):
     gen = torch.Generator().manual_seed(21)
     x, y = torch.rand(1, 1, *size, generator=gen), torch.rand(1, 1, *size, generator=gen)
     eps = {l: torch.randn(1, 3, *[160 // 2 ** (l + 1)] * 3, generator=gen) for l in range(4)}
-    model = models.PULPo(5, 4, 0.1, size, feedback=FB, n0=32)
-    _copy_oracle_sd_into(model, sd)
-    model = model.cuda().train()
-    for l in range(4):
-        model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(eps[l].cuda())
-    outs, _, (total, kl, rec, reg), _ = model._forward_and_losses(x.cuda(), y.cuda())
-    total.backward()
-    torch.cuda.synchronize()
-    gpu_out = [{l: v.detach().cpu() for l, v in d.items()} for d in outs]
-    gpu_loss = [float(v) for v in (total, kl, rec, reg)]
-    gpu_grad = {k: (p.grad.detach().cpu() if p.grad is not None else None) for k, p in model.named_parameters()}
-    del outs, total, kl, rec, reg, model
-    torch.cuda.empty_cache()
+    from pulpo_amd import ops
+    env_det = __import__("os").environ.get("PULPO_DETERMINISTIC", "0") == "1"
+
+    def gpu_step(det):
+        # (round 5: the step is evaluated twice - with the float atomics of the default mode and in deterministic mode - against ONE oracle pair)
+        ops.set_deterministic(det)
+        try:
+            model = models.PULPo(5, 4, 0.1, size, feedback=FB, n0=32)
+            _copy_oracle_sd_into(model, sd)
+            model = model.cuda().train()
+            for l in range(4):
+                model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(eps[l].cuda())
+            outs, _, (total, kl, rec, reg), _ = model._forward_and_losses(x.cuda(), y.cuda())
+            total.backward()
+            torch.cuda.synchronize()
+            res = ([{l: v.detach().cpu() for l, v in d.items()} for d in outs], [float(v) for v in (total, kl, rec, reg)],
+                   {k: (p.grad.detach().cpu() if p.grad is not None else None) for k, p in model.named_parameters()})
+            del outs, total, kl, rec, reg, model
+            torch.cuda.empty_cache()
+            return res
+        finally:
+            ops.set_deterministic(env_det)
+
+    gpu_out, gpu_loss, gpu_grad = gpu_step(False)
+    det_out, det_loss, det_grad = gpu_step(True)
+    assert det_loss == gpu_loss                       # (the forward pass is the same kernels in both modes)
+    del det_out
 
     torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
     ls, grads, outs_o = O.train_step(O.clone_sd(sd, requires_grad=True), cfg, x, y, eps)
@@ -729,26 +756,28 @@ def test_headline_160_step_vs_cpu_oracle(api):
     del outs_o, gpu_out
     sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     _, grads64, _ = O.train_step(O.clone_sd(sd64, requires_grad=True), cfg, x.double(), y.double(), {l: e.double() for l, e in eps.items()})
-    vs64, vs32 = [], []
-    for k, g in gpu_grad.items():
-        gr = grads.get(k)
-        if gr is None:
-            assert g is None or float(g.abs().max()) == 0.0, k
-            continue
-        if k.endswith("_op.0.bias") and "velocity_field._op.2" not in k:
-            wref = float(grads[k[:-4] + "weight"].abs().max())          # true gradient zero (a BatchNorm follows): noise on both sides
-            assert float(g.abs().max()) <= 1e-2 * max(wref, 1e-3), k
-            continue
-        d32 = rel_l2(g, gr)
-        assert d32 < GRAD_BOUND_160, (k, d32)
-        vs32.append((d32, k))
-        vs64.append((rel_l2(g, grads64[k]), rel_l2(gr, grads64[k])))
-    assert len(vs64) > 100
-    e_gpu, e_ref = np.array(vs64).T
-    print(f"160^3 gradients vs fp64: gpu median {np.median(e_gpu):.2e} max {e_gpu.max():.2e}; cpu fp32 oracle median {np.median(e_ref):.2e} max {e_ref.max():.2e}")
-    _write_parity_report(vs32, e_gpu, e_ref)
-    assert np.median(e_gpu) <= 4.0 * np.median(e_ref) + 2e-4, (np.median(e_gpu), np.median(e_ref))
-    assert e_gpu.max() <= 6.0 * e_ref.max() + 1e-3, (e_gpu.max(), e_ref.max())
+    for mode, grad_set, bound in (("atomic", gpu_grad, GRAD_BOUND_160), ("deterministic", det_grad, GRAD_BOUND_160_DETERMINISTIC)):
+        vs64, vs32 = [], []
+        for k, g in grad_set.items():
+            gr = grads.get(k)
+            if gr is None:
+                assert g is None or float(g.abs().max()) == 0.0, k
+                continue
+            if k.endswith("_op.0.bias") and "velocity_field._op.2" not in k:
+                wref = float(grads[k[:-4] + "weight"].abs().max())          # true gradient zero (a BatchNorm follows): noise on both sides
+                assert float(g.abs().max()) <= 1e-2 * max(wref, 1e-3), k
+                continue
+            d32 = rel_l2(g, gr)
+            assert d32 < bound, (mode, k, d32)
+            vs32.append((d32, k))
+            vs64.append((rel_l2(g, grads64[k]), rel_l2(gr, grads64[k])))
+        assert len(vs64) > 100
+        e_gpu, e_ref = np.array(vs64).T
+        print(f"160^3 gradients vs fp64 ({mode} mode): gpu median {np.median(e_gpu):.2e} max {e_gpu.max():.2e}; cpu fp32 oracle median {np.median(e_ref):.2e} "
+              f"max {e_ref.max():.2e}; largest distance from the fp32 oracle {max(vs32)[0]:.2e} (bound {bound:g})")
+        _write_parity_report(vs32, e_gpu, e_ref, mode, bound)
+        assert np.median(e_gpu) <= 4.0 * np.median(e_ref) + 2e-4, (np.median(e_gpu), np.median(e_ref))
+        assert e_gpu.max() <= 6.0 * e_ref.max() + 1e-3, (e_gpu.max(), e_ref.max())
 
 
 def test_config2_96_step_vs_cpu_oracle(api):
@@ -1276,3 +1305,57 @@ def test_training_resumes_bit_identically_from_a_checkpoint(api, tmp_path):
     bad = {"state": dict(back["state"]), "param_groups": [dict(back["param_groups"][0], params=back["param_groups"][0]["params"][:-1])]}
     with pytest.raises(ValueError):
         sc.opt.load_state_dict(bad)
+
+
+def _grads_of_one_step(model, x, y):
+    for p in model.parameters():
+        p.grad = None
+    outs, _, (total, kl, rec, reg), _ = model._forward_and_losses(x, y)
+    total.backward()
+    torch.cuda.synchronize()
+    return float(total), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("size,T_L,n0", [([32, 32, 32], (3, 2), 8), ([160, 160, 160], (5, 4), 32)])
+def test_deterministic_mode_gives_bit_identical_gradients(api, size, T_L, n0):
+    """PULPO_DETERMINISTIC / ops.set_deterministic(True): the weight-gradient flushes (ordered per-split slabs), the VecInt / warp backward
+    scatter (64-bit fixed point) and the generic resize backward (gather) replace the float atomics - two evaluations of the same training step
+    on the same weights, inputs and noise give BIT-identical losses and parameter gradients, as the reference's CPU backward does,
+    at 32^3 and at the metric's 160^3.  The plain mode is held to the deterministic one at 1e-5 relative L2 (atomic order only)."""
+    models, nb = api
+    from pulpo_amd import ops
+    import os
+    torch.manual_seed(0)
+    model = models.PULPo(T_L[0], T_L[1], 0.1, size, feedback=FB, n0=n0).cuda().train()
+    gen = torch.Generator().manual_seed(5)
+    x, y = torch.rand(1, 1, *size, generator=gen).cuda(), torch.rand(1, 1, *size, generator=gen).cuda()
+    for l in range(T_L[1]):
+        shape = [s_ // 2 ** (l + (T_L[0] - T_L[1])) for s_ in size]
+        model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(torch.randn(1, 3, *shape, generator=gen).cuda())
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    env_det = os.environ.get("PULPO_DETERMINISTIC", "0") == "1"
+    try:
+        ops.set_deterministic(True)
+        runs = []
+        for _ in range(3):
+            model.load_state_dict(state)                # (BatchNorm running statistics move with every training forward)
+            runs.append(_grads_of_one_step(model, x, y))
+        for loss_b, grads_b in runs[1:]:
+            assert loss_b == runs[0][0]
+            assert grads_b.keys() == runs[0][1].keys()
+            for k, g in grads_b.items():
+                assert torch.equal(g, runs[0][1][k]), (k, float((g - runs[0][1][k]).abs().max()))
+        ops.set_deterministic(False)
+        model.load_state_dict(state)
+        loss_p, grads_p = _grads_of_one_step(model, x, y)
+        assert loss_p == runs[0][0]                      # (the forward pass has no atomics in either mode)
+        moved = 0
+        for k, g in grads_p.items():
+            ref = runs[0][1][k]
+            if k.endswith("_op.0.bias") and "velocity_field._op.2" not in k:
+                continue                                 # (true gradient zero in front of a BatchNorm: pure rounding noise on both sides)
+            assert rel_l2(g, ref) < 1e-5, (k, rel_l2(g, ref))
+            moved += int(not torch.equal(g, ref))
+        print(f"{size[0]}^3: {moved} of {len(grads_p)} parameter gradients differ in their last bits between the atomic and the deterministic mode")
+    finally:
+        ops.set_deterministic(env_det)
