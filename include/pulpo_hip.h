@@ -349,6 +349,17 @@ int pulpo_feedback_up2_fwd_t(const float* const* srcs /*host array of device ptr
 int pulpo_feedback_up2_bwd_t(const void* gout, int dt, int64_t gops, float* const* gsrcs /*host array, entries may be NULL*/, const int* chans,
                              int nsrc, int B, int Di, int Hi, int Wi, void* stream);
 
+/* ------------------------------------------------------------------------- input-layer weight gradient with the unit's BatchNorm backward fused (since ABI 4)
+ * The ConvUnit of the image pair (src/network_blocks.py:22-26 as down_blocks[0]._op[0], components/pulpo.py:26): nobody needs its data gradient, so
+ * the gradient dy of its pre-norm tensor has ONE reader - this weight gradient.  The kernel forms dy = batch_norm_backward(leaky_relu_backward(dz))
+ * per element while it stages its tiles (pulpo_bn_lrelu_bwd_apply's arithmetic from the same coefficient block and totals), so the pass that
+ * writes dy is not run.  part2: pulpo_conv3d_k3_wgrad_bn_rows() rows of Cout floats - the column sums of dy (conv-bias gradient partials).
+ * Cin <= 4, Cout % 4 == 0; dz fp32 or bf16 (dz_dt), y fp32, channels-last.  scratch / dw / accumulate as pulpo_conv3d_k3_wgrad. */
+int pulpo_conv3d_k3_wgrad_bn_rows(int B, int D, int H, int W, int Cout);
+int pulpo_conv3d_k3_wgrad_bn(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const void* dz, int dz_dt, int64_t dz_bs, int64_t dz_ps,
+                             const float* y, int64_t y_bs, int64_t y_ps, const float* coef, const double* totd, float slope, float* dw,
+                             int accumulate, float* scratch, float* part2, int B, int D, int H, int W, int Cin, int Cout, void* stream);
+
 /* ------------------------------------------------------------------------- DETERMINISTIC forms of the backward kernels that add with float atomics (since ABI 4)
  * The reference's CPU backward is run-to-run deterministic; the plain entry points above add the weight-gradient partial sums
  * of concurrent workgroups (aten::convolution_backward, src/network_blocks.py:23) and the image-gradient scatter of grid_sampler_3d_backward

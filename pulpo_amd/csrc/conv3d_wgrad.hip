@@ -32,6 +32,18 @@ struct WgradArgs {
     int ntz, nty, ntx, ncit, ncot, nsplit;
     long split_stride;            // 0, or (deterministic mode) floats between the per-split copies of dwp: split s adds into dwp + s * split_stride,
                                   // which no other workgroup of the same (ci tile, co tile) touches - every element receives ONE add
+    // conv3d_k3_wgrad_smallc with the BatchNorm / LeakyReLU backward of its own ConvUnit fused into the operand staging (bn_y != nullptr):
+    // `dy` then holds dz (the gradient of the unit's OUTPUT, fp32 or bf16: dz_bf16) and the kernel forms
+    //     dy = scale * lrelu'(scale * y + shift) * dz + B * (y - m32) + C      (bn_lrelu_bwd_apply_kernel's arithmetic, norm_act.hip)
+    // per element while it stages the tile - the pass that writes dy (and reads dz and y once more) disappears where nothing else needs dy:
+    // the input layer, whose data gradient nobody asks for.  bn_part2[split][Cout] receives the column sums of dy (the conv bias gradient).
+    const float* bn_y;
+    long bn_y_bs, bn_y_ps;
+    const float* bn_coef;         // the unit's coefficient block (pulpo_bn_fwd_finalize)
+    const double* bn_totd;        // [2][Cout]: mean(dbn), mean(dbn * xhat) (pulpo_bn_bwd_finalize)
+    float* bn_part2;
+    float slope;
+    int dz_bf16;
 };
 
 constexpr int WG_CH = 32, WG_NT = 32, WG_CP = WG_CH + 1;
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(256, VEC ? 1 : 2) void conv3d_k3_wgrad_mfma(WgradAr
 // owns ALL row tiles and one z-plane (64 voxels = 32 k-steps) of a 4 x 8 x 8 voxel tile - the waves split the GEMM's K -, the next tile's
 // operands are fetched into registers underneath the current tile's MFMAs, and the four partial sums meet in LDS before one atomic flush
 // per workgroup.  x: planar or strided (scalar loads, one channel plane per run of lanes); dy: channels-last, 16-byte aligned.
-template <int NRT>
+template <int NRT, bool BN = false>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_smallc(WgradArgs a) {
     constexpr int HV4 = 6 * HY * HX, XP = HV4 + 4;          // halo voxels of a 4 x 8 x 8 tile; plane stride of the planar halo image
     constexpr int NIX = (4 * HV4 + 255) / 256;              // scalar halo loads per thread (<= 4 channels)
@@ -286,6 +298,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_smallc(WgradArgs a) {
 
     float xr[NIX];
     float4 dr[8];
+    // ---- BN: this thread's four channels (co0 + 4 q .. + 3, q = tid & 7 for every piece it stages) and their constants
+    float4 yr[BN ? 8 : 1];
+    unsigned vmask = 0;                                     // piece u of the fetched tile lies inside the volume
+    float k_sc[4], k_sh[4], k_m[4], k_b[4], k_chi[4], k_clo[4], bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BN) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = co0 + 4 * (tid & 7) + k;
+            k_sc[k] = k_sh[k] = k_m[k] = k_b[k] = k_chi[k] = k_clo[k] = 0.f;
+            if (ch < a.Cout) {
+                const int C = a.Cout;
+                const double* cd = reinterpret_cast<const double*>(a.bn_coef + 4 * C);
+                const float sc_ = a.bn_coef[2 * C + ch], m32_ = a.bn_coef[ch];
+                const double mean = cd[ch], rstd = cd[C + ch], c1 = a.bn_totd[ch], c2 = a.bn_totd[C + ch];
+                const double b = -(double)sc_ * c2 * rstd;
+                const double cc = -(double)sc_ * (c1 + c2 * rstd * ((double)m32_ - mean));
+                k_sc[k] = sc_; k_sh[k] = a.bn_coef[3 * C + ch]; k_m[k] = m32_; k_b[k] = (float)b; k_chi[k] = (float)cc;
+                k_clo[k] = (float)(cc - (double)k_chi[k]);
+            }
+        }
+    }
     auto fetch = [&](int tl) {
         int t = tl;
         const int tx_ = t % a.ntx; t /= a.ntx;
@@ -311,8 +344,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_smallc(WgradArgs a) {
             const int vv = j >> 3, q = j & 7;
             const int gz = z0 + (vv >> 6), gy = y0 + ((vv >> 3) & 7), gx = x0 + (vv & 7);
             dr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gz < a.D && gy < a.H && gx < a.W && co0 + 4 * q < a.Cout)
+            const bool ok = gz < a.D && gy < a.H && gx < a.W && co0 + 4 * q < a.Cout;
+            if constexpr (BN) {
+                yr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                vmask = u == 0 ? 0u : vmask;
+                if (ok) {
+                    const long vox = (long)(gz * a.H + gy) * a.W + gx;
+                    vmask |= 1u << u;
+                    yr[u] = *reinterpret_cast<const float4*>(a.bn_y + (long)b * a.bn_y_bs + vox * a.bn_y_ps + co0 + 4 * q);
+                    if (a.dz_bf16) {
+                        const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.dy) + (long)b * a.dy_bs + vox * a.dy_ps + co0 + 4 * q);
+                        dr[u] = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+                    } else {
+                        dr[u] = *reinterpret_cast<const float4*>(dyb + vox * a.dy_ps + co0 + 4 * q);
+                    }
+                }
+            } else if (ok) {
                 dr[u] = *reinterpret_cast<const float4*>(dyb + ((long)(gz * a.H + gy) * a.W + gx) * a.dy_ps + co0 + 4 * q);
+            }
         }
     };
     auto stash = [&]() {
@@ -325,6 +374,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_smallc(WgradArgs a) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int j = tid + u * 256;
+            if constexpr (BN) {
+                // dy = scale * dbn + B * (y - m32) + C (C as a (hi, lo) pair), zero outside the volume; its column sums ride along
+                const float g_[4] = {dr[u].x, dr[u].y, dr[u].z, dr[u].w}, v_[4] = {yr[u].x, yr[u].y, yr[u].z, yr[u].w};
+                float o_[4];
+                const bool in = (vmask >> u) & 1u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float bn = v_[k] * k_sc[k] + k_sh[k];
+                    const float sg = k_sc[k] * (bn > 0.f ? g_[k] : g_[k] * a.slope);
+                    const float lin = fmaf(k_b[k], v_[k] - k_m[k], k_chi[k]);
+                    o_[k] = in ? (sg + lin) + k_clo[k] : 0.f;
+                    bsum[k] += o_[k];
+                }
+                dr[u] = make_float4(o_[0], o_[1], o_[2], o_[3]);
+            }
             *reinterpret_cast<float4*>(dys + (j >> 3) * WG_NT + 4 * (j & 7)) = dr[u];
         }
     };
@@ -368,6 +432,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_smallc(WgradArgs a) {
         if (co < a.Cout) {
             const int tap = row / a.Cin, ci = row - tap * a.Cin;
             atomicAdd(a.dwp + (long)split * a.split_stride + ((long)tap * a.Cin + ci) * a.NPad + co, red[j]);
+        }
+    }
+    if constexpr (BN) {
+        // column sums of dy over this workgroup's tiles: the 32 threads that share a channel quad, in thread order (deterministic)
+        __syncthreads();
+        float* bs = dys;                                  // [256 threads][4]
+        *reinterpret_cast<float4*>(bs + tid * 4) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+        __syncthreads();
+        if (tid < WG_NT && co0 + tid < a.Cout) {
+            const int q = tid >> 2, k = tid & 3;
+            float t = 0.f;
+            for (int r = 0; r < 32; ++r) t += bs[(q + 8 * r) * 4 + k];
+            a.bn_part2[(long)split * a.Cout + co0 + tid] = t;
         }
     }
 }
@@ -686,7 +763,7 @@ PULPO_API int pulpo_conv3d_k3_wgrad_algo(int B, int D, int H, int W, int Cin, in
 // scratch: pulpo_conv3d_k3_wgrad_scratch_floats floats.
 static int wgrad_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
                       int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, float* slabs, int nslab, int B, int D, int H, int W,
-                      int Cin, int Cout, void* stream) {
+                      int Cin, int Cout, void* stream, const WgradArgs* bnf = nullptr) {
     PULPO_REQUIRE(in && dy && scratch && (dw || accumulate == 2), "conv3d_k3_wgrad: null pointer");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3d_k3_wgrad: bad dims");
     hipStream_t st = (hipStream_t)stream;
@@ -694,12 +771,17 @@ static int wgrad_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_
     a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
     a.dy = dy; a.dy_bs = dy_bs; a.dy_ps = dy_ps; a.dy_cs = dy_cs;
     a.dwp = scratch;
+    a.bn_y = nullptr; a.bn_y_bs = a.bn_y_ps = 0; a.bn_coef = nullptr; a.bn_totd = nullptr; a.bn_part2 = nullptr; a.slope = 0.f; a.dz_bf16 = 0;
+    if (bnf) {
+        a.bn_y = bnf->bn_y; a.bn_y_bs = bnf->bn_y_bs; a.bn_y_ps = bnf->bn_y_ps; a.bn_coef = bnf->bn_coef; a.bn_totd = bnf->bn_totd;
+        a.bn_part2 = bnf->bn_part2; a.slope = bnf->slope; a.dz_bf16 = bnf->dz_bf16;
+    }
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.NPad = npad(Cout);
     a.ntz = pulpo::cdiv(D, TZ); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
     a.ncit = pulpo::cdiv(Cin, WG_CH); a.ncot = pulpo::cdiv(Cout, WG_NT);
     const int ntile = B * a.ntz * a.nty * a.ntx;
     const int npair = a.ncit * a.ncot;
-    const bool vec = (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)in & 15) == 0) &&
+    const bool vec = !a.dz_bf16 && (in_cs == 1) && (in_ps % 4 == 0) && (in_bs % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)in & 15) == 0) &&
                      (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
     // DMA variant: one resident workgroup per CU -> one round of <= 256 persistent workgroups (fewest atomic flushes);
     // scalar variant: two per CU
@@ -750,14 +832,14 @@ static int wgrad_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_
         }                                                                                                                         \
         hipLaunchKernelGGL((conv3d_k3_wgrad_mfma<VECV, NTWV>), dim3(nblk), dim3(256), bytes, st, a);                              \
     }
-    const int algo = pulpo_conv3d_k3_wgrad_algo(B, D, H, W, Cin, Cout, (int)vec);
+    const int algo = bnf ? 0 : pulpo_conv3d_k3_wgrad_algo(B, D, H, W, Cin, Cout, (int)vec);
     if (algo >= 2) {
         // F(2x2,3x3) in (y, x) / F(2x2x2,3x3x3), register-staged transposed operand images, z-streaming workgroups (conv3d_wgrad_w2.hip)
         // (its launcher picks its own split count: it zeroes the copies it will use and reports how many)
         rc = pulpo_conv::launch_wgrad_w2(in, in_bs, in_ps, dy, dy_bs, dy_ps, scratch, B, D, H, W, Cin, Cout, st, slabs, nslab, &used);
         return finish(rc);
     }
-    if (Cin <= 4 && (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0) && algo != 1) {
+    if ((bnf || (Cin <= 4 && (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0))) && algo != 1) {
         const int ntile4 = B * pulpo::cdiv(D, 4) * a.nty * a.ntx;
         used = std::min(std::max(1, 512 / a.ncot), ntile4);
         if (slabs) used = std::min(used, nslab);
@@ -779,7 +861,7 @@ static int wgrad_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_
     }
         if (nrt9 <= 3) PULPO_WGRAD_W(3) else if (nrt9 <= 5) PULPO_WGRAD_W(5) else PULPO_WGRAD_W(9)
 #undef PULPO_WGRAD_W
-    } else if (Cin <= 4 && (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0)) {
+    } else if (bnf || (Cin <= 4 && (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0))) {
         // the 2-/3-channel input layers: waves split K, every wave all row tiles (conv3d_k3_wgrad_smallc)
         WgradArgs b = a;
         b.ntz = pulpo::cdiv(D, 4);
@@ -799,7 +881,17 @@ static int wgrad_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_
             if (ea != hipSuccess) return pulpo::fail((int)ea, "hipFuncSetAttribute(wgrad smallc): %s", hipGetErrorString(ea));    \
             attr = true;                                                                                                          \
         }                                                                                                                         \
-        hipLaunchKernelGGL((conv3d_k3_wgrad_smallc<NRTV>), dim3(b.ncot * b.nsplit), dim3(256), lds_s, st, b);                     \
+        if (bnf) {                                                                                                                \
+            static bool attrb = false;                                                                                            \
+            if (!attrb) {                                                                                                         \
+                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_smallc<NRTV, true>),           \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);                    \
+                if (ea != hipSuccess) return pulpo::fail((int)ea, "hipFuncSetAttribute(wgrad smallc bn): %s", hipGetErrorString(ea)); \
+                attrb = true;                                                                                                     \
+            }                                                                                                                     \
+            hipLaunchKernelGGL((conv3d_k3_wgrad_smallc<NRTV, true>), dim3(b.ncot * b.nsplit), dim3(256), lds_s, st, b);           \
+        } else                                                                                                                    \
+            hipLaunchKernelGGL((conv3d_k3_wgrad_smallc<NRTV>), dim3(b.ncot * b.nsplit), dim3(256), lds_s, st, b);                 \
     }
         if (nrt <= 2) PULPO_WGRAD_S(2) else if (nrt <= 3) PULPO_WGRAD_S(3) else PULPO_WGRAD_S(4)
 #undef PULPO_WGRAD_S
@@ -816,6 +908,30 @@ PULPO_API int pulpo_conv3d_k3_wgrad(const float* in, int64_t in_bs, int64_t in_p
                                     int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, int B, int D, int H, int W,
                                     int Cin, int Cout, void* stream) {
     return wgrad_impl(in, in_bs, in_ps, in_cs, dy, dy_bs, dy_ps, dy_cs, dw, accumulate, scratch, nullptr, 0, B, D, H, W, Cin, Cout, stream);
+}
+
+// ---- the input layer's weight gradient with its ConvUnit's BatchNorm / LeakyReLU backward fused into the operand staging (round 5):
+// dw (+)= wgrad(in, dy) with dy = bn_lrelu_bwd_apply(dz, y, coef, totd) formed per element while the tile is staged; part2 [rows][Cout]
+// (rows = pulpo_conv3d_k3_wgrad_bn_rows) receives the column sums of dy (the conv-bias gradient's partials).  Cin <= 4 only (the layers whose
+// data gradient nobody needs: nothing else reads dy), dz fp32 or bf16 (dz_dt), y fp32, both channels-last with Cout % 4 == 0.
+PULPO_API int pulpo_conv3d_k3_wgrad_bn_rows(int B, int D, int H, int W, int Cout) {
+    const int ntile4 = B * pulpo::cdiv(D, 4) * pulpo::cdiv(H, TY) * pulpo::cdiv(W, TX);
+    return std::min(std::max(1, 512 / pulpo::cdiv(Cout, WG_NT)), ntile4);
+}
+
+PULPO_API int pulpo_conv3d_k3_wgrad_bn(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const void* dz, int dz_dt, int64_t dz_bs,
+                                       int64_t dz_ps, const float* y, int64_t y_bs, int64_t y_ps, const float* coef, const double* totd, float slope,
+                                       float* dw, int accumulate, float* scratch, float* part2, int B, int D, int H, int W, int Cin, int Cout,
+                                       void* stream) {
+    PULPO_REQUIRE(dz && y && coef && totd && part2, "conv3d_k3_wgrad_bn: null pointer");
+    PULPO_REQUIRE(Cin >= 1 && Cin <= 4 && Cout % 4 == 0, "conv3d_k3_wgrad_bn: %d -> %d channels (input layers only: Cin <= 4, Cout %% 4 == 0)", Cin, Cout);
+    PULPO_REQUIRE(dz_dt == 0 || dz_dt == 1, "conv3d_k3_wgrad_bn: dtype code %d", dz_dt);
+    const int g = dz_dt ? 8 : 16;
+    PULPO_REQUIRE(dz_ps % 4 == 0 && dz_bs % 4 == 0 && (((uintptr_t)dz) % g) == 0 && y_ps % 4 == 0 && y_bs % 4 == 0 && (((uintptr_t)y) & 15) == 0,
+                  "conv3d_k3_wgrad_bn: dz and y must be channels-last with aligned four-channel pieces");
+    WgradArgs f{};
+    f.bn_y = y; f.bn_y_bs = y_bs; f.bn_y_ps = y_ps; f.bn_coef = coef; f.bn_totd = totd; f.bn_part2 = part2; f.slope = slope; f.dz_bf16 = dz_dt;
+    return wgrad_impl(in, in_bs, in_ps, in_cs, (const float*)dz, dz_bs, dz_ps, 1, dw, accumulate, scratch, nullptr, 0, B, D, H, W, Cin, Cout, stream, &f);
 }
 
 // ---- deterministic form (PULPO_DETERMINISTIC): the same kernels, but workgroups that share a (ci tile, co tile) add their partial sums into

@@ -508,7 +508,7 @@ def reset_param_grad_buffers(module: Optional[torch.nn.Module] = None) -> None:
     _BN_TILE_PARTS.clear()
     if module is not None:
         for p_ in module.parameters():
-            for name in ("_pulpo_wgrad_scratch", "_pulpo_dbias_part", "_pulpo_heads_part"):
+            for name in ("_pulpo_wgrad_scratch", "_pulpo_dbias_part", "_pulpo_dbias_part_in", "_pulpo_heads_part"):
                 if hasattr(p_, name):
                     delattr(p_, name)
 
@@ -727,6 +727,12 @@ class _ConvBNLReLU(torch.autograd.Function):
         nsd = lib.query("pulpo_bn_bwd_finalize_scratch_doubles", nrow, Cout)
         scratch = torch.empty(nsd, device=dev, dtype=torch.float64) if nsd else None
         lib.call("pulpo_bn_bwd_finalize", _ptr(rows), nrow, Cout, _ptr(coef), float(npix), int(ctx.training), *fin_out, _ptr(scratch), _stream())
+        # The input layer (image pair -> 32 channels at full resolution): nobody asks for its data gradient, so dy has ONE reader - the weight
+        # gradient, which then forms it per element while staging (pulpo_conv3d_k3_wgrad_bn) instead of a pass that reads dz and y and writes dy
+        # (0.29 ms at 160^3 x 32 channels).  PULPO_FUSE_INPUT_WGRAD=0: the separate pass (A/B switch).
+        if (FUSE_INPUT_WGRAD and Cin <= 2 and not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not DETERMINISTIC and y.dtype == torch.float32
+                and Cout % 4 == 0 and is_cl(y) and is_cl(dz) and y.stride(4) % 4 == 0 and dz.stride(4) % 4 == 0 and x.dtype == torch.float32):
+            return _ConvBNLReLU._backward_input_layer(ctx, dz, x, weight, y, coef, totd, tot, direct_bn, (slot_w, slot_b), (w_p, b_p))
         dy = new_cl(B, Cout, D, H, W, dev, y.dtype)            # (the gradient of the pre-norm tensor is stored like the tensor)
         defer_b = DIRECT_PARAM_GRADS and ctx.needs_input_grad[2] and slot_b is not None
         part2 = _persistent_buffer(b_p, "_pulpo_dbias_part", nblk * Cout, zero=False) if defer_b else None
@@ -756,6 +762,57 @@ class _ConvBNLReLU(torch.autograd.Function):
         if defer_w:
             _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, w_p)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def _backward_input_layer(ctx, dz, x, weight, y, coef, totd, tot, direct_bn, slots, params):
+    slot_w, slot_b = slots
+    w_p, b_p = params
+    B, Cin, D, H, W = x.shape
+    Cout = weight.shape[0]
+    dev = x.device
+    nrow = lib.query("pulpo_conv3d_k3_wgrad_bn_rows", B, D, H, W, Cout)
+    defer_b = DIRECT_PARAM_GRADS and ctx.needs_input_grad[2] and slot_b is not None
+    part2 = _persistent_buffer(b_p, "_pulpo_dbias_part_in", nrow * Cout, zero=False) if defer_b else None
+    if defer_b and _pending_src(part2):
+        defer_b = False
+    if not defer_b:
+        part2 = torch.empty(nrow * Cout, device=dev, dtype=torch.float32)
+    deferred = slot_w is not None and w_p is not None
+    dw = slot_w if slot_w is not None else torch.empty((Cout, Cin, 3, 3, 3), device=dev, dtype=torch.float32)
+    nscr = lib.query("pulpo_conv3d_k3_wgrad_scratch_floats", Cin, Cout)
+    scratch = _persistent_buffer(w_p, "_pulpo_wgrad_scratch", nscr, zero=True) if deferred else torch.empty(nscr, device=dev, dtype=torch.float32)
+    xb, xp, xc = grid_strides(x)
+
+    def launch():
+        t0 = _trace_begin()
+        lib.call("pulpo_conv3d_k3_wgrad_bn", _ptr(x), xb, xp, xc, _ptr(dz), _dt(dz), dz.stride(0), dz.stride(4), _ptr(y), y.stride(0), y.stride(4), _ptr(coef),
+                 _ptr(totd), LRELU_SLOPE, _ptr(dw), 2 if deferred else int(slot_w is not None), _ptr(scratch), _ptr(part2), B, D, H, W, Cin, Cout, _stream())
+        _trace_end(t0, "conv3d_k3_wgrad_smallc(+bn backward)" + ("" if deferred else "(+memset,unpack)"), 54.0 * Cin * Cout * B * D * H * W,
+                   (4.0 * Cin + (_esize(dz) + 4.0) * Cout) * B * D * H * W)
+
+    side = ASYNC_WGRAD_STREAM
+    if side is not None and deferred:
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            launch()
+        for t in (x, dz, y, coef, totd):
+            t.record_stream(side)
+    else:
+        launch()
+    if deferred and not _pending_src(scratch):
+        _PENDING_GRAD_JOBS.append((scratch.data_ptr(), dw.data_ptr(), 0, Cin, Cout, (Cout + 63) // 64 * 64))
+        _PENDING_KEEPALIVE.append(scratch)
+    if defer_b:
+        _PENDING_GRAD_JOBS.append((part2.data_ptr(), slot_b.data_ptr(), 1, nrow, Cout, 0))
+        _PENDING_KEEPALIVE.append(part2)
+    dbias = _colsum(part2, nrow, Cout, into=slot_b) if (ctx.needs_input_grad[2] and not defer_b) else None
+    dbeta, dgamma = (None, None) if direct_bn else (tot[:Cout], tot[Cout:])
+    return None, (None if slot_w is not None else dw), dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+_ConvBNLReLU._backward_input_layer = staticmethod(_backward_input_layer)
+FUSE_INPUT_WGRAD = os.environ.get("PULPO_FUSE_INPUT_WGRAD", "1") != "0"
 
 
 def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None,

@@ -406,6 +406,60 @@ def test_training_statistics_on_small_volumes_with_many_work_items(ops, B, Cin, 
                      ctypes.c_void_p(y.data_ptr()), *ops.grid_strides(y), ctypes.c_void_p(stats.data_ptr()), B, *size, Cin, Cout, ops._stream())
 
 
+@pytest.mark.parametrize("B,Cin,Cout,size,bf16", [(1, 2, 32, (64, 64, 64), False), (2, 2, 32, (9, 11, 13), False), (1, 1, 36, (13, 8, 9), False), (1, 2, 64, (20, 24, 24), True)])
+def test_input_layer_weight_gradient_with_the_batchnorm_backward_fused(ops, B, Cin, Cout, size, bf16):
+    """the image-pair ConvUnit (nobody needs its data gradient): the weight-gradient kernel forms dy = BatchNorm / LeakyReLU backward of dz per element
+    while staging (pulpo_conv3d_k3_wgrad_bn) instead of a pass that writes dy - same parameter gradients as the separate passes (fp32 rounding of
+    a different summation order only) and as the oracle in double; also with bf16-stored dz (ACT_BF16: y of this layer stays fp32)"""
+    import src.network_blocks as nb
+    gen = torch.Generator().manual_seed(17 * Cin + Cout)
+    torch.manual_seed(3)
+    unit = nb.ConvUnit(list(size), Cin, Cout)
+    with torch.no_grad():
+        unit._op[1].weight.copy_(torch.rand(Cout, generator=gen) * 0.5 + 0.75)
+        unit._op[1].bias.copy_(torch.randn(Cout, generator=gen) * 0.1)
+    sd = {"u." + k: v.detach().clone() for k, v in unit.state_dict().items()}
+    x = torch.randn(B, Cin, *size, generator=gen)
+    up = torch.randn(B, Cout, *size, generator=gen)
+    unit = unit.cuda().train()
+    ps = [unit._op[0].weight, unit._op[0].bias, unit._op[1].weight, unit._op[1].bias]
+    names = ["u._op.0.weight", "u._op.0.bias", "u._op.1.weight", "u._op.1.bias"]
+    state = {k: v.clone() for k, v in unit.state_dict().items()}
+
+    def run(fused):
+        unit.load_state_dict(state)
+        ops.FUSE_INPUT_WGRAD = fused
+        if bf16:
+            ops.set_conv_precision("bf16", activations="bf16")
+        try:
+            z = unit(x.cuda())
+            return z, torch.autograd.grad((z.float() * up.cuda()).sum(), ps)
+        finally:
+            ops.FUSE_INPUT_WGRAD = True
+            ops.set_conv_precision("fp32")
+
+    z1, g1 = run(True)
+    z0, g0 = run(False)
+    assert torch.equal(z1, z0)
+    for a, b, nme in zip(g1, g0, names):
+        scale = float(g0[0].abs().max()) if nme.endswith("0.bias") else None       # (true gradient zero: compared on the weight gradient's scale)
+        if scale is not None:
+            assert float((a - b).abs().max()) <= 1e-4 * scale, nme
+        else:
+            assert rel_l2(a, b) < (2e-3 if bf16 else 2e-5), (nme, rel_l2(a, b))
+    if not bf16:
+        sdr = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v.clone()))
+               for k, v in sd.items()}
+        zr = O.conv_unit(x.double(), sdr, "u", training=True)
+        gr = torch.autograd.grad((zr * up.double()).sum(), [sdr[n] for n in names])
+        sd32 = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+        g32 = torch.autograd.grad((O.conv_unit(x, sd32, "u", training=True) * up).sum(), [sd32[n] for n in names])
+        for got, want, o32, nme in zip(g1, gr, g32, names):
+            if nme.endswith("0.bias"):
+                continue
+            assert rel_l2(got, want) <= 3.0 * rel_l2(o32, want) + 1e-5, (nme, rel_l2(got, want))
+
+
 @pytest.mark.parametrize("B,Cin,Cout,size", [(1, 32, 32, (64, 64, 64)), (2, 16, 96, (10, 20, 28)), (1, 64, 32, (6, 12, 17)), (1, 8, 8, (4, 16, 16)), (1, 40, 24, (12, 10, 9)),
                                              (1, 32, 64, (9, 16, 16)), (3, 96, 32, (2, 24, 24))])
 def test_weight_gradient_winograd_in_all_three_axes_vs_oracle(ops, B, Cin, Cout, size):

@@ -80,8 +80,8 @@ STEP_CASES = ["step_T3L2_n4_16", "step_T4L3_n2_16x24x16", "step_fullres_T3L2_n2_
 STEP_ALGO_CASES = [(c, None) for c in STEP_CASES] + [("step_T3L2_n8_32", "direct"), ("step_T3L2_n8_32", "deterministic"), ("step_fullres_T3L2_n2_16", "deterministic")]
 
 # the 32^3 golden step in DETERMINISTIC mode: the GPU's gradients are then one fixed set of numbers (bit-identical run to run), so the bound
-# against the reference's fp32 gradients is set on what that evaluation measures (profiles/r5_deterministic.md) instead of leaving room for the
-# spread of the float-atomic sums.  It cannot reach SURVEY 8(c)'s 1e-3: the reference's own fp32 gradients sit up to 2e-3 from an fp64
+# against the reference's fp32 gradients is set on what that evaluation measures (4.24e-3; the atomic mode sits within 1e-5 of it, so the default
+# kernel selection is held to the same bound).  It cannot reach SURVEY 8(c)'s 1e-3: the reference's own fp32 gradients sit up to 2e-3 from an fp64
 # evaluation on this case (windowed-variance cancellation at 9^3 NCC windows), and a LeakyReLU slope that differs moves a gradient by more.
 GRAD_BOUND_32_DETERMINISTIC = 5e-3          # measured 4.24e-3 (0 slope flips), a fixed number in this mode
 
@@ -147,7 +147,10 @@ def _training_step_vs_golden(api, golden, case, det=False):
         sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
         _, g64, _ = O.train_step(O.clone_sd(sd64, requires_grad=True), cfg, T(g["x"]).double(), T(g["y"]).double(),
                                  {l: T(g[f"eps.{l}"]).double() for l in range(L)})
-        grad_bound = GRAD_BOUND_32_DETERMINISTIC if det else 1e-2
+        # (default kernel selection: 4.24e-3 measured, the same to 1e-5 with and without the float atomics; the direct kernels' single 216-term
+        #  fmaf chain per output sits further from the reference's blocked sums: 8.5e-3)
+        from pulpo_amd import ops as _ops
+        grad_bound = GRAD_BOUND_32_DETERMINISTIC if (det or _ops.CONV_ALGO is None) else 1e-2
     for key, val in zip(("total", "kl", "rec", "reg"), (total, kl, rec, reg)):
         np.testing.assert_allclose(float(val), float(g["train." + key]), rtol=1e-4)
     for nm, d in zip(("kl_l", "rec_l", "reg_l"), levels):
