@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--deterministic", action="store_true",
                     help="run the measured loop in deterministic mode (pulpo_amd.ops.set_deterministic: ordered sums instead of float atomics in the "
                          "backward kernels; bit-identical gradients run to run).  Default: off; the line reports the mode's step time either way")
+    ap.add_argument("--graph", action="store_true",
+                    help="stepper loop only: zero_grad + forward + backward + gradient finishing replayed from ONE HIP graph (dp.DataParallelStepper(graph=True)); "
+                         "gradient exchange, fused Adam and weight re-pack stay eager.  For the short bf16 steps, which the host barely keeps ahead of")
     ap.add_argument("--no-loops", action="store_true", help="do not time the other two loops after the measurement (one GPU, train mode)")
     ap.add_argument("--host-input", action="store_true",
                     help="feed every step from host memory through pulpo_amd.prefetch.DevicePrefetcher (PCIe-inclusive rate; the default "
@@ -290,12 +293,12 @@ def pmc_traffic(kernel: str) -> dict:
                               "gathers by scripts/probes/fetch_calib.hip, profiles/r3_fetch_calibration.md)"}
 
 
-def make_loop(kind: str, model):
+def make_loop(kind: str, model, graph: bool = False):
     """-> (run(batch) -> loss, the dp.DataParallelStepper behind it or None, the name reported in the line's "loop" field)"""
     from pulpo_amd import dp
     if kind == "stepper":
-        stepper = dp.DataParallelStepper(model)
-        return stepper.step, stepper, "stepper"
+        stepper = dp.DataParallelStepper(model, graph=graph)
+        return stepper.step, stepper, "stepper (HIP graph)" if graph else "stepper"
     if kind == "lightning":
         from pulpo_amd._lightning import HookOrderTrainer
         trainer = HookOrderTrainer()
@@ -353,7 +356,9 @@ def main():
     if args.loop == "plain-autograd" and world > 1:
         raise SystemExit("bench: --loop plain-autograd has no gradient exchange; one GPU only")
     model = PULPo(T, L, 0.1, size, feedback=FEEDBACK, n0=32).to(dev).train()
-    run_step, stepper, loop_name = make_loop(args.loop, model)       # stepper: the dp.DataParallelStepper that owns arena / streams (None: plain autograd)
+    if args.graph and args.loop != "stepper":
+        raise SystemExit("bench: --graph belongs to --loop stepper")
+    run_step, stepper, loop_name = make_loop(args.loop, model, graph=args.graph)       # stepper: the dp.DataParallelStepper that owns arena / streams (None: plain autograd)
     fallback = "relaunched" if os.environ.get("PULPO_BENCH_RELAUNCHED") == "1" else "none"
     from pulpo_amd import synthetic
     x, y = (synthetic.oasis_like_pair if args.data == "oasis" else synthetic.uniform_pair)(size, B, 1234 + rank, dev)
@@ -430,10 +435,11 @@ def main():
             print(f"[bench] rank {rank}: {world - n_ok} of {world} ranks failed their first step; leaving with code {EXIT_OVERLAP_FAILED}", file=sys.stderr)
             sys.stderr.flush()
             os._exit(EXIT_OVERLAP_FAILED)
-    for _ in range(args.warmup):
+    for _ in range(args.warmup + (3 if args.graph else 0)):      # (graph mode: two eager steps and the capture step come first)
         one_step()
     barrier()
-    if not args.no_trace:
+    graph_replay = bool(args.graph and stepper is not None and stepper._graph is not None)
+    if not args.no_trace and not graph_replay:
         ops.CONV_TRACE = []
         ops.CONV_TRACE_STRIDE = 7        # one in seven conv launches of the timed region is bracketed (drawn at random: no fixed stride can lock onto a layer)
     ops.CONV_TRACE_STRIDE_USED = ops.CONV_TRACE_STRIDE
@@ -448,6 +454,16 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     trace, ops.CONV_TRACE = ops.CONV_TRACE, None
+    trace_steps = args.steps
+    if graph_replay and not args.no_trace:
+        # the timed region replayed a HIP graph (no per-launch events): the dominant kernel's brackets come from two extra EAGER steps of the same
+        # loop, every launch bracketed (the step falls back to its eager form while a trace is armed)
+        ops.CONV_TRACE, ops.CONV_TRACE_STRIDE = [], 1
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        trace, ops.CONV_TRACE = ops.CONV_TRACE, None
+        ops.CONV_TRACE_STRIDE_USED, trace_steps = 1, 2
     # The memory-bound kernel classes (BatchNorm / LeakyReLU passes, warp, VecInt, NCC, pooling / resizing, heads, KL, regulariser, Adam) are
     # bracketed in two EXTRA untimed steps of the same overlapped loop (every launch): their brackets in the timed region would cost host
     # time per launch that the short bf16 steps cannot hide (measured: 17.0 -> 23.6 ms per step), and they are a supplementary report - the
@@ -554,7 +570,8 @@ def main():
             eff = fl / sec / 1e12
             roof = {"bound": "mfma", "kernel": dom[0], "achieved": eff * issued, "peak": peak, "unit": "TFLOP/s",
                     "frac": eff * issued / peak, "traffic": None, "launches": n,
-                    "launch_sampling": f"every {ops.CONV_TRACE_STRIDE_USED}th conv launch of the timed region",
+                    "launch_sampling": (f"every {ops.CONV_TRACE_STRIDE_USED}th conv launch of the timed region" if not graph_replay else
+                                        "every conv launch of two extra eager steps (the timed region replays a HIP graph: no per-launch events)"),
                     "avg_launch_ms": sec / n * 1e3,
                     "issued_flop_per_launch": fl * issued / n,
                     "effective_TFLOPs": eff, "effective_flop_per_launch": fl / n,
@@ -596,7 +613,7 @@ def main():
         time_split = None
         if trace and not infer:
             ms_step = dt / args.steps * 1e3
-            matrix_ms = sum(v[2] for v in per_kernel.values()) * ops.CONV_TRACE_STRIDE_USED / args.steps * 1e3
+            matrix_ms = sum(v[2] for v in per_kernel.values()) * ops.CONV_TRACE_STRIDE_USED / trace_steps * 1e3
             hbm_ms = (sum(s_.elapsed_time(e_) for _, _, s_, e_ in hbm_trace) / 2.0) if hbm_trace else None
             enq = sorted(host_enq)
             overlapped = bool(stepper is not None and stepper.wgrad_on_side_stream())
@@ -639,7 +656,7 @@ def main():
             "hbm_rooflines": hbm_roof,
             "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
             "conv_kernels": {k: {"launches_sampled": v[0], "effective_TFLOPs": v[1] / v[2] / 1e12, "matrix_pipe_TFLOPs": v[1] * ISSUED_FRACTION(k) / v[2] / 1e12,
-                                 "ms_total_per_step_est": v[2] * ops.CONV_TRACE_STRIDE_USED / args.steps * 1e3}
+                                 "ms_total_per_step_est": v[2] * ops.CONV_TRACE_STRIDE_USED / trace_steps * 1e3}
                              for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][2])},
         }
         if is160 and not infer:

@@ -388,12 +388,26 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const float* __res
     //  workgroup have to fit into them or the launch waits for a CU the weight gradient has left)
     double s = 0.0, q = 0.0;
     if (c < C) {
+        if (part != nullptr) {
 #pragma unroll 1
-        for (int r = ry; r < nrow; r += 16) {
-            if (part != nullptr) {
+            for (int r = ry; r < nrow; r += 16) {
                 s += part[((long)r * 2 + 0) * C + c];
                 q += part[((long)r * 2 + 1) * C + c];
-            } else {
+            }
+        } else {
+            // up to 2048 fp32 rows in one stage (round 5: the slice-sum launch in front of this kernel is gone for every level but 160^3): four
+            // rows of independent loads per pass, summed in row order (deterministic)
+            int r = ry;
+#pragma unroll 1
+            for (; r + 48 < nrow; r += 64) {
+                const float a0 = rows[((long)r * 2 + 0) * C + c], b0 = rows[((long)r * 2 + 1) * C + c];
+                const float a1 = rows[((long)(r + 16) * 2 + 0) * C + c], b1 = rows[((long)(r + 16) * 2 + 1) * C + c];
+                const float a2 = rows[((long)(r + 32) * 2 + 0) * C + c], b2 = rows[((long)(r + 32) * 2 + 1) * C + c];
+                const float a3 = rows[((long)(r + 48) * 2 + 0) * C + c], b3 = rows[((long)(r + 48) * 2 + 1) * C + c];
+                s += (double)a0; q += (double)b0; s += (double)a1; q += (double)b1; s += (double)a2; q += (double)b2; s += (double)a3; q += (double)b3;
+            }
+#pragma unroll 1
+            for (; r < nrow; r += 16) {
                 s += (double)rows[((long)r * 2 + 0) * C + c];
                 q += (double)rows[((long)r * 2 + 1) * C + c];
             }
@@ -624,8 +638,8 @@ PULPO_API int pulpo_avgpool2_bwd_bnred(const float* gout, int64_t gops, const fl
 // rows: the block partials of pulpo_bn_lrelu_bwd_reduce (nrow = pulpo_bn_bwd_blocks) or the per-voxel-tile rows of
 // pulpo_conv3d_k3_dgrad_wino2_bnred (nrow = pulpo_conv3d_k3_stat_tiles); coef = the unit's coefficient block.  With more than 64 rows they
 // are first summed slice-wise in double (scratch: pulpo_bn_bwd_finalize_scratch_doubles(nrow, C) doubles, else NULL).
-// (two-stage from 64 tiles up: the second stage alone would walk the rows with 32 threads per channel)
-PULPO_API size_t pulpo_bn_bwd_finalize_scratch_doubles(int ntile, int C) { return ntile > 64 ? (size_t)32 * 2 * C : 0; }
+// (two-stage above 2048 rows - the 160^3 level; until round 5 from 64 rows up: 28 slice-sum launches per step that cost what they saved)
+PULPO_API size_t pulpo_bn_bwd_finalize_scratch_doubles(int ntile, int C) { return ntile > 2048 ? (size_t)32 * 2 * C : 0; }
 
 PULPO_API int pulpo_bn_bwd_finalize(const float* tile_part, int ntile, int C, const float* coef, double count, int use_means, float* dbeta,
                                           float* dgamma, int accumulate, double* totd, double* scratch, void* stream) {

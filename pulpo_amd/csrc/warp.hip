@@ -7,6 +7,7 @@
 // HBM/L2-bound gather kernels: one thread per output voxel, displacement planes read coalesced, 8-corner gather
 // served by L1/L2; the backward scatters with float atomics (memory-side adds, MI355X_MICROARCH.md).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -472,13 +473,21 @@ PULPO_API int pulpo_vecint_fwd(const float* v, float* work, int B, int D, int H,
     return 0;
 }
 
+// fields the LDS-boxed backward step takes.  Round 5: from 8^3 up (16^3 before) - the 10^3 level of the metric's pyramid ran the plain scatter with a
+// device copy in front of every squaring step (14 launches of ~5 + ~10 us); PULPO_VECINT_TILED_MIN moves the threshold (A/B switch)
+static bool vecint_bwd_tiled(int D, int H, int W) {
+    static int lo = -1;
+    if (lo < 0) { const char* e = getenv("PULPO_VECINT_TILED_MIN"); lo = e ? atoi(e) : 8; }
+    return D >= lo && H >= lo && W >= lo && D >= 2;
+}
+
 // floats of scratch pulpo_vecint_bwd needs: one buffer per step for the tiled scatter (zeroed by one fill), two for the plain scatter.
 // (A one-launch variant with the gradient in LDS, as for the forward pass, was measured at 20^3: one compute unit takes 135 us per step
 // for the 27 LDS atomics and 24 gathers per voxel that the tiled kernel spreads over 45 workgroups in 15 us.)
 PULPO_API size_t pulpo_vecint_bwd_tmp_floats(int B, int D, int H, int W, int nsteps) {
     if (B <= 0 || D < 1 || H < 1 || W < 1 || nsteps <= 0) return 0;
     const size_t n = (size_t)B * 3 * D * H * W;
-    return (D >= 16 && H >= 16 && W >= 16) ? (size_t)nsteps * n : 2 * n;
+    return vecint_bwd_tiled(D, H, W) ? (size_t)nsteps * n : 2 * n;
 }
 
 // gin = d loss / d v given gout = d loss / d work[nsteps].  tmp: pulpo_vecint_bwd_tmp_floats() floats (NULL when that is 0).
@@ -488,7 +497,7 @@ PULPO_API int pulpo_vecint_bwd(const float* work, const float* gout, float* gin,
     hipStream_t st = (hipStream_t)stream;
     const long n = (long)B * 3 * D * H * W, total = (long)B * D * H * W;
     const float scale = 1.0f / (float)(1 << nsteps);
-    const bool tiled = D >= 16 && H >= 16 && W >= 16;   // (smaller fields: a handful of tiles, the plain scatter is as fast)
+    const bool tiled = vecint_bwd_tiled(D, H, W);
     if (tiled && nsteps > 0) {
         hipError_t e = hipMemsetAsync(tmp, 0, sizeof(float) * n * nsteps, st);
         if (e != hipSuccess) return pulpo::fail((int)e, "vecint_bwd fill: %s", hipGetErrorString(e));

@@ -218,8 +218,15 @@ class DataParallelStepper:
     the compute stream, and the Adam step waits for all buckets."""
 
     def __init__(self, model: nn.Module, lr: Optional[float] = None, overlap: bool = True, async_wgrad: bool = True,
-                 freeze_gc: Optional[bool] = None):
+                 freeze_gc: Optional[bool] = None, graph: Optional[bool] = None):
         self.model = model
+        # graph: zero_grad + forward + backward + gradient finishing are captured into ONE HIP graph on the third step and replayed from then on
+        # (step() only; the gradient exchange, the fused Adam update - its step count is a kernel argument - and the weight re-pack stay eager).
+        # For steps the host barely keeps ahead of: the bf16 configurations issue ~570 launches in ~12 ms of host time per ~14 ms step.
+        # None = the environment's PULPO_STEP_GRAPH == "1".  Needs a CUDA model; batches of another shape fall back to the eager step.
+        self.graph = (os.environ.get("PULPO_STEP_GRAPH", "0") == "1") if graph is None else bool(graph)
+        self._graph = None                       # (torch.cuda.CUDAGraph, static batch, static loss, static reg levels, signature)
+        self._graph_warm = 0
         # freeze_gc: after the second step move everything alive to the garbage collector's permanent generation (see
         # _freeze_garbage_collector); None = the environment's PULPO_GC_FREEZE == "1" (off unless asked for)
         self.freeze_gc = (os.environ.get("PULPO_GC_FREEZE", "0") == "1") if freeze_gc is None else bool(freeze_gc)
@@ -335,6 +342,8 @@ class DataParallelStepper:
             _freeze_garbage_collector()
 
     def step(self, batch) -> torch.Tensor:
+        if self.graph and self._graph_usable(batch):
+            return self._step_graphed(batch)
         self.zero_grad()
         self.arm()
         try:
@@ -344,6 +353,70 @@ class DataParallelStepper:
             self._armed = False
         self.reduce_and_update()
         return loss.detach()
+
+    # ---- the step as a HIP graph (graph=True) -------------------------------------------------------------------------------------
+    @staticmethod
+    def _signature(batch):
+        return tuple((tuple(t.shape), t.dtype, t.device) for t in batch)
+
+    def _graph_usable(self, batch) -> bool:
+        from . import ops
+        if not all(torch.is_tensor(t) and t.is_cuda for t in batch):
+            return False
+        if ops.CONV_TRACE is not None or ops.HBM_TRACE is not None:
+            return False                      # (per-launch event brackets: bench.py's extra steps run eagerly)
+        return self._graph is None or self._graph[4] == self._signature(batch)
+
+    def _graph_body(self, batch):
+        # (no bucketed exchange from inside the backward pass: collectives stay outside the graph - reduce_and_update exchanges the arena in one piece)
+        self.zero_grad()
+        self._armed = False
+        loss = self.model.training_step(batch, 0)
+        self.backward(loss)
+        return loss
+
+    def _step_graphed(self, batch) -> torch.Tensor:
+        model = self.model
+        if self._graph is None:
+            if self._graph_warm < 2:              # two eager steps first: weight packs, job tables and persistent scratch exist before the capture
+                self._graph_warm += 1
+                self.zero_grad()
+                try:
+                    loss = model.training_step(batch, 0)
+                    self.backward(loss)
+                finally:
+                    self._armed = False
+                self.reduce_and_update()
+                return loss.detach()
+            static = tuple(t.clone() for t in batch)
+            cap = torch.cuda.Stream(device=static[0].device)
+            cap.wait_stream(torch.cuda.current_stream())
+            model._pulpo_in_graph = True          # training_step leaves the host-side NaN probe to us (it synchronises / allocates pinned memory)
+            try:
+                with torch.cuda.stream(cap):
+                    loss_w = self._graph_body(static).detach()      # (autograd's engine streams are bound on first use: warm up ON the capture stream)
+                torch.cuda.current_stream().wait_stream(cap)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap):
+                    loss = self._graph_body(static)
+                    levels = getattr(model, "_pulpo_last_reg_levels", None)
+            finally:
+                model._pulpo_in_graph = False
+            self._graph = (g, static, loss.detach(), levels, self._signature(batch))
+            self.reduce_and_update()              # (the capture-stream warm-up pass has left this step's gradients in the arena: it IS the step)
+            return loss_w
+        g, static, loss, levels, _ = self._graph
+        for dst, src in zip(static, batch):
+            if dst.numel() and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        if hasattr(model, "_check_previous_step_for_nan"):
+            model._check_previous_step_for_nan()
+        g.replay()
+        if levels is not None and hasattr(model, "_arm_nan_probe"):
+            model._arm_nan_probe(levels)
+        self.reduce_and_update()
+        return loss
 
     def wgrad_on_side_stream(self) -> bool:
         """whether this step's weight gradients go to the side stream.  With async_wgrad enabled (the default) the choice follows what was

@@ -186,7 +186,9 @@ class PULPo(ABC, LightningModule):
 
     def training_step(self, batch, batch_idx):
         x, y, seg_x, seg_y, lm1, lm2, mask1, mask2 = batch
-        self._check_previous_step_for_nan()
+        in_graph = getattr(self, "_pulpo_in_graph", False)      # dp.DataParallelStepper(graph=True) is capturing this call into a HIP graph:
+        if not in_graph:                                        # the host-side NaN probe (pinned memory, events) stays outside, driven by the stepper
+            self._check_previous_step_for_nan()
         eng = self._engine()
         if eng is not None and torch.is_grad_enabled():
             eng.arm(not self._ddp_wrapped())          # multi-rank: this forward pass registers the triggers of the bucketed gradient exchange
@@ -194,7 +196,10 @@ class PULPo(ABC, LightningModule):
         self.log_dict({"train/kl_loss": kl, "train/reconstruction_loss": rec, "train/regularization_loss": reg, "train/total_loss": total},
                       on_step=True, on_epoch=True, prog_bar=True)
         self._log_levels("train", outs[0], outs[1], priors, levels, on_step=False, on_epoch=True)
-        self._arm_nan_probe(levels[2])
+        if in_graph:
+            self._pulpo_last_reg_levels = {k: v.detach() for k, v in levels[2].items()}
+        else:
+            self._arm_nan_probe(levels[2])
         return total
 
     def validation_step(self, batch, batch_idx):

@@ -80,9 +80,9 @@ def test_vecint_golden(ops, golden):
         assert rel_l2(gv, g["gv" + s]) < 1e-4
 
 
-@pytest.mark.parametrize("size,amp", [((24, 20, 28), 1.0), ((16, 32, 18), 12.0), ((40, 40, 40), 3.0)])
+@pytest.mark.parametrize("size,amp", [((24, 20, 28), 1.0), ((16, 32, 18), 12.0), ((40, 40, 40), 3.0), ((10, 10, 10), 1.5), ((8, 13, 9), 4.0), ((6, 7, 5), 1.0)])
 def test_vecint_backward_lds_tiled_scatter_vs_oracle(ops, size, amp):
-    """fields of 16^3 and up run the backward squaring steps with the scatter collected in LDS boxes (vecint_bwd_tile_kernel): small
+    """fields of 8^3 and up (round 5; 16^3 before - the last case stays on the plain scatter) run the backward squaring steps with the scatter collected in LDS boxes (vecint_bwd_tile_kernel): small
     displacements stay inside a tile's box, large ones (amp 12: several voxels per step at the end) take the memory-atomic fallback; the
     identity path rides in the box (no copy per step: the step buffers are zeroed by one fill);
     both against autograd through the oracle's VecInt in float64"""

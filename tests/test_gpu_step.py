@@ -1364,3 +1364,43 @@ def test_deterministic_mode_gives_bit_identical_gradients(api, size, T_L, n0):
         print(f"{size[0]}^3: {moved} of {len(grads_p)} parameter gradients differ in their last bits between the atomic and the deterministic mode")
     finally:
         ops.set_deterministic(env_det)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graphed_step_equals_the_eager_step(api, precision):
+    """dp.DataParallelStepper(graph=True): zero_grad + forward + backward + gradient finishing captured into one HIP graph (third step) and replayed;
+    Adam and the weight re-pack stay eager.  With fixed noise the losses of the first six steps equal the eager stepper's on the same weights and
+    batch (bit for bit in fp32 up to the float atomics of the gradients that feed the updates: 1e-5), the batch is read from the static copies
+    (a NEW batch tensor changes the result), and the parameters end up where the eager loop puts them."""
+    models, nb = api
+    from pulpo_amd import dp, ops
+    size, Tl, L, n0 = [32, 32, 32], 3, 2, 8
+    gen = torch.Generator().manual_seed(3)
+    batches = [tuple([torch.rand(1, 1, *size, generator=gen).cuda() for _ in range(2)] + [torch.empty((0,), device="cuda")] * 6) for _ in range(2)]
+    eps = [torch.randn(1, 3, *[s_ // 2 ** (l + 1) for s_ in size], generator=gen).cuda() for l in range(L)]
+
+    def run(graph):
+        torch.manual_seed(0)
+        model = models.PULPo(Tl, L, 0.1, size, feedback=FB, n0=n0).cuda().train()
+        for l in range(L):
+            model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(eps[l])
+        st = dp.DataParallelStepper(model, graph=graph)
+        losses = [float(st.step(batches[i % 2])) for i in range(6)]
+        assert (st._graph is not None) == graph
+        return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    if precision == "bf16":
+        ops.set_conv_precision("bf16", activations="bf16")
+    try:
+        eager, sd_e = run(False)
+        graphed, sd_g = run(True)
+    finally:
+        ops.set_conv_precision("fp32")
+    np.testing.assert_allclose(graphed, eager, rtol=1e-4 if precision == "fp32" else 5e-3)       # (float-atomic noise of five updates)
+    assert abs(eager[0] - eager[1]) > 1e-6 * abs(eager[0])          # (the two batches do differ: the replay really reads the step's batch)
+    for k, v in sd_e.items():
+        if v.is_floating_point():
+            tol = (1e-4 if precision == "fp32" else 5e-3)
+            assert float((sd_g[k] - v).abs().max()) <= tol * max(1.0, float(v.abs().max())), k
+        else:
+            assert torch.equal(sd_g[k], v), k
