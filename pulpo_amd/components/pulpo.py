@@ -51,13 +51,24 @@ class DownPath(nn.Module):
             cin = input_channels if k == 0 else chans[k - 1]
             self.down_blocks[k] = ConvSequence(input_size=input_size, in_channels=cin, out_channels=chans[k], depth=3)
 
+    def _room(self, k: int, like: torch.Tensor):
+        """(buffer, first channel) for level k's activation when a consumer has announced that it will concatenate `_pulpo_skip_room[k]`
+        channels IN FRONT of it (PULPoEncoder: torch.cat([feedback, down_activation], 1)): the activation is then produced as the tail of
+        that concatenation's buffer and the cat costs nothing (ops.cat_channels).  Set by src.models.PULPo; absent -> plain tensors."""
+        room = getattr(self, "_pulpo_skip_room", None)
+        if not room or k not in room or like.dim() != 5:
+            return None
+        cout = self.down_blocks[k]._op[-1]._op[0].out_channels
+        B, _, D, H, W = like.shape
+        return ops.new_cl(B, int(room[k]) + cout, D, H, W, like.device, ops.act_dtype()), int(room[k])
+
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> Dict[int, torch.Tensor]:
         h = torch.cat([x, y], dim=1)            # two planar volumes side by side; read in place by the first conv
-        acts = {0: self.down_blocks[0](h, pool_after=self.total_levels > 1)}
+        acts = {0: self.down_blocks[0](h, pool_after=self.total_levels > 1, out=self._room(0, h))}
         for k in range(1, self.total_levels):
             # (the activation is pooled AND handed out as a skip connection: one operator, so that its two gradients meet in one kernel)
             acts[k - 1], pooled = ops.avg_pool2_skip(acts[k - 1])
-            acts[k] = self.down_blocks[k](pooled, pool_after=k + 1 < self.total_levels)
+            acts[k] = self.down_blocks[k](pooled, pool_after=k + 1 < self.total_levels, out=self._room(k, pooled))
         return acts
 
 
@@ -76,7 +87,7 @@ class PULPoEncoder(nn.Module):
     def forward(self, down_activation: torch.Tensor, feedback: Optional[torch.Tensor] = None):
         h = down_activation
         if feedback is not None:
-            h = self.sample_merge_block(torch.cat([feedback, down_activation], dim=1))
+            h = self.sample_merge_block(ops.cat_channels(feedback, down_activation))     # (the buffer itself where both were produced into it)
         sampler = self.sampler
         if sampler is gauss_sampler:                         # fused: noise drawn once, sample formed in the head kernel
             eps = torch.randn((h.shape[0], self.zdim) + tuple(h.shape[2:]), device=h.device, dtype=torch.float32)
@@ -211,7 +222,8 @@ class Autoencoder(nn.Module):
                 coarser = None
             else:
                 fb = self._gather_feedback(store, l + 1, down_activations[k].shape[2:])
-                mu, sigma, z = self.encoders[l](down_activations[k], feedback=self.up_blocks[k](fb))
+                tag = getattr(down_activations[k], "_pulpo_cat", None)       # DownPath left room in front of its activation: write the feedback path there
+                mu, sigma, z = self.encoders[l](down_activations[k], feedback=self.up_blocks[k](fb, out=(tag[0], 0) if tag is not None else None))
                 coarser = store["combined_dfs"][l + 1]
             store["mus"][l], store["sigmas"][l], store["samples"][l] = mu, sigma, z
             outs = self.decoders[l](mu if deterministic else z, level_x[l], combined_df=coarser)

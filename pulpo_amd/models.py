@@ -80,6 +80,12 @@ class PULPo(ABC, LightningModule):
                                        zdim=self.ndims, input_size=input_size, feedback=self.hparams.feedback,
                                        df_resolution=self.hparams.df_resolution, n0=n0, cp_depth=cp_depth)
 
+        # the encoders concatenate the feedback path's output IN FRONT of the DownPath activation of their level (components/pulpo.py): DownPath
+        # produces those activations as the tail of the concatenation's buffer, the feedback path writes the head (ops.cat_channels).
+        # PULPO_PREWRITTEN_CAT=0: plain torch.cat (A/B switch).
+        if os.environ.get("PULPO_PREWRITTEN_CAT", "1") != "0" and self.ndims == 3:
+            self.downpath._pulpo_skip_room = {int(k): int(blk._op[-1]._op[0].out_channels) for k, blk in self.autoencoder.up_blocks.items()}
+
         if self.hparams.regularizer == "jdet":
             regularization_loss = JDetStd
         elif self.hparams.regularizer == "L2":

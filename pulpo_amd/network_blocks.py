@@ -53,13 +53,14 @@ class ConvUnit(nn.Module):
             nn.LeakyReLU(negative_slope=0.2, inplace=True),
         )
 
-    def forward(self, x: torch.Tensor, pool_after: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, pool_after: bool = False, out=None) -> torch.Tensor:
+        """out: (buffer, first channel) - see ops.conv_bn_lrelu"""
         conv, bn = self._op[0], self._op[1]
         use_batch_stats = self.training or bn.running_mean is None
         # running statistics and num_batches_tracked are updated inside the BatchNorm finalize kernel
         return ops.conv_bn_lrelu(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                  training=use_batch_stats, momentum=bn.momentum, eps=bn.eps,
-                                 num_batches_tracked=bn.num_batches_tracked if self.training else None, pool_after=pool_after)
+                                 num_batches_tracked=bn.num_batches_tracked if self.training else None, pool_after=pool_after, out=out)
 
 
 class ConvSequence(nn.Module):
@@ -71,13 +72,15 @@ class ConvSequence(nn.Module):
         units += [ConvUnit(input_size, out_channels) for _ in range(depth - 1)]
         self._op = nn.Sequential(*units)
 
-    def forward(self, x: torch.Tensor, pool_after: bool = False) -> torch.Tensor:
-        """pool_after: the caller pools the result next (DownPath) - the last unit then writes AvgPool(result) along with it"""
-        if not pool_after:
+    def forward(self, x: torch.Tensor, pool_after: bool = False, out=None) -> torch.Tensor:
+        """pool_after: the caller pools the result next (DownPath) - the last unit then writes AvgPool(result) along with it;
+        out: (buffer, first channel) - the last unit writes its result into that channel range of a wider buffer (ops.conv_bn_lrelu)"""
+        if not pool_after and out is None:
             return self._op(x)
         n = len(self._op)
         for k, unit in enumerate(self._op):
-            x = unit(x, pool_after=k + 1 == n)
+            last = k + 1 == n
+            x = unit(x, pool_after=pool_after and last, out=out if last else None)
         return x
 
 

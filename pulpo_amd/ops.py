@@ -638,6 +638,49 @@ def _take_bn_tile_parts(y: torch.Tensor, coef: torch.Tensor, dz: torch.Tensor):
 _TLS = threading.local()
 
 
+# ---- producers that write straight into a slice of a wider channels-last buffer (round 5).  PULPoEncoder concatenates the up-sampled
+# feedback path's output with the DownPath activation of its level (torch.cat([feedback, down_activation], 1), components/pulpo.py:252): two
+# strided copy kernels per level and step (111 us at 80^3).  DownPath allocates the concatenation's buffer up front and its last ConvUnit, like
+# the feedback path's later, writes its output into its channel range - every kernel addresses operands through explicit pixel strides, so the
+# slices are ordinary operands, and the concatenation is the buffer itself (cat_prewritten).
+def _take_out_slot(B, C, D, H, W, dev, dtype):
+    slot = getattr(_TLS, "out_slot", None)
+    _TLS.out_slot = None
+    if slot is None:
+        return None
+    buf, off = slot
+    if (buf.dim() != 5 or tuple(buf.shape[2:]) != (D, H, W) or buf.shape[0] != B or buf.dtype != dtype or buf.device != dev or off < 0 or off + C > buf.shape[1]
+            or not is_cl(buf) or off % 8 or buf.shape[1] % 8):
+        return None
+    return buf[:, off:off + C]
+
+
+class _CatPrewritten(torch.autograd.Function):
+    """cat([a, b], 1) where a and b ARE the two channel ranges of `buf`: the result is the buffer, the gradient is split by position"""
+
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        ctx.ca = a.shape[1]
+        return buf.as_strided(buf.shape, buf.stride(), buf.storage_offset())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.ca], g[:, ctx.ca:], None
+
+
+def cat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat([a, b], dim=1); free when both were produced into the two channel ranges of one buffer (`_pulpo_cat` tags)"""
+    ta, tb = getattr(a, "_pulpo_cat", None), getattr(b, "_pulpo_cat", None)
+    if ta is not None and tb is not None and ta[0] is tb[0]:
+        buf = ta[0]
+        es = buf.element_size()
+        if (ta[1] == 0 and tb[1] == a.shape[1] and a.shape[1] + b.shape[1] == buf.shape[1] and a.data_ptr() == buf.data_ptr()
+                and b.data_ptr() == buf.data_ptr() + es * tb[1] and a.stride() == buf.stride() and b.stride() == buf.stride()
+                and a.shape[2:] == buf.shape[2:] and b.shape[2:] == buf.shape[2:] and a.shape[0] == buf.shape[0] == b.shape[0]):
+            return _CatPrewritten.apply(a, b, buf)
+    return torch.cat([a, b], dim=1)
+
+
 class _ConvBNLReLU(torch.autograd.Function):
     """ConvUnit: Conv3d(k3,p1,bias) -> BatchNorm3d -> LeakyReLU(0.2)   (reference src/network_blocks.py:22-26)"""
 
@@ -673,10 +716,15 @@ class _ConvBNLReLU(torch.autograd.Function):
             lib.call("pulpo_bn_eval_coef", _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps, Cout, _ptr(coef), _stream())
             if not any(ctx.needs_input_grad) and ydt == zdt:
                 # inference: conv + folded BatchNorm + LeakyReLU in one kernel, the pre-norm tensor is never written
+                zo = _take_out_slot(B, Cout, D, H, W, dev, zdt)
+                if zo is not None:
+                    y = zo
                 _conv_raw(x, wp, bias, y, Cin, Cout, None, coef=coef)
                 return y
             _conv_raw(x, wp, bias, y, Cin, Cout, None)
-        z = new_cl(B, Cout, D, H, W, dev, zdt)
+        z = _take_out_slot(B, Cout, D, H, W, dev, zdt)
+        if z is None:
+            z = new_cl(B, Cout, D, H, W, dev, zdt)
         pooled = None
         nbytes = (_esize(y) + _esize(z)) * Cout * B * D * H * W             # read y, write z
         if pool_after and lib.query("pulpo_bn_lrelu_apply_pool2_ok", Cout, y.stride(4), z.stride(4), Cout):
@@ -816,23 +864,29 @@ FUSE_INPUT_WGRAD = os.environ.get("PULPO_FUSE_INPUT_WGRAD", "1") != "0"
 
 
 def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None,
-                  pool_after: bool = False):
+                  pool_after: bool = False, out=None):
     """ConvUnit forward.  In training mode running_mean / running_var / num_batches_tracked are updated in place by the kernel.
     pool_after: the caller applies avg_pool2_skip() to the result next - where the shapes allow, the pooled tensor is produced by the same
-    pass that writes the result and waits on it (`_pulpo_pooled`)."""
+    pass that writes the result and waits on it (`_pulpo_pooled`).
+    out: (buffer, first channel) - the result is written into that channel range of a wider channels-last buffer and returned as its slice,
+    tagged `_pulpo_cat` (see cat_channels); ignored where the shapes do not fit."""
     if _is2d(x):
         return conv_bn_lrelu(_lift(x), _lift_w3(weight), bias, gamma, beta, running_mean, running_var, training, momentum, eps,
                              num_batches_tracked).squeeze(2)
+    _TLS.out_slot = out
     src = getattr(x, "_pulpo_bn_src", None)          # x is the untouched output of another ConvUnit: (y, coef, version at production)
     bn_src = src[:2] if (src is not None and src[2] == x._version and training and torch.is_grad_enabled()) else None
     z = _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
                            float(eps), bn_src, bool(pool_after))
     produced = getattr(_TLS, "produced", None)
     _TLS.produced = None
+    _TLS.out_slot = None
     if produced is not None:
         z._pulpo_bn_src = (produced[0], produced[1], z._version)
         if produced[2] is not None:
             z._pulpo_pooled = (produced[2], z._version)
+    if out is not None and z.dim() == 5 and z.data_ptr() == out[0].data_ptr() + out[0].element_size() * out[1] and z.stride() == out[0].stride():
+        z._pulpo_cat = (out[0], out[1])
     return z
 
 
@@ -1083,7 +1137,11 @@ def avg_pool2_skip(x):
     ready = getattr(x, "_pulpo_pooled", None)
     src = getattr(x, "_pulpo_bn_src", None)          # x is the untouched output of a ConvUnit: (y, coef, version at production)
     src = src if (src is not None and src[2] == x._version and torch.is_grad_enabled()) else None
-    return _AvgPool2Skip.apply(x, ready[0] if (ready is not None and ready[1] == x._version) else None, src[0] if src else None, src[1] if src else None)
+    alias, pooled = _AvgPool2Skip.apply(x, ready[0] if (ready is not None and ready[1] == x._version) else None, src[0] if src else None, src[1] if src else None)
+    tag = getattr(x, "_pulpo_cat", None)
+    if tag is not None:
+        alias._pulpo_cat = tag                      # (the skip connection's alias is the same slice of the concatenation buffer)
+    return alias, pooled
 
 
 class _Resize(torch.autograd.Function):

@@ -1399,7 +1399,13 @@ def test_graphed_step_equals_the_eager_step(api, precision):
     np.testing.assert_allclose(graphed, eager, rtol=1e-4 if precision == "fp32" else 5e-3)       # (float-atomic noise of five updates)
     assert abs(eager[0] - eager[1]) > 1e-6 * abs(eager[0])          # (the two batches do differ: the replay really reads the step's batch)
     for k, v in sd_e.items():
-        if v.is_floating_point():
+        if k.endswith("_op.0.bias") and "velocity_field._op.2" not in k:
+            # a conv bias in front of a BatchNorm: its true gradient is zero, what Adam normalises to +-lr per step is rounding noise (float atomics)
+            assert float((sd_g[k] - v).abs().max()) <= 6 * 2e-4, k
+        elif k.endswith("running_mean"):
+            # ... and the batch mean of that unit's convolution carries the bias one to one (momentum 0.1 per step)
+            assert float((sd_g[k] - v).abs().max()) <= 2e-3 * max(1.0, float(v.abs().max())), k
+        elif v.is_floating_point():
             tol = (1e-4 if precision == "fp32" else 5e-3)
             assert float((sd_g[k] - v).abs().max()) <= tol * max(1.0, float(v.abs().max())), k
         else:
