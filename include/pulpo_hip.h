@@ -360,6 +360,14 @@ int pulpo_conv3d_k3_wgrad_bn(const float* in, int64_t in_bs, int64_t in_ps, int6
                              const float* y, int64_t y_bs, int64_t y_ps, const float* coef, const double* totd, float slope, float* dw,
                              int accumulate, float* scratch, float* part2, int B, int D, int H, int W, int Cin, int Cout, void* stream);
 
+/* ------------------------------------------------------------------------- BatchNorm backward of a POOLED ConvUnit output without its gradient tensor (since ABI 4)
+ * DownPath pools the output z of every level's last ConvUnit (components/pulpo.py:58: avg_pool3d, ceil mode) and may also use it as a skip
+ * connection.  dz = (skip gradient +) avg_pool3d_backward(gradient of the pooled tensor) is formed per element inside BOTH passes of the unit's
+ * batch_norm_backward + leaky_relu_backward: pulpo_avgpool2_bwd_bnred_t with gin == NULL (first pass) and this entry point (second pass). */
+int pulpo_bn_lrelu_bwd_apply_pooled_t(const void* gout, int64_t gops, const void* add /*nullable*/, int64_t aps, int g_dt, const void* y, int y_dt,
+                                      int64_t yps, const float* coef, const double* totd, void* dy /* y's dtype */, int64_t dyps, float slope,
+                                      float* partial2, int B, int D, int H, int W, int C, void* stream);
+
 /* ------------------------------------------------------------------------- DETERMINISTIC forms of the backward kernels that add with float atomics (since ABI 4)
  * The reference's CPU backward is run-to-run deterministic; the plain entry points above add the weight-gradient partial sums
  * of concurrent workgroups (aten::convolution_backward, src/network_blocks.py:23) and the image-gradient scatter of grid_sampler_3d_backward

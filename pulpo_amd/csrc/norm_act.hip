@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const TG* __re
                 }
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) g[k] = pulpo::as_stored<TG>(g[k]);     // (the sums describe the gradient as stored)
-                pulpo::stv<VEC>(pg.dzout + p * pg.dzops + c, g);
+                if (pg.dzout != nullptr) pulpo::stv<VEC>(pg.dzout + p * pg.dzops + c, g);       // (null: the second pass forms it again, see POOL below)
             } else {
                 pulpo::ldv<VEC>(dz + p * dzps + c, g);
             }
@@ -295,11 +295,14 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const TG* __re
 // bits, the (y - m32) factor is centred (a rounding of B does not shift the channel) and everything else rounds without bias.
 // The six per-channel constants live in LDS and are read per element group (6 ds_read_b128 against 48 bytes of HBM traffic): the kernel
 // then needs ~40 instead of 71 registers, i.e. two waves instead of one fit on a SIMD beside the weight-gradient kernel.
-template <int VEC, typename TG = float, typename TY = float>
+// POOL (round 5): dz is not read but formed per element from the gradient of the POOLED tensor (and the skip connection's gradient, nullable) -
+// the arithmetic of the POOL form of bn_lrelu_bwd_reduce_kernel above - so that the gradient of a pooled ConvUnit output is never written:
+// both passes read the (eight times smaller) pooled gradient instead.
+template <int VEC, typename TG = float, typename TY = float, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const TG* __restrict__ dz, long dzps, const TY* __restrict__ y,
                                                                    long yps, const float* __restrict__ coef, const double* __restrict__ totd,
                                                                    TY* __restrict__ dy, long dyps, long npix, int C,
-                                                                   float slope, float* __restrict__ partial2) {
+                                                                   float slope, float* __restrict__ partial2, PoolGrad<TG> pg = PoolGrad<TG>{}) {
     extern __shared__ float red[];                 // [RB][C] partial sums, then [6][C] constants: scale, shift, m32, B, C hi, C lo
     const int CV = C / VEC, RB = blockDim.x / CV;
     const int col = threadIdx.x % CV, row = threadIdx.x / CV;
@@ -326,7 +329,29 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const TG* __res
     if (row < RB) {
         for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
             float g[VEC], v[VEC], o[VEC];
-            pulpo::ldv<VEC>(dz + p * dzps + c, g);
+            if constexpr (POOL) {
+                long q = p;
+                const int x_ = (int)(q % pg.W); q /= pg.W;
+                const int y_ = (int)(q % pg.H); q /= pg.H;
+                const int z_ = (int)(q % pg.D);
+                const long b_ = q / pg.D;
+                const int oz = z_ >> 1, oy = y_ >> 1, ox = x_ >> 1;
+                const int cnt = (min(2 * oz + 2, pg.D) - 2 * oz) * (min(2 * oy + 2, pg.H) - 2 * oy) * (min(2 * ox + 2, pg.W) - 2 * ox);
+                const float inv = 1.f / (float)cnt;
+                pulpo::ldv<VEC>(pg.gpool + (((b_ * pg.Do + oz) * pg.Ho + oy) * pg.Wo + ox) * pg.gpps + c, g);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) g[k] *= inv;
+                if (pg.add != nullptr) {
+                    float u[VEC];
+                    pulpo::ldv<VEC>(pg.add + p * pg.aps + c, u);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) g[k] = u[k] + g[k];
+                }
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) g[k] = pulpo::as_stored<TG>(g[k]);
+            } else {
+                pulpo::ldv<VEC>(dz + p * dzps + c, g);
+            }
             pulpo::ldv<VEC>(y + p * yps + c, v);
             int cl = c;                                 // (opaque: the constants are to be READ here every time, not kept in registers)
             asm volatile("" : "+v"(cl));
@@ -593,6 +618,18 @@ int bwd_apply_t(const TG* dz, long dzps, const TY* y, long yps, const float* coe
     else hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<1, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2);
     return pulpo::check_launch("bn_lrelu_bwd_apply");
 }
+template <typename TG, typename TY>
+int pool_apply_t(const TG* gout, long gops, const TG* add, long aps, const TY* y, long yps, const float* coef, const double* totd, TY* dy, long dyps,
+                 float slope, float* partial2, int B, int D, int H, int W, int C, hipStream_t st) {
+    const long npix = (long)B * D * H * W;
+    const int nblk = pulpo_bn_bwd_blocks(npix, C);
+    const int RB = std::max(1, 256 / (C / 4));
+    const size_t lds = (size_t)(RB + 6) * C * sizeof(float);
+    PoolGrad<TG> pg{gout, gops, add, aps, nullptr, 0, D, H, W, (D + 1) / 2, (H + 1) / 2, (W + 1) / 2};
+    hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<4, TG, TY, true>), dim3(nblk), dim3(256), lds, st, (const TG*)nullptr, 0L, y, yps, coef, totd, dy, dyps, npix,
+                       C, slope, partial2, pg);
+    return pulpo::check_launch("bn_lrelu_bwd_apply_pooled");
+}
 }  // namespace
 
 PULPO_API int pulpo_bn_lrelu_bwd_reduce_t(const void* dz, int dz_dt, int64_t dzps, const void* y, int y_dt, int64_t yps, const float* coef, int64_t npix,
@@ -617,7 +654,9 @@ PULPO_API int pulpo_bn_lrelu_bwd_reduce(const float* dz, int64_t dzps, const flo
 PULPO_API int pulpo_avgpool2_bwd_bnred_t(const void* gout, int64_t gops, const void* add, int64_t aps, void* gin, int64_t gips, int g_dt, const void* y,
                                          int y_dt, int64_t yps, const float* coef, float slope, float* partial, int B, int D, int H, int W, int C,
                                          void* stream) {
-    PULPO_REQUIRE(gout && gin && y && coef && partial && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "avgpool2_bwd_bnred: bad arguments");
+    // (gin nullable since ABI 4: the caller then runs the second pass in its pooled form, pulpo_bn_lrelu_bwd_apply_pooled_t, and the gradient of
+    //  the un-pooled tensor is never written)
+    PULPO_REQUIRE(gout && y && coef && partial && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "avgpool2_bwd_bnred: bad arguments");
     PULPO_REQUIRE_DT(g_dt, "avgpool2_bwd_bnred"); PULPO_REQUIRE_DT(y_dt, "avgpool2_bwd_bnred");
     const int eg = g_dt ? 8 : 16, ey = y_dt ? 8 : 16;
     PULPO_REQUIRE(C % 4 == 0 && C / 4 <= 256 && gops % 4 == 0 && gips % 4 == 0 && yps % 4 == 0 && (add == nullptr || aps % 4 == 0) &&
@@ -632,6 +671,24 @@ PULPO_API int pulpo_avgpool2_bwd_bnred_t(const void* gout, int64_t gops, const v
 PULPO_API int pulpo_avgpool2_bwd_bnred(const float* gout, int64_t gops, const float* add, int64_t aps, float* gin, int64_t gips, const float* y,
                                        int64_t yps, const float* coef, float slope, float* partial, int B, int D, int H, int W, int C, void* stream) {
     return pulpo_avgpool2_bwd_bnred_t(gout, gops, add, aps, gin, gips, 0, y, 0, yps, coef, slope, partial, B, D, H, W, C, stream);
+}
+
+// Second pass of the BatchNorm / LeakyReLU backward for a ConvUnit whose output was pooled (and possibly used as a skip connection): dz =
+// (add +) avgpool2_bwd(gout) is formed per element, as pulpo_avgpool2_bwd_bnred_t with gin == NULL formed it for the first pass.  Same operand
+// contract as that entry point; dy has y's dtype; partial2 as pulpo_bn_lrelu_bwd_apply_t (pulpo_bn_bwd_blocks(B*D*H*W, C) rows).
+PULPO_API int pulpo_bn_lrelu_bwd_apply_pooled_t(const void* gout, int64_t gops, const void* add, int64_t aps, int g_dt, const void* y, int y_dt, int64_t yps,
+                                                const float* coef, const double* totd, void* dy, int64_t dyps, float slope, float* partial2, int B, int D,
+                                                int H, int W, int C, void* stream) {
+    PULPO_REQUIRE(gout && y && coef && totd && dy && partial2 && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bn_lrelu_bwd_apply_pooled: bad arguments");
+    PULPO_REQUIRE_DT(g_dt, "bn_lrelu_bwd_apply_pooled"); PULPO_REQUIRE_DT(y_dt, "bn_lrelu_bwd_apply_pooled");
+    const int eg = g_dt ? 8 : 16, ey = y_dt ? 8 : 16;
+    PULPO_REQUIRE(C % 4 == 0 && C / 4 <= 256 && gops % 4 == 0 && yps % 4 == 0 && dyps % 4 == 0 && (add == nullptr || aps % 4 == 0) &&
+                      ((((uintptr_t)gout) | ((uintptr_t)add)) % eg) == 0 && ((((uintptr_t)y) | ((uintptr_t)dy)) % ey) == 0 && (((uintptr_t)coef) & 15) == 0,
+                  "bn_lrelu_bwd_apply_pooled: operands must be channels-last, aligned to four elements, C %% 4 == 0");
+    PULPO_DISPATCH_DT(g_dt, TG, PULPO_DISPATCH_DT(y_dt, TY,
+        return pool_apply_t((const TG*)gout, (long)gops, (const TG*)add, (long)aps, (const TY*)y, (long)yps, coef, totd, (TY*)dy, (long)dyps, slope, partial2, B,
+                            D, H, W, C, (hipStream_t)stream)));
+    return -1;
 }
 
 // dbeta / dgamma: [C] each, written (accumulate = 0) or added to (accumulate = 1, e.g. the parameters' .grad storage).

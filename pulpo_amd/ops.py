@@ -743,21 +743,62 @@ class _ConvBNLReLU(torch.autograd.Function):
         ctx.training = training
         ctx.params = (weight, bias, gamma, beta)      # for DIRECT_PARAM_GRADS (their .grad slots)
         _TLS.produced = (y, coef, pooled)            # read back by conv_bn_lrelu (the Function returns tensors only)
+        ctx.pooled_out = pooled is not None
+        if pooled is not None:
+            # (round 5) z AND AvgPool(z) are outputs of this node: their gradients arrive together, and the backward pass forms
+            # dz = gz + avg_pool_backward(gpooled) per element inside the BatchNorm-backward passes instead of writing it
+            ctx.set_materialize_grads(False)
+            return z, pooled
         return z
 
     @staticmethod
-    def backward(ctx, dz):
+    def backward(ctx, dz, dpool=None):
         x, weight, y, coef = ctx.saved_tensors
         B, Cin, D, H, W = x.shape
         Cout = weight.shape[0]
         dev = x.device
         npix = B * D * H * W
-        dz = to_cl(dz)
         nblk = lib.query("pulpo_bn_bwd_blocks", npix, Cout)
-        # first pass (sum dbn, sum dbn * xhat): already done by the epilogue of the data-gradient convolution that PRODUCED dz, if that was
-        # the ConvUnit behind this one (see _BN_TILE_PARTS); else a pass of its own over dz and y
-        tiles = _take_bn_tile_parts(y, coef, dz)
-        if tiles is None:
+        pooled_src = None                            # (gpool, gskip or None): dz = gskip + avg_pool_backward(gpool), never written
+        if dpool is not None:
+            gp = to_cl(dpool)
+            gz = dz
+            if gz is not None and gz.dtype != gp.dtype:
+                gz = gz.to(gp.dtype)
+            grp = 4 * int(_esize(gp))
+            skip_ok = gz is None
+            if gz is not None:
+                sb, sp, sc = grid_strides(gz)
+                skip_ok = _dense_grid(gz) and sc == 1 and sb == D * H * W * sp and sp % 4 == 0 and gz.data_ptr() % grp == 0
+            if (Cout % 4 == 0 and Cout // 4 <= 256 and skip_ok and gp.stride(4) % 4 == 0 and gp.data_ptr() % grp == 0 and y.stride(1) == 1
+                    and y.stride(4) % 4 == 0 and y.data_ptr() % (4 * int(_esize(y))) == 0 and _dense_grid(y) and POOLED_BN_BACKWARD):
+                pooled_src = (gp, gz)
+            else:                                    # shapes the fused passes do not take: the gradient as a tensor, then the plain path
+                gin = new_cl(B, Cout, D, H, W, dev, gp.dtype)
+                if skip_ok and gz is not None:
+                    lib.call("pulpo_avgpool2_bwd_t", _ptr(gp), gp.stride(4), _ptr(gz), grid_strides(gz)[1], _ptr(gin), gin.stride(4), _dt(gp), B, D, H, W, Cout, _stream())
+                else:
+                    lib.call("pulpo_avgpool2_bwd_t", _ptr(gp), gp.stride(4), None, 0, _ptr(gin), gin.stride(4), _dt(gp), B, D, H, W, Cout, _stream())
+                    if gz is not None:
+                        gin = gin + gz
+                dz = gin
+        elif dz is None:
+            return (None,) * 13
+        tiles = None
+        if pooled_src is not None:
+            gp, gz = pooled_src
+            part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
+            t0 = _hbm_begin("avgpool2_bwd_bnred")
+            lib.call("pulpo_avgpool2_bwd_bnred_t", _ptr(gp), gp.stride(4), _ptr(gz), grid_strides(gz)[1] if gz is not None else 0, None, 0, _dt(gp), _ptr(y), _dt(y),
+                     y.stride(4), _ptr(coef), LRELU_SLOPE, _ptr(part), B, D, H, W, Cout, _stream())
+            # read the pooled gradient, the skip gradient and y (the summed gradient is not written)
+            _hbm_end(t0, "avgpool2_bwd_bnred", Cout * (_esize(gp) * (gp.numel() // Cout + (npix if gz is not None else 0)) + _esize(y) * npix))
+        else:
+            dz = to_cl(dz)
+            # first pass (sum dbn, sum dbn * xhat): already done by the epilogue of the data-gradient convolution that PRODUCED dz, if that was
+            # the ConvUnit behind this one (see _BN_TILE_PARTS); else a pass of its own over dz and y
+            tiles = _take_bn_tile_parts(y, coef, dz)
+        if tiles is None and pooled_src is None:
             part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
             t0 = _hbm_begin("bn_lrelu_bwd_reduce")
             lib.call("pulpo_bn_lrelu_bwd_reduce_t", _ptr(dz), _dt(dz), dz.stride(4), _ptr(y), _dt(y), y.stride(4), _ptr(coef), npix, Cout, LRELU_SLOPE,
@@ -771,14 +812,14 @@ class _ConvBNLReLU(torch.autograd.Function):
         totd = torch.empty(2 * Cout, device=dev, dtype=torch.float64)          # mean(dbn) | mean(dbn * xhat), kept in double
         # eval-mode BatchNorm is a fixed affine map (dy = scale * dbn): the batch means do not enter
         fin_out = (_ptr(slot_be if direct_bn else tot), _ptr(slot_g) if direct_bn else ctypes.c_void_p(tot.data_ptr() + 4 * Cout), int(direct_bn), _ptr(totd))
-        rows, nrow = (part, nblk) if tiles is None else tiles
+        rows, nrow = (part, nblk) if tiles is None else tiles       # (pooled_src: `part` from the pooled first pass above)
         nsd = lib.query("pulpo_bn_bwd_finalize_scratch_doubles", nrow, Cout)
         scratch = torch.empty(nsd, device=dev, dtype=torch.float64) if nsd else None
         lib.call("pulpo_bn_bwd_finalize", _ptr(rows), nrow, Cout, _ptr(coef), float(npix), int(ctx.training), *fin_out, _ptr(scratch), _stream())
         # The input layer (image pair -> 32 channels at full resolution): nobody asks for its data gradient, so dy has ONE reader - the weight
         # gradient, which then forms it per element while staging (pulpo_conv3d_k3_wgrad_bn) instead of a pass that reads dz and y and writes dy
         # (0.29 ms at 160^3 x 32 channels).  PULPO_FUSE_INPUT_WGRAD=0: the separate pass (A/B switch).
-        if (FUSE_INPUT_WGRAD and Cin <= 2 and not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not DETERMINISTIC and y.dtype == torch.float32
+        if (FUSE_INPUT_WGRAD and pooled_src is None and Cin <= 2 and not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not DETERMINISTIC and y.dtype == torch.float32
                 and Cout % 4 == 0 and is_cl(y) and is_cl(dz) and y.stride(4) % 4 == 0 and dz.stride(4) % 4 == 0 and x.dtype == torch.float32):
             return _ConvBNLReLU._backward_input_layer(ctx, dz, x, weight, y, coef, totd, tot, direct_bn, (slot_w, slot_b), (w_p, b_p))
         dy = new_cl(B, Cout, D, H, W, dev, y.dtype)            # (the gradient of the pre-norm tensor is stored like the tensor)
@@ -789,9 +830,15 @@ class _ConvBNLReLU(torch.autograd.Function):
         if not defer_b:
             part2 = torch.empty(nblk * Cout, device=dev, dtype=torch.float32)
         t0 = _hbm_begin("bn_lrelu_bwd_apply")
-        lib.call("pulpo_bn_lrelu_bwd_apply_t", _ptr(dz), _dt(dz), dz.stride(4), _ptr(y), _dt(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4),
-                 npix, Cout, LRELU_SLOPE, _ptr(part2), _stream())
-        _hbm_end(t0, "bn_lrelu_bwd_apply", (_esize(dz) + 2 * _esize(y)) * Cout * npix)                # read dz, y; write dy
+        if pooled_src is not None:
+            gp, gz = pooled_src
+            lib.call("pulpo_bn_lrelu_bwd_apply_pooled_t", _ptr(gp), gp.stride(4), _ptr(gz), grid_strides(gz)[1] if gz is not None else 0, _dt(gp), _ptr(y), _dt(y),
+                     y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4), LRELU_SLOPE, _ptr(part2), B, D, H, W, Cout, _stream())
+            _hbm_end(t0, "bn_lrelu_bwd_apply", Cout * (_esize(gp) * (gp.numel() // Cout + (npix if gz is not None else 0)) + 2 * _esize(y) * npix))
+        else:
+            lib.call("pulpo_bn_lrelu_bwd_apply_t", _ptr(dz), _dt(dz), dz.stride(4), _ptr(y), _dt(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4),
+                     npix, Cout, LRELU_SLOPE, _ptr(part2), _stream())
+            _hbm_end(t0, "bn_lrelu_bwd_apply", (_esize(dz) + 2 * _esize(y)) * Cout * npix)                # read dz, y; write dy
         defer_w = ctx.needs_input_grad[1] and slot_w is not None and ASYNC_WGRAD_STREAM is not None
         if defer_b:
             _PENDING_GRAD_JOBS.append((part2.data_ptr(), slot_b.data_ptr(), 1, nblk, Cout, 0))
@@ -861,6 +908,8 @@ def _backward_input_layer(ctx, dz, x, weight, y, coef, totd, tot, direct_bn, slo
 
 _ConvBNLReLU._backward_input_layer = staticmethod(_backward_input_layer)
 FUSE_INPUT_WGRAD = os.environ.get("PULPO_FUSE_INPUT_WGRAD", "1") != "0"
+# the gradient of a pooled ConvUnit output formed inside both BatchNorm-backward passes instead of written (A/B switch: "0" materialises it)
+POOLED_BN_BACKWARD = os.environ.get("PULPO_POOLED_BN_BACKWARD", "1") != "0"
 
 
 def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None,
@@ -878,13 +927,16 @@ def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, train
     bn_src = src[:2] if (src is not None and src[2] == x._version and training and torch.is_grad_enabled()) else None
     z = _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
                            float(eps), bn_src, bool(pool_after))
+    pooled_out = None
+    if isinstance(z, tuple):
+        z, pooled_out = z
     produced = getattr(_TLS, "produced", None)
     _TLS.produced = None
     _TLS.out_slot = None
     if produced is not None:
         z._pulpo_bn_src = (produced[0], produced[1], z._version)
-        if produced[2] is not None:
-            z._pulpo_pooled = (produced[2], z._version)
+        if pooled_out is not None:
+            z._pulpo_pooled = (pooled_out, z._version, True)      # (an output of the same autograd node: avg_pool2_skip hands it out as it is)
     if out is not None and z.dim() == 5 and z.data_ptr() == out[0].data_ptr() + out[0].element_size() * out[1] and z.stride() == out[0].stride():
         z._pulpo_cat = (out[0], out[1])
     return z
@@ -1135,6 +1187,8 @@ def avg_pool2_skip(x):
     if _is2d(x):
         return x, avg_pool2(x)
     ready = getattr(x, "_pulpo_pooled", None)
+    if ready is not None and ready[1] == x._version and len(ready) > 2:
+        return x, ready[0]                            # produced (and differentiated) together with x by the ConvUnit's own autograd node
     src = getattr(x, "_pulpo_bn_src", None)          # x is the untouched output of a ConvUnit: (y, coef, version at production)
     src = src if (src is not None and src[2] == x._version and torch.is_grad_enabled()) else None
     alias, pooled = _AvgPool2Skip.apply(x, ready[0] if (ready is not None and ready[1] == x._version) else None, src[0] if src else None, src[1] if src else None)
