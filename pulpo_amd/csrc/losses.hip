@@ -297,6 +297,80 @@ __global__ __launch_bounds__(256) void l2reg_fwd_kernel(const float* __restrict_
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
+// the same sums for rows that are whole groups of four voxels (W % 4 == 0, 16-byte aligned): one item = four consecutive x of one row - 16-byte
+// loads of the row, the row above (y - 1) and the row behind (z - 1), 32-bit index arithmetic per item instead of 64-bit divisions per voxel
+// (round 5: 61 -> ~15 us at 3 x 160^3).  Which block sums what differs from the scalar kernel (fp32 rounding of the partial sums only).
+__global__ __launch_bounds__(256) void l2reg_fwd_vec_kernel(const float* __restrict__ df, long nplanes, int D, int H, int W, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float local = 0.f;
+    const int W4 = W >> 2;
+    const long items = nplanes * D * H * W4;
+    for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const int x4 = (int)(it % W4);
+        const long row = it / W4;                         // (plane, z, y) linearised
+        const int y = (int)(row % H);
+        const int z = (int)((row / H) % D);
+        if (y >= 1 && (z >= 1 || D == 1)) {
+            const long e = row * W + 4 * x4;
+            const float4 c = *reinterpret_cast<const float4*>(df + e);
+            const float4 u = *reinterpret_cast<const float4*>(df + e - W);
+            float4 bk = c;                                // (D == 1: no depth term)
+            if (D != 1) bk = *reinterpret_cast<const float4*>(df + e - (long)H * W);
+            const float cc[4] = {c.x, c.y, c.z, c.w}, uu[4] = {u.x, u.y, u.z, u.w}, bb[4] = {bk.x, bk.y, bk.z, bk.w};
+            float left = x4 > 0 ? df[e - 1] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (4 * x4 + k >= 1) {
+                    const float a = cc[k] - bb[k], b = cc[k] - uu[k], d = cc[k] - left;
+                    local += a * a + b * b + d * d;
+                }
+                left = cc[k];
+            }
+        }
+    }
+    const float t = block_sum_256(local, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void l2reg_bwd_vec_kernel(const float* __restrict__ df, const float* __restrict__ gscale, float coef,
+                                                              float* __restrict__ gdf, long nplanes, int D, int H, int W) {
+    const float k0 = 2.f * coef * (gscale != nullptr ? gscale[0] : 1.f);
+    const int W4 = W >> 2;
+    const long items = nplanes * D * H * W4;
+    const long sz = (long)H * W;
+    const bool flat = D == 1;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const int x4 = (int)(it % W4);
+        const long row = it / W4;
+        const int y = (int)(row % H);
+        const int z = (int)((row / H) % D);
+        const long e = row * W + 4 * x4;
+        const float4 c = *reinterpret_cast<const float4*>(df + e);
+        const float4 zm = (z >= 1) ? *reinterpret_cast<const float4*>(df + e - sz) : zero;
+        const float4 zp = (z + 1 < D) ? *reinterpret_cast<const float4*>(df + e + sz) : zero;
+        const float4 ym = (y >= 1) ? *reinterpret_cast<const float4*>(df + e - W) : zero;
+        const float4 yp = (y + 1 < H) ? *reinterpret_cast<const float4*>(df + e + W) : zero;
+        const float xm = x4 > 0 ? df[e - 1] : 0.f, xp = x4 + 1 < W4 ? df[e + 4] : 0.f;
+        const float cc[4] = {c.x, c.y, c.z, c.w}, a0[4] = {zm.x, zm.y, zm.z, zm.w}, a1[4] = {zp.x, zp.y, zp.z, zp.w};
+        const float b0[4] = {ym.x, ym.y, ym.z, ym.w}, b1[4] = {yp.x, yp.y, yp.z, yp.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = 4 * x4 + k;
+            const float cv = cc[k];
+            const float lft = k > 0 ? cc[k - 1] : xm, rgt = k < 3 ? cc[k + 1] : xp;
+            float g = 0.f;                                  // the scalar kernel's four terms, in its order
+            if (x >= 1 && y >= 1 && (z >= 1 || flat)) g += (flat ? 0.f : cv - a0[k]) + (cv - b0[k]) + (cv - lft);
+            if (z + 1 < D && y >= 1 && x >= 1) g -= a1[k] - cv;
+            if (y + 1 < H && (z >= 1 || flat) && x >= 1) g -= b1[k] - cv;
+            if (x + 1 < W && (z >= 1 || flat) && y >= 1) g -= rgt - cv;
+            o[k] = k0 * g;
+        }
+        *reinterpret_cast<float4*>(gdf + e) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void l2reg_bwd_kernel(const float* __restrict__ df, const float* __restrict__ gscale, float coef,
                                                           float* __restrict__ gdf, long nplanes, int D, int H, int W) {
     const float k0 = 2.f * coef * (gscale != nullptr ? gscale[0] : 1.f);
@@ -397,13 +471,19 @@ PULPO_API int pulpo_kl_bwd(const float* mu, const float* sigma, const float* mu1
 // finish with pulpo_colsum(scale = lamb*D*H*W / (nplanes*(D-1)*(H-1)*(W-1)))
 PULPO_API int pulpo_l2reg_fwd(const float* df, int64_t nplanes, int D, int H, int W, float* partial, void* stream) {
     PULPO_REQUIRE(df && partial && nplanes > 0 && D >= 1 && H > 1 && W > 1, "l2reg_fwd: bad arguments");
-    hipLaunchKernelGGL(l2reg_fwd_kernel, dim3(pulpo_loss_blocks(nplanes * D * H * W)), dim3(256), 0, (hipStream_t)stream, df, (long)nplanes, D, H, W, partial);
+    if (W % 4 == 0 && (((uintptr_t)df) & 15) == 0)
+        hipLaunchKernelGGL(l2reg_fwd_vec_kernel, dim3(pulpo_loss_blocks(nplanes * D * H * W)), dim3(256), 0, (hipStream_t)stream, df, (long)nplanes, D, H, W, partial);
+    else
+        hipLaunchKernelGGL(l2reg_fwd_kernel, dim3(pulpo_loss_blocks(nplanes * D * H * W)), dim3(256), 0, (hipStream_t)stream, df, (long)nplanes, D, H, W, partial);
     return pulpo::check_launch("l2reg_fwd");
 }
 
 PULPO_API int pulpo_l2reg_bwd(const float* df, const float* gscale, float coef, float* gdf, int64_t nplanes, int D, int H, int W, void* stream) {
     PULPO_REQUIRE(df && gdf && nplanes > 0 && D >= 1 && H > 1 && W > 1, "l2reg_bwd: bad arguments");
-    hipLaunchKernelGGL(l2reg_bwd_kernel, dim3(eblocks(nplanes * D * H * W)), dim3(256), 0, (hipStream_t)stream, df, gscale, coef, gdf, (long)nplanes, D, H, W);
+    if (W % 4 == 0 && ((((uintptr_t)df) | ((uintptr_t)gdf)) & 15) == 0)
+        hipLaunchKernelGGL(l2reg_bwd_vec_kernel, dim3(eblocks(nplanes * D * H * (W / 4))), dim3(256), 0, (hipStream_t)stream, df, gscale, coef, gdf, (long)nplanes, D, H, W);
+    else
+        hipLaunchKernelGGL(l2reg_bwd_kernel, dim3(eblocks(nplanes * D * H * W)), dim3(256), 0, (hipStream_t)stream, df, gscale, coef, gdf, (long)nplanes, D, H, W);
     return pulpo::check_launch("l2reg_bwd");
 }
 
