@@ -406,33 +406,33 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const float* __res
                                                                        const float* __restrict__ coef, double count, int use_means,
                                                                        float* __restrict__ dbeta, float* __restrict__ dgamma, int accumulate,
                                                                        double* __restrict__ totd) {
-    __shared__ double red[2][16][33];      // block = (32 channels, 16 row lanes): 8 waves of <= 32 registers, see below
+    // block = (8 channels, 64 row lanes), grid = ceil(C / 8) (round 5; was 32 channels x 16 row lanes on ceil(C / 32) workgroups: 2 workgroups
+    // walked the 2000 rows of an 80^3 layer in 125 passes).  512 threads at <= 32 registers: the kernel still fits beside a weight-gradient
+    // kernel of the other stream (bf16 mode).  Rows are summed in row order per lane, the lanes in lane order: deterministic.
+    constexpr int CG = 8, RL = 64;
+    __shared__ double red[2][RL][CG + 1];
     const int cx = threadIdx.x, ry = threadIdx.y;
-    const int c = blockIdx.x * 32 + cx;
-    // (no unrolling: this kernel runs beside the weight-gradient kernel, which leaves about 100 registers per SIMD - the 8 waves of a
-    //  workgroup have to fit into them or the launch waits for a CU the weight gradient has left)
+    const int c = blockIdx.x * CG + cx;
     double s = 0.0, q = 0.0;
     if (c < C) {
         if (part != nullptr) {
 #pragma unroll 1
-            for (int r = ry; r < nrow; r += 16) {
+            for (int r = ry; r < nrow; r += RL) {
                 s += part[((long)r * 2 + 0) * C + c];
                 q += part[((long)r * 2 + 1) * C + c];
             }
         } else {
-            // up to 2048 fp32 rows in one stage (round 5: the slice-sum launch in front of this kernel is gone for every level but 160^3): four
-            // rows of independent loads per pass, summed in row order (deterministic)
             int r = ry;
 #pragma unroll 1
-            for (; r + 48 < nrow; r += 64) {
+            for (; r + 3 * RL < nrow; r += 4 * RL) {          // four rows of independent loads per pass
                 const float a0 = rows[((long)r * 2 + 0) * C + c], b0 = rows[((long)r * 2 + 1) * C + c];
-                const float a1 = rows[((long)(r + 16) * 2 + 0) * C + c], b1 = rows[((long)(r + 16) * 2 + 1) * C + c];
-                const float a2 = rows[((long)(r + 32) * 2 + 0) * C + c], b2 = rows[((long)(r + 32) * 2 + 1) * C + c];
-                const float a3 = rows[((long)(r + 48) * 2 + 0) * C + c], b3 = rows[((long)(r + 48) * 2 + 1) * C + c];
+                const float a1 = rows[((long)(r + RL) * 2 + 0) * C + c], b1 = rows[((long)(r + RL) * 2 + 1) * C + c];
+                const float a2 = rows[((long)(r + 2 * RL) * 2 + 0) * C + c], b2 = rows[((long)(r + 2 * RL) * 2 + 1) * C + c];
+                const float a3 = rows[((long)(r + 3 * RL) * 2 + 0) * C + c], b3 = rows[((long)(r + 3 * RL) * 2 + 1) * C + c];
                 s += (double)a0; q += (double)b0; s += (double)a1; q += (double)b1; s += (double)a2; q += (double)b2; s += (double)a3; q += (double)b3;
             }
 #pragma unroll 1
-            for (; r < nrow; r += 16) {
+            for (; r < nrow; r += RL) {
                 s += (double)rows[((long)r * 2 + 0) * C + c];
                 q += (double)rows[((long)r * 2 + 1) * C + c];
             }
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const float* __res
     if (ry == 0 && c < C) {
         double ts = 0.0, tq = 0.0;
 #pragma unroll 1
-        for (int k = 0; k < 16; ++k) { ts += red[0][k][cx]; tq += red[1][k][cx]; }
+        for (int k = 0; k < RL; ++k) { ts += red[0][k][cx]; tq += red[1][k][cx]; }
         const double* cd = reinterpret_cast<const double*>(coef + 4 * C);
         const double tx = cd[C + c] * (tq - (cd[c] - (double)coef[c]) * ts);
         dbeta[c] = accumulate ? dbeta[c] + (float)ts : (float)ts;
@@ -712,7 +712,7 @@ PULPO_API int pulpo_bn_bwd_finalize(const float* tile_part, int ntile, int C, co
         partd = scratch;
         nrow = 32;
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pulpo::cdiv(C, 32)), dim3(32, 16), 0, st, tile_part, partd, nrow, C, coef, count, use_means,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pulpo::cdiv(C, 8)), dim3(8, 64), 0, st, tile_part, partd, nrow, C, coef, count, use_means,
                        dbeta, dgamma, accumulate, totd);
     return pulpo::check_launch("bn_bwd_finalize");
 }

@@ -510,7 +510,15 @@ PULPO_API int pulpo_vecint_bwd(const float* work, const float* gout, float* gin,
         if (tiled) {
             gp = tmp + (long)k * n;
             const int ntz = pulpo::cdiv(D, 4), nty = pulpo::cdiv(H, 8), ntx = pulpo::cdiv(W, 8);
-            hipLaunchKernelGGL(vecint_bwd_tile_kernel<1>, dim3((unsigned)((long)B * ntz * nty * ntx)), dim3(256), 0, st, cur, g, gp, B, D, H, W, ntz, nty, ntx);
+            // the LAST squaring steps move by the largest fraction of the field (v / 2 at k = nsteps - 1): a box with a two-voxel rim keeps their
+            // corners in LDS where the one-voxel rim sent them to memory atomics (80^3: 88 against ~40 us for the other steps).
+            // PULPO_VECINT_R2_STEPS: how many of the last steps take the wider box (default 1; 0 = none, A/B switch)
+            static int r2 = -1;
+            if (r2 < 0) { const char* e = getenv("PULPO_VECINT_R2_STEPS"); r2 = e ? atoi(e) : 1; }
+            if (k >= nsteps - r2 && (long)D * H * W >= 64L * 64 * 64)     // (below 64^3 the wider box costs more than the fallbacks it saves: 14 against 12 us)
+                hipLaunchKernelGGL(vecint_bwd_tile_kernel<2>, dim3((unsigned)((long)B * ntz * nty * ntx)), dim3(256), 0, st, cur, g, gp, B, D, H, W, ntz, nty, ntx);
+            else
+                hipLaunchKernelGGL(vecint_bwd_tile_kernel<1>, dim3((unsigned)((long)B * ntz * nty * ntx)), dim3(256), 0, st, cur, g, gp, B, D, H, W, ntz, nty, ntx);
         } else {
             gp = tmp + (long)(k & 1) * n;
             hipError_t e = hipMemcpyAsync(gp, g, sizeof(float) * n, hipMemcpyDeviceToDevice, st);
