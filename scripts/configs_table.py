@@ -6,9 +6,11 @@ RUNS = [
     ("2: 96^3 T4/L3 fp32 B=2", ["--size", "96", "96", "96", "--levels", "4", "3", "--batch", "2"]),
     ("3: 160^3 T5/L4 fp32 B=1 (the metric)", []),
     ("4: 160^3 T5/L4 bf16 operands + bf16 activation storage, OASIS-style pair, B=1", ["--precision", "bf16", "--data", "oasis"]),
+    ("4, the step replayed from a HIP graph (--graph)", ["--precision", "bf16", "--data", "oasis", "--graph"]),
     ("4 (fp32 activation storage, the round-3 mode)", ["--precision", "bf16", "--data", "oasis", "--activations", "fp32"]),
     ("5: 192x224x160 T6/L5 bf16 operands + bf16 activation storage, training step, B=1", ["--size", "192", "224", "160", "--levels", "6", "5", "--precision", "bf16", "--data", "oasis"]),
     ("5: 192x224x160 T6/L5 bf16 operands + bf16 activation storage, 8-sample MC uncertainty maps", ["--size", "192", "224", "160", "--levels", "6", "5", "--precision", "bf16", "--data", "oasis", "--mode", "mc8"]),
+    ("3, deterministic mode (--deterministic)", ["--deterministic"]),
     ("3 (inference): 160^3 predict_deterministic fp32", ["--mode", "infer"]),
     ("4 (inference): 160^3 predict_deterministic, bf16 operands + bf16 activation storage", ["--mode", "infer", "--precision", "bf16", "--data", "oasis"]),
 ]
