@@ -625,7 +625,7 @@ def main():
                                   "non_matrix = step - matrix (%s); hbm_classes = sum of the brackets of the memory-bound kernel classes listed under "
                                   "hbm_rooflines in two extra untimed steps (finalize / column-sum / torch glue launches and kernel boundaries are in "
                                   "non_matrix but not in hbm_classes); host_enqueue = median host time inside one step's enqueue (timed region).  CAVEAT: an "
-                                  "event bracket spans start-event -> end-event, i.e. the kernel plus its launch turnaround (2 - 3 us each), so bracket sums run ~8 % "
+                                  "event bracket spans start-event -> end-event, i.e. the kernel plus its launch turnaround (2 - 3 us each), so bracket sums run ~8 %% "
                                   "above the kernels' own durations (matrix + hbm_classes exceed the step) and non_matrix = step - matrix is a LOWER bound; the "
                                   "kernel-only split of this build is in profiles/r5_bench160_stream_cost.txt (rocprofv3 --kernel-trace: matrix 21.4, other 6.6 ms)"
                                   % (ops.CONV_TRACE_STRIDE_USED, "weight gradients on a second stream: not defined" if overlapped else "nothing overlaps: weight gradients in line")}

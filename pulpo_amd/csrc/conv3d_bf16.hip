@@ -1183,7 +1183,7 @@ static int wgrad_bf16_impl(const void* in, int64_t in_bs, int64_t in_ps, int64_t
 #undef PULPO_WGRAD_T
 #undef PULPO_WGRAD_H
     int rc = pulpo::check_launch("conv3d_k3_wgrad_bf16");
-    if (rc == 0 && slabs) rc = pulpo_conv::launch_wgrad_slab_reduce(scratch, slabs, a.nsplit, (long)base, st);
+    if (rc == 0 && slabs) rc = pulpo_conv::launch_wgrad_slab_reduce(scratch, slabs, a.nsplit, (long)base, st, npad(Cout), Cout);
     if (rc || deferred) return rc;
     return pulpo_conv::launch_unpack_wgrad(scratch, dw, Cin, Cout, accumulate, st);
 }

@@ -808,7 +808,7 @@ static int wgrad_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_
     auto finish = [&](int rc0) -> int {
         if (rc0) return rc0;
         if (slabs) {
-            const int r = pulpo_conv::launch_wgrad_slab_reduce(scratch, slabs, used, base, st);
+            const int r = pulpo_conv::launch_wgrad_slab_reduce(scratch, slabs, used, base, st, npad(Cout), Cout);
             if (r) return r;
         }
         if (deferred) return 0;
@@ -951,8 +951,13 @@ PULPO_API int pulpo_conv3d_k3_wgrad_det(const float* in, int64_t in_bs, int64_t 
 }
 
 namespace {
-__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(float* __restrict__ scratch, const float* __restrict__ slabs, int nslab, long n) {
-    for (long e = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4; e < n; e += (long)gridDim.x * blockDim.x * 4) {
+// (rows of npad floats of which the first `cols` are ever written: the padding columns of a 32-channel layer - half of every slab - are skipped)
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(float* __restrict__ scratch, const float* __restrict__ slabs, int nslab, long n, int npad,
+                                                                  int cols) {
+    const int q4 = (cols + 3) >> 2;                       // four-float groups per row
+    const long rows = n / npad, items = rows * q4;
+    for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const long e = (it / q4) * npad + (it % q4) * 4;
         float4 t = *reinterpret_cast<const float4*>(scratch + e);
         for (int s_ = 0; s_ < nslab; ++s_) {
             const float4 u = *reinterpret_cast<const float4*>(slabs + (long)s_ * n + e);
@@ -963,10 +968,12 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(float* __restric
 }
 }  // namespace
 
-int pulpo_conv::launch_wgrad_slab_reduce(float* scratch, const float* slabs, int nslab, long n, hipStream_t st) {
+int pulpo_conv::launch_wgrad_slab_reduce(float* scratch, const float* slabs, int nslab, long n, hipStream_t st, int npad_, int cols) {
     // (n = 27 * Cin * npad(Cout) is a multiple of 64 floats; scratch and slabs come from the caller's allocator: 16-byte aligned)
     if ((n & 3) || (((uintptr_t)scratch | (uintptr_t)slabs) & 15)) return pulpo::fail(1, "wgrad slab reduce: operands must be 16-byte aligned");
-    const int nb = (int)std::min<long>((n / 4 + 255) / 256, 4096);
-    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(nb), dim3(256), 0, st, scratch, slabs, nslab, n);
+    if (npad_ <= 0 || n % npad_ != 0) { npad_ = 64; cols = 64; }
+    const long items = (n / npad_) * ((cols + 3) / 4);
+    const int nb = (int)std::min<long>((items + 255) / 256, 4096);
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(nb), dim3(256), 0, st, scratch, slabs, nslab, n, npad_, cols);
     return pulpo::check_launch("wgrad_slab_reduce");
 }

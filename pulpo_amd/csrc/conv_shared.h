@@ -35,7 +35,7 @@ int launch_unpack_wgrad(const float* packed, float* dw, int Cin, int Cout, int a
 int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, long go_bs, long go_ps, float* scratch, int B, int D, int H, int W,
                     int Cin, int Cout, hipStream_t st, float* slabs = nullptr, int nslab = 0, int* used_slabs = nullptr);
 // scratch[e] += slabs[0][e] + slabs[1][e] + ... (fixed order, e < n): the ordered second stage of the deterministic weight gradient
-int launch_wgrad_slab_reduce(float* scratch, const float* slabs, int nslab, long n, hipStream_t st);
+int launch_wgrad_slab_reduce(float* scratch, const float* slabs, int nslab, long n, hipStream_t st, int npad_ = 64, int cols = 64);
 bool wgrad_w3_depth_ok(int D);                      // the F(2x2x2,3x3x3) weight-gradient kernel takes this depth (even, PULPO_WGRAD_W3 != 0)
 
 // forward / data gradient, pipelined F(2x2,3x3) kernel (conv3d_wino2p.hip): channels-last 16-byte-aligned operands, K % 4 == 0; bnr = with the

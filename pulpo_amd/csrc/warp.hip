@@ -332,12 +332,25 @@ __device__ __forceinline__ void fx_add(long long* p, float v, double unit) {
     atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * unit));
 }
 
+// largest value of a workgroup -> ONE atomic per workgroup (thousands of waves hitting one address serialise at the L2: the first version, one
+// atomic per wave, spent 70 us per launch on a 1.5 M-element field); bit patterns of non-negative floats order like the values
+__device__ __forceinline__ void block_absmax_to(float m, unsigned* out) {
+    __shared__ float wm[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (t > 0.f) atomicMax(out, __float_as_uint(t));
+    }
+}
+inline int fx_blocks(long items) { return (int)std::max<long>(1, std::min<long>((items + 255) / 256, 1024)); }
+
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, long n, unsigned* __restrict__ out) {
     float m = 0.f;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(g[e]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));          // (bit patterns of non-negative floats order like the values)
+    block_absmax_to(m, out);
 }
 
 // SELF = a VecInt squaring step (v' = v + warp(v, v): image and displacement are the same 3-channel field; the identity path and the
@@ -407,11 +420,7 @@ __global__ __launch_bounds__(256) void fx_to_float_kernel(long long* __restrict_
         out[e] = val;
         m = fmaxf(m, fabsf(val));
     }
-    if (next_max != nullptr) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(next_max, __float_as_uint(m));
-    }
+    if (next_max != nullptr) block_absmax_to(m, next_max);          // (uniform branch: every thread of the workgroup takes it)
 }
 
 }  // namespace
@@ -552,10 +561,10 @@ PULPO_API int pulpo_warp3d_bwd_det(const float* df, const float* img, const floa
     if (gimg != nullptr) {
         hipError_t e = hipMemsetAsync(ws, 0, 256 + sizeof(long long) * (size_t)ni, st);
         if (e != hipSuccess) return pulpo::fail((int)e, "warp3d_bwd_det memset: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(absmax_kernel, dim3(eblocks((long)B * C * Dg * Hg * Wg)), dim3(256), 0, st, gout, (long)B * C * Dg * Hg * Wg, slots);
+        hipLaunchKernelGGL(absmax_kernel, dim3(fx_blocks((long)B * C * Dg * Hg * Wg)), dim3(256), 0, st, gout, (long)B * C * Dg * Hg * Wg, slots);
     }
     hipLaunchKernelGGL(warp_bwd_fx_kernel<false>, dim3(eblocks(total)), dim3(256), 0, st, df, img, gout, gdf, acc, slots, B, Dg, Hg, Wg, Di, Hi, Wi, C);
-    if (gimg != nullptr) hipLaunchKernelGGL(fx_to_float_kernel, dim3(eblocks(ni)), dim3(256), 0, st, acc, gimg, ni, slots, 1.0f, (unsigned*)nullptr);
+    if (gimg != nullptr) hipLaunchKernelGGL(fx_to_float_kernel, dim3(fx_blocks(ni)), dim3(256), 0, st, acc, gimg, ni, slots, 1.0f, (unsigned*)nullptr);
     return pulpo::check_launch("warp3d_bwd_det");
 }
 
@@ -580,13 +589,13 @@ PULPO_API int pulpo_vecint_bwd_det(const float* work, const float* gout, float* 
     float* buf[2] = {(float*)(acc + n), (float*)(acc + n) + n};
     hipError_t e = hipMemsetAsync(ws, 0, 256 + sizeof(long long) * (size_t)n, st);
     if (e != hipSuccess) return pulpo::fail((int)e, "vecint_bwd_det memset: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(absmax_kernel, dim3(eblocks(n)), dim3(256), 0, st, gout, n, slots + (nsteps - 1));
+    hipLaunchKernelGGL(absmax_kernel, dim3(fx_blocks(n)), dim3(256), 0, st, gout, n, slots + (nsteps - 1));
     const float* g = gout;
     for (int k = nsteps - 1; k >= 0; --k) {
         const float* cur = work + (long)k * n;
         hipLaunchKernelGGL(warp_bwd_fx_kernel<true>, dim3(eblocks(total)), dim3(256), 0, st, cur, cur, g, (float*)nullptr, acc, slots + k, B, D, H, W, D, H, W, 3);
         float* out = k == 0 ? gin : buf[k & 1];
-        hipLaunchKernelGGL(fx_to_float_kernel, dim3(eblocks(n)), dim3(256), 0, st, acc, out, n, slots + k, k == 0 ? scale : 1.0f, k == 0 ? (unsigned*)nullptr : slots + (k - 1));
+        hipLaunchKernelGGL(fx_to_float_kernel, dim3(fx_blocks(n)), dim3(256), 0, st, acc, out, n, slots + k, k == 0 ? scale : 1.0f, k == 0 ? (unsigned*)nullptr : slots + (k - 1));
         g = out;
     }
     return pulpo::check_launch("vecint_bwd_det");
