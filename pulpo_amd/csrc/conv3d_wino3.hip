@@ -70,8 +70,13 @@ constexpr int Q_PART = 8 * 64 * 8;               // a wave's per-lane statistics
 constexpr size_t Q_LDS = (size_t)(2 * Q_IMG + Q_TAB + Q_R + Q_RED + Q_PART) * sizeof(float);
 static_assert(Q_LDS <= 160 * 1024, "one workgroup per CU");
 
-template <bool BNR>
-__global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
+#ifndef PULPO_W3_SKEW
+#define PULPO_W3_SKEW 1          // 1: the two waves of a SIMD (w and w + 4) do their halo staging in DIFFERENT pairs of a chunk (see the kernel below)
+#endif
+
+// SP: the pair of a chunk behind whose first MFMAs a wave transforms and stores its staging item (SP) and requests the next taps (SP + 1)
+template <bool BNR, int SP>
+__device__ __forceinline__ void wino3_body(const ConvArgs& a) {
     constexpr int CH = Q_CH, NT = Q_NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const tab = smem + 2 * Q_IMG;                // [3][ctab]
@@ -358,11 +363,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
                     if (s2 == 0) {                      // behind the pair's first MFMAs: the staging work of the pair
                         __builtin_amdgcn_sched_barrier(0);
                         if (!(PULPO_ABL & 2)) {
-                            if (pp == 0) {
+                            if (pp == SP) {
                                 store_item(img_w);
                                 if (chunk + 2 == nchunk) halo_offsets(has_next ? nxt : cur);
                             }
-                            if (pp == 1) { load_raw(st_rs, st_c0, 0); load_raw(st_rs, st_c0, 1); load_raw(st_rs, st_c0, 2); load_raw(st_rs, st_c0, 3); }
+                            if (pp == SP + 1) { load_raw(st_rs, st_c0, 0); load_raw(st_rs, st_c0, 1); load_raw(st_rs, st_c0, 2); load_raw(st_rs, st_c0, 3); }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -547,6 +552,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
     }
     __syncthreads();
     flush_stats();
+}
+
+// The kernel body exists in two copies that differ in ONE constant, SP.  Waves 0-3 stage behind pairs 0 / 1 of a chunk, their SIMD partners 4-7
+// behind pairs 2 / 3: the kernel's phases ADD UP (ablations, DESIGN 3d: two waves per SIMD in lock step hide nothing of each other) - staggered,
+// one wave's vector and LDS-write work falls into the other's matrix phase.  Two whole copies behind ONE wave-uniform branch at the top (no state
+// joins behind it: the copies share only the kernel arguments and the LDS), and a compile-time constant per copy, because a wave-uniform RUNTIME
+// branch around the tap loads makes every vmcnt behind it a worst-case guess (measured in round 4: -15 %).  Both copies pass the same barriers.
+template <bool BNR>
+__global__ __launch_bounds__(512, 1) void conv3d_k3_wino3_mfma(ConvArgs a) {
+    if (PULPO_W3_SKEW && __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0) wino3_body<BNR, 2>(a);
+    else wino3_body<BNR, 0>(a);
 }
 
 __global__ void pack_weight_wino3_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int NPad, int dgrad, long total) {
