@@ -616,8 +616,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w2x(Wgrad2Args a) {
 constexpr int W3G_EX = 4 * 4 * W2G_ESLOT;                          // [px][4 slots][32 co][36]
 constexpr size_t W3G_LDS = (size_t)(W2G_VX + W3G_EX) * sizeof(float);     // 163,840 bytes
 
-template <int DUMMY>
-__global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
+#ifndef PULPO_WG3_SKEW
+#define PULPO_WG3_SKEW 1         // 1: the two waves of a SIMD (w, w + 4) stage their planes behind DIFFERENT groups of a half step (see the kernel below)
+#endif
+
+// SG: the group of a half step behind whose first MFMAs a wave starts transforming / writing the fetched planes (groups SG, SG + 1; the next planes'
+// loads are issued in group SG + 1)
+template <int SG>
+__device__ __forceinline__ void wgrad_w3x_body(const Wgrad2Args& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* VX = smem;
     float* EX = smem + W2G_VX;
@@ -848,26 +854,26 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
 #ifndef PULPO_W3_STAGE
 #define PULPO_W3_STAGE 0                                  // 0: two points behind the first MFMAs of groups 0 and 1 (the (y, x) kernel's placement), 1: all four in group 0
 #endif
-                    if (s_ == 0 && gi < (PULPO_W3_STAGE ? 1 : 2)) {
+                    if (s_ == 0 && gi >= SG && gi < SG + (PULPO_W3_STAGE ? 1 : 2)) {
                         // the planes fetched during the previous half step are transformed and written behind the group's first MFMAs; their
                         // registers are then free and the next planes are requested.  (All four points in ONE group - 30 instead of 24 of the half
                         // step's 32 MFMAs for the loads to land - measured 1.5 - 2 % SLOWER although a build without any loads is 14 - 18 % faster:
                         // what the loads cost is not their latency.)
                         __builtin_amdgcn_sched_barrier(0);
-                        if (gi == 0) touch_raw();
+                        if (gi == SG) touch_raw();
 #if !(PULPO_ABLX & 2)
                         if (PULPO_W3_STAGE) {
                             write_x(0, xs_slot); write_x(1, xs_slot); write_x(2, xs_slot); write_x(3, xs_slot);
                             write_e(0, ew_slot); write_e(1, ew_slot); write_e(2, ew_slot); write_e(3, ew_slot);
                         } else {
-                            write_x(2 * gi, xs_slot);
-                            write_x(2 * gi + 1, xs_slot);
-                            write_e(2 * gi, ew_slot);
-                            write_e(2 * gi + 1, ew_slot);
+                            write_x(2 * (gi - SG), xs_slot);
+                            write_x(2 * (gi - SG) + 1, xs_slot);
+                            write_e(2 * (gi - SG), ew_slot);
+                            write_e(2 * (gi - SG) + 1, ew_slot);
                         }
 #endif
 #if !(PULPO_ABLX & 4)
-                        if (gi == (PULPO_W3_STAGE ? 0 : 1)) {
+                        if (gi == SG + (PULPO_W3_STAGE ? 0 : 1)) {
                             issue_x(h + 3);
                             issue_e(h + 3);
                         }
@@ -937,6 +943,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
         }
         __syncthreads();
     }
+}
+
+// Two copies of the body that differ in ONE constant (as conv3d_k3_wino3_mfma, conv3d_wino3.hip): waves 0-3 stage behind groups 0 / 1 of a half
+// step, their SIMD partners 4-7 behind groups 2 / 3 - one wave's staging arithmetic and LDS writes fall into the other's matrix instructions.
+template <int DUMMY>
+__global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_w3x(Wgrad2Args a) {
+    if (PULPO_WG3_SKEW && __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0) wgrad_w3x_body<2>(a);
+    else wgrad_w3x_body<0>(a);
 }
 
 }  // namespace
