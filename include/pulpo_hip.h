@@ -328,7 +328,8 @@ int pulpo_conv3d_k3_wgrad_bf16_t(const void* in, int64_t in_bs, int64_t in_ps, i
                                  void* stream);
 int pulpo_bn_lrelu_apply_t(const void* y, int y_dt, int64_t yps, void* z, int z_dt, int64_t zps, const float* coef, int64_t npix, int C, float slope,
                            void* stream);
-int pulpo_bn_lrelu_apply_pool2_t(const void* y, int y_dt, int64_t yps, void* z, int z_dt, int64_t zps, void* pooled /* z's dtype */, int64_t pps,
+int pulpo_bn_lrelu_apply_pool2_t(const void* y, int y_dt, int64_t yps, void* z /* nullable since ABI 4: only the pooled tensor is written */, int z_dt, int64_t zps,
+                                 void* pooled /* z_dt */, int64_t pps,
                                  const float* coef, int B, int D, int H, int W, int C, float slope, void* stream);
 int pulpo_bn_lrelu_bwd_reduce_t(const void* dz, int dz_dt, int64_t dzps, const void* y, int y_dt, int64_t yps, const float* coef, int64_t npix, int C,
                                 float slope, float* partial, void* stream);

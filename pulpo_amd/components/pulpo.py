@@ -62,13 +62,27 @@ class DownPath(nn.Module):
         B, _, D, H, W = like.shape
         return ops.new_cl(B, int(room[k]) + cout, D, H, W, like.device, ops.act_dtype()), int(room[k])
 
-    def forward(self, x: torch.Tensor, y: torch.Tensor) -> Dict[int, torch.Tensor]:
+    def forward(self, x: torch.Tensor, y: torch.Tensor, _needed=None) -> Dict[int, torch.Tensor]:
+        """_needed (private, set by src.models.PULPo): the levels whose activation the caller will read.  The reference's Autoencoder never looks at
+        the levels above its first latent level (down_activations[k], k < lk_offset: pulpo.py:183-207); for those only the POOLED activation has
+        a reader, and with `_needed` given they are neither written (524 MB at 160^3 x 32 channels) nor returned.  Default: every level."""
         h = torch.cat([x, y], dim=1)            # two planar volumes side by side; read in place by the first conv
-        acts = {0: self.down_blocks[0](h, pool_after=self.total_levels > 1, out=self._room(0, h))}
-        for k in range(1, self.total_levels):
-            # (the activation is pooled AND handed out as a skip connection: one operator, so that its two gradients meet in one kernel)
-            acts[k - 1], pooled = ops.avg_pool2_skip(acts[k - 1])
-            acts[k] = self.down_blocks[k](pooled, pool_after=k + 1 < self.total_levels, out=self._room(k, pooled))
+        acts: Dict[int, torch.Tensor] = {}
+        cur = h
+        for k in range(self.total_levels):
+            pool_next = k + 1 < self.total_levels
+            only = bool(_needed is not None and k not in _needed and pool_next and h.dim() == 5)
+            if only:
+                z, pooled = self.down_blocks[k](cur, pool_after=True, pool_only=True)
+                if z is None:                    # (the fused pass took it: the un-pooled tensor does not exist)
+                    cur = pooled
+                    continue
+                acts[k] = z
+            else:
+                acts[k] = self.down_blocks[k](cur, pool_after=pool_next, out=self._room(k, cur))
+            if pool_next:
+                # (the activation is pooled AND handed out as a skip connection: one operator, so that its two gradients meet in one kernel)
+                acts[k], cur = ops.avg_pool2_skip(acts[k])
         return acts
 
 

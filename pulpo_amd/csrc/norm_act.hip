@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_apply_pool2_kernel(const TY* __r
                         v[k] = pulpo::as_stored<TZ>(t > 0.f ? t : t * slope);        // (the pooled tensor averages z as stored)
                         acc[k] += v[k];
                     }
-                    pulpo::stv<4>(z + vox * zps + c, v);
+                    if (z != nullptr) pulpo::stv<4>(z + vox * zps + c, v);       // (null: only the pooled tensor has a reader - DownPath levels above the first latent level)
                 }
         const float inv = 1.f / (float)((z1 - 2 * oz) * (y1 - 2 * oy) * (x1 - 2 * ox));   // ceil_mode: divisor = in-bounds taps
 #pragma unroll
@@ -538,7 +538,8 @@ PULPO_API int pulpo_bn_lrelu_apply_pool2_ok(int C, int64_t yps, int64_t zps, int
 
 PULPO_API int pulpo_bn_lrelu_apply_pool2_t(const void* y, int y_dt, int64_t yps, void* z, int z_dt, int64_t zps, void* pooled, int64_t pps,
                                            const float* coef, int B, int D, int H, int W, int C, float slope, void* stream) {
-    PULPO_REQUIRE(y && z && pooled && coef && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bn_lrelu_apply_pool2: bad arguments");
+    // (z nullable since ABI 4: the un-pooled activation is not written - its only reader would have been the pooling)
+    PULPO_REQUIRE(y && pooled && coef && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bn_lrelu_apply_pool2: bad arguments");
     PULPO_REQUIRE_DT(y_dt, "bn_lrelu_apply_pool2"); PULPO_REQUIRE_DT(z_dt, "bn_lrelu_apply_pool2");
     const int ey = y_dt ? 2 : 4, ez = z_dt ? 2 : 4;
     PULPO_REQUIRE(pulpo_bn_lrelu_apply_pool2_ok(C, yps, zps, pps) && (((uintptr_t)y) % (4 * ey)) == 0 && ((((uintptr_t)z) | ((uintptr_t)pooled)) % (4 * ez)) == 0 &&

@@ -86,6 +86,9 @@ class PULPo(ABC, LightningModule):
         if os.environ.get("PULPO_PREWRITTEN_CAT", "1") != "0" and self.ndims == 3:
             self.downpath._pulpo_skip_room = {int(k): int(blk._op[-1]._op[0].out_channels) for k, blk in self.autoencoder.up_blocks.items()}
 
+        # the Autoencoder reads down_activations[k] for k >= lk_offset only (components/pulpo.py): the levels above are not materialised
+        self._needed_levels = frozenset(range(self.lk_offset, total_levels)) if os.environ.get("PULPO_SKIP_UNUSED_ACTIVATIONS", "1") != "0" else None
+
         if self.hparams.regularizer == "jdet":
             regularization_loss = JDetStd
         elif self.hparams.regularizer == "L2":
@@ -122,7 +125,7 @@ class PULPo(ABC, LightningModule):
 
     # ------------------------------------------------------------------------------------------------ steps
     def _forward_and_losses(self, x, y, seg_x=None, seg_y=None):
-        acts = self.downpath(x, y)
+        acts = self.downpath(x, y, _needed=self._needed_levels)
         outs = self.autoencoder(x, acts)
         mus, sigmas, samples, velocity_fields, individual_dfs, combined_dfs, final_dfs, y_hat = outs
         prior_mus, prior_sigmas = self.prior(mus, sigmas)
@@ -236,11 +239,11 @@ class PULPo(ABC, LightningModule):
         return avg_outputs, avg_dfs
 
     def predict_deterministic(self, x: torch.Tensor, y: torch.Tensor):
-        outs = self.autoencoder(x, self.downpath(x, y), deterministic=True)
+        outs = self.autoencoder(x, self.downpath(x, y, _needed=self._needed_levels), deterministic=True)
         return outs[7], outs[4]
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
-        return self.autoencoder(x, self.downpath(x, y))[7][0]
+        return self.autoencoder(x, self.downpath(x, y, _needed=self._needed_levels))[7][0]
 
     # ------------------------------------------------------------------------------------------------ helpers
     def combine_dfs(self, individual_dfs: Dict[int, torch.Tensor]):

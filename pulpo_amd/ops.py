@@ -686,7 +686,7 @@ class _ConvBNLReLU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool, momentum: float, eps: float,
-                bn_src=None, pool_after: bool = False):
+                bn_src=None, pool_after: bool = False, pool_only: bool = False):
         _require_gpu(x, act=True)
         _require_gpu(weight, bias, gamma, beta)
         ctx.bn_src = bn_src
@@ -722,17 +722,19 @@ class _ConvBNLReLU(torch.autograd.Function):
                 _conv_raw(x, wp, bias, y, Cin, Cout, None, coef=coef)
                 return y
             _conv_raw(x, wp, bias, y, Cin, Cout, None)
-        z = _take_out_slot(B, Cout, D, H, W, dev, zdt)
-        if z is None:
+        # pool_only: nobody reads the un-pooled activation (DownPath levels above the first latent level: only AvgPool(z) goes on) - it is not written
+        pool_only = bool(pool_only and pool_after and lib.query("pulpo_bn_lrelu_apply_pool2_ok", Cout, y.stride(4), Cout, Cout))
+        z = None if pool_only else _take_out_slot(B, Cout, D, H, W, dev, zdt)
+        if z is None and not pool_only:
             z = new_cl(B, Cout, D, H, W, dev, zdt)
         pooled = None
-        nbytes = (_esize(y) + _esize(z)) * Cout * B * D * H * W             # read y, write z
-        if pool_after and lib.query("pulpo_bn_lrelu_apply_pool2_ok", Cout, y.stride(4), z.stride(4), Cout):
+        nbytes = (_esize(y) + (0 if pool_only else (2.0 if zdt == torch.bfloat16 else 4.0))) * Cout * B * D * H * W             # read y, write z
+        if pool_only or (pool_after and lib.query("pulpo_bn_lrelu_apply_pool2_ok", Cout, y.stride(4), z.stride(4), Cout)):
             # the caller pools this output next (DownPath): z and AvgPool(z) from one read of y; avg_pool2_skip() picks the pooled tensor up
             pooled = new_cl(B, Cout, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, dev, zdt)
             t0 = _hbm_begin("bn_lrelu_apply")
-            lib.call("pulpo_bn_lrelu_apply_pool2_t", _ptr(y), _dt(y), y.stride(4), _ptr(z), _dt(z), z.stride(4), _ptr(pooled), pooled.stride(4), _ptr(coef),
-                     B, D, H, W, Cout, LRELU_SLOPE, _stream())
+            lib.call("pulpo_bn_lrelu_apply_pool2_t", _ptr(y), _dt(y), y.stride(4), _ptr(z), _dt(pooled), z.stride(4) if z is not None else Cout, _ptr(pooled),
+                     pooled.stride(4), _ptr(coef), B, D, H, W, Cout, LRELU_SLOPE, _stream())
             _hbm_end(t0, "bn_lrelu_apply", nbytes)
         else:
             t0 = _hbm_begin("bn_lrelu_apply")
@@ -744,6 +746,11 @@ class _ConvBNLReLU(torch.autograd.Function):
         ctx.params = (weight, bias, gamma, beta)      # for DIRECT_PARAM_GRADS (their .grad slots)
         _TLS.produced = (y, coef, pooled)            # read back by conv_bn_lrelu (the Function returns tensors only)
         ctx.pooled_out = pooled is not None
+        ctx.pool_only = pool_only
+        if pool_only:
+            ctx.set_materialize_grads(False)
+            _TLS.pool_only_done = True
+            return pooled
         if pooled is not None:
             # (round 5) z AND AvgPool(z) are outputs of this node: their gradients arrive together, and the backward pass forms
             # dz = gz + avg_pool_backward(gpooled) per element inside the BatchNorm-backward passes instead of writing it
@@ -753,6 +760,8 @@ class _ConvBNLReLU(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz, dpool=None):
+        if ctx.pool_only:                            # (the node's only output is the pooled tensor)
+            dz, dpool = None, dz
         x, weight, y, coef = ctx.saved_tensors
         B, Cin, D, H, W = x.shape
         Cout = weight.shape[0]
@@ -783,7 +792,7 @@ class _ConvBNLReLU(torch.autograd.Function):
                         gin = gin + gz
                 dz = gin
         elif dz is None:
-            return (None,) * 13
+            return (None,) * 14
         tiles = None
         if pooled_src is not None:
             gp, gz = pooled_src
@@ -856,7 +865,7 @@ class _ConvBNLReLU(torch.autograd.Function):
                 _conv_raw(dyc, wpt, None, dx, Cout, Cin, None)
         if defer_w:
             _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, w_p)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 def _backward_input_layer(ctx, dz, x, weight, y, coef, totd, tot, direct_bn, slots, params):
@@ -903,7 +912,7 @@ def _backward_input_layer(ctx, dz, x, weight, y, coef, totd, tot, direct_bn, slo
         _PENDING_KEEPALIVE.append(part2)
     dbias = _colsum(part2, nrow, Cout, into=slot_b) if (ctx.needs_input_grad[2] and not defer_b) else None
     dbeta, dgamma = (None, None) if direct_bn else (tot[:Cout], tot[Cout:])
-    return None, (None if slot_w is not None else dw), dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+    return None, (None if slot_w is not None else dw), dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 _ConvBNLReLU._backward_input_layer = staticmethod(_backward_input_layer)
@@ -913,7 +922,7 @@ POOLED_BN_BACKWARD = os.environ.get("PULPO_POOLED_BN_BACKWARD", "1") != "0"
 
 
 def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None,
-                  pool_after: bool = False, out=None):
+                  pool_after: bool = False, out=None, pool_only: bool = False):
     """ConvUnit forward.  In training mode running_mean / running_var / num_batches_tracked are updated in place by the kernel.
     pool_after: the caller applies avg_pool2_skip() to the result next - where the shapes allow, the pooled tensor is produced by the same
     pass that writes the result and waits on it (`_pulpo_pooled`).
@@ -925,11 +934,21 @@ def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, train
     _TLS.out_slot = out
     src = getattr(x, "_pulpo_bn_src", None)          # x is the untouched output of another ConvUnit: (y, coef, version at production)
     bn_src = src[:2] if (src is not None and src[2] == x._version and training and torch.is_grad_enabled()) else None
+    # pool_only (with pool_after): the caller reads ONLY AvgPool(result) - where the fused pass is available the un-pooled tensor is not written and
+    # the call returns (None, pooled); otherwise (result, None) as without the flag
+    want_tuple = bool(pool_only)
+    pool_only = bool(pool_only and pool_after and training and torch.is_grad_enabled())
+    _TLS.pool_only_done = False
     z = _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
-                           float(eps), bn_src, bool(pool_after))
+                           float(eps), bn_src, bool(pool_after), pool_only)
     pooled_out = None
     if isinstance(z, tuple):
         z, pooled_out = z
+    elif getattr(_TLS, "pool_only_done", False):         # the pooled tensor alone came back
+        _TLS.produced = None
+        _TLS.out_slot = None
+        _TLS.pool_only_done = False
+        return None, z
     produced = getattr(_TLS, "produced", None)
     _TLS.produced = None
     _TLS.out_slot = None
@@ -939,7 +958,7 @@ def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, train
             z._pulpo_pooled = (pooled_out, z._version, True)      # (an output of the same autograd node: avg_pool2_skip hands it out as it is)
     if out is not None and z.dim() == 5 and z.data_ptr() == out[0].data_ptr() + out[0].element_size() * out[1] and z.stride() == out[0].stride():
         z._pulpo_cat = (out[0], out[1])
-    return z
+    return (z, None) if want_tuple else z
 
 
 class _Conv3dK3(torch.autograd.Function):

@@ -43,6 +43,15 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+def _record_unit(store, name, out):
+    """forward hook of a ConvUnit: its output - or nothing where the un-pooled activation is never written (round 5: the last unit of a DownPath
+    level above the first latent level hands on only AvgPool(z): ConvUnit.forward then returns (None, pooled))"""
+    if isinstance(out, tuple):
+        out = out[0]
+    if out is not None:
+        store[name] = out.detach()
+
+
 def build_from_golden(models, nb, g, key="sd0.", case=""):
     Tl, L, n0, B, *size = [int(v) for v in g["cfg"]]
     model = models.PULPo(Tl, L, 0.1, size, feedback=FB, n0=n0, df_resolution="full_res" if "fullres" in case else "level_res",
@@ -111,7 +120,7 @@ def _training_step_vs_golden(api, golden, case, det=False):
     gpu_units = {}
     for name, mod in model.named_modules():
         if isinstance(mod, nb.ConvUnit):
-            mod.register_forward_hook(lambda m, i, o, name=name: gpu_units.__setitem__(name, o.detach()))
+            mod.register_forward_hook(lambda m, i, o, name=name: _record_unit(gpu_units, name, o))
     outs, priors, (total, kl, rec, reg), levels = model._forward_and_losses(x, y)
     check_outputs(outs, g, "train")
     # LeakyReLU slope flips against the reference's own fp32 evaluation (the oracle reproduces the reference to 1e-5, so its
@@ -133,8 +142,9 @@ def _training_step_vs_golden(api, golden, case, det=False):
         O.forward(sd0, cfg, T(g["x"]), T(g["y"]), {l: T(g[f"eps.{l}"]) for l in range(L)}, training=True)
     finally:
         O.conv_unit = orig_unit
-    assert set(gpu_units) == set(ref_units)
-    flips = sum(int(((gpu_units[k].cpu() > 0) != (ref_units[k] > 0)).sum()) for k in ref_units)
+    # (every unit but the ones whose un-pooled output is never written: one per DownPath level above the first latent level)
+    assert set(gpu_units) <= set(ref_units) and len(ref_units) - len(gpu_units) <= Tl - L, (sorted(set(ref_units) - set(gpu_units)))
+    flips = sum(int(((gpu_units[k].cpu() > 0) != (ref_units[k] > 0)).sum()) for k in gpu_units)
     assert flips <= 1e-5 * sum(v.numel() for v in ref_units.values()), flips
     grad_bound = 1e-3 if flips == 0 else 2e-2
     g64 = None
@@ -382,6 +392,7 @@ def test_step_vs_oracle_at_baseline_width(api):
     x, y = torch.rand(1, 1, 32, 32, 32, generator=gen), torch.rand(1, 1, 32, 32, 32, generator=gen)
     eps = {0: torch.randn(1, 3, 16, 16, 16, generator=gen), 1: torch.randn(1, 3, 8, 8, 8, generator=gen)}
     model = models.PULPo(3, 2, 0.1, [32, 32, 32], feedback=FB, n0=32)
+    model._needed_levels = None       # (every ConvUnit's output is materialised here: the slope-flip count below looks at all of them)
     _copy_oracle_sd_into(model, sd)
     model = model.cuda().train()
     for l in range(2):
@@ -389,7 +400,7 @@ def test_step_vs_oracle_at_baseline_width(api):
     gpu_units = {}
     for name, mod in model.named_modules():
         if isinstance(mod, nb.ConvUnit):
-            mod.register_forward_hook(lambda m, i, o, name=name: gpu_units.__setitem__(name, o.detach()))
+            mod.register_forward_hook(lambda m, i, o, name=name: _record_unit(gpu_units, name, o))
 
     # oracle in fp32 (values) and fp64 (gradient ground truth), recording every ConvUnit output
     ref_units = {}
