@@ -47,8 +47,9 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
     const long total = (long)B * Vg;
     const int nch = C > 0 ? C : Cr;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long b = e / Vg, v = e - b * Vg;
-        const int x = (int)(v % Wg), y = (int)((v / Wg) % Hg), z = (int)(v / ((long)Wg * Hg));
+        const long b = B == 1 ? 0 : e / Vg, v = e - b * Vg;          // (one 64-bit division per voxel at most; the voxel's coordinates in 32 bits -
+        const int vi = (int)v;                                        //  three 64-bit divisions per voxel were a third of these kernels' time)
+        const int x = vi % Wg, y = (vi / Wg) % Hg, z = vi / (Wg * Hg);
         const float* d = df + b * 3 * Vg + v;
         const Corner cz = sample_coord((float)z, d[0], Dg, Di);
         const Corner cy = sample_coord((float)y, d[Vg], Hg, Hi);
@@ -77,8 +78,9 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     const long Vg = (long)Dg * Hg * Wg, Vi = (long)Di * Hi * Wi;
     const long total = (long)B * Vg;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long b = e / Vg, v = e - b * Vg;
-        const int x = (int)(v % Wg), y = (int)((v / Wg) % Hg), z = (int)(v / ((long)Wg * Hg));
+        const long b = B == 1 ? 0 : e / Vg, v = e - b * Vg;          // (one 64-bit division per voxel at most; the voxel's coordinates in 32 bits -
+        const int vi = (int)v;                                        //  three 64-bit divisions per voxel were a third of these kernels' time)
+        const int x = vi % Wg, y = (vi / Wg) % Hg, z = vi / (Wg * Hg);
         const float* d = df + b * 3 * Vg + v;
         const Corner cz = sample_coord((float)z, d[0], Dg, Di);
         const Corner cy = sample_coord((float)y, d[Vg], Hg, Hi);
@@ -363,8 +365,9 @@ __global__ __launch_bounds__(256) void warp_bwd_fx_kernel(const float* __restric
     const long total = (long)B * Vg;
     const double unit = fx_unit(maxbits);
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long b = e / Vg, v = e - b * Vg;
-        const int x = (int)(v % Wg), y = (int)((v / Wg) % Hg), z = (int)(v / ((long)Wg * Hg));
+        const long b = B == 1 ? 0 : e / Vg, v = e - b * Vg;          // (one 64-bit division per voxel at most; the voxel's coordinates in 32 bits -
+        const int vi = (int)v;                                        //  three 64-bit divisions per voxel were a third of these kernels' time)
+        const int x = vi % Wg, y = (vi / Wg) % Hg, z = vi / (Wg * Hg);
         const float* d = df + b * 3 * Vg + v;
         const Corner cz = sample_coord((float)z, d[0], Dg, Di);
         const Corner cy = sample_coord((float)y, d[Vg], Hg, Hi);
@@ -430,6 +433,7 @@ PULPO_API int pulpo_warp3d_fwd(const float* df, const float* img, float* out, in
                                void* stream) {
     PULPO_REQUIRE(df && img && out && B > 0 && C > 0, "warp3d_fwd: bad arguments");
     PULPO_REQUIRE(Dg >= 1 && Hg > 1 && Wg > 1 && Di > 0 && Hi > 0 && Wi > 0 && (Dg > 1 || Di == 1), "warp3d_fwd: grid H, W must be > 1 (depth 1 = 2-D form, with a depth-1 image)");
+    PULPO_REQUIRE((long)Dg * Hg * Wg < (1L << 31), "warp3d_fwd: grids of 2^31 voxels and more are not supported");
     const long total = (long)B * Dg * Hg * Wg;
     hipStream_t st = (hipStream_t)stream;
     if (C == 1) hipLaunchKernelGGL(warp_fwd_kernel<1>, dim3(eblocks(total)), dim3(256), 0, st, df, img, nullptr, out, B, Dg, Hg, Wg, Di, Hi, Wi, C);
@@ -442,7 +446,7 @@ PULPO_API int pulpo_warp3d_fwd(const float* df, const float* img, float* out, in
 PULPO_API int pulpo_warp3d_bwd(const float* df, const float* img, const float* gout, float* gdf, float* gimg, int B, int C, int Dg, int Hg, int Wg,
                                int Di, int Hi, int Wi, void* stream) {
     PULPO_REQUIRE(df && img && gout && B > 0 && C > 0, "warp3d_bwd: bad arguments");
-    PULPO_REQUIRE(Dg >= 1 && Hg > 1 && Wg > 1, "warp3d_bwd: grid H, W must be > 1");
+    PULPO_REQUIRE(Dg >= 1 && Hg > 1 && Wg > 1 && (long)Dg * Hg * Wg < (1L << 31), "warp3d_bwd: grid H, W must be > 1 (and fewer than 2^31 voxels)");
     hipStream_t st = (hipStream_t)stream;
     if (gimg != nullptr) {
         hipError_t e = hipMemsetAsync(gimg, 0, sizeof(float) * (size_t)B * C * Di * Hi * Wi, st);
@@ -455,7 +459,7 @@ PULPO_API int pulpo_warp3d_bwd(const float* df, const float* img, const float* g
 
 // work: (nsteps+1) buffers of B*3*D*H*W floats; work[k] is the field after k squarings, work[nsteps] the result.
 PULPO_API int pulpo_vecint_fwd(const float* v, float* work, int B, int D, int H, int W, int nsteps, void* stream) {
-    PULPO_REQUIRE(v && work && B > 0 && D >= 1 && H > 1 && W > 1 && nsteps >= 0, "vecint_fwd: bad arguments");
+    PULPO_REQUIRE(v && work && B > 0 && D >= 1 && H > 1 && W > 1 && nsteps >= 0 && (long)D * H * W < (1L << 31), "vecint_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const long n = (long)B * 3 * D * H * W, total = (long)B * D * H * W;
     if (total / B <= VI_MAXV && nsteps > 0) {          // the field fits LDS: all steps in one launch (fields <= 20^3)
@@ -501,7 +505,7 @@ PULPO_API size_t pulpo_vecint_bwd_tmp_floats(int B, int D, int H, int W, int nst
 
 // gin = d loss / d v given gout = d loss / d work[nsteps].  tmp: pulpo_vecint_bwd_tmp_floats() floats (NULL when that is 0).
 PULPO_API int pulpo_vecint_bwd(const float* work, const float* gout, float* gin, float* tmp, int B, int D, int H, int W, int nsteps, void* stream) {
-    PULPO_REQUIRE(work && gout && gin && B > 0 && D >= 1 && H > 1 && W > 1 && nsteps >= 0, "vecint_bwd: bad arguments");
+    PULPO_REQUIRE(work && gout && gin && B > 0 && D >= 1 && H > 1 && W > 1 && nsteps >= 0 && (long)D * H * W < (1L << 31), "vecint_bwd: bad arguments");
     PULPO_REQUIRE(tmp || pulpo_vecint_bwd_tmp_floats(B, D, H, W, nsteps) == 0, "vecint_bwd: scratch of pulpo_vecint_bwd_tmp_floats() floats required");
     hipStream_t st = (hipStream_t)stream;
     const long n = (long)B * 3 * D * H * W, total = (long)B * D * H * W;
@@ -552,7 +556,7 @@ PULPO_API size_t pulpo_warp3d_bwd_det_ws_bytes(int B, int C, int Di, int Hi, int
 PULPO_API int pulpo_warp3d_bwd_det(const float* df, const float* img, const float* gout, float* gdf, float* gimg, void* ws, int B, int C, int Dg, int Hg,
                                    int Wg, int Di, int Hi, int Wi, void* stream) {
     PULPO_REQUIRE(df && img && gout && B > 0 && C > 0, "warp3d_bwd_det: bad arguments");
-    PULPO_REQUIRE(Dg >= 1 && Hg > 1 && Wg > 1, "warp3d_bwd_det: grid H, W must be > 1");
+    PULPO_REQUIRE(Dg >= 1 && Hg > 1 && Wg > 1 && (long)Dg * Hg * Wg < (1L << 31), "warp3d_bwd_det: grid H, W must be > 1 (and fewer than 2^31 voxels)");
     PULPO_REQUIRE(ws != nullptr || gimg == nullptr, "warp3d_bwd_det: workspace of pulpo_warp3d_bwd_det_ws_bytes() bytes required for the image gradient");
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)B * Dg * Hg * Wg, ni = (long)B * C * Di * Hi * Wi;
@@ -575,7 +579,7 @@ PULPO_API size_t pulpo_vecint_bwd_det_ws_bytes(int B, int D, int H, int W, int n
 }
 
 PULPO_API int pulpo_vecint_bwd_det(const float* work, const float* gout, float* gin, void* ws, int B, int D, int H, int W, int nsteps, void* stream) {
-    PULPO_REQUIRE(work && gout && gin && B > 0 && D >= 1 && H > 1 && W > 1 && nsteps >= 0 && nsteps < 60, "vecint_bwd_det: bad arguments");
+    PULPO_REQUIRE(work && gout && gin && B > 0 && D >= 1 && H > 1 && W > 1 && nsteps >= 0 && nsteps < 60 && (long)D * H * W < (1L << 31), "vecint_bwd_det: bad arguments");
     PULPO_REQUIRE(ws || nsteps == 0, "vecint_bwd_det: workspace of pulpo_vecint_bwd_det_ws_bytes() bytes required");
     hipStream_t st = (hipStream_t)stream;
     const long n = (long)B * 3 * D * H * W, total = (long)B * D * H * W;
