@@ -453,6 +453,7 @@ def main():
         host_enq.append(time.perf_counter() - th)
     barrier()
     dt = time.perf_counter() - t0
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 1e9     # (of the measured loop: the extra steps below - other loops, deterministic mode - allocate their own)
     trace, ops.CONV_TRACE = ops.CONV_TRACE, None
     trace_steps = args.steps
     if graph_replay and not args.no_trace:
@@ -657,7 +658,7 @@ def main():
             "roofline": roof,
             "time_split": time_split,
             "hbm_rooflines": hbm_roof,
-            "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
+            "hbm_peak_allocated_GB": peak_gb,
             "conv_kernels": {k: {"launches_sampled": v[0], "effective_TFLOPs": v[1] / v[2] / 1e12, "matrix_pipe_TFLOPs": v[1] * ISSUED_FRACTION(k) / v[2] / 1e12,
                                  "ms_total_per_step_est": v[2] * ops.CONV_TRACE_STRIDE_USED / trace_steps * 1e3}
                              for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][2])},
