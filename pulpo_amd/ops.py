@@ -655,6 +655,9 @@ def _take_out_slot(B, C, D, H, W, dev, dtype):
     return buf[:, off:off + C]
 
 
+CAT_PREWRITTEN_HITS = 0          # concatenations that cost nothing so far (tests look at it)
+
+
 class _CatPrewritten(torch.autograd.Function):
     """cat([a, b], 1) where a and b ARE the two channel ranges of `buf`: the result is the buffer, the gradient is split by position"""
 
@@ -677,6 +680,8 @@ def cat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         if (ta[1] == 0 and tb[1] == a.shape[1] and a.shape[1] + b.shape[1] == buf.shape[1] and a.data_ptr() == buf.data_ptr()
                 and b.data_ptr() == buf.data_ptr() + es * tb[1] and a.stride() == buf.stride() and b.stride() == buf.stride()
                 and a.shape[2:] == buf.shape[2:] and b.shape[2:] == buf.shape[2:] and a.shape[0] == buf.shape[0] == b.shape[0]):
+            global CAT_PREWRITTEN_HITS
+            CAT_PREWRITTEN_HITS += 1
             return _CatPrewritten.apply(a, b, buf)
     return torch.cat([a, b], dim=1)
 

@@ -1421,3 +1421,58 @@ def test_graphed_step_equals_the_eager_step(api, precision):
             assert float((sd_g[k] - v).abs().max()) <= tol * max(1.0, float(v.abs().max())), k
         else:
             assert torch.equal(sd_g[k], v), k
+
+
+@pytest.mark.parametrize("switch", ["prewritten_cat", "skip_unused_activations", "pooled_bn_backward", "fuse_input_wgrad"])
+def test_round5_fusions_equal_the_separate_passes(api, switch):
+    """Each round-5 shortcut of the step switched OFF gives the same training step as the shipped default: concatenation buffers written in place
+    (ops.cat_channels), activations nobody reads not written (DownPath `_needed`), the gradient of a pooled ConvUnit output formed inside the
+    BatchNorm-backward passes (ops.POOLED_BN_BACKWARD), the input layer's BatchNorm backward inside its weight gradient (ops.FUSE_INPUT_WGRAD).
+    n0 = 16 at 64^3 / T3 / L2 so that the channel counts take the in-place buffers (multiples of 8) and the kernels of the large levels run.
+    Loss bit-equal (the forward pass computes the same values), every parameter gradient within 1e-5 (summation order of fp32 partial sums)."""
+    models, nb = api
+    from pulpo_amd import ops
+    size, Tl, L, n0 = [64, 64, 64], 3, 2, 16
+    gen = torch.Generator().manual_seed(11)
+    x, y = torch.rand(1, 1, *size, generator=gen).cuda(), torch.rand(1, 1, *size, generator=gen).cuda()
+    eps = [torch.randn(1, 3, *[s_ // 2 ** (l + 1) for s_ in size], generator=gen).cuda() for l in range(L)]
+
+    def run(off):
+        torch.manual_seed(0)
+        model = models.PULPo(Tl, L, 0.1, size, feedback=FB, n0=n0).cuda().train()
+        for l in range(L):
+            model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(eps[l])
+        if off == "prewritten_cat":
+            model.downpath._pulpo_skip_room = {}
+        if off == "skip_unused_activations":
+            model._needed_levels = None
+        saved = (ops.POOLED_BN_BACKWARD, ops.FUSE_INPUT_WGRAD)
+        try:
+            if off == "pooled_bn_backward":
+                ops.POOLED_BN_BACKWARD = False
+            if off == "fuse_input_wgrad":
+                ops.FUSE_INPUT_WGRAD = False
+            outs, _, (total, kl, rec, reg), _ = model._forward_and_losses(x, y)
+            total.backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.POOLED_BN_BACKWARD, ops.FUSE_INPUT_WGRAD = saved
+        used = hasattr(outs[0][0], "shape")
+        assert used
+        return float(total), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}, model
+
+    hits0 = ops.CAT_PREWRITTEN_HITS
+    loss_on, g_on, m_on = run(None)
+    assert getattr(m_on.downpath, "_pulpo_skip_room", None), "the in-place concatenation buffers are not armed"
+    assert ops.CAT_PREWRITTEN_HITS == hits0 + (L - 1), "the encoders' concatenations did not take the in-place buffers"
+    hits1 = ops.CAT_PREWRITTEN_HITS
+    loss_off, g_off, _ = run(switch)
+    assert (ops.CAT_PREWRITTEN_HITS == hits1) == (switch == "prewritten_cat")
+    assert loss_on == loss_off
+    assert g_on.keys() == g_off.keys()
+    for k, g in g_on.items():
+        if k.endswith("_op.0.bias") and "velocity_field._op.2" not in k:
+            wscale = float(g_off[k[:-4] + "weight"].abs().max())
+            assert float((g - g_off[k]).abs().max()) <= 1e-3 * max(wscale, 1e-3), k          # (true gradient zero: rounding noise on both sides)
+            continue
+        assert rel_l2(g, g_off[k]) < 1e-5, (k, rel_l2(g, g_off[k]))
