@@ -38,7 +38,7 @@ using pulpo_conv::npad;
 // z extent of this kernel's voxel tile (its own policy: the 4x8x8 tile pays from 64^3 up; pulpo_conv3d_k3_fwd_bf16_stat_tiles follows it)
 inline long conv_tz4_min_voxels() {
     static long v = -1;
-    if (v < 0) { const char* e = getenv("PULPO_CONV_BF16_TZ4_MIN"); v = e ? atol(e) : 64L * 64 * 64; }
+    if (v < 0) { const char* e = getenv("PULPO_CONV_BF16_TZ4_MIN"); v = e ? atol(e) : 40L * 40 * 40; }     // (round 5: 40^3 - config 4 14.51 -> 14.38 ms per step; 64^3 before)
     return v;
 }
 inline int conv_tz(int D, int H, int W) { return (D % 4 == 0 && (long)D * H * W >= conv_tz4_min_voxels()) ? 4 : 2; }
