@@ -237,6 +237,13 @@ class Autoencoder(nn.Module):
             else:
                 fb = self._gather_feedback(store, l + 1, down_activations[k].shape[2:])
                 tag = getattr(down_activations[k], "_pulpo_cat", None)       # DownPath left room in front of its activation: write the feedback path there
+                if tag is not None:
+                    # (a second differentiable pass over the SAME down_activations - several samples from one DownPath call - must not overwrite
+                    #  the head the first pass's backward still reads: it takes plain tensors and torch.cat)
+                    if getattr(tag[0], "_pulpo_head_taken", False) and torch.is_grad_enabled():
+                        tag = None
+                    else:
+                        tag[0]._pulpo_head_taken = True
                 mu, sigma, z = self.encoders[l](down_activations[k], feedback=self.up_blocks[k](fb, out=(tag[0], 0) if tag is not None else None))
                 coarser = store["combined_dfs"][l + 1]
             store["mus"][l], store["sigmas"][l], store["samples"][l] = mu, sigma, z

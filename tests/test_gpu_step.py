@@ -1476,3 +1476,52 @@ def test_round5_fusions_equal_the_separate_passes(api, switch):
             assert float((g - g_off[k]).abs().max()) <= 1e-3 * max(wscale, 1e-3), k          # (true gradient zero: rounding noise on both sides)
             continue
         assert rel_l2(g, g_off[k]) < 1e-5, (k, rel_l2(g, g_off[k]))
+
+
+def test_two_differentiable_passes_over_one_downpath_call(api):
+    """several samples from ONE DownPath call with gradients enabled (user code may do that): the second Autoencoder pass must not write its feedback
+    path into the concatenation buffer the first pass's backward still reads - it falls back to plain tensors.  Gradients of loss_1 + loss_2 equal
+    the sum of two independent evaluations."""
+    models, nb = api
+    from pulpo_amd import ops
+    size, Tl, L, n0 = [32, 32, 32], 3, 2, 16
+    gen = torch.Generator().manual_seed(2)
+    x, y = torch.rand(1, 1, *size, generator=gen).cuda(), torch.rand(1, 1, *size, generator=gen).cuda()
+    eps = [[torch.randn(1, 3, *[s_ // 2 ** (l + 1) for s_ in size], generator=gen).cuda() for l in range(L)] for _ in range(2)]
+    torch.manual_seed(0)
+    model = models.PULPo(Tl, L, 0.1, size, feedback=FB, n0=n0).cuda().train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def set_eps(i):
+        for l in range(L):
+            model.autoencoder.encoders[l].sampler = nb.FixedNoiseSampler(eps[i][l])
+
+    def zero():
+        for p in model.parameters():
+            p.grad = None
+
+    # reference: two independent forward / backward evaluations, gradients added
+    ref = None
+    for i in range(2):
+        model.load_state_dict(state); zero(); set_eps(i)
+        out = model.autoencoder(x, model.downpath(x, y))
+        (out[7][0].sum() + out[6][1].sum()).backward()
+        g = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        ref = g if ref is None else {k: ref[k] + g[k] for k in g}
+    # one DownPath call, two Autoencoder passes, one backward
+    model.load_state_dict(state); zero()
+    hits0 = ops.CAT_PREWRITTEN_HITS
+    down = model.downpath(x, y)
+    total = 0.0
+    for i in range(2):
+        set_eps(i)
+        out = model.autoencoder(x, down)
+        total = total + out[7][0].sum() + out[6][1].sum()
+    assert ops.CAT_PREWRITTEN_HITS == hits0 + (L - 1)          # (the first pass took the in-place buffers, the second did not)
+    total.backward()
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        if k.startswith("downpath.") or (k.endswith("_op.0.bias") and "velocity_field._op.2" not in k):
+            continue          # (DownPath ran once here and twice in the reference: its BatchNorm statistics moved differently; pre-norm biases are noise)
+        assert rel_l2(p.grad, ref[k]) < 2e-4, (k, rel_l2(p.grad, ref[k]))
