@@ -431,14 +431,22 @@ __device__ __forceinline__ void wino3_body(const ConvArgs& a) {
         W3_NOW(t_e0);
 #endif
         // x inverse transform (4 px -> 2 ox), once and in place: acc[p][0] <- out x0 = q0 + q1 + q2, acc[p][1] <- out x1 = q1 - q2 - q3
+        // a - b below is fma(m1, b, a) with m1 = -1 the compiler cannot see through: exact (the product is), and it stays ONE two-wide instruction
+        // (v_pk_fma_f32) - a two-wide subtraction is expanded into two scalar ones by the backend
+        f32x2 m1 = {-1.f, -1.f};
+        asm volatile("" : "+s"(m1));
+        // (two-wide: the accumulator registers of rows r, r + 1 are an aligned pair - v_pk_add_f32 with the association of the scalar form,
+        //  (a0 + a1) + a2 and (a1 - a2) - a3: 64 instead of 128 vector instructions per wave, which the SIMD's two waves issue at the same time)
         if (!(PULPO_ABL & 1)) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float a0 = acc[p][0][r], a1 = acc[p][1][r], a2 = acc[p][2][r], a3 = acc[p][3][r];
-                    acc[p][0][r] = a0 + a1 + a2;
-                    acc[p][1][r] = a1 - a2 - a3;
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 a0 = {acc[p][0][r], acc[p][0][r + 1]}, a1 = {acc[p][1][r], acc[p][1][r + 1]};
+                    const f32x2 a2 = {acc[p][2][r], acc[p][2][r + 1]}, a3 = {acc[p][3][r], acc[p][3][r + 1]};
+                    const f32x2 o0 = (a0 + a1) + a2, o1 = __builtin_elementwise_fma(m1, a3, __builtin_elementwise_fma(m1, a2, a1));
+                    acc[p][0][r] = o0.x; acc[p][0][r + 1] = o0.y;
+                    acc[p][1][r] = o1.x; acc[p][1][r + 1] = o1.y;
                 }
         }
 #pragma unroll
@@ -451,15 +459,19 @@ __device__ __forceinline__ void wino3_body(const ConvArgs& a) {
             float* const r1 = R + ((wave * 2 + 1) * 16) * 64 + elane;
             if (pzh == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    r0[r * 64] = oz == 0 ? acc[0][0][r] + acc[1][0][r] : acc[1][0][r];
-                    r1[r * 64] = oz == 0 ? acc[0][1][r] + acc[1][1][r] : acc[1][1][r];
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 u0 = f32x2{acc[0][0][r], acc[0][0][r + 1]} + f32x2{acc[1][0][r], acc[1][0][r + 1]};
+                    const f32x2 u1 = f32x2{acc[0][1][r], acc[0][1][r + 1]} + f32x2{acc[1][1][r], acc[1][1][r + 1]};
+                    r0[r * 64] = oz == 0 ? u0.x : acc[1][0][r]; r0[(r + 1) * 64] = oz == 0 ? u0.y : acc[1][0][r + 1];
+                    r1[r * 64] = oz == 0 ? u1.x : acc[1][1][r]; r1[(r + 1) * 64] = oz == 0 ? u1.y : acc[1][1][r + 1];
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    r0[r * 64] = oz == 0 ? acc[0][0][r] : acc[1][0][r] - acc[0][0][r];
-                    r1[r * 64] = oz == 0 ? acc[0][1][r] : acc[1][1][r] - acc[0][1][r];
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 u0 = __builtin_elementwise_fma(m1, f32x2{acc[0][0][r], acc[0][0][r + 1]}, f32x2{acc[1][0][r], acc[1][0][r + 1]});
+                    const f32x2 u1 = __builtin_elementwise_fma(m1, f32x2{acc[0][1][r], acc[0][1][r + 1]}, f32x2{acc[1][1][r], acc[1][1][r + 1]});
+                    r0[r * 64] = oz == 0 ? acc[0][0][r] : u0.x; r0[(r + 1) * 64] = oz == 0 ? acc[0][0][r + 1] : u0.y;
+                    r1[r * 64] = oz == 0 ? acc[0][1][r] : u1.x; r1[(r + 1) * 64] = oz == 0 ? acc[0][1][r + 1] : u1.y;
                 }
             }
             const int gz = z0 + 2 * vzb + oz, gy = y0 + 2 * vyb, gx = x0 + 2 * vxb + ox;
