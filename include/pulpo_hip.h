@@ -34,7 +34,7 @@ extern "C" {
  * PULPO_ABI_VERSION is bumped whenever a prototype below changes its argument list or a buffer contract, or an entry point is removed
  * (history: INTEGRATION.md "ABI history").  pulpo_abi_version() returns the value the library was built with: a client compares it with
  * the header it was compiled against before the first call (pulpo_amd/_lib.py does). */
-#define PULPO_ABI_VERSION 4
+#define PULPO_ABI_VERSION 5
 int pulpo_abi_version(void);
 const char* pulpo_last_error(void);
 
@@ -368,6 +368,34 @@ int pulpo_conv3d_k3_wgrad_bn(const float* in, int64_t in_bs, int64_t in_ps, int6
 int pulpo_bn_lrelu_bwd_apply_pooled_t(const void* gout, int64_t gops, const void* add /*nullable*/, int64_t aps, int g_dt, const void* y, int y_dt,
                                       int64_t yps, const float* coef, const double* totd, void* dy /* y's dtype */, int64_t dyps, float slope,
                                       float* partial2, int B, int D, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------- CHANNEL-BLOCKED gradient of the pre-norm tensor (since ABI 5)
+ * Replaces nothing in the reference: inside aten::native_batch_norm_backward -> aten::convolution_backward (src/network_blocks.py:23-25) the gradient
+ * dy of a ConvUnit's pre-norm tensor has exactly two readers, the unit's data- and weight-gradient convolution, so its layout is this library's own
+ * business.  Channels-last, a staging item of the F(2x2x2,3x3x3) data-gradient kernel gathers 32 useful bytes from each of four 128-byte voxel
+ * lines per 8-channel chunk; blocked - element (b, voxel v, channel c) at  p + b * bs + (c / 8) * kb + v * ps + c % 8  floats with ps = 8,
+ * bs = D*H*W * 8, kb = B * D*H*W * 8, i.e. [C / 8][B][D][H][W][8] - the four taps are 128 consecutive bytes (32 -> 32 at 160^3: 0.94 -> 0.80 ms,
+ * profiles/r5_blocked_probe.txt).  kb = 8 with ps = the row pitch addresses an ordinary channels-last tensor through the same entry points.
+ *  - pulpo_bn_lrelu_bwd_apply_kb_t / _pooled_kb_t: the second BatchNorm-backward pass (pulpo_bn_lrelu_bwd_apply_t / _pooled_t) writing dy blocked;
+ *    fp32 y / dy, C % 8 == 0.
+ *  - pulpo_conv3d_k3_fwd_wino3_kb / pulpo_conv3d_k3_dgrad_wino3_bnred_kb: pulpo_conv3d_k3_fwd_wino3 / _dgrad_wino3_bnred on a blocked operand
+ *    (result channels-last); same shape contract (pulpo_conv3d_k3_algo == 3).
+ *  - pulpo_conv3d_k3_wgrad_kb: pulpo_conv3d_k3_wgrad (slabs == NULL) / pulpo_conv3d_k3_wgrad_det on a blocked dy; shapes with
+ *    pulpo_conv3d_k3_wgrad_algo(...) == 3 only (the entry point refuses others). */
+int pulpo_bn_lrelu_bwd_apply_kb_t(const void* dz, int dz_dt, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd, float* dy,
+                                  int64_t dyps, int64_t dykb, int64_t npix, int C, float slope, float* partial2, void* stream);
+int pulpo_bn_lrelu_bwd_apply_pooled_kb_t(const void* gout, int64_t gops, const void* add /*nullable*/, int64_t aps, int g_dt, const float* y, int64_t yps,
+                                         const float* coef, const double* totd, float* dy, int64_t dyps, int64_t dykb, float slope, float* partial2,
+                                         int B, int D, int H, int W, int C, void* stream);
+int pulpo_conv3d_k3_fwd_wino3_kb(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_kb, const float* wp, const float* bias, const float* coef,
+                                 float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_kb, float* stats, int B, int D, int H, int W, int K,
+                                 int N, void* stream);
+int pulpo_conv3d_k3_dgrad_wino3_bnred_kb(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_kb, const float* wp, float* out, int64_t out_bs,
+                                         int64_t out_ps, int64_t out_kb, const float* bn_y, int64_t bn_y_bs, int64_t bn_y_ps, const float* bn_coef, float slope,
+                                         float* part, int B, int D, int H, int W, int K, int N, void* stream);
+int pulpo_conv3d_k3_wgrad_kb(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_kb, const float* dy, int64_t dy_bs, int64_t dy_ps, int64_t dy_kb,
+                             float* dw, int accumulate, float* scratch, float* slabs /*nullable*/, int nslab, int B, int D, int H, int W, int Cin, int Cout,
+                             void* stream);
 
 /* ------------------------------------------------------------------------- DETERMINISTIC forms of the backward kernels that add with float atomics (since ABI 4)
  * The reference's CPU backward is run-to-run deterministic; the plain entry points above add the weight-gradient partial sums

@@ -763,7 +763,7 @@ PULPO_API int pulpo_conv3d_k3_wgrad_algo(int B, int D, int H, int W, int Cin, in
 // scratch: pulpo_conv3d_k3_wgrad_scratch_floats floats.
 static int wgrad_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dy, int64_t dy_bs,
                       int64_t dy_ps, int64_t dy_cs, float* dw, int accumulate, float* scratch, float* slabs, int nslab, int B, int D, int H, int W,
-                      int Cin, int Cout, void* stream, const WgradArgs* bnf = nullptr) {
+                      int Cin, int Cout, void* stream, const WgradArgs* bnf = nullptr, int64_t dy_kb = 8, int64_t in_kb = 8) {
     PULPO_REQUIRE(in && dy && scratch && (dw || accumulate == 2), "conv3d_k3_wgrad: null pointer");
     PULPO_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3d_k3_wgrad: bad dims");
     hipStream_t st = (hipStream_t)stream;
@@ -836,9 +836,10 @@ static int wgrad_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_
     if (algo >= 2) {
         // F(2x2,3x3) in (y, x) / F(2x2x2,3x3x3), register-staged transposed operand images, z-streaming workgroups (conv3d_wgrad_w2.hip)
         // (its launcher picks its own split count: it zeroes the copies it will use and reports how many)
-        rc = pulpo_conv::launch_wgrad_w2(in, in_bs, in_ps, dy, dy_bs, dy_ps, scratch, B, D, H, W, Cin, Cout, st, slabs, nslab, &used);
+        rc = pulpo_conv::launch_wgrad_w2(in, in_bs, in_ps, dy, dy_bs, dy_ps, scratch, B, D, H, W, Cin, Cout, st, slabs, nslab, &used, (long)dy_kb, (long)in_kb);
         return finish(rc);
     }
+    PULPO_REQUIRE(dy_kb == 8 && in_kb == 8, "conv3d_k3_wgrad_kb: %dx%dx%d, %d -> %d channels does not run the F(2x2x2,3x3x3) kernel (pulpo_conv3d_k3_wgrad_algo != 3), the only reader of channel-blocked operands", D, H, W, Cin, Cout);
     if ((bnf || (Cin <= 4 && (dy_cs == 1) && (dy_ps % 4 == 0) && (dy_bs % 4 == 0) && (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0))) && algo != 1) {
         const int ntile4 = B * pulpo::cdiv(D, 4) * a.nty * a.ntx;
         used = std::min(std::max(1, 512 / a.ncot), ntile4);
@@ -948,6 +949,17 @@ PULPO_API int pulpo_conv3d_k3_wgrad_det(const float* in, int64_t in_bs, int64_t 
                                         int D, int H, int W, int Cin, int Cout, void* stream) {
     PULPO_REQUIRE(slabs && nslab >= 1, "conv3d_k3_wgrad_det: slabs of nslab >= 1 copies of the packed scratch required");
     return wgrad_impl(in, in_bs, in_ps, in_cs, dy, dy_bs, dy_ps, dy_cs, dw, accumulate, scratch, slabs, nslab, B, D, H, W, Cin, Cout, stream);
+}
+
+// The gradient in the channel-BLOCKED layout of pulpo_bn_lrelu_bwd_apply_kb_t: element (b, voxel v, channel c) at dy + b * dy_bs + (c / 8) * dy_kb + v * dy_ps + c % 8
+// (dy_ps = 8, dy_bs = V * 8, dy_kb = B * V * 8).  Shapes with pulpo_conv3d_k3_wgrad_algo(...) == 3 only; slabs == NULL: the atomic form, else the
+// deterministic one (as pulpo_conv3d_k3_wgrad_det).
+PULPO_API int pulpo_conv3d_k3_wgrad_kb(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_kb, const float* dy, int64_t dy_bs, int64_t dy_ps, int64_t dy_kb,
+                                       float* dw, int accumulate, float* scratch, float* slabs, int nslab, int B, int D, int H, int W, int Cin, int Cout,
+                                       void* stream) {
+    PULPO_REQUIRE(dy_kb >= 8 && dy_kb % 4 == 0 && in_kb >= 8 && in_kb % 4 == 0 && (slabs == nullptr || nslab >= 1), "conv3d_k3_wgrad_kb: bad block stride / slab count");
+    PULPO_REQUIRE((in_kb == 8 || Cin % 8 == 0) && (dy_kb == 8 || Cout % 8 == 0), "conv3d_k3_wgrad_kb: a channel-blocked operand has whole 8-channel blocks");
+    return wgrad_impl(in, in_bs, in_ps, 1, dy, dy_bs, dy_ps, 1, dw, accumulate, scratch, slabs, slabs ? nslab : 0, B, D, H, W, Cin, Cout, stream, nullptr, dy_kb, in_kb);
 }
 
 namespace {

@@ -51,6 +51,9 @@ struct Wgrad2Args {
     int B, D, H, W, Cin, Cout, NPad;
     int nty, ntx, ncit, ncot, nsplit;
     long split_stride;            // 0, or (deterministic mode) floats between the per-split copies of dwp (see WgradArgs in conv3d_wgrad.hip)
+    long in_kb;                   // F(2x2x2) kernel: the same block stride for the INPUT operand (8 = channels-last)
+    long go_kb;                   // F(2x2x2) kernel: floats between consecutive 8-channel blocks of a gradient voxel - 8 = channels-last, B * V * 8 (go_ps = 8) = the
+                                  // channel-blocked layout [Cout / 8][B][D][H][W][8] of pulpo_bn_lrelu_bwd_apply_kb_t
 };
 
 template <int DUMMY>
@@ -674,7 +677,10 @@ __device__ __forceinline__ void wgrad_w3x_body(const Wgrad2Args& a) {
     // the thread has no item - and a plane step adds the plane's offset as the instruction's scalar offset.  No branch, no zero-initialised
     // destination, no 64-bit address arithmetic inside the loop.  (host: volume bytes < 2^31)
     constexpr unsigned OOB = 0x80000000u;
-    const int x_bytes = (int)((long)a.D * a.H * a.W * a.in_ps * 4), e_bytes = (int)((long)a.D * a.H * a.W * a.go_ps * 4);
+    // (num_records: a raw buffer load is out of range when  voffset >= num_records - soffset;  the plane offset rides in soffset, the channel block's
+    //  offset of the blocked gradient layout in voffset - the extent reaches the last block's voxels)
+    const int x_bytes = (int)((((long)(a.Cin + 7) / 8 - 1) * (a.in_kb == 8 ? 0 : a.in_kb) + (long)a.D * a.H * a.W * a.in_ps) * 4);
+    const int e_bytes = (int)((((long)(a.Cout + 7) / 8 - 1) * (a.go_kb == 8 ? 0 : a.go_kb) + (long)a.D * a.H * a.W * a.go_ps) * 4);
     int cb = 0, y0 = 0, x0 = 0;                           // current column
     unsigned x_off[4], e_off[2];
     __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, x_bytes, 0x00020000);
@@ -692,14 +698,14 @@ __device__ __forceinline__ void wgrad_w3x_body(const Wgrad2Args& a) {
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             const int gx = x0 - 1 + 2 * x_xb + t4;
-            x_off[t4] = (xrow && (unsigned)gx < (unsigned)a.W) ? (unsigned)((gy * a.W + gx) * (int)a.in_ps + ci0 + 4 * x_q) * 4u : OOB;
+            x_off[t4] = (xrow && (unsigned)gx < (unsigned)a.W) ? (unsigned)((long)((ci0 + 4 * x_q) >> 3) * a.in_kb + (gy * a.W + gx) * (int)a.in_ps + ((4 * x_q) & 7)) * 4u : OOB;
         }
         const int ey = y0 + e_y;
         const bool erow = e_item && e_cok && ey < a.H;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             const int gx = x0 + 2 * e_xb + t2;
-            e_off[t2] = (erow && gx < a.W) ? (unsigned)((ey * a.W + gx) * (int)a.go_ps + co0 + 4 * e_q) * 4u : OOB;
+            e_off[t2] = (erow && gx < a.W) ? (unsigned)((long)((co0 + 4 * e_q) >> 3) * a.go_kb + (ey * a.W + gx) * (int)a.go_ps + ((4 * e_q) & 7)) * 4u : OOB;
         }
     };
     const unsigned x_plane = (unsigned)((long)a.H * a.W * a.in_ps * 4), e_plane = (unsigned)((long)a.H * a.W * a.go_ps * 4);
@@ -966,9 +972,10 @@ bool wgrad_w3_depth_ok(int D) {
 
 // launched by pulpo_conv3d_k3_wgrad (conv3d_wgrad.hip) for channels-last operands on large volumes; scratch must be zeroed by the caller
 int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, long go_bs, long go_ps, float* scratch, int B, int D, int H, int W,
-                    int Cin, int Cout, hipStream_t st, float* slabs, int nslab, int* used_slabs) {
+                    int Cin, int Cout, hipStream_t st, float* slabs, int nslab, int* used_slabs, long go_kb, long in_kb) {
     Wgrad2Args a;
     a.split_stride = 0;
+    a.go_kb = go_kb; a.in_kb = in_kb;
     // deterministic mode: the splits of the grid add into their own zeroed copies of the packed sums (zeroed here, once the split count is known)
     auto use_slabs = [&](int nsplit_) -> int {
         if (!slabs) return 0;
@@ -996,7 +1003,10 @@ int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, lo
         if (e != hipSuccess) return pulpo::fail((int)e, "hipFuncSetAttribute(wgrad w2): %s", hipGetErrorString(e));
         attr = true;
     }
-    const bool small32 = (long)D * H * W * in_ps * 4 < (1L << 31) && (long)D * H * W * go_ps * 4 < (1L << 31);
+    const bool small32 = (((long)(Cin + 7) / 8 - 1) * (in_kb == 8 ? 0 : in_kb) + (long)D * H * W * in_ps) * 4 < (1L << 31) &&
+                         (((long)(Cout + 7) / 8 - 1) * (go_kb == 8 ? 0 : go_kb) + (long)D * H * W * go_ps) * 4 < (1L << 31);
+    if ((go_kb != 8 || in_kb != 8) && !(wgrad_w3_depth_ok(D) && small32))
+        return pulpo::fail(1, "conv3d_k3_wgrad: channel-blocked operands are read by the F(2x2x2,3x3x3) kernel only (even depth, operands below 2 GiB)");
     if (wgrad_w3_depth_ok(D) && small32) {
         static bool attr3 = false;
         if (!attr3) {

@@ -48,7 +48,7 @@ PULPO_API int pulpo_debug_read_stamps_w3(void* dst, size_t bytes) {
 #define PULPO_W3_PK 1        // the y / z combinations in two-wide vector arithmetic (v_pk_fma_f32); 0: scalar v_fma_f32 - measured 3-4 % slower here (64-clock fp32 MFMAs leave room)
 #endif
 #ifndef PULPO_ABL
-#define PULPO_ABL 0          // diagnostic builds (scripts/ablate.py): timings only, results are garbage.  Bits: 1 no epilogue, 2 no halo staging,
+#define PULPO_ABL 0          // diagnostic builds (scripts/ablate.py): timings only, results are garbage.  Bits: 1 no epilogue, 2 no halo staging, 64 every tap from one 64 KB window (cache hits),
 #endif                       // 4 no weight re-loads, 8 no chunk barrier, 32 no operand-row reads inside the loop
 
 namespace {
@@ -91,6 +91,7 @@ __device__ __forceinline__ void wino3_body(const ConvArgs& a) {
     const int nwork = a.B * a.ntz * a.nty * a.ntx * a.ncot;
     const int nwg = gridDim.x;
     const unsigned ps_bytes = (unsigned)a.in_ps * 4u;
+    const unsigned kb_bytes = (unsigned)a.in_kb * 4u;        // bytes between consecutive chunks of a voxel (32: channels-last)
 
     // ---- the staging item of this thread (the (y, x) kernel's): (hz, hy, x-pair xb, channel quad q) -> the four x-transformed rows px = 0..3
     unsigned roff;                                      // byte offset of tap 0 relative to the tile's halo origin
@@ -122,7 +123,9 @@ __device__ __forceinline__ void wino3_body(const ConvArgs& a) {
 
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, -1, 0x00020000);
-    const int in_bytes = (int)((long)a.D * a.H * a.W * a.in_ps * 4);
+    // num_records of the operand's descriptor.  The range check of a raw buffer load is  voffset >= num_records - soffset  (the chunk's offset rides in
+    // soffset): the extent must therefore reach the LAST chunk's voxels - in the channel-blocked layout (in_kb = V * 8) that is the whole operand
+    const int in_bytes = (int)((((long)a.Cin / CH - 1) * (a.in_kb == CH ? 0 : a.in_kb) + (long)a.D * a.H * a.W * a.in_ps) * 4);
     struct Tile {
         int tile_lin, b, z0, y0, x0, co0;
         unsigned wbase;              // byte offset of (chunk 0, point (2 pzh, py, 0), cout co0) in the packed weights
@@ -163,7 +166,7 @@ __device__ __forceinline__ void wino3_body(const ConvArgs& a) {
         const bool rowok = item && (unsigned)(t.z0 - 1 + hz) < (unsigned)a.D && (unsigned)(t.y0 - 1 + hy) < (unsigned)a.H;
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
-            hoff[tt] = (rowok && (unsigned)(t.x0 - 1 + 2 * xb + tt) < (unsigned)a.W) ? origin + roff + tt * ps_bytes : OOB;
+            hoff[tt] = (rowok && (unsigned)(t.x0 - 1 + 2 * xb + tt) < (unsigned)a.W) ? ((PULPO_ABL & 64) ? ((origin + roff + tt * ps_bytes) & 0xFFE0u) : origin + roff + tt * ps_bytes) : OOB;
     };
     auto in_rsrc = [&](int b) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + (long)b * a.in_bs), 0, in_bytes, 0x00020000);
@@ -214,7 +217,7 @@ __device__ __forceinline__ void wino3_body(const ConvArgs& a) {
         for (int tt = 0; tt < 4; ++tt) load_raw(rs0, 0u, tt);
         store_item(smem);
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) load_raw(rs0, CH * 4u, tt);
+        for (int tt = 0; tt < 4; ++tt) load_raw(rs0, kb_bytes, tt);
     }
     // (the weight rows are requested AFTER the taps, as in the loop: the compiler's vmcnt bookkeeping merges this path with the loop's back
     //  edge, and with the taps as the youngest loads here every chunk's transform waited for vmcnt(0) - the weight rows of the pair after next)
@@ -268,7 +271,7 @@ __device__ __forceinline__ void wino3_body(const ConvArgs& a) {
             // of chunk + 1 and steps 1 - 2 request those of chunk + 2 (or of the next tile's chunk 0 / 1), which the registers hold for a whole
             // chunk - 2000 matrix clocks, more than a trip to HBM.
             const bool ahead = chunk + 2 >= nchunk;     // (after the last tile: the tile's own first chunks again, into images nobody reads)
-            const unsigned st_c0 = (unsigned)(ahead ? chunk + 2 - nchunk : chunk + 2) * CH * 4u;
+            const unsigned st_c0 = (unsigned)(ahead ? chunk + 2 - nchunk : chunk + 2) * kb_bytes;
             const __amdgpu_buffer_rsrc_t st_rs = in_rsrc(ahead ? nxt.b : cur.b);
             const float* img_r = smem + cb * Q_IMG;
             float* img_w = smem + (cb ^ 1) * Q_IMG;
@@ -515,7 +518,7 @@ __device__ __forceinline__ void wino3_body(const ConvArgs& a) {
                 v0 = make_float4(act(v0.x, sc4.x, sh4.x), act(v0.y, sc4.y, sh4.y), act(v0.z, sc4.z, sh4.z), act(v0.w, sc4.w, sh4.w));
                 v1 = make_float4(act(v1.x, sc4.x, sh4.x), act(v1.y, sc4.y, sh4.y), act(v1.z, sc4.z, sh4.z), act(v1.w, sc4.w, sh4.w));
             }
-            float* obase = out_b + co0 + 4 * q;
+            float* obase = out_b + (long)((co0 + 4 * q) >> 3) * a.out_kb + ((4 * q) & 7);      // (out_kb = 8: channels-last, co0 + 4 q)
             if (qok) {
                 *reinterpret_cast<float4*>(obase + vox * a.out_ps) = v0;
                 *reinterpret_cast<float4*>(obase + (vox + a.W) * a.out_ps) = v1;
@@ -625,19 +628,21 @@ PULPO_API int pulpo_conv3d_k3_pack_weight_wino3(const float* w, float* wp, int C
 
 static int fwd_wino3_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* wp, const float* bias, const float* coef, float slope,
                           float* out, int64_t out_bs, int64_t out_ps, int64_t out_cs, float* stats, const float* bn_y, int64_t bn_y_bs, int64_t bn_y_ps,
-                          const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream) {
+                          const float* bn_coef, int B, int D, int H, int W, int K, int N, void* stream, int64_t in_kb = Q_CH, int64_t out_kb = Q_CH) {
     PULPO_REQUIRE(in && wp && out, "conv3d_k3_fwd_wino3: null pointer");
     PULPO_REQUIRE(B > 0 && K > 0 && N > 0 && D > 0 && D % 4 == 0 && H > 0 && H % TY == 0 && W > 0 && W % TX == 0 && K % Q_CH == 0 && N % 4 == 0 && 3 * ((N + Q_NT - 1) / Q_NT) * Q_NT <= Q_TAB,
                   "conv3d_k3_fwd_wino3: shape %dx%dx%d, %d -> %d channels is not whole 4x8x8 tiles of 8 / 32 channels (see pulpo_conv3d_k3_algo)", D, H, W, K, N);
     PULPO_REQUIRE(K >= 2 * Q_CH, "conv3d_k3_fwd_wino3: at least two 8-channel chunks per tile (%d reduction channels given): the staging runs two chunks ahead", K);
     PULPO_REQUIRE(!stats || conv_tz(D, H, W) == 4, "conv3d_k3_fwd_wino3: %dx%dx%d is tiled 2-deep by pulpo_conv3d_k3_stat_tiles(); this kernel writes 4-deep statistics rows", D, H, W);
     PULPO_REQUIRE(!(coef && stats), "conv3d_k3_fwd_wino3: batch statistics are not available from the fused eval-mode epilogue");
-    PULPO_REQUIRE(in_cs == 1 && in_ps % 4 == 0 && in_bs % 4 == 0 && (((uintptr_t)in) & 15) == 0 && (long)D * H * W * in_ps * 4 < (1L << 31),
-                  "conv3d_k3_fwd_wino3: the operand must be channels-last, 16-byte aligned and smaller than 2 GiB per batch element");
+    PULPO_REQUIRE(in_cs == 1 && in_ps % 4 == 0 && in_bs % 4 == 0 && (((uintptr_t)in) & 15) == 0 && (long)D * H * W * in_ps * 4 < (1L << 31) &&
+                      in_kb >= Q_CH && in_kb % 4 == 0 && ((long)(K / Q_CH - 1) * in_kb + (long)D * H * W * in_ps) * 4 < (1L << 31),
+                  "conv3d_k3_fwd_wino3: the operand must be channels-last (or channel-blocked), 16-byte aligned and smaller than 2 GiB per batch element");
     PULPO_REQUIRE(out_cs == 1 && out_ps % 4 == 0 && out_bs % 4 == 0 && (((uintptr_t)out) & 15) == 0, "conv3d_k3_fwd_wino3: the result must be channels-last, 16-byte aligned");
     PULPO_REQUIRE((((uintptr_t)wp) & 15) == 0, "conv3d_k3_fwd_wino3: packed weights must be 16-byte aligned");
+    PULPO_REQUIRE(out_kb >= Q_CH && out_kb % 4 == 0 && (out_kb == Q_CH || N % Q_CH == 0), "conv3d_k3_fwd_wino3: a channel-blocked result needs whole 8-channel blocks");
     ConvArgs a{};
-    a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
+    a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs; a.in_kb = in_kb; a.out_kb = out_kb;
     a.wp = wp; a.bias = bias;
     a.out = out; a.out_bs = out_bs; a.out_ps = out_ps; a.out_cs = out_cs;
     a.stats = stats;
@@ -679,4 +684,24 @@ PULPO_API int pulpo_conv3d_k3_dgrad_wino3_bnred(const float* in, int64_t in_bs, 
                   "conv3d_k3_dgrad_wino3_bnred: pre-norm tensor and coefficients must be channels-last and 16-byte aligned");
     return fwd_wino3_impl(in, in_bs, in_ps, in_cs, wp, nullptr, nullptr, slope, out, out_bs, out_ps, 1, part, bn_y, bn_y_bs, bn_y_ps, bn_coef, B, D, H, W, K, N,
                           stream);
+}
+
+// The same two kernels on a channel-BLOCKED operand: element (voxel v, channel c) at  in + b * in_bs + (c / 8) * in_kb + v * in_ps + c % 8  (floats).
+// in_kb = 8, in_ps = row pitch is the channels-last tensor of the entries above; in_kb = D * H * W * 8, in_ps = 8 is the layout [K / 8][D][H][W][8], in
+// which the four taps of a staging item are 128 consecutive bytes and a wave's tap load touches a fifth of the cache lines.
+PULPO_API int pulpo_conv3d_k3_fwd_wino3_kb(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_kb, const float* wp, const float* bias,
+                                           const float* coef, float slope, float* out, int64_t out_bs, int64_t out_ps, int64_t out_kb, float* stats, int B,
+                                           int D, int H, int W, int K, int N, void* stream) {
+    return fwd_wino3_impl(in, in_bs, in_ps, 1, wp, bias, coef, slope, out, out_bs, out_ps, 1, stats, nullptr, 0, 0, nullptr, B, D, H, W, K, N, stream, in_kb,
+                          out_kb);
+}
+
+PULPO_API int pulpo_conv3d_k3_dgrad_wino3_bnred_kb(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_kb, const float* wp, float* out, int64_t out_bs,
+                                                   int64_t out_ps, int64_t out_kb, const float* bn_y, int64_t bn_y_bs, int64_t bn_y_ps, const float* bn_coef, float slope,
+                                                   float* part, int B, int D, int H, int W, int K, int N, void* stream) {
+    PULPO_REQUIRE(bn_y && bn_coef && part, "conv3d_k3_dgrad_wino3_bnred_kb: null pointer");
+    PULPO_REQUIRE(bn_y_ps % 4 == 0 && bn_y_bs % 4 == 0 && (((uintptr_t)bn_y) & 15) == 0 && (((uintptr_t)bn_coef) & 15) == 0,
+                  "conv3d_k3_dgrad_wino3_bnred_kb: pre-norm tensor and coefficients must be channels-last and 16-byte aligned");
+    return fwd_wino3_impl(in, in_bs, in_ps, 1, wp, nullptr, nullptr, slope, out, out_bs, out_ps, 1, part, bn_y, bn_y_bs, bn_y_ps, bn_coef, B, D, H, W, K, N,
+                          stream, in_kb, out_kb);
 }

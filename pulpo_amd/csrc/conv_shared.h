@@ -33,7 +33,7 @@ int launch_unpack_wgrad(const float* packed, float* dw, int Cin, int Cout, int a
 // slabs / nslab (deterministic mode, see pulpo_conv3d_k3_wgrad_det): non-null -> split s of the grid accumulates into its own zeroed copy
 // slabs + s * 27 * Cin * npad(Cout) of the packed sums instead of `scratch` (the caller adds the copies up in fixed order), at most nslab splits
 int launch_wgrad_w2(const float* in, long in_bs, long in_ps, const float* go, long go_bs, long go_ps, float* scratch, int B, int D, int H, int W,
-                    int Cin, int Cout, hipStream_t st, float* slabs = nullptr, int nslab = 0, int* used_slabs = nullptr);
+                    int Cin, int Cout, hipStream_t st, float* slabs = nullptr, int nslab = 0, int* used_slabs = nullptr, long go_kb = 8, long in_kb = 8);
 // scratch[e] += slabs[0][e] + slabs[1][e] + ... (fixed order, e < n): the ordered second stage of the deterministic weight gradient
 int launch_wgrad_slab_reduce(float* scratch, const float* slabs, int nslab, long n, hipStream_t st, int npad_ = 64, int cols = 64);
 bool wgrad_w3_depth_ok(int D);                      // the F(2x2x2,3x3x3) weight-gradient kernel takes this depth (even, PULPO_WGRAD_W3 != 0)
@@ -72,6 +72,9 @@ struct ConvArgs {
     const float* bn_coef;
     int tile_order;               // pipelined (y, x) kernel: 0 = tiles in linear order (x fastest), 1 = in 4 x 4 x 4 blocks (see describe())
     int stagger;                  // pipelined (y, x) kernel: diagnostic start-up delay (units of 64 x 127 clocks) of the second half of the grid, 0 = none
+    long out_kb;                  // F(2x2x2) kernel: the same block stride for the RESULT (8 = channels-last; 0 is read as 8)
+    long in_kb;                   // F(2x2x2) kernel: floats between consecutive 8-channel blocks of a voxel - 8 = channels-last; V * 8 (with in_ps = 8) = the channel-BLOCKED layout
+                                  // [C / 8][D][H][W][8] in which the BatchNorm backward writes the gradient it hands to the data- / weight-gradient kernels (0 is read as 8)
 };
 
 

@@ -302,7 +302,7 @@ template <int VEC, typename TG = float, typename TY = float, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const TG* __restrict__ dz, long dzps, const TY* __restrict__ y,
                                                                    long yps, const float* __restrict__ coef, const double* __restrict__ totd,
                                                                    TY* __restrict__ dy, long dyps, long npix, int C,
-                                                                   float slope, float* __restrict__ partial2, PoolGrad<TG> pg = PoolGrad<TG>{}) {
+                                                                   float slope, float* __restrict__ partial2, PoolGrad<TG> pg = PoolGrad<TG>{}, long dykb = 8) {
     extern __shared__ float red[];                 // [RB][C] partial sums, then [6][C] constants: scale, shift, m32, B, C hi, C lo
     const int CV = C / VEC, RB = blockDim.x / CV;
     const int col = threadIdx.x % CV, row = threadIdx.x / CV;
@@ -326,6 +326,9 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const TG* __res
     float s0[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) s0[k] = 0.f;
+    // dy: channel c of pixel p at (c / 8) * dykb + p * dyps + c % 8 - dykb = 8 is the channels-last tensor, dykb = npix * 8 with dyps = 8 the
+    // channel-blocked layout [C / 8][pixels][8] that the F(2x2x2,3x3x3) data- / weight-gradient kernels read (pulpo_bn_lrelu_bwd_apply_kb_t)
+    const long cdst = (long)(c >> 3) * dykb + (c & 7);
     if (row < RB) {
         for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
             float g[VEC], v[VEC], o[VEC];
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const TG* __res
                     s0[k] += o[k];
                 }
             }
-            pulpo::stv<VEC>(dy + p * dyps + c, o);
+            pulpo::stv<VEC>(dy + p * dyps + cdst, o);
         }
 #pragma unroll
         for (int k = 0; k < VEC; ++k) red[row * C + c + k] = s0[k];
@@ -605,7 +608,7 @@ int pool_reduce_t(const TG* gout, long gops, const TG* add, long aps, TG* gin, l
 
 template <typename TG, typename TY>
 int bwd_apply_t(const TG* dz, long dzps, const TY* y, long yps, const float* coef, const double* totd, TY* dy, long dyps, long npix, int C, float slope,
-                float* partial2, hipStream_t st) {
+                float* partial2, hipStream_t st, long dykb = 8) {
     pulpo::GroupProbe g(C);
     g.add(dz, dzps, sizeof(TG)); g.add(y, yps, sizeof(TY)); g.add(dy, dyps, sizeof(TY)); g.add(coef, 8, 4);
     const int vec = bwd_group(g, sizeof(TG) == 2 || sizeof(TY) == 2, C);
@@ -614,21 +617,21 @@ int bwd_apply_t(const TG* dz, long dzps, const TY* y, long yps, const float* coe
     const int nblk = pulpo_bn_bwd_blocks(npix, C);
     const int RB = std::max(1, 256 / (C / vec));
     const size_t lds = (size_t)(RB + 6) * C * sizeof(float);
-    if (vec == 8) hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<8, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2);
-    else if (vec == 4) hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<4, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2);
-    else hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<1, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2);
+    if (vec == 8) hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<8, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2, PoolGrad<TG>{}, dykb);
+    else if (vec == 4) hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<4, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2, PoolGrad<TG>{}, dykb);
+    else hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<1, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2, PoolGrad<TG>{}, dykb);
     return pulpo::check_launch("bn_lrelu_bwd_apply");
 }
 template <typename TG, typename TY>
 int pool_apply_t(const TG* gout, long gops, const TG* add, long aps, const TY* y, long yps, const float* coef, const double* totd, TY* dy, long dyps,
-                 float slope, float* partial2, int B, int D, int H, int W, int C, hipStream_t st) {
+                 float slope, float* partial2, int B, int D, int H, int W, int C, hipStream_t st, long dykb = 8) {
     const long npix = (long)B * D * H * W;
     const int nblk = pulpo_bn_bwd_blocks(npix, C);
     const int RB = std::max(1, 256 / (C / 4));
     const size_t lds = (size_t)(RB + 6) * C * sizeof(float);
     PoolGrad<TG> pg{gout, gops, add, aps, nullptr, 0, D, H, W, (D + 1) / 2, (H + 1) / 2, (W + 1) / 2};
     hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<4, TG, TY, true>), dim3(nblk), dim3(256), lds, st, (const TG*)nullptr, 0L, y, yps, coef, totd, dy, dyps, npix,
-                       C, slope, partial2, pg);
+                       C, slope, partial2, pg, dykb);
     return pulpo::check_launch("bn_lrelu_bwd_apply_pooled");
 }
 }  // namespace
@@ -732,4 +735,33 @@ PULPO_API int pulpo_bn_lrelu_bwd_apply_t(const void* dz, int dz_dt, int64_t dzps
 PULPO_API int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd, float* dy,
                                        int64_t dyps, int64_t npix, int C, float slope, float* partial2, void* stream) {
     return pulpo_bn_lrelu_bwd_apply_t(dz, 0, dzps, y, 0, yps, coef, totd, dy, dyps, npix, C, slope, partial2, stream);
+}
+
+// The second pass with its result in the channel-BLOCKED layout: dy channel c of pixel p at dy + (c / 8) * dykb + p * dyps + c % 8 (dyps = 8,
+// dykb = npix * 8: [C / 8][pixels][8]).  dy is read by nothing but the data- and the weight-gradient convolution of the unit; in this layout the
+// four taps of a staging item of the F(2x2x2,3x3x3) data-gradient kernel are 128 consecutive bytes (pulpo_conv3d_k3_fwd_wino3_kb: 15 % faster
+// at 160^3).  fp32 dy, C % 8 == 0.  The pooled form: as pulpo_bn_lrelu_bwd_apply_pooled_t.
+PULPO_API int pulpo_bn_lrelu_bwd_apply_kb_t(const void* dz, int dz_dt, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd,
+                                            float* dy, int64_t dyps, int64_t dykb, int64_t npix, int C, float slope, float* partial2, void* stream) {
+    PULPO_REQUIRE(dz && y && coef && totd && dy && partial2 && npix > 0 && C > 0, "bn_lrelu_bwd_apply_kb: bad arguments");
+    PULPO_REQUIRE_DT(dz_dt, "bn_lrelu_bwd_apply_kb");
+    PULPO_REQUIRE(C % 8 == 0 && dyps % 4 == 0 && dyps >= 8 && dykb % 4 == 0 && dykb >= 8, "bn_lrelu_bwd_apply_kb: C %% 8 == 0, strides in whole four-channel groups");
+    PULPO_DISPATCH_DT(dz_dt, TG,
+        return bwd_apply_t((const TG*)dz, (long)dzps, y, (long)yps, coef, totd, dy, (long)dyps, (long)npix, C, slope, partial2, (hipStream_t)stream, (long)dykb));
+    return -1;
+}
+
+PULPO_API int pulpo_bn_lrelu_bwd_apply_pooled_kb_t(const void* gout, int64_t gops, const void* add, int64_t aps, int g_dt, const float* y, int64_t yps,
+                                                   const float* coef, const double* totd, float* dy, int64_t dyps, int64_t dykb, float slope,
+                                                   float* partial2, int B, int D, int H, int W, int C, void* stream) {
+    PULPO_REQUIRE(gout && y && coef && totd && dy && partial2 && B > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bn_lrelu_bwd_apply_pooled_kb: bad arguments");
+    PULPO_REQUIRE_DT(g_dt, "bn_lrelu_bwd_apply_pooled_kb");
+    const int eg = g_dt ? 8 : 16;
+    PULPO_REQUIRE(C % 8 == 0 && C / 4 <= 256 && gops % 4 == 0 && yps % 4 == 0 && dyps % 4 == 0 && dyps >= 8 && dykb % 4 == 0 && dykb >= 8 && (add == nullptr || aps % 4 == 0) &&
+                      ((((uintptr_t)gout) | ((uintptr_t)add)) % eg) == 0 && ((((uintptr_t)y) | ((uintptr_t)dy)) & 15) == 0 && (((uintptr_t)coef) & 15) == 0,
+                  "bn_lrelu_bwd_apply_pooled_kb: operands must be aligned to four elements, C %% 8 == 0");
+    PULPO_DISPATCH_DT(g_dt, TG,
+        return pool_apply_t((const TG*)gout, (long)gops, (const TG*)add, (long)aps, y, (long)yps, coef, totd, dy, (long)dyps, slope, partial2, B, D, H, W, C,
+                            (hipStream_t)stream, (long)dykb));
+    return -1;
 }

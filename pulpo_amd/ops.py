@@ -399,9 +399,17 @@ def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], o
               stats: Optional[torch.Tensor], coef: Optional[torch.Tensor] = None):
     """coef: eval-mode BatchNorm coefficients -> BatchNorm + LeakyReLU are applied by the convolution's store (one kernel per ConvUnit)"""
     B, _, D, H, W = x.shape
-    xb, xp, xc = grid_strides(x)
     ob, op, oc = grid_strides(out)
     algo = getattr(wp, "_pulpo_algo", "bf16" if wp.dtype == torch.int16 else "direct")
+    if isinstance(x, _BlockedGrad):                  # a data-gradient convolution on the blocked gradient (_blocked_dy_ok: the F(2x2x2,3x3x3) kernel)
+        if algo != "wino3" or oc != 1 or op % 4 or ob % 4 or out.data_ptr() % 16 or bias is not None or coef is not None:
+            raise PulpoHipError("conv3d on a channel-blocked operand: F(2x2x2,3x3x3) kernel, channels-last 16-byte aligned result only")
+        t0 = _trace_begin()
+        lib.call("pulpo_conv3d_k3_fwd_wino3_kb", _ptr(x.buf), x.bs, x.ps, x.kb, _ptr(wp), None, None, LRELU_SLOPE, _ptr(out), ob, op, 8, _ptr(stats), B, D, H, W, K, N,
+                 _stream())
+        _trace_end(t0, "conv3d_k3_wino3_mfma<false>", 54.0 * K * N * B * D * H * W, 4.0 * (K + N) * B * D * H * W)
+        return
+    xb, xp, xc = grid_strides(x)
     bf16 = algo == "bf16"
     vec_ok = xc == 1 and xp % 4 == 0 and xb % 4 == 0 and K % 4 == 0 and x.data_ptr() % 16 == 0
     if algo == "wino3":
@@ -513,6 +521,47 @@ def reset_param_grad_buffers(module: Optional[torch.nn.Module] = None) -> None:
                     delattr(p_, name)
 
 
+# ---- the gradient of a ConvUnit's pre-norm tensor in a channel-BLOCKED layout (round 5).  dy leaves the BatchNorm backward for exactly two readers,
+# the unit's data- and weight-gradient convolution (aten::convolution_backward, src/network_blocks.py:23): its layout is nobody else's business.
+# Channels-last, a staging item of the F(2x2x2,3x3x3) data-gradient kernel gathers 32 useful bytes from each of four 128-byte voxel lines per
+# 8-channel chunk and the kernel waits on those lines (32 -> 32 at 160^3: 0.94 ms, 0.80 with every tap a cache hit); as [C / 8][B][D][H][W][8] the four
+# taps are 128 consecutive bytes: 0.80 ms (scripts/blocked_probe.py).  Used where BOTH readers run their F(2x2x2) kernel on a volume of at least
+# BLOCKED_DY_MIN_VOXELS voxels (below ~64^3 the tensors live in the caches and the layouts tie).  PULPO_BLOCKED_DY=0: channels-last everywhere.
+BLOCKED_DY = os.environ.get("PULPO_BLOCKED_DY", "1") != "0"
+BLOCKED_DY_MIN_VOXELS = int(os.environ.get("PULPO_BLOCKED_DY_MIN_VOXELS", str(64 ** 3)))
+BLOCKED_DY_HITS = 0              # gradients written in the blocked layout so far (tests look at it)
+
+
+class _BlockedGrad:
+    """fp32 gradient in the layout [C / 8][B][D][H][W][8]: element (b, v, c) at  b * bs + (c // 8) * kb + v * ps + c % 8  of `buf`"""
+    __slots__ = ("buf", "shape", "bs", "ps", "kb", "dtype", "device")
+
+    def __init__(self, B, C, D, H, W, dev):
+        self.buf = torch.empty(B * C * D * H * W, device=dev, dtype=torch.float32)
+        self.shape = (B, C, D, H, W)
+        self.ps, self.bs, self.kb = 8, D * H * W * 8, B * D * H * W * 8
+        self.dtype, self.device = torch.float32, self.buf.device
+
+    def to_cl(self) -> torch.Tensor:
+        """the same values as a channels-last (B, C, D, H, W) tensor (tests, fallbacks)"""
+        B, C, D, H, W = self.shape
+        return self.buf.view(C // 8, B, D, H, W, 8).permute(1, 0, 5, 2, 3, 4).reshape(B, C, D, H, W).contiguous(memory_format=CL)
+
+
+def _blocked_dy_ok(x, y, weight, wpt, need_dx: bool, need_dw: bool) -> bool:
+    B, Cin, D, H, W = x.shape
+    Cout = weight.shape[0]
+    if not (BLOCKED_DY and need_dx and y.dtype == torch.float32 and Cout % 8 == 0 and D * H * W >= BLOCKED_DY_MIN_VOXELS
+            and getattr(wpt, "_pulpo_algo", "") == "wino3" and 4 * B * Cout * D * H * W < 2 ** 31):
+        return False
+    if need_dw:
+        xb, xp, xc = grid_strides(x)
+        if (_use_bf16(Cin) or x.dtype != torch.float32 or xc != 1 or xp % 4 or xb % 4 or Cin % 4 or x.data_ptr() % 16
+                or lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, Cin, Cout, 1) != 3):
+            return False
+    return True
+
+
 def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Optional[torch.Tensor] = None,
                owner: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """weight gradient; `into` -> accumulated into that (Cout,Cin,3,3,3) tensor in place, returns None.  With `owner` (the weight parameter,
@@ -523,7 +572,8 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
     nscr = lib.query("pulpo_conv3d_k3_wgrad_scratch_floats", Cin, Cout)
     scratch = _persistent_buffer(owner, "_pulpo_wgrad_scratch", nscr, zero=True) if deferred else torch.empty(nscr, device=x.device, dtype=torch.float32)
     xb, xp, xc = grid_strides(x)
-    db, dp, dc = grid_strides(dy)
+    blocked = isinstance(dy, _BlockedGrad)
+    db, dp, dc = (dy.bs, dy.ps, 1) if blocked else grid_strides(dy)
     t0 = _trace_begin()
     sfx = "_bf16" if _use_bf16(Cin) else ""
     det = ()
@@ -532,7 +582,11 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
         nslab = lib.query("pulpo_conv3d_k3_wgrad_det_slabs", Cin, Cout)
         slabs = torch.empty(nslab * nscr, device=x.device, dtype=torch.float32)
         det = (_ptr(slabs), nslab)
-    if sfx:
+    if blocked:
+        # (_blocked_dy_ok has checked: fp32 operands, channels-last x, the F(2x2x2,3x3x3) weight-gradient kernel takes the shape)
+        lib.call("pulpo_conv3d_k3_wgrad_kb", _ptr(x), xb, xp, 8, _ptr(dy.buf), db, dp, dy.kb, _ptr(dw), 2 if deferred else int(into is not None), _ptr(scratch),
+                 *(det if det else (None, 0)), B, D, H, W, Cin, Cout, _stream())
+    elif sfx:
         if x.dtype != dy.dtype:                      # (one storage type per launch; a mixed pair - a user's fp32 input to a bf16-storage unit - is rare)
             x, dy = x.float(), dy.float()
             xb, xp, xc = grid_strides(x)
@@ -553,11 +607,13 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
         _PENDING_KEEPALIVE.append(scratch)
     if t0 is not None:
         name = "conv3d_k3_wgrad_bf16"
-        if not sfx:
+        if blocked:
+            name = "conv3d_k3_wgrad_w3x"
+        elif not sfx:
             vec = (xc == 1 and xp % 4 == 0 and xb % 4 == 0 and Cin % 4 == 0 and x.data_ptr() % 16 == 0 and dc == 1 and dp % 4 == 0 and db % 4 == 0
                    and Cout % 4 == 0 and dy.data_ptr() % 16 == 0)
             name = ("conv3d_k3_wgrad_mfma", "conv3d_k3_wgrad_wino", "conv3d_k3_wgrad_w2", "conv3d_k3_wgrad_w3x")[lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, Cin, Cout, int(vec))]
-        _trace_end(t0, name + ("" if deferred else "(+memset,unpack)"), 54.0 * Cin * Cout * B * D * H * W, (_esize(x) * Cin + _esize(dy) * Cout) * B * D * H * W)
+        _trace_end(t0, name + ("" if deferred else "(+memset,unpack)"), 54.0 * Cin * Cout * B * D * H * W, (_esize(x) * Cin + (4 if blocked else _esize(dy)) * Cout) * B * D * H * W)
     return None if into is not None else dw
 
 
@@ -576,7 +632,7 @@ def _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, owner):
     with torch.cuda.stream(side):
         _wgrad_raw(x, dy, Cin, Cout, into=slot_w, owner=owner)
     x.record_stream(side)                        # keep both operands' memory out of the allocator's hands until the side stream is done
-    dy.record_stream(side)
+    (dy.buf if isinstance(dy, _BlockedGrad) else dy).record_stream(side)
 
 
 def join_async_wgrad():
@@ -603,20 +659,25 @@ def _dgrad_with_bn_reduction(bn_src, x, dy, wpt, dx, K: int, N: int) -> bool:
         return False
     y_prev, coef_prev = bn_src
     B, _, D, H, W = dy.shape
-    db, dp, dc = grid_strides(dy)
+    blocked = isinstance(dy, _BlockedGrad)
+    db, dp, dc = (dy.bs, dy.ps, 1) if blocked else grid_strides(dy)
     ob, op, oc = grid_strides(dx)
     yb, yp, yc = grid_strides(y_prev)
     # (the C entry point also needs the gradient operand vectorisable: channels-last, 16-byte aligned, K % 4 == 0 - checked here so that a
     #  consumer unit with an odd channel count falls back to the separate reduction pass instead of raising in the middle of backward)
-    vec_ok = dc == 1 and dp % 4 == 0 and db % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0
+    vec_ok = blocked or (dc == 1 and dp % 4 == 0 and db % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0)
     if (not vec_ok or y_prev.shape != dx.shape or oc != 1 or yc != 1 or op % 4 or ob % 4 or yp % 4 or yb % 4 or dx.data_ptr() % 16
             or y_prev.data_ptr() % 16 or not lib.query("pulpo_conv3d_k3_dgrad_wino2_bnred_ok", B, D, H, W, K, N)):
         return False
     ntile = lib.query("pulpo_conv3d_k3_stat_tiles", B, D, H, W)
     part = torch.empty(ntile * 2 * N, device=dy.device, dtype=torch.float32)
     t0 = _trace_begin()
-    lib.call(f"pulpo_conv3d_k3_dgrad_{algo}_bnred", _ptr(dy), db, dp, dc, _ptr(wpt), _ptr(dx), ob, op, _ptr(y_prev), yb, yp, _ptr(coef_prev), LRELU_SLOPE,
-             _ptr(part), B, D, H, W, K, N, _stream())
+    if blocked:                                      # (algo == "wino3": _blocked_dy_ok)
+        lib.call("pulpo_conv3d_k3_dgrad_wino3_bnred_kb", _ptr(dy.buf), db, dp, dy.kb, _ptr(wpt), _ptr(dx), ob, op, 8, _ptr(y_prev), yb, yp, _ptr(coef_prev),
+                 LRELU_SLOPE, _ptr(part), B, D, H, W, K, N, _stream())
+    else:
+        lib.call(f"pulpo_conv3d_k3_dgrad_{algo}_bnred", _ptr(dy), db, dp, dc, _ptr(wpt), _ptr(dx), ob, op, _ptr(y_prev), yb, yp, _ptr(coef_prev), LRELU_SLOPE,
+                 _ptr(part), B, D, H, W, K, N, _stream())
     kname = "conv3d_k3_wino3_mfma<true>" if algo == "wino3" else "conv3d_k3_wino2_mfma<true>"
     if algo == "wino2" and t0 is not None and lib.query("pulpo_conv3d_k3_wino2_pipelined", D, H, W, K, dp):
         kname = "conv3d_k3_wino2p_mfma<true>"
@@ -836,7 +897,16 @@ class _ConvBNLReLU(torch.autograd.Function):
         if (FUSE_INPUT_WGRAD and pooled_src is None and Cin <= 2 and not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not DETERMINISTIC and y.dtype == torch.float32
                 and Cout % 4 == 0 and is_cl(y) and is_cl(dz) and y.stride(4) % 4 == 0 and dz.stride(4) % 4 == 0 and x.dtype == torch.float32):
             return _ConvBNLReLU._backward_input_layer(ctx, dz, x, weight, y, coef, totd, tot, direct_bn, (slot_w, slot_b), (w_p, b_p))
-        dy = new_cl(B, Cout, D, H, W, dev, y.dtype)            # (the gradient of the pre-norm tensor is stored like the tensor)
+        # the data-gradient weights now (cached pack): their kernel family decides dy's layout
+        wpt = _pack_weight(weight, dgrad=True, shape=(B, D, H, W)) if ctx.needs_input_grad[0] else None
+        blocked = (_blocked_dy_ok(x, y, weight, wpt, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+                   and (pooled_src is not None or (is_cl(dz) and dz.stride(4) % 4 == 0)) and is_cl(y) and y.stride(4) % 4 == 0)
+        if blocked:
+            global BLOCKED_DY_HITS
+            BLOCKED_DY_HITS += 1
+            dy = _BlockedGrad(B, Cout, D, H, W, dev)
+        else:
+            dy = new_cl(B, Cout, D, H, W, dev, y.dtype)        # (the gradient of the pre-norm tensor is stored like the tensor)
         defer_b = DIRECT_PARAM_GRADS and ctx.needs_input_grad[2] and slot_b is not None
         part2 = _persistent_buffer(b_p, "_pulpo_dbias_part", nblk * Cout, zero=False) if defer_b else None
         if defer_b and _pending_src(part2):          # this unit has already run a backward pass in this step: its partials are still waiting
@@ -846,12 +916,20 @@ class _ConvBNLReLU(torch.autograd.Function):
         t0 = _hbm_begin("bn_lrelu_bwd_apply")
         if pooled_src is not None:
             gp, gz = pooled_src
-            lib.call("pulpo_bn_lrelu_bwd_apply_pooled_t", _ptr(gp), gp.stride(4), _ptr(gz), grid_strides(gz)[1] if gz is not None else 0, _dt(gp), _ptr(y), _dt(y),
-                     y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4), LRELU_SLOPE, _ptr(part2), B, D, H, W, Cout, _stream())
+            if blocked:
+                lib.call("pulpo_bn_lrelu_bwd_apply_pooled_kb_t", _ptr(gp), gp.stride(4), _ptr(gz), grid_strides(gz)[1] if gz is not None else 0, _dt(gp), _ptr(y),
+                         y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy.buf), dy.ps, dy.kb, LRELU_SLOPE, _ptr(part2), B, D, H, W, Cout, _stream())
+            else:
+                lib.call("pulpo_bn_lrelu_bwd_apply_pooled_t", _ptr(gp), gp.stride(4), _ptr(gz), grid_strides(gz)[1] if gz is not None else 0, _dt(gp), _ptr(y), _dt(y),
+                         y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4), LRELU_SLOPE, _ptr(part2), B, D, H, W, Cout, _stream())
             _hbm_end(t0, "bn_lrelu_bwd_apply", Cout * (_esize(gp) * (gp.numel() // Cout + (npix if gz is not None else 0)) + 2 * _esize(y) * npix))
         else:
-            lib.call("pulpo_bn_lrelu_bwd_apply_t", _ptr(dz), _dt(dz), dz.stride(4), _ptr(y), _dt(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4),
-                     npix, Cout, LRELU_SLOPE, _ptr(part2), _stream())
+            if blocked:
+                lib.call("pulpo_bn_lrelu_bwd_apply_kb_t", _ptr(dz), _dt(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy.buf), dy.ps, dy.kb,
+                         npix, Cout, LRELU_SLOPE, _ptr(part2), _stream())
+            else:
+                lib.call("pulpo_bn_lrelu_bwd_apply_t", _ptr(dz), _dt(dz), dz.stride(4), _ptr(y), _dt(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4),
+                         npix, Cout, LRELU_SLOPE, _ptr(part2), _stream())
             _hbm_end(t0, "bn_lrelu_bwd_apply", (_esize(dz) + 2 * _esize(y)) * Cout * npix)                # read dz, y; write dy
         defer_w = ctx.needs_input_grad[1] and slot_w is not None and ASYNC_WGRAD_STREAM is not None
         if defer_b:
@@ -862,7 +940,6 @@ class _ConvBNLReLU(torch.autograd.Function):
         dw = _wgrad_raw(x, dy, Cin, Cout, into=slot_w, owner=w_p if slot_w is not None else None) if (ctx.needs_input_grad[1] and not defer_w) else None
         dx = None
         if ctx.needs_input_grad[0]:
-            wpt = _pack_weight(weight, dgrad=True, shape=(B, D, H, W))
             # (the bf16-operand kernel takes operand and result in one storage type; every other kernel is fp32)
             dyc = dy if (wpt._pulpo_algo == "bf16" or dy.dtype == torch.float32) else dy.float()
             dx = torch.empty_like(x, dtype=dyc.dtype) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, dev, dyc.dtype)

@@ -1340,3 +1340,114 @@ def test_deterministic_warp_and_resize_backward(ops, deterministic):
         xr = xg.double().requires_grad_(True)
         gr, = torch.autograd.grad((1.5 * F.interpolate(xr, size=out_size, mode="trilinear", align_corners=False) * u.double()).sum(), [xr])
         assert rel_l2(g0, gr) < 1e-6, (in_size, out_size, rel_l2(g0, gr))
+
+
+# ================================================================================================ channel-blocked gradient of the pre-norm tensor (ABI 5)
+def _blocked_from_cl(ops, t):
+    """channels-last (B, C, D, H, W) -> the blocked buffer [C / 8][B][D][H][W][8]"""
+    B, C, D, H, W = t.shape
+    g = ops._BlockedGrad(B, C, D, H, W, t.device)
+    g.buf.copy_(t.permute(0, 2, 3, 4, 1).reshape(B, D, H, W, C // 8, 8).permute(4, 0, 1, 2, 3, 5).reshape(-1))
+    return g
+
+
+@pytest.mark.parametrize("B,K,N,size", [(2, 32, 32, (32, 32, 32)), (1, 64, 32, (32, 64, 32)), (1, 24, 48, (64, 32, 32))])
+def test_data_gradient_on_the_channel_blocked_operand_is_bit_identical(ops, B, K, N, size):
+    """pulpo_conv3d_k3_fwd_wino3_kb / _dgrad_wino3_bnred_kb read the SAME numbers through another address map ([K / 8][B][D][H][W][8] instead of
+    channels-last): results, BatchNorm statistics rows and the fused BatchNorm-backward partial sums must be bit-identical to the channels-last entry
+    points (several batch elements: the batch stride lies inside a channel block; 24 channels: three chunks)"""
+    from pulpo_amd._lib import lib
+    gen = torch.Generator().manual_seed(K + N)
+    D, H, W = size
+    dy = torch.randn(B, K, D, H, W, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(K, N, 3, 3, 3, generator=gen) * 0.1).cuda()                     # (a data gradient: weight (Cout = K, Cin = N))
+    wpt = ops._pack_weight(w, True, shape=(B, D, H, W))
+    assert wpt._pulpo_algo == "wino3"
+    blk = _blocked_from_cl(ops, dy)
+    assert torch.equal(blk.to_cl(), dy)
+    dx0, dx1 = ops.new_cl(B, N, D, H, W, dy.device), ops.new_cl(B, N, D, H, W, dy.device)
+    ntile = lib.query("pulpo_conv3d_k3_stat_tiles", B, D, H, W)
+    st0, st1 = torch.zeros(ntile * 2 * N, device="cuda"), torch.zeros(ntile * 2 * N, device="cuda")
+    ops._conv_raw(dy, wpt, None, dx0, K, N, st0)
+    ops._conv_raw(blk, wpt, None, dx1, K, N, st1)
+    assert torch.equal(dx0, dx1) and torch.equal(st0, st1)
+    # the form with the previous unit's BatchNorm-backward reduction in the epilogue
+    y_prev = torch.randn(B, N, D, H, W, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    coef = torch.rand(8 * N, generator=gen).cuda()
+    outs = []
+    for op_ in (dy, blk):
+        dx = ops.new_cl(B, N, D, H, W, dy.device)
+        if not ops._dgrad_with_bn_reduction((y_prev, coef), dx, op_, wpt, dx, K, N):
+            assert (B, K, N) != (2, 32, 32), "the fused reduction must take the 32 -> 32 case"
+            return
+        part, nt = ops._take_bn_tile_parts(y_prev, coef, dx)
+        outs.append((dx, part.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], dx0)
+
+
+@pytest.mark.parametrize("pooled", [False, True])
+@pytest.mark.parametrize("B,C,size", [(2, 32, (8, 12, 10)), (1, 64, (6, 6, 6)), (1, 24, (5, 7, 9))])
+def test_batchnorm_backward_apply_writes_the_blocked_layout(ops, B, C, size, pooled):
+    """pulpo_bn_lrelu_bwd_apply_kb_t / _pooled_kb_t: the second BatchNorm-backward pass with its result in [C / 8][B][D][H][W][8] - the same values and the
+    same column sums as the channels-last pass (odd sizes: ceil-mode pooling windows at the rims)"""
+    from pulpo_amd._lib import lib
+    gen = torch.Generator().manual_seed(C + sum(size))
+    D, H, W = size
+    npix = B * D * H * W
+    y = torch.randn(B, C, D, H, W, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    coef = torch.zeros(8 * C)
+    coef[:C] = torch.randn(C, generator=gen) * 0.1
+    coef[2 * C:3 * C] = torch.rand(C, generator=gen) + 0.5
+    coef[3 * C:4 * C] = torch.randn(C, generator=gen) * 0.1
+    cd = coef[4 * C:].view(torch.float64)
+    cd[:C] = coef[:C].double() + 1e-9
+    cd[C:] = torch.rand(C, generator=gen, dtype=torch.float64) + 0.5
+    coef = coef.cuda()
+    totd = (torch.randn(2 * C, generator=gen, dtype=torch.float64) * 0.01).cuda()
+    nblk = lib.query("pulpo_bn_bwd_blocks", npix, C)
+    p0, p1 = torch.empty(nblk * C, device="cuda"), torch.empty(nblk * C, device="cuda")
+    dy0 = ops.new_cl(B, C, D, H, W, y.device)
+    dy1 = ops._BlockedGrad(B, C, D, H, W, y.device)
+    st = ops._stream()
+    if pooled:
+        Do, Ho, Wo = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+        gp = torch.randn(B, C, Do, Ho, Wo, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+        gz = torch.randn(B, C, D, H, W, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+        lib.call("pulpo_bn_lrelu_bwd_apply_pooled_t", ops._ptr(gp), gp.stride(4), ops._ptr(gz), gz.stride(4), 0, ops._ptr(y), 0, y.stride(4), ops._ptr(coef),
+                 ops._ptr(totd), ops._ptr(dy0), dy0.stride(4), 0.2, ops._ptr(p0), B, D, H, W, C, st)
+        lib.call("pulpo_bn_lrelu_bwd_apply_pooled_kb_t", ops._ptr(gp), gp.stride(4), ops._ptr(gz), gz.stride(4), 0, ops._ptr(y), y.stride(4), ops._ptr(coef),
+                 ops._ptr(totd), ops._ptr(dy1.buf), dy1.ps, dy1.kb, 0.2, ops._ptr(p1), B, D, H, W, C, st)
+    else:
+        dz = torch.randn(B, C, D, H, W, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+        lib.call("pulpo_bn_lrelu_bwd_apply_t", ops._ptr(dz), 0, dz.stride(4), ops._ptr(y), 0, y.stride(4), ops._ptr(coef), ops._ptr(totd), ops._ptr(dy0),
+                 dy0.stride(4), npix, C, 0.2, ops._ptr(p0), st)
+        lib.call("pulpo_bn_lrelu_bwd_apply_kb_t", ops._ptr(dz), 0, dz.stride(4), ops._ptr(y), y.stride(4), ops._ptr(coef), ops._ptr(totd), ops._ptr(dy1.buf),
+                 dy1.ps, dy1.kb, npix, C, 0.2, ops._ptr(p1), st)
+    assert torch.equal(dy1.to_cl(), dy0)
+    assert torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("det", [False, True])
+@pytest.mark.parametrize("B,Cin,Cout,size", [(2, 32, 32, (32, 32, 32)), (1, 16, 96, (10, 20, 28)), (1, 64, 40, (6, 12, 17))])
+def test_weight_gradient_on_the_channel_blocked_gradient(ops, B, Cin, Cout, size, det):
+    """pulpo_conv3d_k3_wgrad_kb: the F(2x2x2,3x3x3) weight-gradient kernel reading dy as [Cout / 8][B][D][H][W][8] (ragged rows and columns, 40 output
+    channels: a partly empty 32-channel tile whose last block is the fifth) - bit-identical to the channels-last call in deterministic mode, within the
+    atomics' summation-order noise otherwise"""
+    gen = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, *size, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    dy = torch.randn(B, Cout, *size, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
+    blk = _blocked_from_cl(ops, dy)
+    was = ops.DETERMINISTIC
+    ops.set_deterministic(det)
+    try:
+        g0 = ops._wgrad_raw(x, dy, Cin, Cout)
+        g1 = ops._wgrad_raw(x, blk, Cin, Cout)
+    finally:
+        ops.set_deterministic(was)
+    if det:
+        assert torch.equal(g0, g1)
+    else:
+        assert rel_l2(g1, g0) < 1e-5
+    ref = torch.nn.grad.conv3d_weight(x.double(), (Cout, Cin, 3, 3, 3), dy.double(), padding=1)
+    assert rel_l2(g1, ref) < 2e-5

@@ -1423,11 +1423,12 @@ def test_graphed_step_equals_the_eager_step(api, precision):
             assert torch.equal(sd_g[k], v), k
 
 
-@pytest.mark.parametrize("switch", ["prewritten_cat", "skip_unused_activations", "pooled_bn_backward", "fuse_input_wgrad"])
+@pytest.mark.parametrize("switch", ["prewritten_cat", "skip_unused_activations", "pooled_bn_backward", "fuse_input_wgrad", "blocked_dy"])
 def test_round5_fusions_equal_the_separate_passes(api, switch):
     """Each round-5 shortcut of the step switched OFF gives the same training step as the shipped default: concatenation buffers written in place
     (ops.cat_channels), activations nobody reads not written (DownPath `_needed`), the gradient of a pooled ConvUnit output formed inside the
-    BatchNorm-backward passes (ops.POOLED_BN_BACKWARD), the input layer's BatchNorm backward inside its weight gradient (ops.FUSE_INPUT_WGRAD).
+    BatchNorm-backward passes (ops.POOLED_BN_BACKWARD), the input layer's BatchNorm backward inside its weight gradient (ops.FUSE_INPUT_WGRAD), the
+    gradient of the pre-norm tensors in the channel-blocked layout where the F(2x2x2,3x3x3) kernels read it (ops.BLOCKED_DY).
     n0 = 16 at 64^3 / T3 / L2 so that the channel counts take the in-place buffers (multiples of 8) and the kernels of the large levels run.
     Loss bit-equal (the forward pass computes the same values), every parameter gradient within 1e-5 (summation order of fp32 partial sums)."""
     models, nb = api
@@ -1446,8 +1447,10 @@ def test_round5_fusions_equal_the_separate_passes(api, switch):
             model.downpath._pulpo_skip_room = {}
         if off == "skip_unused_activations":
             model._needed_levels = None
-        saved = (ops.POOLED_BN_BACKWARD, ops.FUSE_INPUT_WGRAD)
+        saved = (ops.POOLED_BN_BACKWARD, ops.FUSE_INPUT_WGRAD, ops.BLOCKED_DY)
         try:
+            if off == "blocked_dy":
+                ops.BLOCKED_DY = False
             if off == "pooled_bn_backward":
                 ops.POOLED_BN_BACKWARD = False
             if off == "fuse_input_wgrad":
@@ -1456,18 +1459,21 @@ def test_round5_fusions_equal_the_separate_passes(api, switch):
             total.backward()
             torch.cuda.synchronize()
         finally:
-            ops.POOLED_BN_BACKWARD, ops.FUSE_INPUT_WGRAD = saved
+            ops.POOLED_BN_BACKWARD, ops.FUSE_INPUT_WGRAD, ops.BLOCKED_DY = saved
         used = hasattr(outs[0][0], "shape")
         assert used
         return float(total), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}, model
 
-    hits0 = ops.CAT_PREWRITTEN_HITS
+    hits0, blk0 = ops.CAT_PREWRITTEN_HITS, ops.BLOCKED_DY_HITS
     loss_on, g_on, m_on = run(None)
+    blk1 = ops.BLOCKED_DY_HITS
+    assert blk1 > blk0, "no ConvUnit of the 64^3 level took the channel-blocked gradient"
     assert getattr(m_on.downpath, "_pulpo_skip_room", None), "the in-place concatenation buffers are not armed"
     assert ops.CAT_PREWRITTEN_HITS == hits0 + (L - 1), "the encoders' concatenations did not take the in-place buffers"
     hits1 = ops.CAT_PREWRITTEN_HITS
     loss_off, g_off, _ = run(switch)
     assert (ops.CAT_PREWRITTEN_HITS == hits1) == (switch == "prewritten_cat")
+    assert (ops.BLOCKED_DY_HITS == blk1) == (switch == "blocked_dy")
     assert loss_on == loss_off
     assert g_on.keys() == g_off.keys()
     for k, g in g_on.items():
