@@ -378,12 +378,20 @@ int pulpo_bn_lrelu_bwd_apply_pooled_t(const void* gout, int64_t gops, const void
  * profiles/r5_blocked_probe.txt).  kb = 8 with ps = the row pitch addresses an ordinary channels-last tensor through the same entry points.
  *  - pulpo_bn_lrelu_bwd_apply_kb_t / _pooled_kb_t: the second BatchNorm-backward pass (pulpo_bn_lrelu_bwd_apply_t / _pooled_t) writing dy blocked;
  *    fp32 y / dy, C % 8 == 0.
+ *  The same holds for the activation z BETWEEN two ConvUnits of a ConvSequence (src/network_blocks.py:40-46: read by the next unit's convolution,
+ *  forward and weight gradient, and by nothing else) and for its gradient dz:
+ *  - pulpo_bn_lrelu_apply_kb: the BatchNorm + LeakyReLU pass writing z blocked; the *_kb convolution entries take it (in_kb) and write the gradient dz
+ *    blocked (out_kb); pulpo_bn_lrelu_bwd_apply_kb_t (dzkb) and, for the input layer, pulpo_conv3d_k3_wgrad_bn_kb (dz_kb) read it.
  *  - pulpo_conv3d_k3_fwd_wino3_kb / pulpo_conv3d_k3_dgrad_wino3_bnred_kb: pulpo_conv3d_k3_fwd_wino3 / _dgrad_wino3_bnred on a blocked operand
  *    (result channels-last); same shape contract (pulpo_conv3d_k3_algo == 3).
  *  - pulpo_conv3d_k3_wgrad_kb: pulpo_conv3d_k3_wgrad (slabs == NULL) / pulpo_conv3d_k3_wgrad_det on a blocked dy; shapes with
  *    pulpo_conv3d_k3_wgrad_algo(...) == 3 only (the entry point refuses others). */
-int pulpo_bn_lrelu_bwd_apply_kb_t(const void* dz, int dz_dt, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd, float* dy,
-                                  int64_t dyps, int64_t dykb, int64_t npix, int C, float slope, float* partial2, void* stream);
+int pulpo_bn_lrelu_apply_kb(const float* y, int64_t yps, float* z, int64_t zps, int64_t zkb, const float* coef, int64_t npix, int C, float slope, void* stream);
+int pulpo_bn_lrelu_bwd_apply_kb_t(const void* dz, int dz_dt, int64_t dzps, int64_t dzkb, const float* y, int64_t yps, const float* coef, const double* totd,
+                                  float* dy, int64_t dyps, int64_t dykb, int64_t npix, int C, float slope, float* partial2, void* stream);
+int pulpo_conv3d_k3_wgrad_bn_kb(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dz, int64_t dz_bs, int64_t dz_ps, int64_t dz_kb,
+                                const float* y, int64_t y_bs, int64_t y_ps, const float* coef, const double* totd, float slope, float* dw, int accumulate,
+                                float* scratch, float* part2, int B, int D, int H, int W, int Cin, int Cout, void* stream);
 int pulpo_bn_lrelu_bwd_apply_pooled_kb_t(const void* gout, int64_t gops, const void* add /*nullable*/, int64_t aps, int g_dt, const float* y, int64_t yps,
                                          const float* coef, const double* totd, float* dy, int64_t dyps, int64_t dykb, float slope, float* partial2,
                                          int B, int D, int H, int W, int C, void* stream);

@@ -44,6 +44,7 @@ struct WgradArgs {
     float* bn_part2;
     float slope;
     int dz_bf16;
+    long dz_kb;                   // floats between consecutive 8-channel blocks of a dz voxel: 8 = channels-last, else the channel-blocked layout (fp32 dz only)
 };
 
 constexpr int WG_CH = 32, WG_NT = 32, WG_CP = WG_CH + 1;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_smallc(WgradArgs a) {
                         const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.dy) + (long)b * a.dy_bs + vox * a.dy_ps + co0 + 4 * q);
                         dr[u] = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
                     } else {
-                        dr[u] = *reinterpret_cast<const float4*>(dyb + vox * a.dy_ps + co0 + 4 * q);
+                        dr[u] = *reinterpret_cast<const float4*>(dyb + (long)((co0 + 4 * q) >> 3) * a.dz_kb + vox * a.dy_ps + ((4 * q) & 7));
                     }
                 }
             } else if (ok) {
@@ -771,10 +772,10 @@ static int wgrad_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_
     a.in = in; a.in_bs = in_bs; a.in_ps = in_ps; a.in_cs = in_cs;
     a.dy = dy; a.dy_bs = dy_bs; a.dy_ps = dy_ps; a.dy_cs = dy_cs;
     a.dwp = scratch;
-    a.bn_y = nullptr; a.bn_y_bs = a.bn_y_ps = 0; a.bn_coef = nullptr; a.bn_totd = nullptr; a.bn_part2 = nullptr; a.slope = 0.f; a.dz_bf16 = 0;
+    a.bn_y = nullptr; a.bn_y_bs = a.bn_y_ps = 0; a.bn_coef = nullptr; a.bn_totd = nullptr; a.bn_part2 = nullptr; a.slope = 0.f; a.dz_bf16 = 0; a.dz_kb = 8;
     if (bnf) {
         a.bn_y = bnf->bn_y; a.bn_y_bs = bnf->bn_y_bs; a.bn_y_ps = bnf->bn_y_ps; a.bn_coef = bnf->bn_coef; a.bn_totd = bnf->bn_totd;
-        a.bn_part2 = bnf->bn_part2; a.slope = bnf->slope; a.dz_bf16 = bnf->dz_bf16;
+        a.bn_part2 = bnf->bn_part2; a.slope = bnf->slope; a.dz_bf16 = bnf->dz_bf16; a.dz_kb = bnf->dz_kb ? bnf->dz_kb : 8;
     }
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.NPad = npad(Cout);
     a.ntz = pulpo::cdiv(D, TZ); a.nty = pulpo::cdiv(H, TY); a.ntx = pulpo::cdiv(W, TX);
@@ -920,10 +921,9 @@ PULPO_API int pulpo_conv3d_k3_wgrad_bn_rows(int B, int D, int H, int W, int Cout
     return std::min(std::max(1, 512 / pulpo::cdiv(Cout, WG_NT)), ntile4);
 }
 
-PULPO_API int pulpo_conv3d_k3_wgrad_bn(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const void* dz, int dz_dt, int64_t dz_bs,
-                                       int64_t dz_ps, const float* y, int64_t y_bs, int64_t y_ps, const float* coef, const double* totd, float slope,
-                                       float* dw, int accumulate, float* scratch, float* part2, int B, int D, int H, int W, int Cin, int Cout,
-                                       void* stream) {
+static int wgrad_bn_impl(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const void* dz, int dz_dt, int64_t dz_bs, int64_t dz_ps, int64_t dz_kb,
+                         const float* y, int64_t y_bs, int64_t y_ps, const float* coef, const double* totd, float slope, float* dw, int accumulate,
+                         float* scratch, float* part2, int B, int D, int H, int W, int Cin, int Cout, void* stream) {
     PULPO_REQUIRE(dz && y && coef && totd && part2, "conv3d_k3_wgrad_bn: null pointer");
     PULPO_REQUIRE(Cin >= 1 && Cin <= 4 && Cout % 4 == 0, "conv3d_k3_wgrad_bn: %d -> %d channels (input layers only: Cin <= 4, Cout %% 4 == 0)", Cin, Cout);
     PULPO_REQUIRE(dz_dt == 0 || dz_dt == 1, "conv3d_k3_wgrad_bn: dtype code %d", dz_dt);
@@ -931,8 +931,27 @@ PULPO_API int pulpo_conv3d_k3_wgrad_bn(const float* in, int64_t in_bs, int64_t i
     PULPO_REQUIRE(dz_ps % 4 == 0 && dz_bs % 4 == 0 && (((uintptr_t)dz) % g) == 0 && y_ps % 4 == 0 && y_bs % 4 == 0 && (((uintptr_t)y) & 15) == 0,
                   "conv3d_k3_wgrad_bn: dz and y must be channels-last with aligned four-channel pieces");
     WgradArgs f{};
-    f.bn_y = y; f.bn_y_bs = y_bs; f.bn_y_ps = y_ps; f.bn_coef = coef; f.bn_totd = totd; f.bn_part2 = part2; f.slope = slope; f.dz_bf16 = dz_dt;
+    PULPO_REQUIRE(dz_kb >= 8 && dz_kb % 4 == 0 && (dz_kb == 8 || (dz_dt == 0 && Cout % 8 == 0)), "conv3d_k3_wgrad_bn: a channel-blocked dz is fp32 with whole 8-channel blocks");
+    f.bn_y = y; f.bn_y_bs = y_bs; f.bn_y_ps = y_ps; f.bn_coef = coef; f.bn_totd = totd; f.bn_part2 = part2; f.slope = slope; f.dz_bf16 = dz_dt; f.dz_kb = dz_kb;
     return wgrad_impl(in, in_bs, in_ps, in_cs, (const float*)dz, dz_bs, dz_ps, 1, dw, accumulate, scratch, nullptr, 0, B, D, H, W, Cin, Cout, stream, &f);
+}
+
+PULPO_API int pulpo_conv3d_k3_wgrad_bn(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const void* dz, int dz_dt, int64_t dz_bs,
+                                       int64_t dz_ps, const float* y, int64_t y_bs, int64_t y_ps, const float* coef, const double* totd, float slope,
+                                       float* dw, int accumulate, float* scratch, float* part2, int B, int D, int H, int W, int Cin, int Cout,
+                                       void* stream) {
+    return wgrad_bn_impl(in, in_bs, in_ps, in_cs, dz, dz_dt, dz_bs, dz_ps, 8, y, y_bs, y_ps, coef, totd, slope, dw, accumulate, scratch, part2, B, D, H, W, Cin,
+                         Cout, stream);
+}
+
+// (since ABI 5) dz in the channel-blocked layout: element (b, v, c) at dz + b * dz_bs + (c / 8) * dz_kb + v * dz_ps + c % 8 (fp32) - the gradient of a
+// blocked activation (pulpo_bn_lrelu_apply_kb) as the next unit's data-gradient kernel writes it (pulpo_conv3d_k3_fwd_wino3_kb, out_kb)
+PULPO_API int pulpo_conv3d_k3_wgrad_bn_kb(const float* in, int64_t in_bs, int64_t in_ps, int64_t in_cs, const float* dz, int64_t dz_bs, int64_t dz_ps,
+                                          int64_t dz_kb, const float* y, int64_t y_bs, int64_t y_ps, const float* coef, const double* totd, float slope,
+                                          float* dw, int accumulate, float* scratch, float* part2, int B, int D, int H, int W, int Cin, int Cout,
+                                          void* stream) {
+    return wgrad_bn_impl(in, in_bs, in_ps, in_cs, dz, 0, dz_bs, dz_ps, dz_kb, y, y_bs, y_ps, coef, totd, slope, dw, accumulate, scratch, part2, B, D, H, W, Cin,
+                         Cout, stream);
 }
 
 // ---- deterministic form (PULPO_DETERMINISTIC): the same kernels, but workgroups that share a (ci tile, co tile) add their partial sums into

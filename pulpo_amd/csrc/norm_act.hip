@@ -142,7 +142,7 @@ struct Vec {
 // z = leaky_relu(y * scale[c] + shift[c])
 template <int VEC, typename TY = float, typename TZ = float>
 __global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(const TY* __restrict__ y, long yps, TZ* __restrict__ z, long zps,
-                                                               const float* __restrict__ coef, long npix, int C, float slope) {
+                                                               const float* __restrict__ coef, long npix, int C, float slope, long zkb = 8) {
     const int CV = C / VEC;
     const long total = npix * CV;
     const float* scale = coef + 2 * C;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(const TY* __restric
             const float t = v[k] * sc[k] + sh[k];
             v[k] = t > 0.f ? t : t * slope;
         }
-        pulpo::stv<VEC>(z + p * zps + c, v);
+        pulpo::stv<VEC>(z + (long)(c >> 3) * zkb + p * zps + (c & 7), v);      // (zkb = 8: channels-last, c; else the channel-blocked layout [C / 8][pixels][8])
     }
 }
 
@@ -302,7 +302,7 @@ template <int VEC, typename TG = float, typename TY = float, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const TG* __restrict__ dz, long dzps, const TY* __restrict__ y,
                                                                    long yps, const float* __restrict__ coef, const double* __restrict__ totd,
                                                                    TY* __restrict__ dy, long dyps, long npix, int C,
-                                                                   float slope, float* __restrict__ partial2, PoolGrad<TG> pg = PoolGrad<TG>{}, long dykb = 8) {
+                                                                   float slope, float* __restrict__ partial2, PoolGrad<TG> pg = PoolGrad<TG>{}, long dykb = 8, long dzkb = 8) {
     extern __shared__ float red[];                 // [RB][C] partial sums, then [6][C] constants: scale, shift, m32, B, C hi, C lo
     const int CV = C / VEC, RB = blockDim.x / CV;
     const int col = threadIdx.x % CV, row = threadIdx.x / CV;
@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const TG* __res
     // dy: channel c of pixel p at (c / 8) * dykb + p * dyps + c % 8 - dykb = 8 is the channels-last tensor, dykb = npix * 8 with dyps = 8 the
     // channel-blocked layout [C / 8][pixels][8] that the F(2x2x2,3x3x3) data- / weight-gradient kernels read (pulpo_bn_lrelu_bwd_apply_kb_t)
     const long cdst = (long)(c >> 3) * dykb + (c & 7);
+    const long csrc = (long)(c >> 3) * dzkb + (c & 7);      // (dz likewise: the gradient of a blocked activation arrives blocked)
     if (row < RB) {
         for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
             float g[VEC], v[VEC], o[VEC];
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const TG* __res
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) g[k] = pulpo::as_stored<TG>(g[k]);
             } else {
-                pulpo::ldv<VEC>(dz + p * dzps + c, g);
+                pulpo::ldv<VEC>(dz + p * dzps + csrc, g);
             }
             pulpo::ldv<VEC>(y + p * yps + c, v);
             int cl = c;                                 // (opaque: the constants are to be READ here every time, not kept in registers)
@@ -509,16 +510,16 @@ PULPO_API int pulpo_bn_eval_coef(const float* gamma, const float* beta, const fl
 // The untyped names below them are the fp32 forms.
 namespace {
 template <typename TY, typename TZ>
-int apply_t(const TY* y, long yps, TZ* z, long zps, const float* coef, long npix, int C, float slope, hipStream_t st) {
+int apply_t(const TY* y, long yps, TZ* z, long zps, const float* coef, long npix, int C, float slope, hipStream_t st, long zkb = 8) {
     pulpo::GroupProbe g(C);
     g.add(y, yps, sizeof(TY)); g.add(z, zps, sizeof(TZ)); g.add(coef, 8, 4);
     constexpr bool half = sizeof(TY) == 2 || sizeof(TZ) == 2;
     if (half && g.ok8)
-        hipLaunchKernelGGL((bn_lrelu_apply_kernel<8, TY, TZ>), dim3(stream_blocks(npix * (C / 8))), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope);
+        hipLaunchKernelGGL((bn_lrelu_apply_kernel<8, TY, TZ>), dim3(stream_blocks(npix * (C / 8))), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope, zkb);
     else if (g.ok4)
-        hipLaunchKernelGGL((bn_lrelu_apply_kernel<4, TY, TZ>), dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope);
+        hipLaunchKernelGGL((bn_lrelu_apply_kernel<4, TY, TZ>), dim3(stream_blocks(npix * (C / 4))), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope, zkb);
     else
-        hipLaunchKernelGGL((bn_lrelu_apply_kernel<1, TY, TZ>), dim3(stream_blocks(npix * C)), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope);
+        hipLaunchKernelGGL((bn_lrelu_apply_kernel<1, TY, TZ>), dim3(stream_blocks(npix * C)), dim3(256), 0, st, y, yps, z, zps, coef, npix, C, slope, zkb);
     return pulpo::check_launch("bn_lrelu_apply");
 }
 }  // namespace
@@ -534,6 +535,14 @@ PULPO_API int pulpo_bn_lrelu_apply_t(const void* y, int y_dt, int64_t yps, void*
 PULPO_API int pulpo_bn_lrelu_apply(const float* y, int64_t yps, float* z, int64_t zps, const float* coef, int64_t npix, int C, float slope,
                                    void* stream) {
     return pulpo_bn_lrelu_apply_t(y, 0, yps, z, 0, zps, coef, npix, C, slope, stream);
+}
+
+// z in the channel-BLOCKED layout [C / 8][pixels][8] (zps = 8, zkb = npix * 8; see pulpo_conv3d_k3_fwd_wino3_kb): the activation between two ConvUnits
+// of a ConvSequence is read by the next unit's convolution and weight gradient only.  fp32, C % 8 == 0.
+PULPO_API int pulpo_bn_lrelu_apply_kb(const float* y, int64_t yps, float* z, int64_t zps, int64_t zkb, const float* coef, int64_t npix, int C, float slope,
+                                      void* stream) {
+    PULPO_REQUIRE(y && z && coef && npix > 0 && C > 0 && C % 8 == 0 && zps % 4 == 0 && zps >= 8 && zkb % 4 == 0 && zkb >= 8, "bn_lrelu_apply_kb: bad arguments");
+    return apply_t(y, (long)yps, z, (long)zps, coef, (long)npix, C, slope, (hipStream_t)stream, (long)zkb);
 }
 
 // 1 when pulpo_bn_lrelu_apply_pool2 accepts the operands (groups of four channels: C % 4 == 0, strides % 4 == 0)
@@ -608,7 +617,7 @@ int pool_reduce_t(const TG* gout, long gops, const TG* add, long aps, TG* gin, l
 
 template <typename TG, typename TY>
 int bwd_apply_t(const TG* dz, long dzps, const TY* y, long yps, const float* coef, const double* totd, TY* dy, long dyps, long npix, int C, float slope,
-                float* partial2, hipStream_t st, long dykb = 8) {
+                float* partial2, hipStream_t st, long dykb = 8, long dzkb = 8) {
     pulpo::GroupProbe g(C);
     g.add(dz, dzps, sizeof(TG)); g.add(y, yps, sizeof(TY)); g.add(dy, dyps, sizeof(TY)); g.add(coef, 8, 4);
     const int vec = bwd_group(g, sizeof(TG) == 2 || sizeof(TY) == 2, C);
@@ -617,9 +626,9 @@ int bwd_apply_t(const TG* dz, long dzps, const TY* y, long yps, const float* coe
     const int nblk = pulpo_bn_bwd_blocks(npix, C);
     const int RB = std::max(1, 256 / (C / vec));
     const size_t lds = (size_t)(RB + 6) * C * sizeof(float);
-    if (vec == 8) hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<8, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2, PoolGrad<TG>{}, dykb);
-    else if (vec == 4) hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<4, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2, PoolGrad<TG>{}, dykb);
-    else hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<1, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2, PoolGrad<TG>{}, dykb);
+    if (vec == 8) hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<8, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2, PoolGrad<TG>{}, dykb, dzkb);
+    else if (vec == 4) hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<4, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2, PoolGrad<TG>{}, dykb, dzkb);
+    else hipLaunchKernelGGL((bn_lrelu_bwd_apply_kernel<1, TG, TY>), dim3(nblk), dim3(256), lds, st, dz, dzps, y, yps, coef, totd, dy, dyps, npix, C, slope, partial2, PoolGrad<TG>{}, dykb, dzkb);
     return pulpo::check_launch("bn_lrelu_bwd_apply");
 }
 template <typename TG, typename TY>
@@ -741,13 +750,16 @@ PULPO_API int pulpo_bn_lrelu_bwd_apply(const float* dz, int64_t dzps, const floa
 // dykb = npix * 8: [C / 8][pixels][8]).  dy is read by nothing but the data- and the weight-gradient convolution of the unit; in this layout the
 // four taps of a staging item of the F(2x2x2,3x3x3) data-gradient kernel are 128 consecutive bytes (pulpo_conv3d_k3_fwd_wino3_kb: 15 % faster
 // at 160^3).  fp32 dy, C % 8 == 0.  The pooled form: as pulpo_bn_lrelu_bwd_apply_pooled_t.
-PULPO_API int pulpo_bn_lrelu_bwd_apply_kb_t(const void* dz, int dz_dt, int64_t dzps, const float* y, int64_t yps, const float* coef, const double* totd,
-                                            float* dy, int64_t dyps, int64_t dykb, int64_t npix, int C, float slope, float* partial2, void* stream) {
+PULPO_API int pulpo_bn_lrelu_bwd_apply_kb_t(const void* dz, int dz_dt, int64_t dzps, int64_t dzkb, const float* y, int64_t yps, const float* coef,
+                                            const double* totd, float* dy, int64_t dyps, int64_t dykb, int64_t npix, int C, float slope, float* partial2,
+                                            void* stream) {
     PULPO_REQUIRE(dz && y && coef && totd && dy && partial2 && npix > 0 && C > 0, "bn_lrelu_bwd_apply_kb: bad arguments");
     PULPO_REQUIRE_DT(dz_dt, "bn_lrelu_bwd_apply_kb");
-    PULPO_REQUIRE(C % 8 == 0 && dyps % 4 == 0 && dyps >= 8 && dykb % 4 == 0 && dykb >= 8, "bn_lrelu_bwd_apply_kb: C %% 8 == 0, strides in whole four-channel groups");
+    PULPO_REQUIRE(C % 8 == 0 && dyps % 4 == 0 && dyps >= 8 && dykb % 4 == 0 && dykb >= 8 && dzkb % 4 == 0 && dzkb >= 8 && (dzkb == 8 || dz_dt == 0),
+                  "bn_lrelu_bwd_apply_kb: C %% 8 == 0, strides in whole four-channel groups, a blocked dz is fp32");
     PULPO_DISPATCH_DT(dz_dt, TG,
-        return bwd_apply_t((const TG*)dz, (long)dzps, y, (long)yps, coef, totd, dy, (long)dyps, (long)npix, C, slope, partial2, (hipStream_t)stream, (long)dykb));
+        return bwd_apply_t((const TG*)dz, (long)dzps, y, (long)yps, coef, totd, dy, (long)dyps, (long)npix, C, slope, partial2, (hipStream_t)stream, (long)dykb,
+                           (long)dzkb));
     return -1;
 }
 

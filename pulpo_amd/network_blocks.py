@@ -53,15 +53,16 @@ class ConvUnit(nn.Module):
             nn.LeakyReLU(negative_slope=0.2, inplace=True),
         )
 
-    def forward(self, x: torch.Tensor, pool_after: bool = False, out=None, pool_only: bool = False):
-        """out: (buffer, first channel), pool_only: the caller reads only AvgPool(result) -> (result or None, pooled or None); see ops.conv_bn_lrelu"""
+    def forward(self, x: torch.Tensor, pool_after: bool = False, out=None, pool_only: bool = False, blocked_out: bool = False):
+        """out: (buffer, first channel), pool_only: the caller reads only AvgPool(result) -> (result or None, pooled or None); blocked_out: the result in the
+        channel-blocked form (C / 8, B, D, H, W, 8) for the next unit of a ConvSequence; see ops.conv_bn_lrelu"""
         conv, bn = self._op[0], self._op[1]
         use_batch_stats = self.training or bn.running_mean is None
         # running statistics and num_batches_tracked are updated inside the BatchNorm finalize kernel
         return ops.conv_bn_lrelu(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                  training=use_batch_stats, momentum=bn.momentum, eps=bn.eps,
                                  num_batches_tracked=bn.num_batches_tracked if self.training else None, pool_after=pool_after, out=out,
-                                 pool_only=pool_only)
+                                 pool_only=pool_only, blocked_out=blocked_out)
 
 
 class ConvSequence(nn.Module):
@@ -77,14 +78,15 @@ class ConvSequence(nn.Module):
         """pool_after: the caller pools the result next (DownPath) - the last unit then writes AvgPool(result) along with it;
         out: (buffer, first channel) - the last unit writes its result into that channel range of a wider buffer (ops.conv_bn_lrelu);
         pool_only (with pool_after): the caller reads ONLY the pooled result -> returns (result or None, pooled or None)"""
-        if not pool_after and out is None:
-            return self._op(x)
         n = len(self._op)
         for k, unit in enumerate(self._op):
             last = k + 1 == n
             if last and pool_only:
                 return unit(x, pool_after=pool_after, out=out, pool_only=True)
-            x = unit(x, pool_after=pool_after and last, out=out if last else None)
+            # an activation between two units has no reader but the next unit's convolution and weight gradient: where those run the F(2x2x2,3x3x3)
+            # kernels it travels in the channel-blocked layout (ops.blocked_z_wanted; a six-dimensional tensor, also in the unit's forward hooks)
+            blk = (not last) and x.dim() in (5, 6) and ops.blocked_z_wanted(x, unit._op[0].weight, self._op[k + 1]._op[0].weight, unit.training and self._op[k + 1].training)
+            x = unit(x, pool_after=pool_after and last, out=out if last else None, blocked_out=blk)
         return x
 
 

@@ -398,15 +398,18 @@ def _pack_weight_now(w: torch.Tensor, dgrad: bool, shape=None, register: bool = 
 def _conv_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, K: int, N: int,
               stats: Optional[torch.Tensor], coef: Optional[torch.Tensor] = None):
     """coef: eval-mode BatchNorm coefficients -> BatchNorm + LeakyReLU are applied by the convolution's store (one kernel per ConvUnit)"""
-    B, _, D, H, W = x.shape
-    ob, op, oc = grid_strides(out)
+    B, _, D, H, W = _dims5(x)
+    ob, op, oc = (0, 0, 1) if is_blocked(out) else grid_strides(out)
     algo = getattr(wp, "_pulpo_algo", "bf16" if wp.dtype == torch.int16 else "direct")
-    if isinstance(x, _BlockedGrad):                  # a data-gradient convolution on the blocked gradient (_blocked_dy_ok: the F(2x2x2,3x3x3) kernel)
-        if algo != "wino3" or oc != 1 or op % 4 or ob % 4 or out.data_ptr() % 16 or bias is not None or coef is not None:
-            raise PulpoHipError("conv3d on a channel-blocked operand: F(2x2x2,3x3x3) kernel, channels-last 16-byte aligned result only")
+    if isinstance(x, _BlockedGrad) or is_blocked(x) or is_blocked(out):
+        # operand and / or result in the channel-blocked layout: the F(2x2x2,3x3x3) kernel's *_kb entry (the callers have checked the kernel family)
+        xt, xb_, xp_, xkb, xblk = _opnd(x)
+        ot, ob_, op_, okb, oblk = _opnd(out)
+        if algo != "wino3" or (not oblk and (oc != 1 or op % 4 or ob % 4 or out.data_ptr() % 16)) or (not xblk and grid_strides(x)[2] != 1):
+            raise PulpoHipError("conv3d on channel-blocked tensors: F(2x2x2,3x3x3) kernel, channels-last or blocked fp32 operands only")
         t0 = _trace_begin()
-        lib.call("pulpo_conv3d_k3_fwd_wino3_kb", _ptr(x.buf), x.bs, x.ps, x.kb, _ptr(wp), None, None, LRELU_SLOPE, _ptr(out), ob, op, 8, _ptr(stats), B, D, H, W, K, N,
-                 _stream())
+        lib.call("pulpo_conv3d_k3_fwd_wino3_kb", _ptr(xt), xb_, xp_, xkb, _ptr(wp), _ptr(bias), _ptr(coef), LRELU_SLOPE, _ptr(ot), ob_, op_, okb, _ptr(stats),
+                 B, D, H, W, K, N, _stream())
         _trace_end(t0, "conv3d_k3_wino3_mfma<false>", 54.0 * K * N * B * D * H * W, 4.0 * (K + N) * B * D * H * W)
         return
     xb, xp, xc = grid_strides(x)
@@ -533,14 +536,20 @@ BLOCKED_DY_HITS = 0              # gradients written in the blocked layout so fa
 
 
 class _BlockedGrad:
-    """fp32 gradient in the layout [C / 8][B][D][H][W][8]: element (b, v, c) at  b * bs + (c // 8) * kb + v * ps + c % 8  of `buf`"""
+    """fp32 operand in the layout [C / 8][B][D][H][W][8]: element (b, v, c) at  b * bs + (c // 8) * kb + v * ps + c % 8  of `buf`"""
     __slots__ = ("buf", "shape", "bs", "ps", "kb", "dtype", "device")
 
-    def __init__(self, B, C, D, H, W, dev):
-        self.buf = torch.empty(B * C * D * H * W, device=dev, dtype=torch.float32)
+    def __init__(self, B, C, D, H, W, dev, buf=None):
+        self.buf = torch.empty(B * C * D * H * W, device=dev, dtype=torch.float32) if buf is None else buf
         self.shape = (B, C, D, H, W)
         self.ps, self.bs, self.kb = 8, D * H * W * 8, B * D * H * W * 8
         self.dtype, self.device = torch.float32, self.buf.device
+
+    @classmethod
+    def of(cls, t6: torch.Tensor):
+        """the operand view of a blocked 6-D tensor (is_blocked)"""
+        B, C, D, H, W = blocked_shape(t6)
+        return cls(B, C, D, H, W, t6.device, buf=t6)
 
     def to_cl(self) -> torch.Tensor:
         """the same values as a channels-last (B, C, D, H, W) tensor (tests, fallbacks)"""
@@ -548,17 +557,87 @@ class _BlockedGrad:
         return self.buf.view(C // 8, B, D, H, W, 8).permute(1, 0, 5, 2, 3, 4).reshape(B, C, D, H, W).contiguous(memory_format=CL)
 
 
+# ---- blocked ACTIVATIONS between the ConvUnits of a ConvSequence (round 5).  The output z of every unit but the last has two readers, the next
+# unit's convolution (forward pass) and weight gradient (src/network_blocks.py:40-46) - where both run their F(2x2x2,3x3x3) kernel it is produced as a
+# contiguous fp32 tensor of shape (C / 8, B, D, H, W, 8) (`is_blocked`: six dimensions), and autograd carries its gradient in the same shape: the next
+# unit's data-gradient kernel writes dz blocked, this unit's BatchNorm backward reads it that way.  A forward hook on such a ConvUnit sees the 6-D
+# tensor (blocked_to_cl() gives the usual view).
+# OFF by default (PULPO_BLOCKED_Z=1 / ops.BLOCKED_Z = True turns it on): alone on the machine the 32 -> 32 forward convolution at 160^3 gains 15 - 18 %
+# (0.95 -> 0.78 ms, profiles/r5_blocked_probe.txt), but inside the training step it already runs at 0.80 ms on channels-last input - the activation has
+# just been written and its tail still sits in the 256 MB Infinity Cache - and gains 3 - 5 %, while the data-gradient kernel that now stores a blocked
+# dz loses 2.5 % and the weight gradient 1.5 %: 26.53 against 26.55 ms per step, same box (profiles/r5_blocked_z_ab.txt).  The blocked dy above, whose
+# producer and consumers are all streaming / staging kernels of the backward pass, keeps 0.14 ms.
+BLOCKED_Z = os.environ.get("PULPO_BLOCKED_Z", "0") == "1"
+BLOCKED_Z_MIN_VOXELS = int(os.environ.get("PULPO_BLOCKED_Z_MIN_VOXELS", str(64 ** 3)))
+BLOCKED_Z_HITS = 0               # activations written in the blocked layout so far (tests look at it)
+
+
+def is_blocked(t) -> bool:
+    return isinstance(t, torch.Tensor) and t.dim() == 6
+
+
+def blocked_shape(t: torch.Tensor):
+    Cb, B, D, H, W, e = t.shape
+    if e != 8:
+        raise PulpoHipError(f"a six-dimensional activation must be channel-blocked (C / 8, B, D, H, W, 8), got {tuple(t.shape)}")
+    return B, Cb * 8, D, H, W
+
+
+def blocked_to_cl(t: torch.Tensor) -> torch.Tensor:
+    """(C / 8, B, D, H, W, 8) -> channels-last (B, C, D, H, W); differentiable"""
+    B, C, D, H, W = blocked_shape(t)
+    return t.permute(1, 0, 5, 2, 3, 4).reshape(B, C, D, H, W).contiguous(memory_format=CL)
+
+
+def cl_to_blocked(t: torch.Tensor) -> torch.Tensor:
+    B, C, D, H, W = t.shape
+    return t.permute(0, 2, 3, 4, 1).reshape(B, D, H, W, C // 8, 8).permute(4, 0, 1, 2, 3, 5).contiguous()
+
+
+def _opnd(t):
+    """(tensor to take the pointer of, batch stride, pixel stride, block stride, blocked?) of a convolution operand / result"""
+    if isinstance(t, _BlockedGrad):
+        return t.buf, t.bs, t.ps, t.kb, True
+    if t.dim() == 6:
+        B, C, D, H, W = blocked_shape(t)
+        return t, D * H * W * 8, 8, B * D * H * W * 8, True
+    b, p, c = grid_strides(t)
+    return t, b, p, 8, False
+
+
+def _dims5(t):
+    return t.shape if isinstance(t, _BlockedGrad) else (blocked_shape(t) if t.dim() == 6 else tuple(t.shape))
+
+
+def blocked_z_wanted(x, unit_weight, next_weight, training: bool) -> bool:
+    """should the ConvUnit with `unit_weight`, applied to x, hand its output to the unit with `next_weight` in the blocked layout?"""
+    if not (BLOCKED_Z and training and torch.is_grad_enabled() and CONV_PRECISION == "fp32" and not ACT_BF16 and next_weight.requires_grad
+            and isinstance(x, torch.Tensor) and x.dim() in (5, 6) and x.is_cuda):
+        return False
+    B, _, D, H, W = _dims5(x)
+    C, Cn = unit_weight.shape[0], next_weight.shape[0]
+    if C % 8 or next_weight.shape[1] != C or D * H * W < BLOCKED_Z_MIN_VOXELS or 4 * B * max(C, Cn) * D * H * W >= 2 ** 31:
+        return False
+    if lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, C, Cn, 1) != 3:
+        return False
+    shape = (B, D, H, W)
+    return (getattr(_pack_weight(next_weight, False, shape=shape, both=True), "_pulpo_algo", "") == "wino3"
+            and getattr(_pack_weight(next_weight, True, shape=shape), "_pulpo_algo", "") == "wino3")
+
+
 def _blocked_dy_ok(x, y, weight, wpt, need_dx: bool, need_dw: bool) -> bool:
-    B, Cin, D, H, W = x.shape
+    B, Cin, D, H, W = _dims5(x)
     Cout = weight.shape[0]
     if not (BLOCKED_DY and need_dx and y.dtype == torch.float32 and Cout % 8 == 0 and D * H * W >= BLOCKED_DY_MIN_VOXELS
             and getattr(wpt, "_pulpo_algo", "") == "wino3" and 4 * B * Cout * D * H * W < 2 ** 31):
         return False
     if need_dw:
-        xb, xp, xc = grid_strides(x)
-        if (_use_bf16(Cin) or x.dtype != torch.float32 or xc != 1 or xp % 4 or xb % 4 or Cin % 4 or x.data_ptr() % 16
-                or lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, Cin, Cout, 1) != 3):
+        if _use_bf16(Cin) or x.dtype != torch.float32 or lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, Cin, Cout, 1) != 3:
             return False
+        if not is_blocked(x):
+            xb, xp, xc = grid_strides(x)
+            if xc != 1 or xp % 4 or xb % 4 or Cin % 4 or x.data_ptr() % 16:
+                return False
     return True
 
 
@@ -566,14 +645,20 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
                owner: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """weight gradient; `into` -> accumulated into that (Cout,Cin,3,3,3) tensor in place, returns None.  With `owner` (the weight parameter,
     data-parallel stepper) the accumulation is DEFERRED to flush_param_grads(): the packed sums stay in the parameter's persistent scratch."""
-    B, _, D, H, W = x.shape
+    B, _, D, H, W = _dims5(x)
+    if is_blocked(x) and (_use_bf16(Cin) or lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, Cin, Cout, 1) != 3):
+        x = blocked_to_cl(x)                         # (a blocked operand outside the F(2x2x2,3x3x3) kernel's shapes: a copy - BLOCKED_Z switched between passes)
     deferred = into is not None and owner is not None
     dw = into if into is not None else torch.empty((Cout, Cin, 3, 3, 3), device=x.device, dtype=torch.float32)
     nscr = lib.query("pulpo_conv3d_k3_wgrad_scratch_floats", Cin, Cout)
     scratch = _persistent_buffer(owner, "_pulpo_wgrad_scratch", nscr, zero=True) if deferred else torch.empty(nscr, device=x.device, dtype=torch.float32)
-    xb, xp, xc = grid_strides(x)
-    blocked = isinstance(dy, _BlockedGrad)
-    db, dp, dc = (dy.bs, dy.ps, 1) if blocked else grid_strides(dy)
+    xblk = is_blocked(x)
+    xt, xb, xp, xkb, _ = _opnd(x)
+    xc = 1 if xblk else grid_strides(x)[2]
+    blocked = isinstance(dy, _BlockedGrad) or xblk
+    if blocked and not isinstance(dy, _BlockedGrad):
+        dy = to_cl(dy.float())
+    db, dp, dc = (dy.bs, dy.ps, 1) if isinstance(dy, _BlockedGrad) else grid_strides(dy)
     t0 = _trace_begin()
     sfx = "_bf16" if _use_bf16(Cin) else ""
     det = ()
@@ -584,7 +669,8 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
         det = (_ptr(slabs), nslab)
     if blocked:
         # (_blocked_dy_ok has checked: fp32 operands, channels-last x, the F(2x2x2,3x3x3) weight-gradient kernel takes the shape)
-        lib.call("pulpo_conv3d_k3_wgrad_kb", _ptr(x), xb, xp, 8, _ptr(dy.buf), db, dp, dy.kb, _ptr(dw), 2 if deferred else int(into is not None), _ptr(scratch),
+        dyt, _, _, dkb, _ = _opnd(dy)
+        lib.call("pulpo_conv3d_k3_wgrad_kb", _ptr(xt), xb, xp, xkb, _ptr(dyt), db, dp, dkb, _ptr(dw), 2 if deferred else int(into is not None), _ptr(scratch),
                  *(det if det else (None, 0)), B, D, H, W, Cin, Cout, _stream())
     elif sfx:
         if x.dtype != dy.dtype:                      # (one storage type per launch; a mixed pair - a user's fp32 input to a bf16-storage unit - is rare)
@@ -613,7 +699,7 @@ def _wgrad_raw(x: torch.Tensor, dy: torch.Tensor, Cin: int, Cout: int, into: Opt
             vec = (xc == 1 and xp % 4 == 0 and xb % 4 == 0 and Cin % 4 == 0 and x.data_ptr() % 16 == 0 and dc == 1 and dp % 4 == 0 and db % 4 == 0
                    and Cout % 4 == 0 and dy.data_ptr() % 16 == 0)
             name = ("conv3d_k3_wgrad_mfma", "conv3d_k3_wgrad_wino", "conv3d_k3_wgrad_w2", "conv3d_k3_wgrad_w3x")[lib.query("pulpo_conv3d_k3_wgrad_algo", B, D, H, W, Cin, Cout, int(vec))]
-        _trace_end(t0, name + ("" if deferred else "(+memset,unpack)"), 54.0 * Cin * Cout * B * D * H * W, (_esize(x) * Cin + (4 if blocked else _esize(dy)) * Cout) * B * D * H * W)
+        _trace_end(t0, name + ("" if deferred else "(+memset,unpack)"), 54.0 * Cin * Cout * B * D * H * W, ((4 if blocked else _esize(x)) * Cin + (4 if blocked else _esize(dy)) * Cout) * B * D * H * W)
     return None if into is not None else dw
 
 
@@ -658,22 +744,25 @@ def _dgrad_with_bn_reduction(bn_src, x, dy, wpt, dx, K: int, N: int) -> bool:
     if bn_src is None or not BN_REDUCE_IN_DGRAD or algo not in ("wino2", "wino3"):
         return False
     y_prev, coef_prev = bn_src
-    B, _, D, H, W = dy.shape
-    blocked = isinstance(dy, _BlockedGrad)
-    db, dp, dc = (dy.bs, dy.ps, 1) if blocked else grid_strides(dy)
-    ob, op, oc = grid_strides(dx)
+    B, _, D, H, W = _dims5(dy)
+    dyt, db, dp, dkb, blocked = _opnd(dy)
+    dc = 1 if blocked else grid_strides(dy)[2]
+    dxt, ob, op, okb, oblk = _opnd(dx)
+    oc = 1 if oblk else grid_strides(dx)[2]
+    if (blocked or oblk) and algo != "wino3":
+        return False
     yb, yp, yc = grid_strides(y_prev)
     # (the C entry point also needs the gradient operand vectorisable: channels-last, 16-byte aligned, K % 4 == 0 - checked here so that a
     #  consumer unit with an odd channel count falls back to the separate reduction pass instead of raising in the middle of backward)
     vec_ok = blocked or (dc == 1 and dp % 4 == 0 and db % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0)
-    if (not vec_ok or y_prev.shape != dx.shape or oc != 1 or yc != 1 or op % 4 or ob % 4 or yp % 4 or yb % 4 or dx.data_ptr() % 16
+    if (not vec_ok or tuple(y_prev.shape) != tuple(_dims5(dx)) or oc != 1 or yc != 1 or op % 4 or ob % 4 or yp % 4 or yb % 4 or dx.data_ptr() % 16
             or y_prev.data_ptr() % 16 or not lib.query("pulpo_conv3d_k3_dgrad_wino2_bnred_ok", B, D, H, W, K, N)):
         return False
     ntile = lib.query("pulpo_conv3d_k3_stat_tiles", B, D, H, W)
     part = torch.empty(ntile * 2 * N, device=dy.device, dtype=torch.float32)
     t0 = _trace_begin()
-    if blocked:                                      # (algo == "wino3": _blocked_dy_ok)
-        lib.call("pulpo_conv3d_k3_dgrad_wino3_bnred_kb", _ptr(dy.buf), db, dp, dy.kb, _ptr(wpt), _ptr(dx), ob, op, 8, _ptr(y_prev), yb, yp, _ptr(coef_prev),
+    if blocked or oblk:
+        lib.call("pulpo_conv3d_k3_dgrad_wino3_bnred_kb", _ptr(dyt), db, dp, dkb, _ptr(wpt), _ptr(dxt), ob, op, okb, _ptr(y_prev), yb, yp, _ptr(coef_prev),
                  LRELU_SLOPE, _ptr(part), B, D, H, W, K, N, _stream())
     else:
         lib.call(f"pulpo_conv3d_k3_dgrad_{algo}_bnred", _ptr(dy), db, dp, dc, _ptr(wpt), _ptr(dx), ob, op, _ptr(y_prev), yb, yp, _ptr(coef_prev), LRELU_SLOPE,
@@ -752,18 +841,23 @@ class _ConvBNLReLU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool, momentum: float, eps: float,
-                bn_src=None, pool_after: bool = False, pool_only: bool = False):
+                bn_src=None, pool_after: bool = False, pool_only: bool = False, blocked_out: bool = False):
         _require_gpu(x, act=True)
         _require_gpu(weight, bias, gamma, beta)
         ctx.bn_src = bn_src
-        x = as_grid(x)
-        B, Cin, D, H, W = x.shape
+        # x: (B, C, D, H, W), or the blocked output (C / 8, B, D, H, W, 8) of the previous ConvUnit of the sequence (is_blocked)
+        ctx.dx_blocked = is_blocked(x)
+        if not ctx.dx_blocked:
+            x = as_grid(x)
+        B, Cin, D, H, W = _dims5(x)
         Cout = weight.shape[0]
         dev = x.device
         wp = _pack_weight(weight, dgrad=False, shape=(B, D, H, W), both=bool(training and ctx.needs_input_grad[0]))
         # storage types (ACT_BF16): z - what the next operator reads - is bf16; the pre-norm tensor y is bf16 when the bf16-operand kernel
         # produces it and fp32 behind the exact-fp32 kernel of the <= 4-channel input layers; the kernels take operand and result in ONE type
         half_conv = ACT_BF16 and wp._pulpo_algo == "bf16"
+        if ctx.dx_blocked and (wp._pulpo_algo != "wino3" or half_conv or not training):
+            x = blocked_to_cl(x)                     # (a blocked activation in front of another kernel family: the producer's check and this call disagree - a copy)
         if x.dtype != (torch.bfloat16 if half_conv else torch.float32):
             x = x.to(torch.bfloat16 if half_conv else torch.float32)
         ydt = torch.bfloat16 if half_conv else torch.float32
@@ -790,12 +884,21 @@ class _ConvBNLReLU(torch.autograd.Function):
             _conv_raw(x, wp, bias, y, Cin, Cout, None)
         # pool_only: nobody reads the un-pooled activation (DownPath levels above the first latent level: only AvgPool(z) goes on) - it is not written
         pool_only = bool(pool_only and pool_after and lib.query("pulpo_bn_lrelu_apply_pool2_ok", Cout, y.stride(4), Cout, Cout))
-        z = None if pool_only else _take_out_slot(B, Cout, D, H, W, dev, zdt)
-        if z is None and not pool_only:
+        blocked_out = bool(blocked_out and training and not pool_after and not pool_only and zdt == torch.float32 and ydt == torch.float32 and Cout % 8 == 0)
+        z = None if (pool_only or blocked_out) else _take_out_slot(B, Cout, D, H, W, dev, zdt)
+        if z is None and not pool_only and not blocked_out:
             z = new_cl(B, Cout, D, H, W, dev, zdt)
         pooled = None
         nbytes = (_esize(y) + (0 if pool_only else (2.0 if zdt == torch.bfloat16 else 4.0))) * Cout * B * D * H * W             # read y, write z
-        if pool_only or (pool_after and lib.query("pulpo_bn_lrelu_apply_pool2_ok", Cout, y.stride(4), z.stride(4), Cout)):
+        if blocked_out:
+            # the next ConvUnit of the sequence reads z through its F(2x2x2,3x3x3) kernels only (blocked_z_wanted): [Cout / 8][B][D][H][W][8]
+            global BLOCKED_Z_HITS
+            BLOCKED_Z_HITS += 1
+            z = torch.empty((Cout // 8, B, D, H, W, 8), device=dev, dtype=torch.float32)
+            t0 = _hbm_begin("bn_lrelu_apply")
+            lib.call("pulpo_bn_lrelu_apply_kb", _ptr(y), y.stride(4), _ptr(z), 8, B * D * H * W * 8, _ptr(coef), B * D * H * W, Cout, LRELU_SLOPE, _stream())
+            _hbm_end(t0, "bn_lrelu_apply", nbytes)
+        elif pool_only or (pool_after and lib.query("pulpo_bn_lrelu_apply_pool2_ok", Cout, y.stride(4), z.stride(4), Cout)):
             # the caller pools this output next (DownPath): z and AvgPool(z) from one read of y; avg_pool2_skip() picks the pooled tensor up
             pooled = new_cl(B, Cout, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, dev, zdt)
             t0 = _hbm_begin("bn_lrelu_apply")
@@ -829,11 +932,15 @@ class _ConvBNLReLU(torch.autograd.Function):
         if ctx.pool_only:                            # (the node's only output is the pooled tensor)
             dz, dpool = None, dz
         x, weight, y, coef = ctx.saved_tensors
-        B, Cin, D, H, W = x.shape
+        B, Cin, D, H, W = _dims5(x)
         Cout = weight.shape[0]
         dev = x.device
         npix = B * D * H * W
         nblk = lib.query("pulpo_bn_bwd_blocks", npix, Cout)
+        NG = 15                                      # inputs of forward()
+        dz_blk = is_blocked(dz)                      # the gradient of a blocked activation arrives blocked (the next unit's data-gradient kernel wrote it so)
+        if dz_blk and (dz.dtype != torch.float32 or not dz.is_contiguous() or tuple(blocked_shape(dz)) != (B, Cout, D, H, W)):
+            dz, dz_blk = blocked_to_cl(dz.float()), False
         pooled_src = None                            # (gpool, gskip or None): dz = gskip + avg_pool_backward(gpool), never written
         if dpool is not None:
             gp = to_cl(dpool)
@@ -858,7 +965,7 @@ class _ConvBNLReLU(torch.autograd.Function):
                         gin = gin + gz
                 dz = gin
         elif dz is None:
-            return (None,) * 14
+            return (None,) * NG
         tiles = None
         if pooled_src is not None:
             gp, gz = pooled_src
@@ -869,10 +976,13 @@ class _ConvBNLReLU(torch.autograd.Function):
             # read the pooled gradient, the skip gradient and y (the summed gradient is not written)
             _hbm_end(t0, "avgpool2_bwd_bnred", Cout * (_esize(gp) * (gp.numel() // Cout + (npix if gz is not None else 0)) + _esize(y) * npix))
         else:
-            dz = to_cl(dz)
+            if not dz_blk:
+                dz = to_cl(dz)
             # first pass (sum dbn, sum dbn * xhat): already done by the epilogue of the data-gradient convolution that PRODUCED dz, if that was
             # the ConvUnit behind this one (see _BN_TILE_PARTS); else a pass of its own over dz and y
             tiles = _take_bn_tile_parts(y, coef, dz)
+            if tiles is None and dz_blk:             # (the separate reduction pass reads channels-last: autograd summed several gradients of z - a copy)
+                dz, dz_blk = blocked_to_cl(dz), False
         if tiles is None and pooled_src is None:
             part = torch.empty(nblk * 2 * Cout, device=dev, dtype=torch.float32)
             t0 = _hbm_begin("bn_lrelu_bwd_reduce")
@@ -895,12 +1005,12 @@ class _ConvBNLReLU(torch.autograd.Function):
         # gradient, which then forms it per element while staging (pulpo_conv3d_k3_wgrad_bn) instead of a pass that reads dz and y and writes dy
         # (0.29 ms at 160^3 x 32 channels).  PULPO_FUSE_INPUT_WGRAD=0: the separate pass (A/B switch).
         if (FUSE_INPUT_WGRAD and pooled_src is None and Cin <= 2 and not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not DETERMINISTIC and y.dtype == torch.float32
-                and Cout % 4 == 0 and is_cl(y) and is_cl(dz) and y.stride(4) % 4 == 0 and dz.stride(4) % 4 == 0 and x.dtype == torch.float32):
+                and Cout % 4 == 0 and is_cl(y) and (dz_blk or (is_cl(dz) and dz.stride(4) % 4 == 0)) and y.stride(4) % 4 == 0 and x.dtype == torch.float32):
             return _ConvBNLReLU._backward_input_layer(ctx, dz, x, weight, y, coef, totd, tot, direct_bn, (slot_w, slot_b), (w_p, b_p))
         # the data-gradient weights now (cached pack): their kernel family decides dy's layout
         wpt = _pack_weight(weight, dgrad=True, shape=(B, D, H, W)) if ctx.needs_input_grad[0] else None
         blocked = (_blocked_dy_ok(x, y, weight, wpt, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-                   and (pooled_src is not None or (is_cl(dz) and dz.stride(4) % 4 == 0)) and is_cl(y) and y.stride(4) % 4 == 0)
+                   and (pooled_src is not None or dz_blk or (is_cl(dz) and dz.stride(4) % 4 == 0)) and is_cl(y) and y.stride(4) % 4 == 0)
         if blocked:
             global BLOCKED_DY_HITS
             BLOCKED_DY_HITS += 1
@@ -924,9 +1034,11 @@ class _ConvBNLReLU(torch.autograd.Function):
                          y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4), LRELU_SLOPE, _ptr(part2), B, D, H, W, Cout, _stream())
             _hbm_end(t0, "bn_lrelu_bwd_apply", Cout * (_esize(gp) * (gp.numel() // Cout + (npix if gz is not None else 0)) + 2 * _esize(y) * npix))
         else:
-            if blocked:
-                lib.call("pulpo_bn_lrelu_bwd_apply_kb_t", _ptr(dz), _dt(dz), dz.stride(4), _ptr(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy.buf), dy.ps, dy.kb,
-                         npix, Cout, LRELU_SLOPE, _ptr(part2), _stream())
+            if blocked or dz_blk:
+                dzs = (8, npix * 8) if dz_blk else (dz.stride(4), 8)
+                dys = (_ptr(dy.buf), dy.ps, dy.kb) if blocked else (_ptr(dy), dy.stride(4), 8)
+                lib.call("pulpo_bn_lrelu_bwd_apply_kb_t", _ptr(dz), _dt(dz), *dzs, _ptr(y), y.stride(4), _ptr(coef), _ptr(totd), *dys, npix, Cout, LRELU_SLOPE,
+                         _ptr(part2), _stream())
             else:
                 lib.call("pulpo_bn_lrelu_bwd_apply_t", _ptr(dz), _dt(dz), dz.stride(4), _ptr(y), _dt(y), y.stride(4), _ptr(coef), _ptr(totd), _ptr(dy), dy.stride(4),
                          npix, Cout, LRELU_SLOPE, _ptr(part2), _stream())
@@ -942,12 +1054,20 @@ class _ConvBNLReLU(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # (the bf16-operand kernel takes operand and result in one storage type; every other kernel is fp32)
             dyc = dy if (wpt._pulpo_algo == "bf16" or dy.dtype == torch.float32) else dy.float()
-            dx = torch.empty_like(x, dtype=dyc.dtype) if (x.is_contiguous() and Cin <= 3) else new_cl(B, Cin, D, H, W, dev, dyc.dtype)
+            dx_blk = ctx.dx_blocked and wpt._pulpo_algo == "wino3" and dyc.dtype == torch.float32
+            if dx_blk:                                   # the input was a blocked activation: its gradient in the same layout, straight from the kernel
+                dx = torch.empty((Cin // 8, B, D, H, W, 8), device=dev, dtype=torch.float32)
+            elif is_blocked(x) or not (x.is_contiguous() and Cin <= 3):
+                dx = new_cl(B, Cin, D, H, W, dev, dyc.dtype)
+            else:
+                dx = torch.empty_like(x, dtype=dyc.dtype)
             if not _dgrad_with_bn_reduction(ctx.bn_src, x, dyc, wpt, dx, Cout, Cin):
                 _conv_raw(dyc, wpt, None, dx, Cout, Cin, None)
+            if ctx.dx_blocked and not dx_blk:
+                dx = cl_to_blocked(dx.float())
         if defer_w:
             _wgrad_on_side_stream(x, dy, Cin, Cout, slot_w, w_p)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def _backward_input_layer(ctx, dz, x, weight, y, coef, totd, tot, direct_bn, slots, params):
@@ -971,8 +1091,12 @@ def _backward_input_layer(ctx, dz, x, weight, y, coef, totd, tot, direct_bn, slo
 
     def launch():
         t0 = _trace_begin()
-        lib.call("pulpo_conv3d_k3_wgrad_bn", _ptr(x), xb, xp, xc, _ptr(dz), _dt(dz), dz.stride(0), dz.stride(4), _ptr(y), y.stride(0), y.stride(4), _ptr(coef),
-                 _ptr(totd), LRELU_SLOPE, _ptr(dw), 2 if deferred else int(slot_w is not None), _ptr(scratch), _ptr(part2), B, D, H, W, Cin, Cout, _stream())
+        if is_blocked(dz):                           # (the gradient of a blocked activation: the next unit's data-gradient kernel wrote it that way)
+            lib.call("pulpo_conv3d_k3_wgrad_bn_kb", _ptr(x), xb, xp, xc, _ptr(dz), D * H * W * 8, 8, B * D * H * W * 8, _ptr(y), y.stride(0), y.stride(4), _ptr(coef),
+                     _ptr(totd), LRELU_SLOPE, _ptr(dw), 2 if deferred else int(slot_w is not None), _ptr(scratch), _ptr(part2), B, D, H, W, Cin, Cout, _stream())
+        else:
+            lib.call("pulpo_conv3d_k3_wgrad_bn", _ptr(x), xb, xp, xc, _ptr(dz), _dt(dz), dz.stride(0), dz.stride(4), _ptr(y), y.stride(0), y.stride(4), _ptr(coef),
+                     _ptr(totd), LRELU_SLOPE, _ptr(dw), 2 if deferred else int(slot_w is not None), _ptr(scratch), _ptr(part2), B, D, H, W, Cin, Cout, _stream())
         _trace_end(t0, "conv3d_k3_wgrad_smallc(+bn backward)" + ("" if deferred else "(+memset,unpack)"), 54.0 * Cin * Cout * B * D * H * W,
                    (4.0 * Cin + (_esize(dz) + 4.0) * Cout) * B * D * H * W)
 
@@ -994,7 +1118,7 @@ def _backward_input_layer(ctx, dz, x, weight, y, coef, totd, tot, direct_bn, slo
         _PENDING_KEEPALIVE.append(part2)
     dbias = _colsum(part2, nrow, Cout, into=slot_b) if (ctx.needs_input_grad[2] and not defer_b) else None
     dbeta, dgamma = (None, None) if direct_bn else (tot[:Cout], tot[Cout:])
-    return None, (None if slot_w is not None else dw), dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+    return None, (None if slot_w is not None else dw), dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 _ConvBNLReLU._backward_input_layer = staticmethod(_backward_input_layer)
@@ -1004,12 +1128,14 @@ POOLED_BN_BACKWARD = os.environ.get("PULPO_POOLED_BN_BACKWARD", "1") != "0"
 
 
 def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, training=True, momentum=0.1, eps=1e-5, num_batches_tracked=None,
-                  pool_after: bool = False, out=None, pool_only: bool = False):
+                  pool_after: bool = False, out=None, pool_only: bool = False, blocked_out: bool = False):
     """ConvUnit forward.  In training mode running_mean / running_var / num_batches_tracked are updated in place by the kernel.
     pool_after: the caller applies avg_pool2_skip() to the result next - where the shapes allow, the pooled tensor is produced by the same
     pass that writes the result and waits on it (`_pulpo_pooled`).
     out: (buffer, first channel) - the result is written into that channel range of a wider channels-last buffer and returned as its slice,
-    tagged `_pulpo_cat` (see cat_channels); ignored where the shapes do not fit."""
+    tagged `_pulpo_cat` (see cat_channels); ignored where the shapes do not fit.
+    x may be the blocked output (C / 8, B, D, H, W, 8) of the previous ConvUnit of a sequence; blocked_out: produce this unit's output in that form
+    (network_blocks.ConvSequence asks ops.blocked_z_wanted first)."""
     if _is2d(x):
         return conv_bn_lrelu(_lift(x), _lift_w3(weight), bias, gamma, beta, running_mean, running_var, training, momentum, eps,
                              num_batches_tracked).squeeze(2)
@@ -1022,7 +1148,7 @@ def conv_bn_lrelu(x, weight, bias, gamma, beta, running_mean, running_var, train
     pool_only = bool(pool_only and pool_after and training and torch.is_grad_enabled())
     _TLS.pool_only_done = False
     z = _ConvBNLReLU.apply(x, weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
-                           float(eps), bn_src, bool(pool_after), pool_only)
+                           float(eps), bn_src, bool(pool_after), pool_only, bool(blocked_out))
     pooled_out = None
     if isinstance(z, tuple):
         z, pooled_out = z

@@ -1422,8 +1422,24 @@ def test_batchnorm_backward_apply_writes_the_blocked_layout(ops, B, C, size, poo
         dz = torch.randn(B, C, D, H, W, generator=gen).cuda().contiguous(memory_format=torch.channels_last_3d)
         lib.call("pulpo_bn_lrelu_bwd_apply_t", ops._ptr(dz), 0, dz.stride(4), ops._ptr(y), 0, y.stride(4), ops._ptr(coef), ops._ptr(totd), ops._ptr(dy0),
                  dy0.stride(4), npix, C, 0.2, ops._ptr(p0), st)
-        lib.call("pulpo_bn_lrelu_bwd_apply_kb_t", ops._ptr(dz), 0, dz.stride(4), ops._ptr(y), y.stride(4), ops._ptr(coef), ops._ptr(totd), ops._ptr(dy1.buf),
+        lib.call("pulpo_bn_lrelu_bwd_apply_kb_t", ops._ptr(dz), 0, dz.stride(4), 8, ops._ptr(y), y.stride(4), ops._ptr(coef), ops._ptr(totd), ops._ptr(dy1.buf),
                  dy1.ps, dy1.kb, npix, C, 0.2, ops._ptr(p1), st)
+        # dz blocked as well (the gradient of a blocked activation), dy channels-last and blocked
+        dzb = ops.cl_to_blocked(dz)
+        assert torch.equal(ops.blocked_to_cl(dzb), dz)
+        dy2, p2 = ops.new_cl(B, C, D, H, W, y.device), torch.empty(nblk * C, device="cuda")
+        lib.call("pulpo_bn_lrelu_bwd_apply_kb_t", ops._ptr(dzb), 0, 8, npix * 8, ops._ptr(y), y.stride(4), ops._ptr(coef), ops._ptr(totd), ops._ptr(dy2),
+                 dy2.stride(4), 8, npix, C, 0.2, ops._ptr(p2), st)
+        assert torch.equal(dy2, dy0) and torch.equal(p2, p0)
+        dy3 = ops._BlockedGrad(B, C, D, H, W, y.device)
+        lib.call("pulpo_bn_lrelu_bwd_apply_kb_t", ops._ptr(dzb), 0, 8, npix * 8, ops._ptr(y), y.stride(4), ops._ptr(coef), ops._ptr(totd), ops._ptr(dy3.buf),
+                 dy3.ps, dy3.kb, npix, C, 0.2, ops._ptr(p2), st)
+        assert torch.equal(dy3.to_cl(), dy0) and torch.equal(p2, p0)
+        # the forward pass's counterpart: z blocked
+        z0, z1 = ops.new_cl(B, C, D, H, W, y.device), torch.empty(C // 8, B, D, H, W, 8, device="cuda")
+        lib.call("pulpo_bn_lrelu_apply", ops._ptr(y), y.stride(4), ops._ptr(z0), z0.stride(4), ops._ptr(coef), npix, C, 0.2, st)
+        lib.call("pulpo_bn_lrelu_apply_kb", ops._ptr(y), y.stride(4), ops._ptr(z1), 8, npix * 8, ops._ptr(coef), npix, C, 0.2, st)
+        assert torch.equal(ops.blocked_to_cl(z1), z0)
     assert torch.equal(dy1.to_cl(), dy0)
     assert torch.equal(p0, p1)
 
@@ -1451,3 +1467,48 @@ def test_weight_gradient_on_the_channel_blocked_gradient(ops, B, Cin, Cout, size
         assert rel_l2(g1, g0) < 1e-5
     ref = torch.nn.grad.conv3d_weight(x.double(), (Cout, Cin, 3, 3, 3), dy.double(), padding=1)
     assert rel_l2(g1, ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,chans,size", [(1, (2, 32, 32, 32), (64, 64, 64)), (2, (16, 32, 64, 64), (32, 64, 64)), (1, (24, 48, 48), (64, 32, 64))])
+def test_conv_sequence_with_blocked_activations_between_its_units(ops, B, chans, size):
+    """the activations between the ConvUnits of a sequence as (C / 8, B, D, H, W, 8) tensors (ops.BLOCKED_Z; the input layer's fused BatchNorm backward
+    reads a blocked dz; two batch elements; 24 -> 48 -> 48 channels): outputs bit-identical to the channels-last run, every parameter and input
+    gradient within the summation-order noise of the atomics, hooks see the 6-D tensors"""
+    import src.network_blocks as nb
+    torch.manual_seed(5)
+    units = [nb.ConvUnit(list(size), chans[k], chans[k + 1]) for k in range(len(chans) - 1)]
+    seq = nb.ConvSequence(list(size), chans[0], chans[1], 1)
+    seq._op = torch.nn.Sequential(*units)
+    seq = seq.cuda().train()
+    state = {k: v.clone() for k, v in seq.state_dict().items()}
+    gen = torch.Generator().manual_seed(B + sum(chans))
+    x = torch.randn(B, chans[0], *size, generator=gen).cuda().requires_grad_(chans[0] > 3)
+    up = torch.randn(B, chans[-1], *size, generator=gen).cuda()
+    seen = []
+    for u in units[:-1]:
+        u.register_forward_hook(lambda m, i, o: seen.append(o.dim()))
+
+    def run(on):
+        seq.load_state_dict(state)
+        was, was_min = ops.BLOCKED_Z, ops.BLOCKED_Z_MIN_VOXELS
+        ops.BLOCKED_Z, ops.BLOCKED_Z_MIN_VOXELS = on, 1
+        try:
+            z = seq(x)
+            ps = list(seq.parameters()) + ([x] if x.requires_grad else [])
+            return z, torch.autograd.grad((z * up).sum(), ps)
+        finally:
+            ops.BLOCKED_Z, ops.BLOCKED_Z_MIN_VOXELS = was, was_min
+
+    h0 = ops.BLOCKED_Z_HITS
+    z1, g1 = run(True)
+    assert ops.BLOCKED_Z_HITS > h0 and 6 in seen, "no unit of the sequence produced a blocked activation"
+    seen.clear()
+    z0, g0 = run(False)
+    assert seen and all(d == 5 for d in seen)
+    assert z1.dim() == 5 and torch.equal(z1, z0)
+    names = [n for n, _ in seq.named_parameters()] + (["x"] if x.requires_grad else [])
+    for a, b, nme in zip(g1, g0, names):
+        if nme.endswith("0.bias"):                   # (conv bias in front of a BatchNorm: true gradient zero)
+            assert float((a - b).abs().max()) <= 1e-4 * max(float(g0[0].abs().max()), 1e-6), nme
+        else:
+            assert rel_l2(a, b) < 2e-5, (nme, rel_l2(a, b))

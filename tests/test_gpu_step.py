@@ -49,6 +49,9 @@ def _record_unit(store, name, out):
     if isinstance(out, tuple):
         out = out[0]
     if out is not None:
+        if out.dim() == 6:                           # (round 5: the activation between two units of a ConvSequence may travel channel-blocked)
+            from pulpo_amd import ops
+            out = ops.blocked_to_cl(out)
         store[name] = out.detach()
 
 
@@ -1423,12 +1426,13 @@ def test_graphed_step_equals_the_eager_step(api, precision):
             assert torch.equal(sd_g[k], v), k
 
 
-@pytest.mark.parametrize("switch", ["prewritten_cat", "skip_unused_activations", "pooled_bn_backward", "fuse_input_wgrad", "blocked_dy"])
+@pytest.mark.parametrize("switch", ["prewritten_cat", "skip_unused_activations", "pooled_bn_backward", "fuse_input_wgrad", "blocked_dy", "blocked_z"])
 def test_round5_fusions_equal_the_separate_passes(api, switch):
     """Each round-5 shortcut of the step switched OFF gives the same training step as the shipped default: concatenation buffers written in place
     (ops.cat_channels), activations nobody reads not written (DownPath `_needed`), the gradient of a pooled ConvUnit output formed inside the
     BatchNorm-backward passes (ops.POOLED_BN_BACKWARD), the input layer's BatchNorm backward inside its weight gradient (ops.FUSE_INPUT_WGRAD), the
-    gradient of the pre-norm tensors in the channel-blocked layout where the F(2x2x2,3x3x3) kernels read it (ops.BLOCKED_DY).
+    gradient of the pre-norm tensors in the channel-blocked layout where the F(2x2x2,3x3x3) kernels read it (ops.BLOCKED_DY), the activations between
+    the units of a ConvSequence and their gradients in that layout (ops.BLOCKED_Z).
     n0 = 16 at 64^3 / T3 / L2 so that the channel counts take the in-place buffers (multiples of 8) and the kernels of the large levels run.
     Loss bit-equal (the forward pass computes the same values), every parameter gradient within 1e-5 (summation order of fp32 partial sums)."""
     models, nb = api
@@ -1447,8 +1451,10 @@ def test_round5_fusions_equal_the_separate_passes(api, switch):
             model.downpath._pulpo_skip_room = {}
         if off == "skip_unused_activations":
             model._needed_levels = None
-        saved = (ops.POOLED_BN_BACKWARD, ops.FUSE_INPUT_WGRAD, ops.BLOCKED_DY)
+        saved = (ops.POOLED_BN_BACKWARD, ops.FUSE_INPUT_WGRAD, ops.BLOCKED_DY, ops.BLOCKED_Z)
         try:
+            if off == "blocked_z":                  # (an opt-in: this one is switched ON against the default)
+                ops.BLOCKED_Z = True
             if off == "blocked_dy":
                 ops.BLOCKED_DY = False
             if off == "pooled_bn_backward":
@@ -1459,21 +1465,23 @@ def test_round5_fusions_equal_the_separate_passes(api, switch):
             total.backward()
             torch.cuda.synchronize()
         finally:
-            ops.POOLED_BN_BACKWARD, ops.FUSE_INPUT_WGRAD, ops.BLOCKED_DY = saved
+            ops.POOLED_BN_BACKWARD, ops.FUSE_INPUT_WGRAD, ops.BLOCKED_DY, ops.BLOCKED_Z = saved
         used = hasattr(outs[0][0], "shape")
         assert used
         return float(total), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}, model
 
-    hits0, blk0 = ops.CAT_PREWRITTEN_HITS, ops.BLOCKED_DY_HITS
+    hits0, blk0, blz0 = ops.CAT_PREWRITTEN_HITS, ops.BLOCKED_DY_HITS, ops.BLOCKED_Z_HITS
     loss_on, g_on, m_on = run(None)
-    blk1 = ops.BLOCKED_DY_HITS
+    blk1, blz1 = ops.BLOCKED_DY_HITS, ops.BLOCKED_Z_HITS
     assert blk1 > blk0, "no ConvUnit of the 64^3 level took the channel-blocked gradient"
+    assert blz1 == blz0, "blocked activations are an opt-in"
     assert getattr(m_on.downpath, "_pulpo_skip_room", None), "the in-place concatenation buffers are not armed"
     assert ops.CAT_PREWRITTEN_HITS == hits0 + (L - 1), "the encoders' concatenations did not take the in-place buffers"
     hits1 = ops.CAT_PREWRITTEN_HITS
     loss_off, g_off, _ = run(switch)
     assert (ops.CAT_PREWRITTEN_HITS == hits1) == (switch == "prewritten_cat")
     assert (ops.BLOCKED_DY_HITS == blk1) == (switch == "blocked_dy")
+    assert (ops.BLOCKED_Z_HITS > blz1) == (switch == "blocked_z"), "no ConvUnit of the 64^3 level handed a channel-blocked activation to the next one"
     assert loss_on == loss_off
     assert g_on.keys() == g_off.keys()
     for k, g in g_on.items():
