@@ -70,6 +70,9 @@ constexpr int Q_PART = 8 * 64 * 8;               // a wave's per-lane statistics
 constexpr size_t Q_LDS = (size_t)(2 * Q_IMG + Q_TAB + Q_R + Q_RED + Q_PART) * sizeof(float);
 static_assert(Q_LDS <= 160 * 1024, "one workgroup per CU");
 
+#ifndef PULPO_W3_YEARLY
+#define PULPO_W3_YEARLY 1          // BNR epilogue: y requested early (see the epilogue)
+#endif
 #ifndef PULPO_W3_SKEW
 #define PULPO_W3_SKEW 1          // 1: the two waves of a SIMD (w and w + 4) do their halo staging in DIFFERENT pairs of a chunk (see the kernel below)
 #endif
@@ -434,6 +437,19 @@ __device__ __forceinline__ void wino3_body(const ConvArgs& a) {
         W3_NOW(t_e0);
 #endif
         // x inverse transform (4 px -> 2 ox), once and in place: acc[p][0] <- out x0 = q0 + q1 + q2, acc[p][1] <- out x1 = q1 - q2 - q3
+        // BNR: the pre-norm values of this lane's two output voxels of a parity are requested EARLY - parity 0 in front of the x inverse transform,
+        // parity 1 as soon as parity 0's have been used - so that a miss (y is read once per step: HBM) lands under the transform and the exchange
+        // instead of in front of the sums that need it (PULPO_W3_YEARLY=0: requested right in front of the exchange barrier of their parity)
+        float4 yv0 = zero4, yv1 = zero4;
+        const bool qok = co0 + 4 * q < a.Cout;         // (a partly empty cout tile: channel quads beyond the tensor are neither read nor stored)
+        auto load_y = [&](int oz_) {
+            if (BNR && qok) {
+                const long vox_ = (long)((z0 + 2 * vzb + oz_) * a.H + y0 + 2 * vyb) * a.W + x0 + 2 * vxb + ox;
+                yv0 = *reinterpret_cast<const float4*>(bn_b + vox_ * a.bn_y_ps);
+                yv1 = *reinterpret_cast<const float4*>(bn_b + (vox_ + a.W) * a.bn_y_ps);
+            }
+        };
+        if (PULPO_W3_YEARLY) { load_y(0); __builtin_amdgcn_sched_barrier(0); }
         // a - b below is fma(m1, b, a) with m1 = -1 the compiler cannot see through: exact (the product is), and it stays ONE two-wide instruction
         // (v_pk_fma_f32) - a two-wide subtraction is expanded into two scalar ones by the backend
         f32x2 m1 = {-1.f, -1.f};
@@ -479,9 +495,7 @@ __device__ __forceinline__ void wino3_body(const ConvArgs& a) {
             }
             const int gz = z0 + 2 * vzb + oz, gy = y0 + 2 * vyb, gx = x0 + 2 * vxb + ox;
             const long vox = (long)(gz * a.H + gy) * a.W + gx;
-            float4 yv0 = zero4, yv1 = zero4;
-            const bool qok = co0 + 4 * q < a.Cout;     // (a partly empty cout tile: channel quads beyond the tensor are neither read nor stored)
-            if (BNR && qok) {
+            if (BNR && !PULPO_W3_YEARLY && qok) {
                 yv0 = *reinterpret_cast<const float4*>(bn_b + vox * a.bn_y_ps);
                 yv1 = *reinterpret_cast<const float4*>(bn_b + (vox + a.W) * a.bn_y_ps);
             }
@@ -509,6 +523,7 @@ __device__ __forceinline__ void wino3_body(const ConvArgs& a) {
                 red1(v0.z, yv0.z, sc4.z, sh4.z, bm4.z, s4.z, q4.z); red1(v0.w, yv0.w, sc4.w, sh4.w, bm4.w, s4.w, q4.w);
                 red1(v1.x, yv1.x, sc4.x, sh4.x, bm4.x, s4.x, q4.x); red1(v1.y, yv1.y, sc4.y, sh4.y, bm4.y, s4.y, q4.y);
                 red1(v1.z, yv1.z, sc4.z, sh4.z, bm4.z, s4.z, q4.z); red1(v1.w, yv1.w, sc4.w, sh4.w, bm4.w, s4.w, q4.w);
+                if (PULPO_W3_YEARLY && oz == 0) { __builtin_amdgcn_sched_barrier(0); load_y(1); __builtin_amdgcn_sched_barrier(0); }
             } else {
                 s4.x += v0.x + v1.x; s4.y += v0.y + v1.y; s4.z += v0.z + v1.z; s4.w += v0.w + v1.w;
                 q4.x += v0.x * v0.x + v1.x * v1.x; q4.y += v0.y * v0.y + v1.y * v1.y; q4.z += v0.z * v0.z + v1.z * v1.z; q4.w += v0.w * v0.w + v1.w * v1.w;
