@@ -104,25 +104,57 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const TH* __restrict__ h
 #pragma unroll
         for (int k = 0; k < VEC; ++k) { dw[j][k] = 0.f; w[j][k] = (row < RB) ? Wt[j * C + c + k] : 0.f; }
     }
-    if (row < RB) {
+    if constexpr (NOUT == 6) {
+        // The five planar 3-channel operands of a pixel (upstream gradients of mu / sigma / z, the noise, sigma) are the same 15 values for every
+        // thread of the pixel's row.  Loaded by each thread they were 15 of the 16 load instructions a wave issued per trip, and the kernel ran at
+        // what the vector-memory unit issues (2.3 TB/s at 96 channels) instead of what HBM delivers: the row's first threads now fetch them once,
+        // the row reads them from LDS (two buffers by trip parity: one barrier per trip).  Uniform trip count per block for that barrier.
+        float (*sc)[16] = reinterpret_cast<float (*)[16]>(red + (size_t)RB * ROWLEN);       // [2 * RB][16], behind the reduction rows (sized by the launcher)
+        int it = 0;
+        for (long pb = (long)blockIdx.x * RB; pb < npix; pb += (long)gridDim.x * RB, it ^= 1) {
+            const long p = pb + row;
+            const bool live = row < RB && p < npix;
+            const long pc = live ? p : 0;
+            const long b = pc / V, v = pc - b * V;
+            const long base = b * 3 * V + v;
+            if (live)
+                for (int q = col; q < 15; q += CV) {
+                    const int arr = q / 3, j = q - 3 * arr;
+                    const float* src = arr == 0 ? g0 : arr == 1 ? g1 : arr == 2 ? g2 : arr == 3 ? eps : sigma;
+                    sc[it * RB + row][q] = src != nullptr ? src[base + j * V] : 0.f;
+                }
+            float x[VEC];
+            if (live) pulpo::ldv<VEC>(h + p * ps + c, x);
+            __syncthreads();
+            if (live) {
+                const float* sv = sc[it * RB + row];
+                float dpre[6];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float gz = sv[6 + j];
+                    dpre[j] = sv[j] + gz;                                      // dmu = g0 + g2
+                    const float gs = sv[3 + j] + gz * sv[9 + j];               // dsigma = g1 + g2 * eps (eps absent: stored as 0)
+                    dpre[3 + j] = gs * (1.f - expf(-sv[12 + j]));
+                }
+                float o[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o[k] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) {
+                    db[j] += dpre[j];
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) { o[k] += dpre[j] * w[j][k]; dw[j][k] += dpre[j] * x[k]; }
+                }
+                pulpo::stv<VEC>(dh + p * dps + c, o);
+            }
+        }
+    } else if (row < RB) {
         for (long p = (long)blockIdx.x * RB + row; p < npix; p += (long)gridDim.x * RB) {
             const long b = p / V, v = p - b * V;
             const long base = b * 3 * V + v;
             float dpre[NOUT];
-            if constexpr (NOUT == 3) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) dpre[j] = g0[base + j * V];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float gz = g2 != nullptr ? g2[base + j * V] : 0.f;
-                    const float gm = (g0 != nullptr ? g0[base + j * V] : 0.f) + gz;
-                    float gs = (g1 != nullptr ? g1[base + j * V] : 0.f);
-                    if (eps != nullptr) gs += gz * eps[base + j * V];
-                    dpre[j] = gm;
-                    dpre[3 + j] = gs * (1.f - expf(-sigma[base + j * V]));
-                }
-            }
+            for (int j = 0; j < 3; ++j) dpre[j] = g0[base + j * V];
             float x[VEC], o[VEC];
             pulpo::ldv<VEC>(h + p * ps + c, x);
 #pragma unroll
@@ -135,6 +167,8 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const TH* __restrict__ h
             }
             pulpo::stv<VEC>(dh + p * dps + c, o);
         }
+    }
+    if (row < RB) {
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) {
 #pragma unroll
@@ -203,7 +237,7 @@ PULPO_API int pulpo_heads_bwd_t(const void* h, int h_dt, int64_t ps, const float
     PULPO_REQUIRE(C / (v4 ? 4 : 1) <= 256, "heads_bwd: too many channels");
     const int nblk = pulpo_heads_bwd_blocks(B, V, C);
     const int RB = std::max(1, 256 / (C / (v4 ? 4 : 1)));
-    const size_t lds = (size_t)RB * (nout * C + nout) * sizeof(float);
+    const size_t lds = ((size_t)RB * (nout * C + nout) + (nout == 6 ? (size_t)2 * RB * 16 : 0)) * sizeof(float);       // reduction rows + (nout 6) the per-pixel operand rows
     PULPO_REQUIRE(lds <= 64 * 1024, "heads_bwd: LDS budget exceeded");
     PULPO_DISPATCH_DT(h_dt, TH, {
         const TH* hp = (const TH*)h;

@@ -1,7 +1,8 @@
 """heads_fwd / heads_bwd (the 1x1x1 mu / sigma / velocity heads) at the step's shapes, alone on the machine: time and achieved bandwidth.
 Round 5: 2.3 TB/s at 96 channels x 6 outputs (85 / 168 us at 80^3; 3.9 / 5.7 TB/s at 32 channels x 3 outputs).  Larger grids (4096 workgroups: forward 85 -> 70 us),
-2 / 4 pixels per trip in the backward kernel (168 -> 165 / 233 us): not what bounds it - the backward kernel issues 16 load instructions per wave and
-pixel row (15 of them the same five planar gradient / noise / sigma values for every thread of the row).  0.3 ms of the step in total; left as it is.
+2 / 4 pixels per trip in the backward kernel (168 -> 165 / 233 us): not what bounds it - the backward kernel issued 16 load instructions per wave and
+trip, 15 of them the same five planar gradient / noise / sigma values for every thread of a pixel's row.  Those now go through LDS (fetched once per row):
+170 -> 130 us at 80^3 x 96 channels alone on the machine; inside the step the difference is below the run-to-run noise (0.3 ms of heads kernels in total).
 usage: python scripts/heads_probe.py"""
 import sys, os, torch
 sys.path.insert(0, '.')
