@@ -61,21 +61,21 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const TH* __restrict__ h
         }
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) acc[j] = group_sum(acc[j]);
-        if (live && g == 0) {
+        // every lane of the group holds the sums (xor shuffles): lane g < 3 finishes output component g - one load / store instruction per output
+        // tensor and trip instead of three from the group's first lane (the kernel ran at what the vector-memory unit issues, not at what HBM delivers)
+        if (live && g < 3) {
             const long b = p / V, v = p - b * V;
-            const long base = b * 3 * V + v;
+            const long at = b * 3 * V + v + g * V;
+            const float a_lo = g == 0 ? acc[0] : g == 1 ? acc[1] : acc[2];
             if constexpr (NOUT == 3) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) o0[base + j * V] = acc[j] + bias[j];
+                o0[at] = a_lo + bias[g];
             } else {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float mu = acc[j] + bias[j];
-                    const float sg = softplus_f(acc[3 + j] + bias[3 + j]);
-                    o0[base + j * V] = mu;
-                    o1[base + j * V] = sg;
-                    o2[base + j * V] = eps != nullptr ? mu + sg * eps[base + j * V] : mu;
-                }
+                const float a_hi = g == 0 ? acc[3] : g == 1 ? acc[4] : acc[5];
+                const float mu = a_lo + bias[g];
+                const float sg = softplus_f(a_hi + bias[3 + g]);
+                o0[at] = mu;
+                o1[at] = sg;
+                o2[at] = eps != nullptr ? mu + sg * eps[at] : mu;
             }
         }
     }
