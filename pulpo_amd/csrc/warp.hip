@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ in
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) out[e] = in[e] * s;
 }
 
-// VecInt forward for fields that fit LDS (3 * D*H*W floats <= 96 KB: the 20^3 and 10^3 pyramid levels): ALL squaring steps in ONE launch, one
+// VecInt forward for small fields (3 * D*H*W floats <= 96 KB fit; used up to 2048 voxels - the 10^3 pyramid level - see pulpo_vecint_fwd): ALL squaring steps in ONE launch, one
 // workgroup of 1024 threads per batch element.  The field lives in LDS (image and displacement at once: every gather is an LDS read); a
 // step's new values are formed in registers (up to 8 voxels per thread), then written back over the field and to work[k + 1] (the backward
 // pass needs every intermediate field).  Same arithmetic as scale_kernel + nsteps x warp_fwd_kernel<3> with add = cur (agreement to fp32
@@ -462,7 +462,11 @@ PULPO_API int pulpo_vecint_fwd(const float* v, float* work, int B, int D, int H,
     PULPO_REQUIRE(v && work && B > 0 && D >= 1 && H > 1 && W > 1 && nsteps >= 0 && (long)D * H * W < (1L << 31), "vecint_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const long n = (long)B * 3 * D * H * W, total = (long)B * D * H * W;
-    if (total / B <= VI_MAXV && nsteps > 0) {          // the field fits LDS: all steps in one launch (fields <= 20^3)
+    // the one-launch form: ONE workgroup per batch element does every gather of every step - 16.6 us at 10^3 against 36 for seven launches, but 76 us
+    // at 20^3 against 38 (scripts/vecint_probe.py): up to 2048 voxels by default (PULPO_VECINT_LDS_MAXV moves it; it fits up to 8192)
+    static long lds_maxv = -1;
+    if (lds_maxv < 0) { const char* e = getenv("PULPO_VECINT_LDS_MAXV"); lds_maxv = e ? atol(e) : 2048; }
+    if (total / B <= std::min<long>(VI_MAXV, lds_maxv) && nsteps > 0) {
         const size_t lds = sizeof(float) * 3 * (size_t)(total / B);
         static bool attr_set = false;
         if (!attr_set) {
