@@ -26,7 +26,7 @@
 #define PULPO_ABL 0          // diagnostic builds (scripts/ablate.py): 21 no matrix instructions, 22 no staging writes, 23 no global loads, 24 no barrier per plane step
 #endif
 #ifndef PULPO_ABLX
-#define PULPO_ABLX 0         // diagnostic builds of the eight-wave kernel (bit mask): 1 no barrier per plane step, 2 no staging writes, 4 no global loads,
+#define PULPO_ABLX 0         // diagnostic builds of the eight-wave kernel (bit mask): 1 no barrier per plane step, 2 no staging writes, 4 no global loads, 32 / 64 (F(2x2x2) kernel) input / gradient taps from one 64 KB window,
 #endif                       // 8 no flush, 16 no operand combinations
 #include <stdlib.h>
 #include <type_traits>
@@ -699,6 +699,7 @@ __device__ __forceinline__ void wgrad_w3x_body(const Wgrad2Args& a) {
         for (int t4 = 0; t4 < 4; ++t4) {
             const int gx = x0 - 1 + 2 * x_xb + t4;
             x_off[t4] = (xrow && (unsigned)gx < (unsigned)a.W) ? (unsigned)((long)((ci0 + 4 * x_q) >> 3) * a.in_kb + (gy * a.W + gx) * (int)a.in_ps + ((4 * x_q) & 7)) * 4u : OOB;
+            if ((PULPO_ABLX & 32) && x_off[t4] != OOB) x_off[t4] &= 0xFFF0u;       // (diagnostic: every input tap from one 64 KB window - cache hits)
         }
         const int ey = y0 + e_y;
         const bool erow = e_item && e_cok && ey < a.H;
@@ -706,6 +707,7 @@ __device__ __forceinline__ void wgrad_w3x_body(const Wgrad2Args& a) {
         for (int t2 = 0; t2 < 2; ++t2) {
             const int gx = x0 + 2 * e_xb + t2;
             e_off[t2] = (erow && gx < a.W) ? (unsigned)((long)((co0 + 4 * e_q) >> 3) * a.go_kb + (ey * a.W + gx) * (int)a.go_ps + ((4 * e_q) & 7)) * 4u : OOB;
+            if ((PULPO_ABLX & 64) && e_off[t2] != OOB) e_off[t2] &= 0xFFF0u;       // (diagnostic: the same for the gradient operand)
         }
     };
     const unsigned x_plane = (unsigned)((long)a.H * a.W * a.in_ps * 4), e_plane = (unsigned)((long)a.H * a.W * a.go_ps * 4);
@@ -713,14 +715,14 @@ __device__ __forceinline__ void wgrad_w3x_body(const Wgrad2Args& a) {
     float4 xr[4], er[2];                                  // raw registers of the plane being fetched
     auto issue_x = [&](int zp) {                          // input plane zp (zeros outside the volume)
         const unsigned zmask = (unsigned)zp < (unsigned)a.D ? 0u : OOB;          // (wave-uniform)
-        const unsigned zo = zmask ? 0u : (unsigned)zp * x_plane;
+        const unsigned zo = (zmask | (unsigned)(PULPO_ABLX & 32)) ? 0u : (unsigned)zp * x_plane;
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4)
             xr[t4] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)(x_off[t4] | zmask), (int)zo, 0));
     };
     auto issue_e = [&](int zp) {                          // output-gradient plane zp
         const unsigned zmask = (unsigned)zp < (unsigned)a.D ? 0u : OOB;
-        const unsigned zo = zmask ? 0u : (unsigned)zp * e_plane;
+        const unsigned zo = (zmask | (unsigned)(PULPO_ABLX & 64)) ? 0u : (unsigned)zp * e_plane;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
             er[t2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(e_rs, (int)(e_off[t2] | zmask), (int)zo, 0));
