@@ -78,6 +78,8 @@ class ConvSequence(nn.Module):
         """pool_after: the caller pools the result next (DownPath) - the last unit then writes AvgPool(result) along with it;
         out: (buffer, first channel) - the last unit writes its result into that channel range of a wider buffer (ops.conv_bn_lrelu);
         pool_only (with pool_after): the caller reads ONLY the pooled result -> returns (result or None, pooled or None)"""
+        if not pool_after and out is None and not ops.BLOCKED_Z:
+            return self._op(x)                       # (the reference's own call: hooks on the Sequential fire)
         n = len(self._op)
         for k, unit in enumerate(self._op):
             last = k + 1 == n
